@@ -1,0 +1,104 @@
+"""VGGUnet -- same module surface as the reference's ``VGG.py:13-203`` (parameter names, ctor
+argument, ``forward(x) -> ([feat_l], [conf_l])``), computed by libhla's MFMA convolution kernels.
+
+Differences a caller can observe:
+  * returned maps are logically [B,C,H,W] but stored channels-last (NHWC); values match the reference
+  * ``precision='fp32'`` (default) runs exact-fp32 MFMA; ``'bf16'`` is the throughput mode
+  * pretrained torchvision weights are not downloaded here: load a state dict (keys are identical)
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+
+_W_ORDER = ['conv0', 'conv2', 'conv5', 'conv7', 'conv10', 'conv12', 'conv14',
+            'conv_dec1.1', 'conv_dec1.3', 'conv_dec2.1', 'conv_dec2.3', 'conv_dec3.1', 'conv_dec3.3',
+            'conf0.1', 'conf1.1', 'conf2.1', 'conf3.1']
+_LEVEL_SEL = {-1: [0], -2: [1], -3: [2], 2: [1, 2], 3: [0, 1, 2]}
+_CH = (256, 128, 64, 16)
+
+
+def _dtype_code(precision: str) -> int:
+    if precision == 'bf16':
+        return _lib.HLA_BF16
+    if precision == 'fp32':
+        return _lib.HLA_F32
+    raise ValueError(f"precision must be 'fp32' or 'bf16', got {precision!r}")
+
+
+def vgg_forward_nhwc(module: 'VGGUnet', x: torch.Tensor, want_conf: bool = True):
+    """Run the three-level extractor.  Returns (feats, confs): lists of NHWC fp32 tensors
+    [B,h,w,C] (L2-normalised) and [B,h,w] (or None)."""
+    _lib.require_gpu(x, 'VGGUnet input')
+    if x.dim() != 4 or x.shape[1] != 3:
+        raise ValueError(f'expected [B,3,H,W], got {tuple(x.shape)}')
+    lib = _lib.load()
+    x = x.contiguous().float()
+    B, _, H, W = x.shape
+    sd = dict(module.named_parameters())
+    prm = _lib.VggParams()
+    keep = []
+    for i, name in enumerate(_W_ORDER):
+        w = sd[name + '.weight'].detach().contiguous().float()
+        keep.append(w)
+        prm.w[i] = w.data_ptr()
+        if i < 7:
+            b = sd[name + '.bias'].detach().contiguous().float()
+            keep.append(b)
+            prm.b[i] = b.data_ptr()
+    dt = _dtype_code(module.precision)
+    feats = [torch.empty(B, H >> (3 - l), W >> (3 - l), _CH[l], device=x.device, dtype=torch.float32) for l in range(3)]
+    confs = [torch.empty(B, H >> (3 - l), W >> (3 - l), device=x.device, dtype=torch.float32) if want_conf else None
+             for l in range(3)]
+    fp = (C.c_void_p * 4)(*[f.data_ptr() for f in feats], 0)
+    cp = (C.c_void_p * 4)(*[(c.data_ptr() if c is not None else 0) for c in confs], 0)
+    nbytes = lib.hla_vgg_workspace_bytes(B, H, W, 3, dt)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+    rc = lib.hla_vgg_forward(_lib.ptr(x), C.byref(prm), fp, cp, _lib.ptr(ws), nbytes, B, H, W, 3, dt,
+                             _lib.HLA_VGG_WANT_CONF if want_conf else 0, _lib.stream_ptr())
+    _lib.check(rc, 'hla_vgg_forward')
+    # ws / packed weights are only used by work already enqueued on this stream; the caching allocator
+    # keeps the block stream-ordered, so dropping the Python reference here is safe.
+    return feats, confs
+
+
+class VGGUnet(nn.Module):
+    def __init__(self, level, estimate_depth=0, precision: str = 'fp32'):
+        super().__init__()
+        if estimate_depth:
+            raise NotImplementedError('estimate_depth=1 (Ford height heads, VGG.py:85-118) is out of scope')
+        if level not in _LEVEL_SEL:
+            raise NotImplementedError(f'VGGUnet level {level}: levels -1,-2,-3,2,3 are built (level 4 = x24 is not yet)')
+        self.level = level
+        self.precision = precision
+
+        def c(ci, co, bias):
+            return nn.Conv2d(ci, co, kernel_size=(3, 3), stride=(1, 1), padding=1, bias=bias)
+
+        self.conv0, self.conv2 = c(3, 64, True), c(64, 64, True)
+        self.conv5, self.conv7 = c(64, 128, True), c(128, 128, True)
+        self.conv10, self.conv12, self.conv14 = c(128, 256, True), c(256, 256, True), c(256, 256, True)
+        self.conv_dec1 = nn.Sequential(nn.ReLU(inplace=True), c(384, 128, False), nn.ReLU(inplace=True), c(128, 128, False))
+        self.conv_dec2 = nn.Sequential(nn.ReLU(inplace=True), c(192, 64, False), nn.ReLU(inplace=True), c(64, 64, False))
+        self.conv_dec3 = nn.Sequential(nn.ReLU(inplace=True), c(128, 32, False), nn.ReLU(inplace=True), c(32, 16, False))
+        self.conf0 = nn.Sequential(nn.ReLU(), c(256, 1, False), nn.Sigmoid())
+        self.conf1 = nn.Sequential(nn.ReLU(), c(128, 1, False), nn.Sigmoid())
+        self.conf2 = nn.Sequential(nn.ReLU(), c(64, 1, False), nn.Sigmoid())
+        self.conf3 = nn.Sequential(nn.ReLU(), c(16, 1, False), nn.Sigmoid())
+
+    def forward(self, x):
+        feats, confs = vgg_forward_nhwc(self, x, want_conf=True)
+        sel = _LEVEL_SEL[self.level]
+        # NCHW-shaped views over the NHWC storage
+        return [feats[i].permute(0, 3, 1, 2) for i in sel], [confs[i].unsqueeze(1) for i in sel]
+
+
+def L2_norm(x):
+    """VGG.py:511-514 (host-side helper kept for API parity; the fused path normalises in-kernel)."""
+    B = x.shape[0]
+    n = x.reshape(B, -1).norm(dim=1).clamp_min(1e-12)
+    return x / n.view(B, 1, 1, 1)

@@ -1,0 +1,85 @@
+"""ctypes binding of libhla.so (the C ABI declared in include/hla.h).
+
+The product path has no fallback: if the HIP library cannot be loaded, or a tensor is not
+on a HIP device, calls raise.  PyTorch is used only for device memory and streams.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, 'libhla.so')
+
+HLA_F32, HLA_BF16 = 0, 1
+HLA_VGG_WANT_CONF, HLA_VGG_KEEP_RAW = 1, 2
+
+
+class HlaError(RuntimeError):
+    pass
+
+
+class VggParams(C.Structure):
+    _fields_ = [('w', C.c_void_p * 17), ('b', C.c_void_p * 7)]
+
+
+class S2GLevel(C.Structure):
+    _fields_ = [('sat_feat', C.c_void_p), ('grd_feat', C.c_void_p), ('grd_conf', C.c_void_p), ('xyz', C.c_void_p),
+                ('A', C.c_int), ('h', C.c_int), ('w', C.c_int), ('C', C.c_int), ('row0', C.c_int),
+                ('meter_per_pixel', C.c_double), ('centre', C.c_double)]
+
+
+class S2GConfig(C.Structure):
+    _fields_ = [('ford', C.c_int), ('n_levels', C.c_int), ('n_iters', C.c_int), ('level_first', C.c_int),
+                ('using_weight', C.c_int), ('use_hessian', C.c_int), ('dof', C.c_int),
+                ('shift_range_lat', C.c_double), ('shift_range_lon', C.c_double), ('rotation_range', C.c_double),
+                ('damping', C.c_double * 3)]
+
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Load libhla.so; build it with hipcc first if it is missing and a compiler is present."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        from . import build as _b
+        _b.build()
+    lib = C.CDLL(LIB_PATH)
+    vp, i, sz = C.c_void_p, C.c_int, C.c_size_t
+    lib.hla_last_error.restype = C.c_char_p
+    lib.hla_abi_version.restype = i
+    lib.hla_vgg_workspace_bytes.restype = sz
+    lib.hla_vgg_workspace_bytes.argtypes = [i, i, i, i, i]
+    lib.hla_vgg_forward.restype = i
+    lib.hla_vgg_forward.argtypes = [vp, C.POINTER(VggParams), C.POINTER(vp), C.POINTER(vp), vp, sz, i, i, i, i, i, i, vp]
+    lib.hla_grid_sample.restype = i
+    lib.hla_grid_sample.argtypes = [vp, vp, vp, vp, vp, i, i, i, i, i, i, i, vp]
+    lib.hla_s2g_workspace_bytes.restype = sz
+    lib.hla_s2g_workspace_bytes.argtypes = [C.POINTER(S2GConfig), C.POINTER(S2GLevel), i]
+    lib.hla_s2g_lm_solve.restype = i
+    lib.hla_s2g_lm_solve.argtypes = [C.POINTER(S2GConfig), C.POINTER(S2GLevel), vp, vp, vp, vp, vp, vp, vp, sz, i, vp]
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        raise HlaError(f'{what} failed (status {rc}): {load().hla_last_error().decode()}')
+
+
+def stream_ptr() -> C.c_void_p:
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def require_gpu(t: torch.Tensor, name: str) -> None:
+    if not t.is_cuda:
+        raise HlaError(f'{name} must live on the HIP device (got {t.device}); highlyaccurate_amd has no CPU path')
+
+
+def ptr(t) -> C.c_void_p:
+    return C.c_void_p(0 if t is None else t.data_ptr())

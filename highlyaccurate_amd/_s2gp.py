@@ -1,0 +1,193 @@
+"""Shared host logic of the satellite->ground LM localisation models.
+
+Mirrors the orchestration of ``models_kitti.py:1141-1316`` / ``models_ford.py:652-866`` but the whole
+N_iters x levels loop is one C-ABI call (``hla_s2g_lm_solve``): no per-step host sync, no per-step
+H2D copies (the reference does ~60 syncs and ~100 small uploads per forward).
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import _lib, utils
+from .VGG import VGGUnet, vgg_forward_nhwc
+
+KITTI_K = [[582.9802, 0.0, 496.2420], [0.0, 482.7076, 125.0034], [0.0, 0.0, 1.0]]      # models_kitti.py:657-660
+FORD_K_FL = [945.391406, 0.0, 855.502825, 0.0, 945.668274, 566.372868, 0.0, 0.0, 1.0]   # models_ford.py:116
+FORD_H_FL, FORD_W_FL = 860, 1656                                                        # models_ford.py:119-120
+
+
+def ground_plane_table(K_ori, grd_H, grd_W, ori_H, ori_W):
+    """Back-project the pixel grid onto the ground plane y = camera height
+    (models_kitti.py:655-682 / models_ford.py:132-155).  Same fp32 op sequence as the reference so the
+    table is bit-identical.  Returns xyz [h,w,3] fp32 (CPU)."""
+    K = torch.tensor(K_ori, dtype=torch.float32).reshape(1, 3, 3)
+    Ks = K.clone()
+    Ks[:, :1, :] = K[:, :1, :] * grd_W / ori_W
+    Ks[:, 1:2, :] = K[:, 1:2, :] * grd_H / ori_H
+    Kinv = torch.inverse(Ks)
+    v, u = torch.meshgrid(torch.arange(0, grd_H, dtype=torch.float32),
+                          torch.arange(0, grd_W, dtype=torch.float32), indexing='ij')
+    uv1 = torch.stack([u, v, torch.ones_like(u)], dim=-1).unsqueeze(0)
+    xyz_w = torch.sum(Kinv[:, None, None, :, :] * uv1[:, :, :, None, :], dim=-1)
+    y = xyz_w[..., 1:2]
+    w = utils.Camera_height / torch.where(torch.abs(y) > utils.EPS, y, utils.EPS * torch.ones_like(y))
+    return (xyz_w * w)[0].contiguous()
+
+
+def ford_K_network_input():
+    """models_ford.py:116-130: K_FL rescaled from the 860x1656 sensor to the 256x1024 network input."""
+    K = torch.tensor(FORD_K_FL, dtype=torch.float32).reshape(3, 3)
+    out = torch.zeros_like(K)
+    out[0] = K[0] / FORD_W_FL * 1024
+    out[1] = K[1] / FORD_H_FL * 256
+    out[2] = K[2]
+    return out.tolist()
+
+
+def loss_func(loss_method, ref_feat_list, pred_feat_dict, gt_feat_dict, shift_lats, shift_lons, thetas,
+              gt_shift_lat, gt_shift_lon, gt_theta, pred_uv_dict, gt_uv_dict,
+              coe_shift_lat=100, coe_shift_lon=100, coe_theta=100, coe_L1=100, coe_L2=100, coe_L3=100, coe_L4=100):
+    """models_ford.py:1041-1093, method 0 (the only valid one per models_ford.py:1040).  Same positional
+    signature as the reference; the feature/uv dictionaries are unused by method 0 and may be None."""
+    if loss_method != 0:
+        raise NotImplementedError('only loss_method=0 is supported (the reference marks 1-3 as failed trials)')
+    d_lat = torch.abs(shift_lats - gt_shift_lat[:, None, None]).mean(dim=0)
+    d_lon = torch.abs(shift_lons - gt_shift_lon[:, None, None]).mean(dim=0)
+    d_th = torch.abs(thetas - gt_theta[:, None, None]).mean(dim=0)
+    losses = coe_shift_lat * d_lat + coe_shift_lon * d_lon + coe_theta * d_th
+    return (losses.mean(), losses[0] - losses[-1], d_lat[0] - d_lat[-1], d_lon[0] - d_lon[-1], d_th[0] - d_th[-1],
+            losses[-1], d_lat[-1], d_lon[-1], d_th[-1], None, None, None, None)
+
+
+class S2GPBase(nn.Module):
+    ford = False
+
+    def __init__(self, args):
+        super().__init__()
+        self.args = args
+        self.level = args.level
+        self.N_iters = args.N_iters
+        self.using_weight = args.using_weight
+        self.loss_method = args.loss_method
+        if args.level != 3:
+            raise NotImplementedError('only args.level == 3 (x15, x18, x21) is built so far')
+        if getattr(args, 'proj', 'geo') != 'geo':
+            raise NotImplementedError("only proj='geo' is in scope")
+        if getattr(args, 'Optimizer', 'LM') != 'LM':
+            raise NotImplementedError("only Optimizer='LM' is in scope (SURVEY section 2)")
+        if getattr(args, 'dropout', 0) or getattr(args, 'use_gt_depth', 0) or getattr(args, 'estimate_depth', 0):
+            raise NotImplementedError('dropout / use_gt_depth / estimate_depth are out of scope')
+        precision = getattr(args, 'precision', 'fp32')
+        self.SatFeatureNet = VGGUnet(self.level, precision=precision)
+        self.GrdFeatureNet = VGGUnet(self.level, precision=precision)
+        if self.ford or args.rotation_range > 0:
+            self.damping = nn.Parameter(torch.zeros(size=(1, 3), dtype=torch.float32))
+        else:
+            self.damping = nn.Parameter(torch.zeros(size=(), dtype=torch.float32))
+        self.meters_per_pixel = [utils.get_meter_per_pixel() * (2 ** (3 - l)) for l in range(4)]
+        self._tables = {}
+        self.last_trace = None       # [B, N_iters, Level, 3] (shift_u, shift_v, theta) of the last forward
+        self.last_normal_eq = None
+        self.keep_normal_eq = False
+
+    # -- geometry tables ---------------------------------------------------------------------
+    def xyz_tables(self, grd_H: int, grd_W: int, device):
+        key = (grd_H, grd_W, str(device))
+        if key not in self._tables:
+            K = ford_K_network_input() if self.ford else KITTI_K
+            self._tables[key] = [ground_plane_table(K, grd_H / 2 ** (3 - l), grd_W / 2 ** (3 - l), grd_H, grd_W).to(device)
+                                 for l in range(3)]
+        return self._tables[key]
+
+    # -- LM options -> C structs -------------------------------------------------------------
+    def _config(self, n_levels: int, level_first: int) -> _lib.S2GConfig:
+        a = self.args
+        cfg = _lib.S2GConfig()
+        cfg.ford = 1 if self.ford else 0
+        cfg.n_levels, cfg.n_iters, cfg.level_first = n_levels, self.N_iters, 1 if level_first else 0
+        cfg.using_weight = 1 if self.using_weight else 0
+        cfg.use_hessian = 1 if getattr(a, 'use_hessian', 0) else 0
+        if self.ford:
+            cfg.dof = 3
+        elif a.rotation_range == 0:
+            cfg.dof = 2
+        elif a.shift_range_lat == 0 and a.shift_range_lon == 0:
+            cfg.dof = 1
+        else:
+            cfg.dof = 3
+        cfg.shift_range_lat, cfg.shift_range_lon = float(a.shift_range_lat), float(a.shift_range_lon)
+        cfg.rotation_range = float(a.rotation_range)
+        if getattr(a, 'train_damping', 0):
+            lam = (10.0 ** (-6 + torch.sigmoid(self.damping.detach().double()) * 11.0)).reshape(-1).tolist()
+        else:
+            lam = [float(a.damping)] * 3
+        lam = (lam + lam + lam)[:3]
+        if not self.ford and cfg.dof == 1 and getattr(a, 'train_damping', 0):
+            lam = [lam[0]] * 3
+        for i in range(3):
+            cfg.damping[i] = lam[i]
+        return cfg
+
+    def _draw_reinit(self, n_steps: int, B: int, device):
+        """Reproduce the reference's global-RNG consumption: two Uniform(-1,1).sample([B,1]) draws per
+        LM step (models_kitti.py:1028-1029), in step order, from torch's CPU generator."""
+        draws = []
+        for _ in range(n_steps):
+            ru = torch.distributions.uniform.Uniform(-1, 1).sample([B, 1])
+            rv = torch.distributions.uniform.Uniform(-1, 1).sample([B, 1])
+            draws.append(torch.stack([ru[:, 0], rv[:, 0]], 0))
+        return torch.stack(draws, 0).to(device)
+
+    def lm_solve(self, sat_feats, grd_feats, grd_confs, grd_hw, extra=None, level_first=0, init_pose=None):
+        """sat_feats/grd_feats: NHWC fp32 lists; returns trace [B,N_iters,L,3] = (shift_u, shift_v, theta)."""
+        lib = _lib.load()
+        dev = sat_feats[0].device
+        B = sat_feats[0].shape[0]
+        L = len(sat_feats)
+        tables = self.xyz_tables(grd_hw[0], grd_hw[1], dev)
+        cfg = self._config(L, level_first)
+        lv = (_lib.S2GLevel * L)()
+        for l in range(L):
+            s, g = sat_feats[l], grd_feats[l]
+            A, h, w, Cn = s.shape[1], g.shape[1], g.shape[2], g.shape[3]
+            assert s.shape[2] == A and s.shape[3] == Cn and tuple(tables[l].shape) == (h, w, 3)
+            lv[l].sat_feat, lv[l].grd_feat = s.data_ptr(), g.data_ptr()
+            lv[l].grd_conf = grd_confs[l].data_ptr() if (self.using_weight and grd_confs[l] is not None) else 0
+            lv[l].xyz = tables[l].data_ptr()
+            lv[l].A, lv[l].h, lv[l].w, lv[l].C, lv[l].row0 = A, h, w, Cn, h // 2
+            if self.ford:
+                lv[l].meter_per_pixel = float(extra['side_m']) / A          # models_ford.py:230
+                lv[l].centre = float(A // 2)                                # models_ford.py:231
+            else:
+                lv[l].meter_per_pixel = utils.get_meter_per_pixel() * utils.get_process_satmap_sidelength() / A
+                lv[l].centre = A / 2.0                                      # models_kitti.py:765-767
+        steps = L * self.N_iters
+        reinit = self.ford or cfg.dof == 3
+        rand_uv = self._draw_reinit(steps, B, dev) if reinit else None
+        trace = torch.empty(B, self.N_iters, L, 3, device=dev, dtype=torch.float32)
+        neq = torch.empty(steps, B, 16, device=dev, dtype=torch.float64) if self.keep_normal_eq else None
+        nbytes = lib.hla_s2g_workspace_bytes(C.byref(cfg), lv, B)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        R_FL = extra['R_FL'].to(dev).float().contiguous() if self.ford else None
+        T_FL = extra['T_FL'].to(dev).float().contiguous() if self.ford else None
+        p0 = init_pose.to(dev).float().contiguous() if init_pose is not None else None
+        rc = lib.hla_s2g_lm_solve(C.byref(cfg), lv, _lib.ptr(R_FL), _lib.ptr(T_FL), _lib.ptr(p0), _lib.ptr(rand_uv),
+                                  _lib.ptr(trace), _lib.ptr(neq), _lib.ptr(ws), nbytes, B, _lib.stream_ptr())
+        _lib.check(rc, 'hla_s2g_lm_solve')
+        self.last_trace, self.last_normal_eq = trace, neq
+        return trace
+
+    def _features(self, sat_map, grd_img, want_conf):
+        sat_feats, _ = vgg_forward_nhwc(self.SatFeatureNet, sat_map, want_conf=False)
+        grd_feats, grd_confs = vgg_forward_nhwc(self.GrdFeatureNet, grd_img, want_conf=want_conf)
+        return sat_feats, grd_feats, grd_confs
+
+    def _check_train_supported(self):
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            raise NotImplementedError(
+                "mode='train' with autograd enabled needs the HIP backward kernels, which are not built yet; "
+                "call under torch.no_grad() for the forward values")

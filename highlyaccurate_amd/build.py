@@ -1,0 +1,80 @@
+"""Build libhla.so (gfx950) in-tree with hipcc.  `python -m highlyaccurate_amd.build [--force] [--verbose]`"""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, 'csrc')
+LIB = os.path.join(HERE, 'libhla.so')
+SOURCES = ['capi.hip', 'lm_solve.hip', 'grid_sample.hip', 'vgg.hip']
+FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=fast', '-Wno-unused-result']
+
+
+def _stale() -> bool:
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, '..', 'include', 'hla.h')]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def _resource_table(text: str) -> None:
+    """Condense -Rpass-analysis=kernel-resource-usage remarks into one line per kernel."""
+    import re
+    cur = None
+    rows = {}
+    for line in text.splitlines():
+        m = re.search(r'remark: +(Function Name|VGPRs|AGPRs|ScratchSize \[bytes/lane\]|Occupancy \[waves/SIMD\]|'
+                      r'VGPRs Spill|LDS Size \[bytes/block\]|SGPRs): (\S+)', line)
+        if not m:
+            if 'warning' in line or 'error' in line:
+                print(line)
+            continue
+        k, v = m.group(1), m.group(2)
+        if k == 'Function Name':
+            cur = v
+            rows[cur] = {}
+        elif cur:
+            rows[cur][k.split(' ')[0] + ('Spill' if 'Spill' in k else '')] = v
+    for name, r in rows.items():
+        try:
+            name = subprocess.run(['c++filt', name], capture_output=True, text=True).stdout.strip()[:90]
+        except Exception:
+            pass
+        print(f"  {name:<90} vgpr {r.get('VGPRs','?'):>3} agpr {r.get('AGPRs','?'):>3} sgpr {r.get('SGPRs','?'):>3} "
+              f"spill {r.get('VGPRsSpill','?'):>3} scratch {r.get('ScratchSize','?'):>4} occ {r.get('Occupancy','?')} "
+              f"lds {r.get('LDS','?')}")
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    if not force and not _stale():
+        return LIB
+    hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+    objs = []
+    procs = []
+    os.makedirs(os.path.join(HERE, 'build'), exist_ok=True)
+    for s in SOURCES:
+        o = os.path.join(HERE, 'build', s.replace('.hip', '.o'))
+        cmd = [hipcc, *FLAGS, '-c', os.path.join(CSRC, s), '-o', o]
+        if verbose:
+            cmd.insert(1, '-Rpass-analysis=kernel-resource-usage')
+            print(' '.join(cmd), flush=True)
+        procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+        objs.append(o)
+    for s, p in procs:
+        out, _ = p.communicate()
+        if p.returncode:
+            print(out)
+        elif verbose:
+            _resource_table(out)
+        if p.returncode:
+            raise RuntimeError(f'hipcc failed on {s}')
+    cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', *objs, '-o', LIB]
+    subprocess.run(cmd, check=True)
+    return LIB
+
+
+if __name__ == '__main__':
+    print(build(force='--force' in sys.argv, verbose='--verbose' in sys.argv))

@@ -1,0 +1,535 @@
+// VGG16-U-Net feature extractor on gfx950 matrix cores: VGG.py:13-203, L2_norm VGG.py:511-514.
+//
+// Layout: activations NHWC; T = bf16 (perf mode, fp32 accumulate) or float (exact-fp32 MFMA, parity mode).
+//
+// conv3x3_kernel -- implicit GEMM, D^T = W * X^T so that a lane owns one output pixel and 4 consecutive
+//   output channels per accumulator quad:
+//     M (MFMA rows)  = 32 output channels        (A operand = weight fragment, straight from global/L2,
+//                                                 pre-packed in fragment order: one coalesced 1 KiB load)
+//     N (MFMA cols)  = 32 consecutive pixels of one image row (B operand = pixel fragment from the LDS halo tile)
+//     K              = 9 taps x Cin, walked as  chunk(128 B of channels) -> tap -> 4 k-groups of 16 B
+//   The (TH+2)x34 input halo tile of one channel chunk is staged once in LDS (144-B pixel stride: conflict-free
+//   ds_read_b128) and reused by all 9 taps; the next chunk is prefetched into registers during the MFMAs.
+//   Loader handles "virtual concat + nearest 2x upsample" (VGG.py:144-151) without materialising it.
+//   Epilogue fuses bias, 2x2 max-pool, ReLU, the raw fp32 feature copy and its per-sample sum of squares.
+#include "common.h"
+
+typedef __bf16 bf16;
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+
+template <typename T> __device__ __forceinline__ void mma16(f32x16& acc, const uint4& w, const uint4& p);
+template <> __device__ __forceinline__ void mma16<bf16>(f32x16& acc, const uint4& w, const uint4& p) {
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w), __builtin_bit_cast(bf16x8, p), acc, 0, 0, 0);
+}
+template <> __device__ __forceinline__ void mma16<float>(f32x16& acc, const uint4& w, const uint4& p) {
+  // element t of both fragments: channels {8q+t (lanes 0-31), 8q+4+t (lanes 32-63)}
+  acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(w.x), __uint_as_float(p.x), acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(w.y), __uint_as_float(p.y), acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(w.z), __uint_as_float(p.z), acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(w.w), __uint_as_float(p.w), acc, 0, 0, 0);
+}
+
+__device__ __forceinline__ void store4(bf16* p, float a, float b, float c, float d) {
+  const bf16 h[4] = {(bf16)a, (bf16)b, (bf16)c, (bf16)d};
+  *(uint2*)p = __builtin_bit_cast(uint2, h);
+}
+__device__ __forceinline__ void store4(float* p, float a, float b, float c, float d) {
+  *(float4*)p = make_float4(a, b, c, d);
+}
+__device__ __forceinline__ float to_f32(bf16 v) { return (float)v; }
+__device__ __forceinline__ float to_f32(float v) { return v; }
+
+struct ConvArgs {
+  const void* src1;   // NHWC T, C1 channels; at half resolution when up1
+  const void* src2;   // NHWC T, C2 channels (virtual concat after src1), or null
+  const uint4* wpk;   // fragment-packed weights
+  const float* bias;  // [Cout] or null
+  void* out_act;      // NHWC T [B,Ho,Wo,Cout] (post-ReLU when relu_act) or null
+  float* out_raw;     // NHWC fp32 (pre-ReLU) or null
+  double* sumsq;      // [B, tiles_per_img * gridDim.y] sum of squares of out_raw, or null
+  int C1, C2, up1;
+  int B, H, W, Cout;
+  int relu_act;
+  int tiles_x, tiles_y;
+};
+
+constexpr int HWID = 34;   // halo tile width in pixels
+constexpr int SB = 64;     // bytes of channels per pixel per pipeline stage
+constexpr int PSTR = 80;   // LDS bytes per halo pixel (64 B of channels + 16 B pad: conflict-free ds_read_b128)
+
+// shared epilogue: acc[i][j] holds, for lane (x = lane&31, g = lane>>5), output channels
+// cb + j*32 + 8q + 4g + {0..3} (q = r>>2) of pixel (row i, column x).
+template <typename T, int MT, int NT, bool POOL>
+__device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[MT][NT], const ConvArgs& a, int b, int yrow0, int x0,
+                                              int cb, float* red) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, x = lane & 31, g = lane >> 5;
+  const int Ho = POOL ? a.H >> 1 : a.H, Wo = POOL ? a.W >> 1 : a.W;
+  float ss = 0.f;
+#pragma unroll
+  for (int i = 0; i < MT; i += (POOL ? 2 : 1)) {
+    const int y = yrow0 + i, xg = x0 + x;
+    const bool ok = (y < a.H) && (xg < a.W) && (!POOL || !(x & 1));
+    const int yo = POOL ? y >> 1 : y, xo = POOL ? xg >> 1 : xg;
+    const size_t pix = ((size_t)b * Ho + yo) * Wo + xo;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float t = acc[i][j][q * 4 + e];
+          if (POOL) {
+            t = fmaxf(t, acc[i + 1][j][q * 4 + e]);
+            t = fmaxf(t, __shfl_xor(t, 1, 64));
+          }
+          v[e] = t;
+        }
+        const int co = cb + j * 32 + q * 8 + g * 4;
+        if (a.bias) {
+          const float4 bb = *(const float4*)(a.bias + co);
+          v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
+        }
+        if (ok) {
+          if (a.out_raw) {
+            *(float4*)(a.out_raw + pix * a.Cout + co) = make_float4(v[0], v[1], v[2], v[3]);
+            ss += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+          }
+          if (a.out_act) {
+            if (a.relu_act) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+            store4((T*)a.out_act + pix * a.Cout + co, v[0], v[1], v[2], v[3]);
+          }
+        }
+      }
+    }
+  }
+  if (a.sumsq) {
+    ss = wave_sum_f32(ss);
+    if (lane == 0) red[wv] = ss;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const int np = a.tiles_x * a.tiles_y * gridDim.y;
+      const int tile = (blockIdx.x % (a.tiles_x * a.tiles_y)) * gridDim.y + blockIdx.y;
+      a.sumsq[(size_t)b * np + tile] = ((double)red[0] + (double)red[1]) + ((double)red[2] + (double)red[3]);
+    }
+  }
+}
+
+template <typename T, int MT, int NT, int WM, int WN, bool POOL>
+__global__ __launch_bounds__(256, 2) void conv3x3_kernel(ConvArgs a) {
+  static_assert(WM * WN == 4, "4 waves per block");
+  constexpr int EPL = 16 / sizeof(T), KC = SB / sizeof(T);     // channels per stage: 32 (bf16) / 16 (fp32)
+  constexpr int TH = WM * MT, HPIX = (TH + 2) * HWID, BUF = HPIX * PSTR;
+  constexpr int NPIECE = (HPIX * 4 + 255) / 256;               // 16-B pieces per thread per stage
+  __shared__ __attribute__((aligned(16))) char lds[2 * BUF];
+  __shared__ float red[4];
+
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6, wm = wv / WN, wn = wv % WN;
+  int bid = blockIdx.x;
+  const int tx = bid % a.tiles_x; bid /= a.tiles_x;
+  const int ty = bid % a.tiles_y;
+  const int b = bid / a.tiles_y;
+  const int y0 = ty * TH, x0 = tx * 32;
+  const int nstage = (a.C1 + a.C2) / KC;
+  const int part = t & 3, pbase = t >> 2;   // 256 % 4 == 0: a thread always moves the same 16-B part of a pixel
+
+  auto load_stage = [&](int sg, uint4 (&st)[NPIECE]) {
+    const int c0 = sg * KC;
+    const bool first = c0 < a.C1;       // wave-uniform
+    const T* src = first ? (const T*)a.src1 : (const T*)a.src2;
+    const int Cs = first ? a.C1 : a.C2;
+    const int coff = (first ? c0 : c0 - a.C1) + part * EPL;
+    const int sh = (first && a.up1) ? 1 : 0;
+    const int Hs = a.H >> sh, Ws = a.W >> sh;
+#pragma unroll
+    for (int i = 0; i < NPIECE; ++i) {
+      const int pix = pbase + 64 * i;
+      const int hy = pix / HWID, hx = pix - hy * HWID;
+      const int y = y0 - 1 + hy, x = x0 - 1 + hx;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (pix < HPIX && y >= 0 && y < a.H && x >= 0 && x < a.W)
+        v = *(const uint4*)(src + (((size_t)b * Hs + (y >> sh)) * Ws + (x >> sh)) * Cs + coff);
+      st[i] = v;
+    }
+  };
+  auto write_stage = [&](char* buf, const uint4 (&st)[NPIECE]) {
+#pragma unroll
+    for (int i = 0; i < NPIECE; ++i) {
+      const int pix = pbase + 64 * i;
+      if (pix < HPIX) *(uint4*)(buf + pix * PSTR + part * 16) = st[i];
+    }
+  };
+
+  f32x16 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int x = lane & 31, g = lane >> 5;
+  const int aoff = ((wm * MT) * HWID + x) * PSTR + g * 16;
+  const int ntg0 = (blockIdx.y * WN + wn) * NT;     // first global 32-channel output tile of this wave
+  // packed weights: [ntile][stage][tap][kg(2)][lane] 16-B fragments
+  const uint4* wq[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) wq[j] = a.wpk + (size_t)(ntg0 + j) * nstage * 18 * 64 + lane;
+
+  uint4 st[NPIECE];
+  load_stage(0, st);
+  write_stage(lds, st);
+  __syncthreads();
+  uint4 wnext[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) wnext[j] = wq[j][0];
+
+  for (int sg = 0; sg < nstage; ++sg) {
+    const char* cur = lds + (sg & 1) * BUF + aoff;
+    if (sg + 1 < nstage) load_stage(sg + 1, st);     // in flight during the MFMAs below
+#pragma unroll 1
+    for (int ky = 0; ky < 3; ++ky) {
+#pragma unroll 1
+      for (int kx = 0; kx < 3; ++kx) {
+        const char* ap = cur + (ky * HWID + kx) * PSTR;
+#pragma unroll
+        for (int kg = 0; kg < 2; ++kg) {
+          uint4 wcur[NT];
+#pragma unroll
+          for (int j = 0; j < NT; ++j) { wcur[j] = wnext[j]; wq[j] += 64; wnext[j] = wq[j][0]; }
+          uint4 pf[MT];
+#pragma unroll
+          for (int i = 0; i < MT; ++i) pf[i] = *(const uint4*)(ap + i * HWID * PSTR + kg * 32);
+#pragma unroll
+          for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) mma16<T>(acc[i][j], wcur[j], pf[i]);
+        }
+      }
+    }
+    if (sg + 1 < nstage) write_stage(lds + ((sg + 1) & 1) * BUF, st);
+    __syncthreads();
+  }
+  conv_epilogue<T, MT, NT, POOL>(acc, a, b, y0 + wm * MT, x0, ntg0 * 32, red);
+}
+
+// ---------------------------------------------------------------------------------------------
+// conv0: 3 -> 64 on the NCHW fp32 network input (VGG.py:123-124), K = 27 padded to 32.
+struct Conv0Args {
+  const float* x;     // [B,3,H,W]
+  const uint4* wpk;   // [2 ntiles][NFRAG][64 lanes] fragments, k = cin*9 + tap
+  const float* bias;  // [64]
+  void* out_act;      // NHWC T [B,H,W,64], post-ReLU
+  int B, H, W, tiles_x, tiles_y;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void conv0_kernel(Conv0Args a0) {
+  constexpr int EPL = 16 / sizeof(T), NFRAG = 32 / (2 * EPL);
+  constexpr int TH = 8, MT = 2, NT = 2, LW = 36;
+  __shared__ float in[3][TH + 2][LW];
+  __shared__ float red[4];
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  int bid = blockIdx.x;
+  const int tx = bid % a0.tiles_x; bid /= a0.tiles_x;
+  const int ty = bid % a0.tiles_y;
+  const int b = bid / a0.tiles_y;
+  const int y0 = ty * TH, x0 = tx * 32;
+  for (int e = t; e < 3 * (TH + 2) * HWID; e += 256) {
+    const int c = e / ((TH + 2) * HWID), r = e % ((TH + 2) * HWID), hy = r / HWID, hx = r % HWID;
+    const int y = y0 - 1 + hy, x = x0 - 1 + hx;
+    float v = 0.f;
+    if (y >= 0 && y < a0.H && x >= 0 && x < a0.W) v = a0.x[(((size_t)b * 3 + c) * a0.H + y) * a0.W + x];
+    in[c][hy][hx] = v;
+  }
+  __syncthreads();
+  const int x = lane & 31, g = lane >> 5;
+  f32x16 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+#pragma unroll
+  for (int f = 0; f < NFRAG; ++f) {
+    uint4 wf[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) wf[j] = a0.wpk[(j * NFRAG + f) * 64 + lane];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      T e[EPL];
+#pragma unroll
+      for (int jj = 0; jj < EPL; ++jj) {
+        const int klo = f * 2 * EPL + jj, khi = klo + EPL;   // compile-time
+        float lo = 0.f, hi = 0.f;
+        if (klo < 27) lo = in[klo / 9][wv * MT + i + (klo % 9) / 3][x + (klo % 9) % 3];
+        if (khi < 27) hi = in[khi / 9][wv * MT + i + (khi % 9) / 3][x + (khi % 9) % 3];
+        e[jj] = (T)(g ? hi : lo);
+      }
+      const uint4 pf = __builtin_bit_cast(uint4, e);
+#pragma unroll
+      for (int j = 0; j < NT; ++j) mma16<T>(acc[i][j], wf[j], pf);
+    }
+  }
+  ConvArgs a{};
+  a.bias = a0.bias; a.out_act = a0.out_act; a.B = a0.B; a.H = a0.H; a.W = a0.W; a.Cout = 64; a.relu_act = 1;
+  a.tiles_x = a0.tiles_x; a.tiles_y = a0.tiles_y;
+  conv_epilogue<T, MT, NT, false>(acc, a, b, y0 + wv * MT, x0, 0, red);
+}
+
+// ---------------------------------------------------------------------------------------------
+// weight packing: OIHW fp32 -> MFMA fragment order, T elements.
+//   generic: idx = ((((nt*nstage + sg)*9 + tap)*2 + kg)*64 + lane)*EPL + j
+//            cout = nt*32 + (lane&31), cin = sg*KC + kg*2*EPL + (lane>>5)*EPL + j      (KC = 64 B of channels)
+//   conv0:   idx = ((nt*NFRAG + f)*64 + lane)*EPL + j,  k = f*2*EPL + (lane>>5)*EPL + j  (k = cin*9+tap, <27)
+//   The tail of every layer's buffer is padded by one fragment row (the kernel prefetches one step ahead).
+template <typename T>
+__global__ void pack_weights_kernel(const float* __restrict__ w, T* __restrict__ out, int Cout, int Cin, int first) {
+  constexpr int EPL = 16 / sizeof(T), KC = SB / sizeof(T), NFRAG = 32 / (2 * EPL);
+  const size_t total = first ? (size_t)(Cout / 32) * NFRAG * 64 * EPL : (size_t)Cout * Cin * 9;
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+    size_t r = e;
+    const int j = r % EPL; r /= EPL;
+    const int lane = r % 64; r /= 64;
+    float v = 0.f;
+    if (first) {
+      const int f = r % NFRAG; r /= NFRAG;
+      const int nt = (int)r;
+      const int k = f * 2 * EPL + (lane >> 5) * EPL + j, cout = nt * 32 + (lane & 31);
+      if (k < 27) v = w[(size_t)cout * 27 + k];
+    } else {
+      const int kg = r % 2; r /= 2;
+      const int tap = r % 9; r /= 9;
+      const int nsg = Cin / KC;
+      const int sg = r % nsg; r /= nsg;
+      const int nt = (int)r;
+      const int cout = nt * 32 + (lane & 31), cin = sg * KC + kg * 2 * EPL + (lane >> 5) * EPL + j;
+      v = w[((size_t)cout * Cin + cin) * 9 + tap];
+    }
+    out[e] = (T)v;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// confidence head: sigmoid(-sigmoid(conv3x3(relu(x), C->1)))  VGG.py:62-81,160-163.  `act` is already ReLU'd.
+template <typename T>
+__global__ __launch_bounds__(256) void conf_kernel(const T* __restrict__ act, const float* __restrict__ w,
+                                                   float* __restrict__ out, int B, int H, int W, int C) {
+  constexpr int EPL = 16 / sizeof(T);
+  extern __shared__ float ws[];   // [9][C]
+  for (int e = threadIdx.x; e < 9 * C; e += 256) ws[(e % 9) * C + e / 9] = w[e];   // OIHW (O=1): w[c*9+tap]
+  __syncthreads();
+  const int G = C / EPL;                     // threads per pixel (8 channels bf16 / 4 fp32 each), power of 2 <= 64
+  const int ppb = 256 / G;
+  const size_t npix = (size_t)B * H * W;
+  const int gi = threadIdx.x % G;
+  for (size_t pix = (size_t)blockIdx.x * ppb + threadIdx.x / G; pix < (npix + ppb - 1) / ppb * ppb;
+       pix += (size_t)gridDim.x * ppb) {
+    float s = 0.f;
+    const bool live = pix < npix;
+    if (live) {
+      const int x = (int)(pix % W), y = (int)((pix / W) % H);
+      const size_t b = pix / ((size_t)W * H);
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        const int yy = y + tap / 3 - 1, xx = x + tap % 3 - 1;
+        if (yy < 0 || yy >= H || xx < 0 || xx >= W) continue;
+        const uint4 raw = *(const uint4*)(act + ((b * H + yy) * W + xx) * C + gi * EPL);
+        T e[EPL];
+        __builtin_memcpy(e, &raw, 16);
+#pragma unroll
+        for (int k = 0; k < EPL; ++k) s += to_f32(e[k]) * ws[tap * C + gi * EPL + k];
+      }
+    }
+    for (int o = G >> 1; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if (live && gi == 0) {
+      const float sg = 1.f / (1.f + __expf(-s));
+      out[pix] = 1.f / (1.f + __expf(sg));
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// L2_norm (VGG.py:511-514): x / max(||x||, 1e-12) per sample, in place on the raw fp32 map.
+__global__ __launch_bounds__(256) void l2norm_kernel(float* __restrict__ x, const double* __restrict__ sumsq, int np,
+                                                     size_t per_sample, int blocks_per_sample) {
+  __shared__ double sh[4];
+  const int b = blockIdx.x / blocks_per_sample, k = blockIdx.x % blocks_per_sample;
+  double s = 0.0;
+  for (int i = threadIdx.x; i < np; i += 256) s += sumsq[(size_t)b * np + i];
+  s = wave_sum_f64(s);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+  __syncthreads();
+  const double tot = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+  const double scale = 1.0 / fmax(sqrt(tot), 1e-12);
+  float4* p = (float4*)(x + (size_t)b * per_sample);
+  const size_t n4 = per_sample / 4;
+  for (size_t i = (size_t)k * 256 + threadIdx.x; i < n4; i += (size_t)blocks_per_sample * 256) {
+    float4 v = p[i];
+    v.x = (float)((double)v.x * scale); v.y = (float)((double)v.y * scale);
+    v.z = (float)((double)v.z * scale); v.w = (float)((double)v.w * scale);
+    p[i] = v;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// host side
+struct LayerDef { int cin, cout, has_bias; };
+static const LayerDef kLayers[13] = {
+    {3, 64, 1}, {64, 64, 1}, {64, 128, 1}, {128, 128, 1}, {128, 256, 1}, {256, 256, 1}, {256, 256, 1},
+    {384, 128, 0}, {128, 128, 0}, {192, 64, 0}, {64, 64, 0}, {128, 32, 0}, {32, 16, 0}};
+
+struct VggPlan {
+  size_t wpk[13];
+  size_t a0, x3, a5, x8, a10, a12, x15r, d1a, x18r, d2a, x21r;
+  size_t ss[3];
+  int np[3];
+  size_t total;
+};
+
+static size_t packed_bytes(int l, int dtype) {
+  const size_t es = dtype == HLA_BF16 ? 2 : 4;
+  if (l == 0) return (size_t)2 * 32 * 32 * es;   // 2 ntiles x 32 (padded K) x 32 couts
+  return (size_t)kLayers[l].cin * kLayers[l].cout * 9 * es + 1024;   // + one fragment row: prefetch overrun
+}
+
+static void vgg_plan(int B, int H, int W, int dtype, VggPlan* p) {
+  const size_t es = dtype == HLA_BF16 ? 2 : 4;
+  size_t o = 0;
+  auto take = [&](size_t bytes) { size_t r = o; o += hla_align_up(bytes, 256); return r; };
+  for (int l = 0; l < 11; ++l) p->wpk[l] = take(packed_bytes(l, dtype));
+  p->wpk[11] = p->wpk[12] = 0;
+  const size_t P = (size_t)B * H * W;
+  p->a0 = take(P * 64 * es);
+  p->x3 = take(P / 4 * 64 * es);
+  p->a5 = take(P / 4 * 128 * es);
+  p->x8 = take(P / 16 * 128 * es);
+  p->a10 = take(P / 16 * 256 * es);
+  p->a12 = take(P / 16 * 256 * es);
+  p->x15r = take(P / 64 * 256 * es);
+  p->d1a = take(P / 16 * 128 * es);
+  p->x18r = take(P / 16 * 128 * es);
+  p->d2a = take(P / 4 * 64 * es);
+  p->x21r = take(P / 4 * 64 * es);
+  // sum-of-squares partials: one per (image tile, cout block) of the producing layer
+  auto tiles = [](int h, int w) { return ((h + 7) / 8) * ((w + 31) / 32); };
+  p->np[0] = tiles(H / 4, W / 4) * 2;   // conv14: Cout 256 in blocks of 128
+  p->np[1] = tiles(H / 4, W / 4) * 1;   // dec1.3: Cout 128
+  p->np[2] = tiles(H / 2, W / 2) * 1;   // dec2.3: Cout 64
+  for (int i = 0; i < 3; ++i) p->ss[i] = take((size_t)B * p->np[i] * sizeof(double));
+  p->total = o;
+}
+
+extern "C" size_t hla_vgg_workspace_bytes(int B, int H, int W, int level, int dtype) {
+  (void)level;
+  VggPlan p;
+  vgg_plan(B, H, W, dtype, &p);
+  return p.total;
+}
+
+template <typename T>
+static void launch_conv(hipStream_t st, ConvArgs a, bool pool) {
+  a.tiles_x = (a.W + 31) / 32;
+  a.tiles_y = (a.H + 7) / 8;
+  const dim3 grid(a.tiles_x * a.tiles_y * a.B, a.Cout >= 128 ? a.Cout / 128 : 1);
+  if (a.Cout >= 128) {
+    if (pool) hipLaunchKernelGGL((conv3x3_kernel<T, 4, 2, 2, 2, true>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((conv3x3_kernel<T, 4, 2, 2, 2, false>), grid, dim3(256), 0, st, a);
+  } else {
+    if (pool) hipLaunchKernelGGL((conv3x3_kernel<T, 4, 1, 2, 2, true>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((conv3x3_kernel<T, 4, 1, 2, 2, false>), grid, dim3(256), 0, st, a);
+  }
+}
+
+template <typename T>
+static int vgg_forward_t(const float* x, const hla_vgg_params* prm, float* const feat[4], float* const conf[4],
+                         char* ws, const VggPlan& pl, int B, int H, int W, int flags, hipStream_t st) {
+  // 1. pack weights (parameters may have changed since the last call: training)
+  for (int l = 0; l < 11; ++l) {
+    const size_t n = l == 0 ? (size_t)2 * 32 * 32 : (size_t)kLayers[l].cin * kLayers[l].cout * 9;
+    const int grid = (int)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024);
+    hipLaunchKernelGGL((pack_weights_kernel<T>), dim3(grid), dim3(256), 0, st, prm->w[l], (T*)(ws + pl.wpk[l]),
+                       kLayers[l].cout, kLayers[l].cin, l == 0 ? 1 : 0);
+  }
+  auto W_ = [&](int l) { return (const uint4*)(ws + pl.wpk[l]); };
+  // 2. conv0
+  {
+    Conv0Args a{};
+    a.x = x; a.wpk = W_(0); a.bias = prm->b[0]; a.out_act = ws + pl.a0; a.B = B; a.H = H; a.W = W;
+    a.tiles_x = (W + 31) / 32; a.tiles_y = (H + 7) / 8;
+    hipLaunchKernelGGL((conv0_kernel<T>), dim3(a.tiles_x * a.tiles_y * B), dim3(256), 0, st, a);
+  }
+  auto conv = [&](int l, const void* s1, int C1, int H_, int W_h, void* act, int relu, bool pool, const void* s2 = nullptr,
+                  int C2 = 0, int up1 = 0, float* raw = nullptr, double* ss = nullptr) {
+    ConvArgs a{};
+    a.src1 = s1; a.src2 = s2; a.C1 = C1; a.C2 = C2; a.up1 = up1; a.wpk = W_(l);
+    a.bias = kLayers[l].has_bias ? prm->b[l] : nullptr;
+    a.out_act = act; a.out_raw = raw; a.sumsq = ss; a.B = B; a.H = H_; a.W = W_h; a.Cout = kLayers[l].cout;
+    a.relu_act = relu;
+    launch_conv<T>(st, a, pool);
+  };
+  char* w = ws;
+  // encoder (VGG.py:123-141).  ReLU commutes with max-pool, so pooled maps are stored post-ReLU.
+  conv(1, w + pl.a0, 64, H, W, w + pl.x3, 1, true);                                   // conv2 + pool -> relu(x3)
+  conv(2, w + pl.x3, 64, H / 2, W / 2, w + pl.a5, 1, false);                          // conv5
+  conv(3, w + pl.a5, 128, H / 2, W / 2, w + pl.x8, 1, true);                          // conv7 + pool -> relu(x8)
+  conv(4, w + pl.x8, 128, H / 4, W / 4, w + pl.a10, 1, false);                        // conv10
+  conv(5, w + pl.a10, 256, H / 4, W / 4, w + pl.a12, 1, false);                       // conv12
+  conv(6, w + pl.a12, 256, H / 4, W / 4, w + pl.x15r, 1, true, nullptr, 0, 0, feat[0],
+       (double*)(w + pl.ss[0]));                                                      // conv14 + pool -> x15
+  // decoder (VGG.py:144-151): conv(relu(cat(up(a), skip))) with both inputs stored post-ReLU
+  conv(7, w + pl.x15r, 256, H / 4, W / 4, w + pl.d1a, 1, false, w + pl.x8, 128, 1);   // dec1.1
+  conv(8, w + pl.d1a, 128, H / 4, W / 4, w + pl.x18r, 1, false, nullptr, 0, 0, feat[1],
+       (double*)(w + pl.ss[1]));                                                      // dec1.3 -> x18
+  conv(9, w + pl.x18r, 128, H / 2, W / 2, w + pl.d2a, 1, false, w + pl.x3, 64, 1);    // dec2.1
+  conv(10, w + pl.d2a, 64, H / 2, W / 2, w + pl.x21r, 1, false, nullptr, 0, 0, feat[2],
+       (double*)(w + pl.ss[2]));                                                      // dec2.3 -> x21
+  // confidence heads on the ReLU'd maps
+  if ((flags & HLA_VGG_WANT_CONF) && conf) {
+    const T* acts[3] = {(const T*)(w + pl.x15r), (const T*)(w + pl.x18r), (const T*)(w + pl.x21r)};
+    const int Cs[3] = {256, 128, 64}, hs[3] = {H / 8, H / 4, H / 2}, wsz[3] = {W / 8, W / 4, W / 2};
+    for (int l = 0; l < 3; ++l) {
+      if (!conf[l]) continue;
+      constexpr int EPL = 16 / sizeof(T);
+      const int ppb = 256 / (Cs[l] / EPL);
+      const size_t npix = (size_t)B * hs[l] * wsz[l];
+      const int grid = (int)((npix + ppb - 1) / ppb < 4096 ? (npix + ppb - 1) / ppb : 4096);
+      hipLaunchKernelGGL((conf_kernel<T>), dim3(grid), dim3(256), 9 * Cs[l] * sizeof(float), st, acts[l],
+                         prm->w[13 + l], conf[l], B, hs[l], wsz[l], Cs[l]);
+    }
+  }
+  // L2 normalisation of the three returned maps, in place
+  {
+    const size_t per[3] = {(size_t)(H / 8) * (W / 8) * 256, (size_t)(H / 4) * (W / 4) * 128, (size_t)(H / 2) * (W / 2) * 64};
+    for (int l = 0; l < 3; ++l) {
+      if (!feat[l]) continue;
+      int bps = (int)(per[l] / 4 / 256 / 4);
+      bps = bps < 1 ? 1 : (bps > 64 ? 64 : bps);
+      hipLaunchKernelGGL(l2norm_kernel, dim3(B * bps), dim3(256), 0, st, feat[l], (const double*)(w + pl.ss[l]),
+                         pl.np[l], per[l], bps);
+    }
+  }
+  HLA_CHECK_HIP(hipGetLastError());
+  return HLA_OK;
+}
+
+extern "C" int hla_vgg_forward(const float* x, const hla_vgg_params* params, float* const feat[4],
+                               float* const conf[4], void* workspace, size_t workspace_bytes, int B, int H, int W,
+                               int level, int dtype, int flags, hla_stream_t stream) {
+  HLA_REQUIRE(x && params && feat && workspace, "hla_vgg_forward: null argument");
+  HLA_REQUIRE(dtype == HLA_F32 || dtype == HLA_BF16, "hla_vgg_forward: dtype must be HLA_F32 or HLA_BF16");
+  HLA_REQUIRE(B > 0 && H >= 8 && W >= 8 && H % 8 == 0 && W % 8 == 0, "hla_vgg_forward: H and W must be multiples of 8");
+  HLA_REQUIRE(level == 3, "hla_vgg_forward: only level 3 (x15,x18,x21) is built so far (got %d)", level);
+  HLA_REQUIRE(feat[0] && feat[1] && feat[2], "hla_vgg_forward: level 3 needs feat[0..2]");
+  VggPlan pl;
+  vgg_plan(B, H, W, dtype, &pl);
+  if (workspace_bytes < pl.total) {
+    hla_set_error("hla_vgg_forward: workspace %zu < %zu", workspace_bytes, pl.total);
+    return HLA_ERR_WORKSPACE;
+  }
+  if (dtype == HLA_BF16)
+    return vgg_forward_t<bf16>(x, params, feat, conf, (char*)workspace, pl, B, H, W, flags, (hipStream_t)stream);
+  return vgg_forward_t<float>(x, params, feat, conf, (char*)workspace, pl, B, H, W, flags, (hipStream_t)stream);
+}

@@ -1,0 +1,129 @@
+/* hla.h -- C ABI of libhla.so: the MI355X (gfx950) implementation of the
+ * HighlyAccurate per-pair localisation hot path.
+ *
+ * This is the drop-in boundary.  The reference is pure Python on PyTorch, so the
+ * "FFI" a maintainer binds is ctypes; every entry point below
+ * names the reference function it replaces (file:line under /root/reference).
+ *
+ * Conventions
+ *   - plain pointers + sizes only; all pointers are DEVICE pointers unless marked [host]
+ *   - the caller allocates every buffer (PyTorch's caching allocator in practice);
+ *     the library never allocates or frees device memory and keeps no global state
+ *     except a thread-local last-error string
+ *   - all work is enqueued on the given hipStream_t (passed as void*); no implicit
+ *     synchronisation, no host<->device copies except the small [host] structs
+ *     passed by value
+ *   - return 0 on success, negative hla_status on error; hla_last_error() explains
+ *   - activations are NHWC ("channels last"): element (b,y,x,c) at ((b*H+y)*W+x)*C+c
+ */
+#ifndef HLA_H
+#define HLA_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* hla_stream_t; /* hipStream_t */
+
+typedef enum hla_status {
+  HLA_OK = 0,
+  HLA_ERR_ARG = -1,       /* bad argument / unsupported shape */
+  HLA_ERR_HIP = -2,       /* a HIP runtime call failed */
+  HLA_ERR_WORKSPACE = -3  /* workspace too small */
+} hla_status;
+
+typedef enum hla_dtype {
+  HLA_F32 = 0,  /* exact-fp32 MFMA (v_mfma_f32_32x32x2_f32): the parity mode      */
+  HLA_BF16 = 1  /* bf16 MFMA (v_mfma_f32_32x32x16_bf16), fp32 accumulate: perf mode */
+} hla_dtype;
+
+const char* hla_last_error(void);
+int hla_abi_version(void);
+
+/* ------------------------------------------------------------------------- *
+ * VGGUnet.forward  (VGG.py:121-203; L2_norm VGG.py:511-514)
+ * ------------------------------------------------------------------------- */
+
+/* Device pointers to the 17 weight and 7 bias tensors exactly as PyTorch holds
+ * them (OIHW fp32, contiguous), in state-dict order:
+ *   w[0..6]  conv0,conv2,conv5,conv7,conv10,conv12,conv14   (b[0..6] their biases)
+ *   w[7..12] conv_dec1.1, conv_dec1.3, conv_dec2.1, conv_dec2.3, conv_dec3.1, conv_dec3.3
+ *   w[13..16] conf0.1, conf1.1, conf2.1, conf3.1                                    */
+typedef struct hla_vgg_params {
+  const float* w[17];
+  const float* b[7];
+} hla_vgg_params;
+
+enum {
+  HLA_VGG_WANT_CONF = 1,   /* compute the confidence maps (VGG.py:160-163)            */
+  HLA_VGG_KEEP_RAW = 2     /* also keep un-normalised maps in feat_raw (for backward) */
+};
+
+/* Bytes of scratch hla_vgg_forward needs for this shape. */
+size_t hla_vgg_workspace_bytes(int B, int H, int W, int level, int dtype);
+
+/* x        [B,3,H,W] NCHW fp32 (what the reference's DataLoader hands over)
+ * feat[l]  [B,H/2^(3-l),W/2^(3-l),C_l] NHWC fp32, L2-normalised per sample; C = 256,128,64,16
+ *          for l = 0..3 (x15,x18,x21,x24).  Entries the `level` does not return may be NULL.
+ * conf[l]  [B,h_l,w_l] fp32 = sigmoid(-sigmoid(conv(relu(.)))), or NULL
+ * level    the reference's VGGUnet(level): 3 -> maps 0..2, 4 -> maps 0..3 (the dead dec3/conf3
+ *          work at level 3, VGG.py:153-155,163, is skipped)                                   */
+int hla_vgg_forward(const float* x, const hla_vgg_params* params, float* const feat[4], float* const conf[4],
+                    void* workspace, size_t workspace_bytes, int B, int H, int W, int level, int dtype,
+                    int flags, hla_stream_t stream);
+
+/* ------------------------------------------------------------------------- *
+ * jacobian.grid_sample  (jacobian.py:138-205) -- the stand-alone operator
+ * ------------------------------------------------------------------------- */
+/* image   [N,IH,IW,C] NHWC fp32;  optical [N,H,W,2] pixel coords (x,y)
+ * jac     [M,N,H,W,2] or NULL;    out [N,H,W,C] NHWC;  jac_out [M,N,H,W,C] NHWC or NULL */
+int hla_grid_sample(const float* image, const float* optical, const float* jac, float* out, float* jac_out,
+                    int N, int C, int IH, int IW, int H, int W, int M, hla_stream_t stream);
+
+/* ------------------------------------------------------------------------- *
+ * The LM pose loop: project_map_to_grd + LM_update, N_iters x levels steps
+ *   KITTI  models_kitti.py:700-1041, loop 1176-1283 (level-first 1352-1459)
+ *   Ford   models_ford.py:173-466,  loop 682-835
+ * ------------------------------------------------------------------------- */
+typedef struct hla_s2g_level {
+  const float* sat_feat; /* [B,A,A,C]  NHWC fp32 */
+  const float* grd_feat; /* [B,h,w,C]  NHWC fp32 */
+  const float* grd_conf; /* [B,h,w] fp32 or NULL (needed iff using_weight) */
+  const float* xyz;      /* [h,w,3] fp32 ground-plane points in the camera frame
+                            (models_kitti.py:655-682 / models_ford.py:110-155) */
+  int A, h, w, C;
+  int row0;              /* first ground-image row that takes part (h/2 for proj=='geo') */
+  double meter_per_pixel;/* metres per satellite-feature pixel at this level */
+  double centre;         /* A/2 (KITTI, float) or A//2 (Ford, integer) */
+} hla_s2g_level;
+
+typedef struct hla_s2g_config {
+  int ford;               /* 0: KITTI camera chain, 1: Ford cam->body->world chain */
+  int n_levels, n_iters;
+  int level_first;        /* 0: iter-outer/level-inner, 1: level-outer/iter-inner */
+  int using_weight;       /* weight = grd_conf (models_kitti.py:994-996) */
+  int use_hessian;        /* damping * diag(H) instead of damping * I */
+  int dof;                /* 3: (u,v,theta); 2: rotation_range==0; 1: shift ranges == 0 (KITTI only) */
+  double shift_range_lat, shift_range_lon, rotation_range; /* metres, metres, degrees */
+  double damping[3];      /* lambda per pose component (already 10^(-6+11*sigmoid) if trained) */
+} hla_s2g_config;
+
+size_t hla_s2g_workspace_bytes(const hla_s2g_config* cfg, const hla_s2g_level* levels, int B);
+
+/* R_FL [B,3,3], T_FL [B,3] fp32 (Ford only, else NULL)
+ * pose0    [B,3] fp32 (shift_u, shift_v, theta) normalised units, or NULL for zeros
+ * rand_uv  [n_steps,2,B] fp32: the (rand_u, rand_v) re-initialisation draws of every step
+ *          (models_kitti.py:1028-1033), drawn by the caller from torch's CPU generator
+ * trace    [B,n_iters,n_levels,3] fp32 out: (shift_u, shift_v, theta) after every step
+ * normal_eq[n_steps,B,16] fp64 out or NULL: ||s||^2, ||g||^2, H(6), J^T s (3), J^T g (3), pad(2) */
+int hla_s2g_lm_solve(const hla_s2g_config* cfg, const hla_s2g_level* levels, const float* R_FL,
+                     const float* T_FL, const float* pose0, const float* rand_uv, float* trace,
+                     double* normal_eq, void* workspace, size_t workspace_bytes, int B, hla_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HLA_H */

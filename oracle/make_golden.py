@@ -1,0 +1,320 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by running the REAL reference (/root/reference).
+
+Build-container only: the reference's Python never travels to the GPU box, so
+this script is run here, once, and its outputs (data only: seeds -> numbers) are
+committed.  Inputs and weights are regenerated on both sides from
+``numpy.random.RandomState(seed)`` (see oracle/ref_cpu.py ``synth_*``), so the
+fixtures hold expected outputs plus the tiny explicit inputs of the
+known-answer tests.
+
+The reference imports ``torchvision`` (absent in this image) and asks for
+pretrained VGG-16 weights (no network); both are satisfied by a shim that
+provides a randomly initialised ``vgg16().features`` whose weights are then
+overwritten by ``load_state_dict``.
+
+Usage:  python oracle/make_golden.py [--only kat|e2e|ford|train|screen]
+"""
+import argparse
+import os
+import sys
+import types
+import time
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+GOLD = os.path.join(ROOT, 'tests', 'golden')
+sys.path.insert(0, ROOT)
+sys.dont_write_bytecode = True  # /root/reference is read-only
+
+from oracle import ref_cpu as O  # noqa: E402
+
+
+def install_torchvision_shim():
+    tv = types.ModuleType('torchvision')
+    models = types.ModuleType('torchvision.models')
+    transforms = types.ModuleType('torchvision.transforms')
+    tfun = types.ModuleType('torchvision.transforms.functional')
+    tutils = types.ModuleType('torchvision.utils')
+
+    def vgg16(pretrained=False, **kw):
+        cfg = [64, 64, 'M', 128, 128, 'M', 256, 256, 256, 'M']
+        layers, cin = [], 3
+        for v in cfg:
+            if v == 'M':
+                layers.append(nn.MaxPool2d(2, 2))
+            else:
+                layers += [nn.Conv2d(cin, v, 3, padding=1), nn.ReLU(inplace=True)]
+                cin = v
+        return types.SimpleNamespace(features=nn.Sequential(*layers))
+
+    models.vgg16 = vgg16
+    tfun.center_crop = lambda img, size: img
+    transforms.functional = tfun
+    transforms.ToPILImage = lambda *a, **k: None
+    tv.models, tv.transforms, tv.utils = models, transforms, tutils
+    for name, mod in (('torchvision', tv), ('torchvision.models', models), ('torchvision.transforms', transforms),
+                      ('torchvision.transforms.functional', tfun), ('torchvision.utils', tutils)):
+        sys.modules[name] = mod
+
+
+def import_reference():
+    install_torchvision_shim()
+    sys.path.insert(0, '/root/reference')
+    import models_kitti  # noqa
+    import models_ford   # noqa
+    import jacobian      # noqa
+    import VGG           # noqa
+    return models_kitti, models_ford, jacobian, VGG
+
+
+def ref_model(mod, cls, args, seed, dtype, bias_scale=0.0):
+    net = getattr(mod, cls)(args)
+    torch.autograd.set_detect_anomaly(False)
+    rot = 10.0 if cls.endswith('Ford') else args.rotation_range
+    net.load_state_dict(O.synth_model_state(seed, bias_scale, rotation_range=rot))
+    return net.to(dtype)
+
+
+SAMPLE_N = 64
+
+
+def sample_idx(numel, salt):
+    return np.random.RandomState(1000 + salt).randint(0, numel, size=SAMPLE_N)
+
+
+def feat_stats(feats, B):
+    """Per level: per-sample [sum, sumsq] and SAMPLE_N sampled values (NCHW flat order per sample)."""
+    out = []
+    for l, f in enumerate(feats):
+        f = f.detach().double().reshape(B, -1)
+        idx = sample_idx(f.shape[1], l)
+        out.append(np.concatenate([f.sum(1, keepdim=True).numpy(), (f * f).sum(1, keepdim=True).numpy(),
+                                   f[:, idx].numpy()], 1))
+    return out
+
+
+# ----------------------------------------------------------------------------
+def gen_kat(mk, mf, jac, VGG):
+    out = {}
+    rs = np.random.RandomState(7)
+    # (1) grid_sample: random in/out-of-bounds coords + exact-edge cases (jacobian.py:216-225)
+    img = rs.standard_normal((2, 4, 8, 10)).astype(np.float32)
+    uv = np.stack([rs.uniform(-1.5, 10.5, size=(2, 6, 7)), rs.uniform(-1.5, 8.5, size=(2, 6, 7))], -1).astype(np.float32)
+    uv[0, 0, 0] = [9.0, 3.25]     # x exactly IW-1 -> 0
+    uv[0, 0, 1] = [4.5, 7.0]      # y exactly IH-1 -> 0
+    uv[0, 0, 2] = [-0.5, 2.0]     # outside -> 0
+    uv[0, 0, 3] = [0.0, 0.0]      # exact corner
+    uv[0, 0, 4] = [3.0, 5.0]      # integer coords
+    uv[0, 0, 5] = [8.999, 6.999]
+    jc = rs.standard_normal((3, 2, 6, 7, 2)).astype(np.float32)
+    o, j = jac.grid_sample(torch.from_numpy(img), torch.from_numpy(uv), torch.from_numpy(jc))
+    out.update(gs_img=img, gs_uv=uv, gs_jac=jc, gs_out=o.numpy(), gs_jac_out=j.numpy())
+    # identity with F.grid_sample(align_corners=True) for in-bounds coords is asserted in the test itself.
+
+    # (2) geometry: KITTI + Ford pose->uv and analytic Jacobians at level 0 (32x128)
+    args = O.default_args()
+    netk = mk.LM_S2GP(args)
+    torch.autograd.set_detect_anomaly(False)
+    pose = torch.tensor([[0.31], [-0.72]]), torch.tensor([[-0.55], [0.18]]), torch.tensor([[0.83], [-0.4]])
+    for level, A in ((0, 64), (2, 256)):
+        uvk, mask, ju, jv, jt = netk.grd2cam2world2sat(pose[0], pose[1], pose[2], level, A, require_jac=True)
+        out[f'kitti_uv_l{level}'] = uvk.detach().numpy()
+        out[f'kitti_jac_l{level}'] = torch.stack([ju, jv, jt]).detach().numpy()
+        out[f'kitti_mask_l{level}'] = mask.numpy()
+        out[f'kitti_xyz_l{level}'] = netk.xyz_grds[level][0].detach().numpy()
+    netf = mf.LM_S2GP_Ford(args)
+    torch.autograd.set_detect_anomaly(False)
+    R_FL = torch.tensor([[[0., 0., 1.], [1., 0., 0.], [0., 1., 0.]]]).repeat(2, 1, 1)
+    T_FL = torch.tensor([[1.7, 0.3, -1.2]]).repeat(2, 1)
+    for level, A in ((0, 64), (2, 256)):
+        uvf, mask, ju, jv, jt = netf.cam2body2world2sat(R_FL, T_FL, pose[0], pose[1], pose[2], level, 112.64, A,
+                                                        require_jac=True)
+        out[f'ford_uv_l{level}'] = uvf.detach().numpy()
+        out[f'ford_jac_l{level}'] = torch.stack([ju, jv, jt]).detach().numpy()
+        out[f'ford_mask_l{level}'] = mask.numpy()
+        out[f'ford_xyz_l{level}'] = netf.xyz_grds[level][0].detach().numpy()
+    out.update(geo_pose=torch.stack(pose).numpy(), ford_R=R_FL.numpy(), ford_T=T_FL.numpy())
+
+    # (3) LM_update on small random tensors, option sweep
+    B, C, H, W = 2, 8, 8, 16
+    sp = rs.standard_normal((B, C, H, W)).astype(np.float32)
+    gf = rs.standard_normal((B, C, H, W)).astype(np.float32)
+    gc = rs.uniform(0.27, 0.5, size=(B, 1, H, W)).astype(np.float32)
+    dj = rs.standard_normal((3, B, C, H, W)).astype(np.float32)
+    p0 = rs.uniform(-0.5, 0.5, size=(3, B, 1)).astype(np.float32)
+    out.update(lm_sat=sp, lm_grd=gf, lm_conf=gc, lm_jac=dj, lm_pose=p0)
+    combos = [dict(), dict(using_weight=1), dict(use_hessian=1), dict(train_damping=1),
+              dict(rotation_range=0.0), dict(shift_range_lat=0.0, shift_range_lon=0.0), dict(damping=1e-3)]
+    for i, kw in enumerate(combos):
+        a = O.default_args(**kw)
+        net = mk.LM_S2GP(a)
+        torch.autograd.set_detect_anomaly(False)
+        if kw.get('train_damping'):
+            with torch.no_grad():
+                net.damping.copy_(torch.tensor([[0.3, -0.2, 0.1]]))
+        torch.manual_seed(5)
+        r = net.LM_update(torch.from_numpy(p0[0]), torch.from_numpy(p0[1]), torch.from_numpy(p0[2]),
+                          torch.from_numpy(sp), torch.from_numpy(gc), torch.from_numpy(gf), torch.from_numpy(gc),
+                          torch.from_numpy(dj))
+        out[f'lm_out_{i}'] = torch.stack([x.detach() for x in r]).numpy()
+    out['lm_combos'] = np.array([repr(c) for c in combos])
+    # out-of-range re-initialisation branch: huge Jacobian-free step via tiny damping & big residual
+    a = O.default_args(damping=1e-9)
+    net = mk.LM_S2GP(a)
+    torch.autograd.set_detect_anomaly(False)
+    torch.manual_seed(11)
+    r = net.LM_update(torch.from_numpy(p0[0]), torch.from_numpy(p0[1]), torch.from_numpy(p0[2]),
+                      torch.from_numpy(sp), torch.from_numpy(gc), torch.from_numpy(gf), torch.from_numpy(gc),
+                      torch.from_numpy(dj * 1e-3))
+    out['lm_out_reinit'] = torch.stack([x.detach() for x in r]).numpy()
+
+    # (4) VGGUnet on a small image, level 4 (all maps + confidences), non-zero biases
+    vrs = np.random.RandomState(21)
+    vsd = O.synth_vgg_state(vrs, bias_scale=0.05)
+    vnet = VGG.VGGUnet(4)
+    vnet.load_state_dict(vsd)
+    x = torch.from_numpy(vrs.random_sample((2, 3, 32, 64)).astype(np.float32))
+    with torch.no_grad():
+        f32, c32 = vnet(x)
+        f64, c64 = vnet.double()(x.double())
+    for l in range(4):
+        out[f'vgg_feat32_l{l}'] = f32[l].numpy()
+        out[f'vgg_feat64_l{l}'] = f64[l].numpy()
+        out[f'vgg_conf64_l{l}'] = c64[l].numpy()
+    np.savez_compressed(os.path.join(GOLD, 'kat_small.npz'), **out)
+    print('kat_small.npz written,', len(out), 'arrays')
+
+
+def run_e2e(mod, cls, args, seed, B, dtype, extra=None, level_first=0, bias_scale=0.0):
+    net = ref_model(mod, cls, args, seed, dtype, bias_scale)
+    sat, grd, gu, gv, gh = O.synth_images(seed + 100, B)
+    sat, grd = sat.to(dtype), grd.to(dtype)
+    torch.manual_seed(seed)
+    # capture per-step poses through the train-mode return path: run test mode and
+    # recover the full [B,N,L] traces by re-running the loop pieces is intrusive; instead
+    # monkey-patch loss_func-free access: call train mode with gt to get nothing extra, so
+    # we wrap LM_update to log.
+    log = []
+    orig = net.LM_update
+
+    def wrap(*a, **k):
+        r = orig(*a, **k)
+        log.append(torch.stack([x.detach()[:, 0] for x in r], -1))  # [B,3] = (u, v, theta)
+        return r
+    net.LM_update = wrap
+    with torch.no_grad():
+        sf, _ = net.SatFeatureNet(sat)
+        gf, _ = net.GrdFeatureNet(grd)
+        if extra is None:
+            res = net(sat, grd, mode='test', level_first=level_first)
+        else:
+            res = net(sat, grd, extra[2], extra[0].to(dtype), extra[1].to(dtype), mode='test', level_first=level_first)
+    trace = torch.stack(log, 1).double().numpy()          # [B, steps, 3] in execution order
+    final = torch.stack([r.detach() for r in res], -1).double().numpy()
+    return trace, final, feat_stats(sf, B), feat_stats(gf, B)
+
+
+def gen_screen(mk):
+    """Conditioning screen (SURVEY B-5): |fp32 - fp64| of the final pose per seed."""
+    args = O.default_args()
+    for seed in range(1, 13):
+        t0 = time.time()
+        t32, f32, _, _ = run_e2e(mk, 'LM_S2GP', args, seed, 1, torch.float32)
+        t64, f64, _, _ = run_e2e(mk, 'LM_S2GP', args, seed, 1, torch.float64)
+        print(f'seed {seed}: final64 {f64[0]}  |32-64| final {np.abs(f32 - f64).max():.2e} '
+              f'trace {np.abs(t32 - t64).max():.2e}  ({time.time() - t0:.1f}s)', flush=True)
+
+
+def gen_e2e(mk, seeds, B=2):
+    args = O.default_args()
+    out = {'seeds': np.array(seeds), 'B': np.array(B)}
+    for seed in seeds:
+        t32, f32, _, _ = run_e2e(mk, 'LM_S2GP', args, seed, B, torch.float32)
+        t64, f64, sf, gf = run_e2e(mk, 'LM_S2GP', args, seed, B, torch.float64)
+        out[f'trace32_{seed}'], out[f'trace64_{seed}'] = t32, t64
+        out[f'final32_{seed}'], out[f'final64_{seed}'] = f32, f64
+        for l in range(3):
+            out[f'satfeat64_{seed}_l{l}'] = sf[l]
+            out[f'grdfeat64_{seed}_l{l}'] = gf[l]
+        print(f'kitti seed {seed}: gap {np.abs(t32 - t64).max():.2e} final {f64.tolist()}', flush=True)
+    # level-first ordering and the option flags, one seed, B=1
+    seed = seeds[0]
+    for tag, kw, lf in (('levelfirst', {}, 1), ('weight', dict(using_weight=1), 0),
+                        ('hess', dict(use_hessian=1, damping=0.5), 0), ('rot0', dict(rotation_range=0.0), 0)):
+        a = O.default_args(**kw)
+        t64, f64, _, _ = run_e2e(mk, 'LM_S2GP', a, seed, 1, torch.float64, level_first=lf)
+        t32, f32, _, _ = run_e2e(mk, 'LM_S2GP', a, seed, 1, torch.float32, level_first=lf)
+        out[f'trace64_{tag}'], out[f'trace32_{tag}'] = t64, t32
+        print(f'kitti {tag}: gap {np.abs(t32 - t64).max():.2e}', flush=True)
+    np.savez_compressed(os.path.join(GOLD, 'e2e_kitti.npz'), **out)
+
+
+def ford_extra(B):
+    R_FL = torch.tensor([[[0., 0., 1.], [1., 0., 0.], [0., 1., 0.]]]).repeat(B, 1, 1)
+    T_FL = torch.tensor([[1.7, 0.3, -1.2]]).repeat(B, 1)
+    return R_FL, T_FL, 112.64
+
+
+def gen_ford(mf, seeds, B=1):
+    args = O.default_args(N_iters=10)
+    out = {'seeds': np.array(seeds), 'B': np.array(B)}
+    for seed in seeds:
+        t32, f32, _, _ = run_e2e(mf, 'LM_S2GP_Ford', args, seed, B, torch.float32, extra=ford_extra(B))
+        t64, f64, _, _ = run_e2e(mf, 'LM_S2GP_Ford', args, seed, B, torch.float64, extra=ford_extra(B))
+        out[f'trace32_{seed}'], out[f'trace64_{seed}'] = t32, t64
+        out[f'final32_{seed}'], out[f'final64_{seed}'] = f32, f64
+        print(f'ford seed {seed}: gap {np.abs(t32 - t64).max():.2e} final {f64.tolist()}', flush=True)
+    np.savez_compressed(os.path.join(GOLD, 'e2e_ford.npz'), **out)
+
+
+GRAD_KEYS = ['SatFeatureNet.conv0.weight', 'SatFeatureNet.conv14.weight', 'SatFeatureNet.conv_dec2.3.weight',
+             'GrdFeatureNet.conv0.weight', 'GrdFeatureNet.conv14.weight', 'GrdFeatureNet.conv_dec1.1.weight',
+             'GrdFeatureNet.conv2.bias']
+
+
+def gen_train(mk, seed, B=1):
+    """Train-mode 14-tuple + gradient samples, fp64."""
+    args = O.default_args()
+    out = {'seed': np.array(seed), 'B': np.array(B)}
+    for dtype, tag in ((torch.float64, '64'), (torch.float32, '32')):
+        net = ref_model(mk, 'LM_S2GP', args, seed, dtype)
+        sat, grd, gu, gv, gh = O.synth_images(seed + 100, B)
+        torch.manual_seed(seed)
+        res = net(sat.to(dtype), grd.to(dtype), gu.to(dtype), gv.to(dtype), gh.to(dtype), mode='train')
+        res[0].backward()
+        out['tuple' + tag] = np.stack([np.atleast_1d(r.detach().double().numpy()) if r.dim() else
+                                       np.full(3, float(r)) for r in res[:9]])
+        sd = dict(net.named_parameters())
+        for k in GRAD_KEYS:
+            g = sd[k].grad.double().reshape(-1)
+            idx = sample_idx(g.numel(), 77)
+            out[f'grad{tag}_{k}'] = np.concatenate([[g.abs().sum().item(), (g * g).sum().item()], g[idx].numpy()])
+        out['nograd_' + tag] = np.array([k for k, p in sd.items() if p.grad is None])
+        print('train', tag, 'loss', float(res[0]), flush=True)
+    np.savez_compressed(os.path.join(GOLD, 'train_kitti.npz'), **out)
+
+
+if __name__ == '__main__':
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--only', default='all')
+    ap.add_argument('--seeds', default='')
+    a = ap.parse_args()
+    os.makedirs(GOLD, exist_ok=True)
+    torch.set_num_threads(8)
+    mk, mf, jac, VGG = import_reference()
+    seeds = [int(s) for s in a.seeds.split(',')] if a.seeds else None
+    if a.only == 'screen':
+        gen_screen(mk)
+    if a.only in ('all', 'kat'):
+        gen_kat(mk, mf, jac, VGG)
+    if a.only in ('all', 'e2e'):
+        gen_e2e(mk, seeds or [1, 2, 3])
+    if a.only in ('all', 'ford'):
+        gen_ford(mf, (seeds or [1])[:2])
+    if a.only in ('all', 'train'):
+        gen_train(mk, (seeds or [1])[0])

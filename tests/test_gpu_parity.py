@@ -1,0 +1,356 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle and the committed
+golden vectors recorded from the real reference.  Run with `pytest -m gpu` on an MI355X.
+
+Tolerances (stated per SURVEY 8(c)):
+  * features (fp32 mode): 1e-5 relative to the map's max-abs, against the fp64 oracle / fp64 golden
+  * pose (fp32 mode): |hip - ref_fp64| <= max(tol, 2*|ref_fp32 - ref_fp64|), tol = 5e-6 normalised for the
+    shifts (= 1e-4 m at 20 m range) and 5.7e-4 normalised for yaw (= 1e-4 rad at 10 deg)
+  * bf16 mode is the throughput mode; its pose deviation is reported and bounded loosely
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+TOL_SHIFT, TOL_YAW = 5e-6, 5.7e-4
+
+
+def _dev():
+    assert torch.cuda.is_available(), 'these tests need the MI355X'
+    return torch.device('cuda:0')
+
+
+def T(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def test_library_loaded_and_exports():
+    from highlyaccurate_amd import _lib
+    lib = _lib.load()
+    assert lib.hla_abi_version() == 1
+    for sym in ('hla_vgg_forward', 'hla_s2g_lm_solve', 'hla_grid_sample', 'hla_vgg_workspace_bytes',
+                'hla_s2g_workspace_bytes', 'hla_last_error'):
+        assert hasattr(lib, sym)
+
+
+def test_cpu_tensor_is_rejected():
+    from highlyaccurate_amd import _lib
+    from highlyaccurate_amd.VGG import VGGUnet
+    with pytest.raises(_lib.HlaError):
+        VGGUnet(3)(torch.zeros(1, 3, 32, 64))
+
+
+def test_grid_sample_kat(kat):
+    from highlyaccurate_amd.jacobian import grid_sample
+    d = _dev()
+    out, jac = grid_sample(T(kat['gs_img']).to(d), T(kat['gs_uv']).to(d), T(kat['gs_jac']).to(d))
+    np.testing.assert_allclose(out.cpu().numpy(), kat['gs_out'], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(jac.cpu().numpy(), kat['gs_jac_out'], rtol=0, atol=2e-6)
+    o2, j2 = grid_sample(T(kat['gs_img']).to(d), T(kat['gs_uv']).to(d))
+    assert j2 is None and torch.equal(o2, out)
+
+
+def _rel(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)
+
+
+@pytest.mark.parametrize('precision,tol', [('fp32', 1e-5), ('bf16', 3e-2)])
+def test_vgg_small_vs_golden(kat, precision, tol):
+    """VGGUnet on [2,3,32,64] with non-zero biases against the reference's fp64 maps."""
+    from oracle import ref_cpu as O
+    from highlyaccurate_amd.VGG import VGGUnet
+    d = _dev()
+    rs = np.random.RandomState(21)
+    sd = O.synth_vgg_state(rs, bias_scale=0.05)
+    x = T(rs.random_sample((2, 3, 32, 64)).astype(np.float32))
+    net = VGGUnet(3, precision=precision)
+    net.load_state_dict(sd)
+    net = net.to(d)
+    feats, confs = net(x.to(d))
+    for l in range(3):
+        f = feats[l].cpu().numpy()
+        assert f.shape == kat[f'vgg_feat64_l{l}'].shape
+        e = _rel(f, kat[f'vgg_feat64_l{l}'])
+        ec = _rel(confs[l].cpu().numpy(), kat[f'vgg_conf64_l{l}'])
+        print(f'vgg small {precision} level {l}: feat rel {e:.2e} conf rel {ec:.2e}')
+        assert e < tol, (precision, l, e)
+        assert ec < max(tol, 2e-6), (precision, l, ec)
+
+
+def _oracle_small(args, seed, B, grd_hw, sat_a, dtype=torch.float64, ford=False):
+    """Random NHWC feature pyramids + the oracle's solve on them."""
+    from oracle import ref_cpu as O
+    rs = np.random.RandomState(seed)
+    Cs = (256, 128, 64)
+    sat, grd, conf = [], [], []
+    for l in range(3):
+        A = sat_a >> (2 - l)
+        h, w = grd_hw[0] >> (3 - l), grd_hw[1] >> (3 - l)
+        sat.append(T(rs.standard_normal((B, Cs[l], A, A)).astype(np.float32)))
+        grd.append(T(rs.standard_normal((B, Cs[l], h, w)).astype(np.float32)))
+        conf.append(T(rs.uniform(0.27, 0.5, size=(B, 1, h, w)).astype(np.float32)))
+    cls = O.LM_S2GP_Ford if ford else O.LM_S2GP
+    net = cls(args, grd_hw=grd_hw).to(dtype)
+    return net, sat, grd, conf
+
+
+def _oracle_normal_eq(onet, sat, grd, conf, pose, level, using_weight, extra=None):
+    """The 14 sums of one step, from the oracle's own projection (fp64): S, G, H(6), U(3), V(3)."""
+    su, sv, th = pose
+    f, _, jac, _, mask = onet.project_map_to_grd(sat[level].double(), None, su, sv, th, level, extra)
+    h = grd[level].shape[-2]
+    g = grd[level].double() * mask[:, None]
+    w = conf[level].double() * mask[:, None] if using_weight else torch.ones_like(g[:, :1])
+    f, g, w, jac = f[:, :, h // 2:], g[:, :, h // 2:], w[:, :, h // 2:], jac[:, :, :, h // 2:]
+    B = f.shape[0]
+    s_, g_, J = f.reshape(B, -1), g.reshape(B, -1), jac.reshape(3, B, -1)
+    W = w.expand(-1, f.shape[1], -1, -1).reshape(B, -1)
+    out = [(s_ * s_).sum(1), (g_ * g_).sum(1)]
+    for p, q in ((0, 0), (0, 1), (0, 2), (1, 1), (1, 2), (2, 2)):
+        out.append((W * J[p] * J[q]).sum(1))
+    out += [(W * J[p] * s_).sum(1) for p in range(3)] + [(W * J[p] * g_).sum(1) for p in range(3)]
+    return torch.stack(out, 1).numpy()
+
+
+@pytest.mark.parametrize('kw', [dict(), dict(using_weight=1), dict(use_hessian=1, damping=0.5),
+                                dict(rotation_range=0.0), dict(shift_range_lat=0.0, shift_range_lon=0.0),
+                                dict(level_first=1), dict(N_iters=2, damping=10.0)])
+def test_lm_solve_small_vs_oracle(kw):
+    """The fused projection+Jacobian+normal-equation+solve loop on random feature pyramids:
+    first-step normal equations (tight) and the whole pose trace."""
+    from oracle import ref_cpu as O
+    from highlyaccurate_amd.models_kitti import LM_S2GP
+    d = _dev()
+    kw = dict(kw)
+    lf = kw.pop('level_first', 0)
+    args = O.default_args(**{'N_iters': 3, 'damping': 1.0, **kw})
+    B, grd_hw, sat_a = 3, (64, 256), 128
+    onet, sat, grd, conf = _oracle_small(args, 3, B, grd_hw, sat_a)
+    p0 = T(np.random.RandomState(4).uniform(-0.3, 0.3, size=(B, 3)).astype(np.float32))
+    net = LM_S2GP(args).to(d)
+    net.keep_normal_eq = True
+    nh = lambda t: t.permute(0, 2, 3, 1).contiguous().to(d)
+    torch.manual_seed(0)
+    trace = net.lm_solve([nh(s) for s in sat], [nh(g) for g in grd], [c[:, 0].contiguous().to(d) for c in conf],
+                         grd_hw, None, lf, init_pose=p0).cpu().numpy()
+    neq = net.last_normal_eq[0, :, :14].cpu().numpy()
+    pose = [p0[:, i:i + 1].double() for i in range(3)]
+    ref_neq = _oracle_normal_eq(onet, sat, grd, conf, pose, 0, args.using_weight)
+    e_neq = np.abs(neq - ref_neq).max(0) / np.abs(ref_neq).max(0).clip(1e-30)
+    print('normal-eq rel err per sum:', np.array2string(e_neq, precision=1))
+    assert e_neq.max() < 2e-6, e_neq
+    # whole trace: restart the oracle from the same pose by running its loop manually
+    torch.manual_seed(0)
+    su, sv, th = pose
+    L, N = 3, args.N_iters
+    order = [(i, l) for l in range(L) for i in range(N)] if lf else [(i, l) for i in range(N) for l in range(L)]
+    ref = np.zeros((B, N, L, 3))
+    for i, l in order:
+        su, sv, th = onet._step(l, sat[l].double(), None, grd[l].double(), conf[l].double(), su, sv, th, None)
+        ref[:, i, l] = torch.cat([su, sv, th], 1).numpy()
+    err = np.abs(trace - ref).max()
+    print('lm small', kw, 'lf', lf, 'trace max err', err, 'ref range', np.abs(ref).max())
+    assert np.isfinite(trace).all()
+    assert err < 1e-4 * max(1.0, np.abs(ref).max()), (kw, err)
+
+
+def test_lm_solve_ford_small_vs_oracle():
+    from oracle import ref_cpu as O
+    from highlyaccurate_amd.models_ford import LM_S2GP_Ford
+    d = _dev()
+    args = O.default_args(N_iters=3, damping=1.0)
+    B, grd_hw, sat_a = 2, (64, 256), 128
+    onet, sat, grd, conf = _oracle_small(args, 5, B, grd_hw, sat_a, ford=True)
+    R_FL = torch.tensor([[[0., 0., 1.], [1., 0., 0.], [0., 1., 0.]]]).repeat(B, 1, 1)
+    T_FL = torch.tensor([[1.7, 0.3, -1.2]]).repeat(B, 1)
+    torch.manual_seed(0)
+    us, vs, ts = onet.solve([s.double() for s in sat], [None] * 3, [g.double() for g in grd],
+                            [c.double() for c in conf], (R_FL.double(), T_FL.double(), 112.64), 0)
+    ref = torch.stack([us, vs, ts], -1).numpy()
+    net = LM_S2GP_Ford(args).to(d)
+    nh = lambda t: t.permute(0, 2, 3, 1).contiguous().to(d)
+    torch.manual_seed(0)
+    trace = net.lm_solve([nh(s) for s in sat], [nh(g) for g in grd], [None] * 3, grd_hw,
+                         dict(R_FL=R_FL, T_FL=T_FL, side_m=112.64), 0).cpu().numpy()
+    err = np.abs(trace - ref).max()
+    print('lm ford small max err', err, 'ref range', np.abs(ref).max())
+    assert err < 2e-5 * max(1.0, np.abs(ref).max())
+
+
+def _pose_gate(got, g64, g32, what):
+    """|hip - ref64| <= max(tol, 2*|ref32 - ref64|), componentwise; last axis = (u, v, theta)."""
+    tol = np.array([TOL_SHIFT, TOL_SHIFT, TOL_YAW])
+    allow = np.maximum(tol, 2 * np.abs(g32 - g64))
+    err = np.abs(got - g64)
+    worst = (err / allow).max()
+    print(f'{what}: max err {err.max():.2e} (ref fp32-fp64 gap {np.abs(g32 - g64).max():.2e}), worst ratio {worst:.2f}')
+    assert worst <= 1.0, (what, err.max())
+
+
+def _run_kitti(seed, B, precision='fp32', level_first=0, **kw):
+    from oracle import ref_cpu as O
+    from highlyaccurate_amd.models_kitti import LM_S2GP
+    d = _dev()
+    args = O.default_args(precision=precision, **kw)
+    net = LM_S2GP(args)
+    net.load_state_dict(O.synth_model_state(seed, rotation_range=args.rotation_range))
+    net = net.to(d)
+    sat, grd, gu, gv, gh = O.synth_images(seed + 100, B)
+    torch.manual_seed(seed)
+    with torch.no_grad():
+        res = net(sat.to(d), grd.to(d), mode='test', level_first=level_first)
+    return net, res
+
+
+def _exec_order(trace, level_first):
+    """[B,N,L,3] -> [B,steps,3] in execution order (what make_golden.py logged)."""
+    B, N, L, _ = trace.shape
+    t = trace.permute(0, 2, 1, 3) if level_first else trace
+    return t.reshape(B, N * L, 3)
+
+
+def test_e2e_kitti_full_shape_vs_golden():
+    """Full KITTI shapes, B=2, fp32 mode: pose trace of all 15 steps + feature samples vs the reference."""
+    g = load_golden('e2e_kitti.npz')
+    B = int(g['B'])
+    from make_idx import sample_idx
+    for seed in g['seeds']:
+        seed = int(seed)
+        net, res = _run_kitti(seed, B)
+        trace = _exec_order(net.last_trace, 0).cpu().numpy().astype(np.float64)
+        _pose_gate(trace, g[f'trace64_{seed}'], g[f'trace32_{seed}'], f'kitti seed {seed}')
+        final = torch.stack(res, -1).cpu().numpy()
+        np.testing.assert_allclose(final, g[f'final64_{seed}'], atol=2e-3)   # ordering check (lat, lon, theta)
+        np.testing.assert_array_equal(final[:, [1, 0, 2]], trace[:, -1].astype(np.float32))
+
+
+def test_e2e_kitti_features_vs_golden():
+    from oracle import ref_cpu as O
+    from highlyaccurate_amd.models_kitti import LM_S2GP
+    from make_idx import sample_idx
+    g = load_golden('e2e_kitti.npz')
+    B = int(g['B'])
+    seed = int(g['seeds'][0])
+    d = _dev()
+    net = LM_S2GP(O.default_args())
+    net.load_state_dict(O.synth_model_state(seed))
+    net = net.to(d)
+    sat, grd, *_ = O.synth_images(seed + 100, B)
+    for name, mod, img in (('sat', net.SatFeatureNet, sat), ('grd', net.GrdFeatureNet, grd)):
+        feats, _ = mod(img.to(d))
+        for l in range(3):
+            ref = g[f'{name}feat64_{seed}_l{l}']
+            f = feats[l].contiguous().reshape(B, -1).double().cpu()       # NCHW flat order
+            idx = sample_idx(f.shape[1], l)
+            got = np.concatenate([f.sum(1, keepdim=True).numpy(), (f * f).sum(1, keepdim=True).numpy(), f[:, idx].numpy()], 1)
+            scale = np.abs(ref[:, 2:]).max()
+            e = np.abs(got[:, 2:] - ref[:, 2:]).max() / scale
+            print(f'{name} level {l}: sampled rel err {e:.2e}, sumsq {got[:, 1]}, sum err {np.abs(got[:, 0] - ref[:, 0]).max():.2e}')
+            assert e < 1e-5
+            np.testing.assert_allclose(got[:, 1], 1.0, atol=1e-6)
+
+
+@pytest.mark.parametrize('tag,kw,lf', [('levelfirst', {}, 1), ('weight', dict(using_weight=1), 0),
+                                       ('hess', dict(use_hessian=1, damping=0.5), 0),
+                                       ('rot0', dict(rotation_range=0.0), 0)])
+def test_e2e_kitti_variants_vs_golden(tag, kw, lf):
+    g = load_golden('e2e_kitti.npz')
+    seed = int(g['seeds'][0])
+    net, _ = _run_kitti(seed, 1, level_first=lf, **kw)
+    trace = _exec_order(net.last_trace, lf).cpu().numpy().astype(np.float64)
+    _pose_gate(trace, g[f'trace64_{tag}'], g[f'trace32_{tag}'], f'kitti {tag}')
+
+
+def test_e2e_ford_full_shape_vs_golden():
+    from oracle import ref_cpu as O
+    from highlyaccurate_amd.models_ford import LM_S2GP_Ford
+    g = load_golden('e2e_ford.npz')
+    B = int(g['B'])
+    d = _dev()
+    for seed in g['seeds']:
+        seed = int(seed)
+        args = O.default_args(N_iters=10)
+        net = LM_S2GP_Ford(args)
+        net.load_state_dict(O.synth_model_state(seed))
+        net = net.to(d)
+        sat, grd, *_ = O.synth_images(seed + 100, B)
+        R_FL = torch.tensor([[[0., 0., 1.], [1., 0., 0.], [0., 1., 0.]]]).repeat(B, 1, 1)
+        T_FL = torch.tensor([[1.7, 0.3, -1.2]]).repeat(B, 1)
+        torch.manual_seed(seed)
+        with torch.no_grad():
+            res = net(sat.to(d), grd.to(d), 112.64, R_FL.to(d), T_FL.to(d), mode='test')
+        trace = _exec_order(net.last_trace, 0).cpu().numpy().astype(np.float64)
+        _pose_gate(trace, g[f'trace64_{seed}'], g[f'trace32_{seed}'], f'ford seed {seed}')
+        np.testing.assert_array_equal(torch.stack(res, -1).cpu().numpy(), trace[:, -1].astype(np.float32))
+
+
+def test_bf16_mode_pose_deviation_reported():
+    g = load_golden('e2e_kitti.npz')
+    seed, B = int(g['seeds'][0]), int(g['B'])
+    net, _ = _run_kitti(seed, B, precision='bf16')
+    trace = _exec_order(net.last_trace, 0).cpu().numpy().astype(np.float64)
+    err = np.abs(trace - g[f'trace64_{seed}'])
+    print(f'bf16 mode pose deviation vs fp64 reference: shift {err[..., :2].max():.3e} yaw {err[..., 2].max():.3e} (normalised)')
+    assert np.isfinite(trace).all() and err.max() < 0.2
+
+
+def test_determinism_and_batch_independence():
+    """Same input twice -> bitwise identical; a sample's pose does not depend on its batch mates
+    (the path shards over the batch with no exchange)."""
+    n1, r1 = _run_kitti(2, 2)
+    t1 = n1.last_trace.clone()
+    n2, r2 = _run_kitti(2, 2)
+    assert torch.equal(t1, n2.last_trace)
+    n3, r3 = _run_kitti(2, 1)
+    assert torch.equal(t1[:1], n3.last_trace)
+
+
+def test_train_mode_forward_values_vs_golden():
+    """mode='train' 14-tuple values (no autograd yet) against the reference's fp64 tuple."""
+    from oracle import ref_cpu as O
+    from highlyaccurate_amd.models_kitti import LM_S2GP
+    g = load_golden('train_kitti.npz')
+    seed, B = int(g['seed']), int(g['B'])
+    d = _dev()
+    net = LM_S2GP(O.default_args())
+    net.load_state_dict(O.synth_model_state(seed))
+    net = net.to(d)
+    sat, grd, gu, gv, gh = O.synth_images(seed + 100, B)
+    torch.manual_seed(seed)
+    with torch.no_grad():
+        res = net(sat.to(d), grd.to(d), gu.to(d), gv.to(d), gh.to(d), mode='train')
+    assert len(res) == 14 and res[9] is None and res[12] is None and len(res[13]) == 3
+    ref = g['tuple64']
+    assert abs(float(res[0]) - ref[0][0]) < 1e-3 * abs(ref[0][0])
+    for i in range(1, 9):
+        np.testing.assert_allclose(res[i].cpu().numpy(), ref[i], rtol=1e-3, atol=2e-3)
+    assert tuple(res[13][0].shape) == (B, 1, 32, 128)
+    with pytest.raises(NotImplementedError):
+        net(sat.to(d), grd.to(d), gu.to(d), gv.to(d), gh.to(d), mode='train')
+
+
+def test_full_bench_config_runs_and_is_consistent():
+    """BASELINE config 2 shape (B=32, bf16): finite, deterministic, and each sample equals its B=1 run."""
+    from oracle import ref_cpu as O
+    from highlyaccurate_amd.models_kitti import LM_S2GP
+    d = _dev()
+    net = LM_S2GP(O.default_args(precision='bf16'))
+    net.load_state_dict(O.synth_model_state(1))
+    net = net.to(d)
+    rs = np.random.RandomState(9)
+    gen = torch.Generator(device='cpu').manual_seed(9)
+    sat = torch.rand(32, 3, 512, 512, generator=gen).to(d)
+    grd = torch.rand(32, 3, 256, 1024, generator=gen).to(d)
+    with torch.no_grad():
+        torch.manual_seed(1)
+        net(sat, grd, mode='test')
+        t = net.last_trace.clone()
+        torch.manual_seed(1)
+        net(sat[5:6], grd[5:6], mode='test')
+        t5 = net.last_trace.clone()
+    assert torch.isfinite(t).all()
+    assert torch.equal(t[5:6], t5)

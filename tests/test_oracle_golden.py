@@ -1,0 +1,122 @@
+"""Pin the CPU oracle (oracle/ref_cpu.py) against vectors recorded from the real
+reference by oracle/make_golden.py.  CPU only."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import ref_cpu as O
+from conftest import load_golden
+
+
+def T(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def test_grid_sample_matches_reference(kat):
+    out, jac = O.grid_sample(T(kat['gs_img']), T(kat['gs_uv']), T(kat['gs_jac']))
+    np.testing.assert_allclose(out.numpy(), kat['gs_out'], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(jac.numpy(), kat['gs_jac_out'], rtol=0, atol=2e-6)
+    # edge semantics (jacobian.py:156-177): exact last row/col and outside -> 0
+    assert np.all(kat['gs_out'][0, :, 0, 0] == 0) and np.all(kat['gs_out'][0, :, 0, 1] == 0)
+    assert np.all(kat['gs_out'][0, :, 0, 2] == 0)
+    np.testing.assert_allclose(kat['gs_out'][0, :, 0, 3], kat['gs_img'][0, :, 0, 0], atol=1e-7)
+    np.testing.assert_allclose(kat['gs_out'][0, :, 0, 4], kat['gs_img'][0, :, 5, 3], atol=1e-7)
+
+
+def test_grid_sample_equals_torch_align_corners_inbounds():
+    # the reference's commented self-check, jacobian.py:216-225
+    rs = np.random.RandomState(0)
+    x = T(rs.rand(1, 3, 32, 32).astype(np.float32))
+    g = T(rs.uniform(-0.999, 0.999, size=(1, 32, 32, 2)).astype(np.float32))
+    a = F.grid_sample(x, g, align_corners=True)
+    b, _ = O.grid_sample(x, (g + 1) / 2 * 31)
+    assert (a - b).abs().max() < 1e-5
+
+
+@pytest.mark.parametrize('level,A', [(0, 64), (2, 256)])
+def test_kitti_geometry(kat, level, A):
+    args = O.default_args()
+    net = O.LM_S2GP(args)
+    xyz, mask = net.xyz_grds[level]
+    np.testing.assert_array_equal(xyz.numpy(), kat[f'kitti_xyz_l{level}'])  # bit-exact fp32 table
+    p = T(kat['geo_pose'])
+    uv, jac = O.kitti_pose_to_uv(args, xyz, p[0], p[1], p[2], A)
+    np.testing.assert_allclose(uv.numpy(), kat[f'kitti_uv_l{level}'], rtol=1e-5, atol=2e-3)
+    np.testing.assert_allclose(torch.stack(jac).numpy(), kat[f'kitti_jac_l{level}'], rtol=1e-5, atol=2e-3)
+    np.testing.assert_array_equal(mask.numpy(), kat[f'kitti_mask_l{level}'][:1])
+
+
+@pytest.mark.parametrize('level,A', [(0, 64), (2, 256)])
+def test_ford_geometry(kat, level, A):
+    args = O.default_args()
+    net = O.LM_S2GP_Ford(args)
+    xyz, mask = net.xyz_grds[level]
+    np.testing.assert_array_equal(xyz.numpy(), kat[f'ford_xyz_l{level}'])
+    p = T(kat['geo_pose'])
+    uv, jac = O.ford_pose_to_uv(args, xyz, T(kat['ford_R']), T(kat['ford_T']), p[0], p[1], p[2], 112.64, A)
+    np.testing.assert_allclose(uv.numpy(), kat[f'ford_uv_l{level}'], rtol=1e-5, atol=2e-3)
+    np.testing.assert_allclose(torch.stack(jac).numpy(), kat[f'ford_jac_l{level}'], rtol=1e-5, atol=2e-3)
+    np.testing.assert_array_equal(mask.numpy(), kat[f'ford_mask_l{level}'][:1])
+
+
+def test_geometry_jacobian_vs_autograd():
+    # the reference's commented check models_kitti.py:825-910: analytic d(uv)/d(pose) == autograd
+    args = O.default_args()
+    net = O.LM_S2GP(args).double()
+    xyz, _ = net.xyz_grds[0]
+    p0 = torch.tensor([0.3, -0.2, 0.5], dtype=torch.float64)
+
+    def f(p):
+        uv, _ = O.kitti_pose_to_uv(args, xyz, p[0].view(1, 1), p[1].view(1, 1), p[2].view(1, 1), 64, False)
+        return uv[0, 16:]          # bottom half (finite depths)
+    Jauto = torch.autograd.functional.jacobian(f, p0)               # [h,w,2,3]
+    _, jac = O.kitti_pose_to_uv(args, xyz, p0[0].view(1, 1), p0[1].view(1, 1), p0[2].view(1, 1), 64)
+    Jana = torch.stack(jac, -1)[0, 16:]
+    assert (Jauto - Jana).abs().max() < 1e-8 * Jana.abs().max()
+
+
+def test_lm_update_matches_reference(kat):
+    combos = [eval(s) for s in kat['lm_combos']]
+    p0 = T(kat['lm_pose'])
+    for i, kw in enumerate(combos):
+        args = O.default_args(**kw)
+        dp = torch.tensor([[0.3, -0.2, 0.1]]) if kw.get('train_damping') else torch.zeros(1, 3)
+        torch.manual_seed(5)
+        r = O.lm_update(args, dp, p0[0], p0[1], p0[2], T(kat['lm_sat']), T(kat['lm_grd']), T(kat['lm_conf']),
+                        T(kat['lm_jac']), kw.get('using_weight', 0))
+        got = torch.stack(list(r)).numpy()
+        np.testing.assert_allclose(got, kat[f'lm_out_{i}'], rtol=2e-4, atol=2e-5, err_msg=str(kw))
+    # re-initialisation branch consumes the same global RNG draws as the reference
+    args = O.default_args(damping=1e-9)
+    torch.manual_seed(11)
+    r = O.lm_update(args, torch.zeros(1, 3), p0[0], p0[1], p0[2], T(kat['lm_sat']), T(kat['lm_grd']),
+                    T(kat['lm_conf']), T(kat['lm_jac'] * 1e-3), 0)
+    got = torch.stack(list(r)).numpy()
+    ref = kat['lm_out_reinit']
+    assert np.any(np.abs(ref[:2]) <= 1.0)
+    np.testing.assert_allclose(got[:2], ref[:2], rtol=1e-3, atol=1e-5)
+
+
+def test_vgg_small_matches_reference(kat):
+    rs = np.random.RandomState(21)
+    sd = O.synth_vgg_state(rs, bias_scale=0.05)
+    net = O.VGGUnet(4)
+    net.load_state_dict(sd)
+    x = T(rs.random_sample((2, 3, 32, 64)).astype(np.float32))
+    with torch.no_grad():
+        f32, _ = net(x)
+        f64, c64 = net.double()(x.double())
+    for l in range(4):
+        np.testing.assert_allclose(f64[l].numpy(), kat[f'vgg_feat64_l{l}'], rtol=1e-9, atol=1e-12)
+        np.testing.assert_allclose(c64[l].numpy(), kat[f'vgg_conf64_l{l}'], rtol=1e-9, atol=1e-12)
+        np.testing.assert_allclose(f32[l].numpy(), kat[f'vgg_feat32_l{l}'], rtol=2e-4, atol=1e-6)
+
+
+def test_state_dict_keys_and_sizes():
+    net = O.LM_S2GP(O.default_args())
+    sd = net.state_dict()
+    assert len(sd) == 49 and sum(v.numel() for v in sd.values()) == 5036835   # SURVEY B-1
+    assert sd['damping'].shape == (1, 3)
+    assert sd['SatFeatureNet.conv_dec1.1.weight'].shape == (128, 384, 3, 3)
+    assert sd['GrdFeatureNet.conf3.1.weight'].shape == (1, 16, 3, 3)
