@@ -1,0 +1,183 @@
+#!/usr/bin/env python3
+"""bench.py -- image-pairs/sec through the N-iter LM pose loop (BASELINE.json metric).
+
+One "step" = one pass of the hot path over one synthetic batch already resident in HBM:
+LM_S2GP.forward(sat, grd, mode='test') = two VGG16-U-Nets (bf16 MFMA) + 15 fused
+projection/Jacobian/normal-equation/solve steps.  Workload at N=1: BASELINE configs[1]
+(KITTI shapes, batch 32 per GPU, VGG-16 two-branch, 5 LM iters, 3-DoF, bf16).
+
+    python bench.py --gpus 1 --steps 10 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Multi-GPU: one process per GPU; the batch shards over ranks with no data-path collective
+(every sample's solve is independent); a barrier + synchronize brackets the timed
+region and the reported time is the MAX over ranks.  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+# dense peaks, /opt/skills/guides/MI355X_MICROARCH.md "Chip-level parameters"
+PEAK_TFLOPS = {'bf16': 2500.0, 'fp32': 157.3}
+PEAK_HBM_GBS = 8000.0
+# conv FLOPs per pair, forward, live outputs at level 3: 272.4 GFLOP
+GFLOP_PER_PAIR_LIVE = 272.4
+
+
+def cpu_baseline(max_seconds=30.0):
+    """Time the CPU oracle (oracle/ref_cpu.py, a port of the reference's PyTorch path) on this host:
+    B=1 KITTI-shape forward(mode='test'), no_grad, fp32, all cores.  Bounded sample."""
+    from oracle import ref_cpu as O
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    net = O.build('kitti', O.default_args(), seed=1)
+    sat, grd, *_ = O.synth_images(101, 1)
+    n, t_tot = 0, 0.0
+    with torch.no_grad():
+        t0 = time.time()
+        net(sat, grd, mode='test')                      # warm-up (also bounds the sample)
+        warm = time.time() - t0
+        reps = max(1, min(3, int(max_seconds / max(warm, 1e-3)) - 1))
+        for _ in range(reps):
+            t0 = time.time()
+            net(sat, grd, mode='test')
+            t_tot += time.time() - t0
+            n += 1
+    return {'value': round(n / t_tot, 4), 'unit': 'pairs/s', 'cores': cores, 'kind': 'port',
+            'sample': f'{n} x (B=1 KITTI-shape forward, mode=test, no_grad, fp32) after 1 warm-up, '
+                      f'torch {torch.__version__} CPU, {torch.get_num_threads()} threads'}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--batch', type=int, default=32, help='pairs per GPU')
+    ap.add_argument('--precision', default='bf16', choices=['bf16', 'fp32'])
+    ap.add_argument('--n-iters', type=int, default=5)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-kernel-timing', action='store_true')
+    a = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    assert torch.cuda.is_available(), 'bench.py needs an MI355X'
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+
+    from types import SimpleNamespace
+    from highlyaccurate_amd import _lib
+    from highlyaccurate_amd.models_kitti import LM_S2GP
+    _lib.load()
+    args = SimpleNamespace(level=3, N_iters=a.n_iters, using_weight=0, loss_method=0, proj='geo', Optimizer='LM',
+                           rotation_range=10.0, shift_range_lat=20.0, shift_range_lon=20.0, damping=0.1,
+                           train_damping=0, dropout=0, use_hessian=0, use_gt_depth=0, visualize=0,
+                           coe_shift_lat=100.0, coe_shift_lon=100.0, coe_heading=100.0, coe_L1=100.0, coe_L2=100.0,
+                           coe_L3=100.0, coe_L4=100.0, estimate_depth=0, precision=a.precision)
+    torch.manual_seed(1234 + rank)
+    net = LM_S2GP(args)
+    # random-init weights of the reference architecture: Kaiming-normal(fan_out), zero bias (torchvision's
+    # non-pretrained VGG init; there is no network for the pretrained checkpoint)
+    for m in net.modules():
+        if isinstance(m, torch.nn.Conv2d):
+            torch.nn.init.kaiming_normal_(m.weight, mode='fan_out', nonlinearity='relu')
+            if m.bias is not None:
+                torch.nn.init.zeros_(m.bias)
+    net = net.to(dev).eval()
+    B = a.batch
+    sat = torch.rand(B, 3, 512, 512, device=dev)
+    grd = torch.rand(B, 3, 256, 1024, device=dev)
+
+    def step():
+        with torch.no_grad():
+            return net(sat, grd, mode='test')
+
+    for _ in range(a.warmup):
+        step()
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    want_kt = (rank == 0) and not a.no_kernel_timing
+    if want_kt:
+        _lib.prof_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        out = step()
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    recs = []
+    if want_kt:
+        _lib.prof_enable(False)
+        recs = _lib.prof_fetch()
+    if dist:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    assert all(torch.isfinite(o).all() for o in out)
+
+    if rank == 0:
+        pairs = B * world * a.steps
+        res = {
+            'metric': 'image-pairs/sec through N-iter LM pose loop, KITTI shapes',
+            'value': round(pairs / dt, 3), 'unit': 'pairs/s', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
+            'ms_per_step': round(dt / a.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': a.precision, 'data': 'synthetic',
+            'config': {'workload': "BASELINE configs[1]: LM_S2GP.forward(mode='test'), KITTI shapes (sat 512x512, grd 256x1024), "
+                                   f"VGG-16 two-branch, level 3, {a.n_iters} LM iters x 3 levels, 3-DoF, random-init weights",
+                       'pairs_per_gpu': B, 'global_batch': B * world, 'parallelism': f'batch-sharded x{world}, no collective'},
+        }
+        # whole-forward conv roofline (live FLOPs; the dead dec3/conf3 branch of VGG.py:153-155 is skipped)
+        res['conv_tflops_live'] = round(GFLOP_PER_PAIR_LIVE * 1e-3 * pairs / world / dt, 2)   # per GPU
+        if recs:
+            agg = {}
+            for name, ms, fl, by in recs:
+                e = agg.setdefault(name, [0, 0.0, 0.0, 0.0])
+                e[0] += 1; e[1] += ms; e[2] += fl; e[3] += by
+            tot_ms = sum(v[1] for v in agg.values())
+            kern = {k: {'launches': v[0], 'avg_us': round(v[1] / v[0] * 1e3, 2), 'share': round(v[1] / tot_ms, 4),
+                        'tflops': round(v[2] / (v[1] * 1e-3) / 1e12, 2) if v[2] else None,
+                        'gbs': round(v[3] / (v[1] * 1e-3) / 1e9, 1) if v[3] else None}
+                    for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])}
+            dom = max((k for k in agg if agg[k][2] > 0), key=lambda k: agg[k][1])
+            n, ms, fl, by = agg[dom]
+            ach = fl / (ms * 1e-3) / 1e12
+            res['roofline'] = {'kernel': dom, 'bound': 'mfma', 'achieved': round(ach, 2), 'peak': PEAK_TFLOPS[a.precision],
+                               'unit': 'TFLOP/s', 'frac': round(ach / PEAK_TFLOPS[a.precision], 4), 'traffic': None,
+                               'launches': n, 'avg_launch_us': round(ms / n * 1e3, 2),
+                               'flops_per_launch': round(fl / n / 1e9, 3), 'flops_unit': 'GFLOP'}
+            lm = [k for k in agg if k.startswith('lm_accum')]
+            if lm:
+                lms, lby = sum(agg[k][1] for k in lm), sum(agg[k][3] for k in lm)
+                res['lm_roofline'] = {'kernel': 'lm_accum<*>', 'bound': 'hbm', 'achieved': round(lby / (lms * 1e-3) / 1e9, 1),
+                                      'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'frac': round(lby / (lms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)}
+            res['kernels'] = kern
+        if not a.no_cpu_baseline:
+            res['cpu_baseline'] = cpu_baseline()
+        print(json.dumps(res), flush=True)
+    if dist:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

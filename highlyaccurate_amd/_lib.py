@@ -38,6 +38,10 @@ class S2GConfig(C.Structure):
                 ('damping', C.c_double * 3)]
 
 
+class ProfRecord(C.Structure):
+    _fields_ = [('kernel_id', C.c_int), ('ms', C.c_float), ('flops', C.c_double), ('bytes', C.c_double)]
+
+
 _lib = None
 
 
@@ -63,8 +67,28 @@ def load() -> C.CDLL:
     lib.hla_s2g_workspace_bytes.argtypes = [C.POINTER(S2GConfig), C.POINTER(S2GLevel), i]
     lib.hla_s2g_lm_solve.restype = i
     lib.hla_s2g_lm_solve.argtypes = [C.POINTER(S2GConfig), C.POINTER(S2GLevel), vp, vp, vp, vp, vp, vp, vp, sz, i, vp]
+    lib.hla_prof_enable.restype = i
+    lib.hla_prof_enable.argtypes = [i]
+    lib.hla_prof_kernel_name.restype = C.c_char_p
+    lib.hla_prof_kernel_name.argtypes = [i]
+    lib.hla_prof_fetch.restype = i
+    lib.hla_prof_fetch.argtypes = [C.POINTER(ProfRecord), i, C.POINTER(i)]
     _lib = lib
     return lib
+
+
+def prof_enable(on: bool) -> None:
+    load().hla_prof_enable(1 if on else 0)
+
+
+def prof_fetch(max_records: int = 1 << 16):
+    """Synchronise and return [(kernel_name, ms, flops, bytes)] for every launch since the last fetch."""
+    lib = load()
+    buf = (ProfRecord * max_records)()
+    n = C.c_int(0)
+    lib.hla_prof_fetch(buf, max_records, C.byref(n))
+    return [(lib.hla_prof_kernel_name(buf[k].kernel_id).decode(), buf[k].ms, buf[k].flops, buf[k].bytes)
+            for k in range(n.value)]
 
 
 def check(rc: int, what: str) -> None:

@@ -96,10 +96,13 @@ class S2GPBase(nn.Module):
 
     # -- geometry tables ---------------------------------------------------------------------
     def xyz_tables(self, grd_H: int, grd_W: int, device):
+        """Per-level ground-plane tables.  K is given for a 256x1024 image (models_kitti.py:657-667); the
+        table of level l is grd_img2cam(H/2^(3-l), W/2^(3-l), 256, 1024): identical to the reference for its
+        own 256x1024 input, and the same camera resampled for any other input size (BASELINE config 5)."""
         key = (grd_H, grd_W, str(device))
         if key not in self._tables:
             K = ford_K_network_input() if self.ford else KITTI_K
-            self._tables[key] = [ground_plane_table(K, grd_H / 2 ** (3 - l), grd_W / 2 ** (3 - l), grd_H, grd_W).to(device)
+            self._tables[key] = [ground_plane_table(K, grd_H / 2 ** (3 - l), grd_W / 2 ** (3 - l), 256, 1024).to(device)
                                  for l in range(3)]
         return self._tables[key]
 

@@ -271,10 +271,12 @@ __global__ __launch_bounds__(64) void lm_solve(SolveArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------
-static int pick_tile(int npix, int B) {
-  int tp = MAX_TP;
-  while (tp > 32 && (long)((npix + tp - 1) / tp) * B < 2048) tp >>= 1;
-  return tp;
+// Pixels per block.  Depends on the level only, never on the batch size, so that a sample's partial-sum
+// grouping -- and therefore its pose, bit for bit -- does not depend on its batch mates.
+static int pick_tile(int npix, int /*B*/) {
+  if (npix >= 16384) return 256;
+  if (npix >= 4096) return 128;
+  return 64;
 }
 
 static size_t ws_layout(const hla_s2g_config* cfg, const hla_s2g_level* lv, int B, size_t* off_coef, size_t* off_pose,
@@ -364,8 +366,11 @@ extern "C" int hla_s2g_lm_solve(const hla_s2g_config* cfg, const hla_s2g_level* 
     aa.TP = pick_tile(aa.npix, B); aa.nt = (aa.npix + aa.TP - 1) / aa.TP; aa.B = B;
     aa.xcd_affine = (B >= 8) ? 1 : 0;
     const int nblk = aa.xcd_affine ? 8 * ((B + 7) / 8) * aa.nt : B * aa.nt;
+    hla_prof_begin(v.C == 256 ? K_LM256 : v.C == 128 ? K_LM128 : v.C == 64 ? K_LM64 : K_LM16, 0,
+                   (double)B * ((double)v.A * v.A + (double)aa.npix) * v.C * 4.0, st);
     if (cfg->using_weight) launch_accum<true>(v.C, dim3(nblk), st, aa);
     else launch_accum<false>(v.C, dim3(nblk), st, aa);
+    hla_prof_end(st);
 
     sa.part = part; sa.nt = aa.nt;
     sa.trace_out = trace + ((size_t)it * L + l) * 3; sa.trace_stride = N * L * 3;
@@ -376,7 +381,9 @@ extern "C" int hla_s2g_lm_solve(const hla_s2g_config* cfg, const hla_s2g_level* 
     } else {
       sa.coef = nullptr;
     }
+    hla_prof_begin(K_LMSOLVE, 0, (double)B * aa.nt * PART_N * 8.0, st);
     hipLaunchKernelGGL(lm_solve, dim3(B), dim3(64), 0, st, sa);
+    hla_prof_end(st);
   }
   HLA_CHECK_HIP(hipGetLastError());
   return HLA_OK;

@@ -434,6 +434,10 @@ static void launch_conv(hipStream_t st, ConvArgs a, bool pool) {
   a.tiles_x = (a.W + 31) / 32;
   a.tiles_y = (a.H + 7) / 8;
   const dim3 grid(a.tiles_x * a.tiles_y * a.B, a.Cout >= 128 ? a.Cout / 128 : 1);
+  const size_t es = sizeof(T), P = (size_t)a.B * a.H * a.W, Po = pool ? P / 4 : P;
+  const double flops = 2.0 * 9.0 * (a.C1 + a.C2) * a.Cout * (double)P;
+  const double bytes = (double)P * ((a.up1 ? a.C1 / 4.0 : a.C1) + a.C2) * es + (double)Po * a.Cout * ((a.out_act ? es : 0) + (a.out_raw ? 4 : 0));
+  hla_prof_begin(a.Cout >= 128 ? (pool ? K_CONV_NT2_POOL : K_CONV_NT2) : (pool ? K_CONV_NT1_POOL : K_CONV_NT1), flops, bytes, st);
   if (a.Cout >= 128) {
     if (pool) hipLaunchKernelGGL((conv3x3_kernel<T, 4, 2, 2, 2, true>), grid, dim3(256), 0, st, a);
     else hipLaunchKernelGGL((conv3x3_kernel<T, 4, 2, 2, 2, false>), grid, dim3(256), 0, st, a);
@@ -441,6 +445,7 @@ static void launch_conv(hipStream_t st, ConvArgs a, bool pool) {
     if (pool) hipLaunchKernelGGL((conv3x3_kernel<T, 4, 1, 2, 2, true>), grid, dim3(256), 0, st, a);
     else hipLaunchKernelGGL((conv3x3_kernel<T, 4, 1, 2, 2, false>), grid, dim3(256), 0, st, a);
   }
+  hla_prof_end(st);
 }
 
 template <typename T>
@@ -450,8 +455,10 @@ static int vgg_forward_t(const float* x, const hla_vgg_params* prm, float* const
   for (int l = 0; l < 11; ++l) {
     const size_t n = l == 0 ? (size_t)2 * 32 * 32 : (size_t)kLayers[l].cin * kLayers[l].cout * 9;
     const int grid = (int)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024);
+    hla_prof_begin(K_PACK, 0, (double)n * (4 + sizeof(T)), st);
     hipLaunchKernelGGL((pack_weights_kernel<T>), dim3(grid), dim3(256), 0, st, prm->w[l], (T*)(ws + pl.wpk[l]),
                        kLayers[l].cout, kLayers[l].cin, l == 0 ? 1 : 0);
+    hla_prof_end(st);
   }
   auto W_ = [&](int l) { return (const uint4*)(ws + pl.wpk[l]); };
   // 2. conv0
@@ -459,7 +466,10 @@ static int vgg_forward_t(const float* x, const hla_vgg_params* prm, float* const
     Conv0Args a{};
     a.x = x; a.wpk = W_(0); a.bias = prm->b[0]; a.out_act = ws + pl.a0; a.B = B; a.H = H; a.W = W;
     a.tiles_x = (W + 31) / 32; a.tiles_y = (H + 7) / 8;
+    const double P = (double)B * H * W;
+    hla_prof_begin(K_CONV0, 2.0 * 27 * 64 * P, P * (3 * 4 + 64 * sizeof(T)), st);
     hipLaunchKernelGGL((conv0_kernel<T>), dim3(a.tiles_x * a.tiles_y * B), dim3(256), 0, st, a);
+    hla_prof_end(st);
   }
   auto conv = [&](int l, const void* s1, int C1, int H_, int W_h, void* act, int relu, bool pool, const void* s2 = nullptr,
                   int C2 = 0, int up1 = 0, float* raw = nullptr, double* ss = nullptr) {
@@ -496,8 +506,10 @@ static int vgg_forward_t(const float* x, const hla_vgg_params* prm, float* const
       const int ppb = 256 / (Cs[l] / EPL);
       const size_t npix = (size_t)B * hs[l] * wsz[l];
       const int grid = (int)((npix + ppb - 1) / ppb < 4096 ? (npix + ppb - 1) / ppb : 4096);
+      hla_prof_begin(K_CONF, 2.0 * 9 * Cs[l] * (double)npix, (double)npix * (Cs[l] * sizeof(T) + 4), st);
       hipLaunchKernelGGL((conf_kernel<T>), dim3(grid), dim3(256), 9 * Cs[l] * sizeof(float), st, acts[l],
                          prm->w[13 + l], conf[l], B, hs[l], wsz[l], Cs[l]);
+      hla_prof_end(st);
     }
   }
   // L2 normalisation of the three returned maps, in place
@@ -507,8 +519,10 @@ static int vgg_forward_t(const float* x, const hla_vgg_params* prm, float* const
       if (!feat[l]) continue;
       int bps = (int)(per[l] / 4 / 256 / 4);
       bps = bps < 1 ? 1 : (bps > 64 ? 64 : bps);
+      hla_prof_begin(K_L2NORM, 0, (double)B * per[l] * 8, st);
       hipLaunchKernelGGL(l2norm_kernel, dim3(B * bps), dim3(256), 0, st, feat[l], (const double*)(w + pl.ss[l]),
                          pl.np[l], per[l], bps);
+      hla_prof_end(st);
     }
   }
   HLA_CHECK_HIP(hipGetLastError());

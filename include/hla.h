@@ -123,6 +123,22 @@ int hla_s2g_lm_solve(const hla_s2g_config* cfg, const hla_s2g_level* levels, con
                      const float* T_FL, const float* pose0, const float* rand_uv, float* trace,
                      double* normal_eq, void* workspace, size_t workspace_bytes, int B, hla_stream_t stream);
 
+/* ------------------------------------------------------------------------- *
+ * Measurement hooks (no reference counterpart; used by bench.py for the roofline numbers).
+ * When enabled, every kernel launch of the entry points above is bracketed by two hipEvents
+ * on its own stream; hla_prof_fetch synchronises them and returns one record per launch.
+ * ------------------------------------------------------------------------- */
+#define HLA_PROF_NKERNELS 14
+typedef struct hla_prof_record {
+  int kernel_id;  /* index for hla_prof_kernel_name */
+  float ms;       /* event-to-event duration on the launch stream */
+  double flops;   /* algorithmic FLOPs of the launch (2*9*Cin*Cout*H*W*B for a conv), else 0 */
+  double bytes;   /* algorithmic HBM bytes of the launch (maps read once + outputs), else 0 */
+} hla_prof_record;
+int hla_prof_enable(int on);
+const char* hla_prof_kernel_name(int kernel_id);
+int hla_prof_fetch(hla_prof_record* out, int max_records, int* n_out); /* also clears the log */
+
 #ifdef __cplusplus
 }
 #endif

@@ -123,10 +123,11 @@ def gen_kat(mk, mf, jac, VGG):
     pose = torch.tensor([[0.31], [-0.72]]), torch.tensor([[-0.55], [0.18]]), torch.tensor([[0.83], [-0.4]])
     for level, A in ((0, 64), (2, 256)):
         uvk, mask, ju, jv, jt = netk.grd2cam2world2sat(pose[0], pose[1], pose[2], level, A, require_jac=True)
-        out[f'kitti_uv_l{level}'] = uvk.detach().numpy()
-        out[f'kitti_jac_l{level}'] = torch.stack([ju, jv, jt]).detach().numpy()
-        out[f'kitti_mask_l{level}'] = mask.numpy()
-        out[f'kitti_xyz_l{level}'] = netk.xyz_grds[level][0].detach().numpy()
+        st = 1 if level == 0 else 8      # level 2 is stored on a stride-8 pixel lattice to keep the fixture small
+        out[f'kitti_uv_l{level}'] = uvk.detach().numpy()[:, ::st, ::st]
+        out[f'kitti_jac_l{level}'] = torch.stack([ju, jv, jt]).detach().numpy()[:, :, ::st, ::st]
+        out[f'kitti_mask_l{level}'] = mask.numpy()[:, ::st, ::st]
+        out[f'kitti_xyz_l{level}'] = netk.xyz_grds[level][0].detach().numpy()[:, ::st, ::st]
     netf = mf.LM_S2GP_Ford(args)
     torch.autograd.set_detect_anomaly(False)
     R_FL = torch.tensor([[[0., 0., 1.], [1., 0., 0.], [0., 1., 0.]]]).repeat(2, 1, 1)
@@ -134,10 +135,11 @@ def gen_kat(mk, mf, jac, VGG):
     for level, A in ((0, 64), (2, 256)):
         uvf, mask, ju, jv, jt = netf.cam2body2world2sat(R_FL, T_FL, pose[0], pose[1], pose[2], level, 112.64, A,
                                                         require_jac=True)
-        out[f'ford_uv_l{level}'] = uvf.detach().numpy()
-        out[f'ford_jac_l{level}'] = torch.stack([ju, jv, jt]).detach().numpy()
-        out[f'ford_mask_l{level}'] = mask.numpy()
-        out[f'ford_xyz_l{level}'] = netf.xyz_grds[level][0].detach().numpy()
+        st = 1 if level == 0 else 8
+        out[f'ford_uv_l{level}'] = uvf.detach().numpy()[:, ::st, ::st]
+        out[f'ford_jac_l{level}'] = torch.stack([ju, jv, jt]).detach().numpy()[:, :, ::st, ::st]
+        out[f'ford_mask_l{level}'] = mask.numpy()[:, ::st, ::st]
+        out[f'ford_xyz_l{level}'] = netf.xyz_grds[level][0].detach().numpy()[:, ::st, ::st]
     out.update(geo_pose=torch.stack(pose).numpy(), ford_R=R_FL.numpy(), ford_T=T_FL.numpy())
 
     # (3) LM_update on small random tensors, option sweep

@@ -410,9 +410,10 @@ class _S2GPBase(nn.Module):
             self.damping = nn.Parameter(torch.zeros(()))
         oh, ow = grd_hw
         K = ford_K_256x1024() if self.ford else KITTI_K
-        # the K tables are expressed for a 256x1024 image; other sizes (BASELINE config 5)
-        # rescale exactly as the reference's own grd_img2cam(h, w, ori_h, ori_w) call would.
-        self.xyz_grds = [ground_points(K, oh / 2 ** (3 - l), ow / 2 ** (3 - l), oh, ow) for l in range(4)]
+        # K is expressed for a 256x1024 image (models_kitti.py:657-667).  For the reference's own input size
+        # this is exactly grd_img2cam(h_l, w_l, 256, 1024); for any other size the same call rescales the
+        # intrinsics to the level grid, i.e. the image is treated as a resampled view of the same camera.
+        self.xyz_grds = [ground_points(K, oh / 2 ** (3 - l), ow / 2 ** (3 - l), 256, 1024) for l in range(4)]
         self.trace = None
 
     # level index into xyz_grds for feature-list position `pos`
