@@ -133,7 +133,8 @@ def main():
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
-    assert all(torch.isfinite(o).all() for o in out)
+    if not os.environ.get('HLA_BENCH_NOCHECK'):     # timing-ablation builds (tools/variants.py) produce garbage
+        assert all(torch.isfinite(o).all() for o in out)
 
     if rank == 0:
         pairs = B * world * a.steps

@@ -30,40 +30,69 @@ def _dtype_code(precision: str) -> int:
     raise ValueError(f"precision must be 'fp32' or 'bf16', got {precision!r}")
 
 
-def vgg_forward_nhwc(module: 'VGGUnet', x: torch.Tensor, want_conf: bool = True):
-    """Run the three-level extractor.  Returns (feats, confs): lists of NHWC fp32 tensors
-    [B,h,w,C] (L2-normalised) and [B,h,w] (or None)."""
+def _param_table(module: 'VGGUnet'):
+    sd = dict(module.named_parameters())
+    prm = _lib.VggParams()
+    keep, versions = [], []
+    for i, name in enumerate(_W_ORDER):
+        w = sd[name + '.weight']
+        versions.append((w.data_ptr(), w._version))
+        w = w.detach().contiguous().float()
+        keep.append(w)
+        prm.w[i] = w.data_ptr()
+        if i < 7:
+            b = sd[name + '.bias']
+            b = b.detach().contiguous().float()
+            keep.append(b)
+            prm.b[i] = b.data_ptr()
+    return prm, keep, tuple(versions)
+
+
+def _packed_weights(module: 'VGGUnet', prm, versions, dt: int, device):
+    """MFMA-fragment-ordered copy of the conv weights, rebuilt only when a parameter changed
+    (tensor version counters / storage pointers), e.g. after an optimizer step or load_state_dict."""
+    key = (dt, str(device), versions)
+    cache = module.__dict__.setdefault('_hla_packed', {})
+    if cache.get('key') != key:
+        lib = _lib.load()
+        buf = cache.get('buf')
+        nbytes = lib.hla_vgg_packed_weight_bytes(dt)
+        if buf is None or buf.numel() != nbytes or buf.device != device:
+            buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        _lib.check(lib.hla_vgg_pack_weights(C.byref(prm), _lib.ptr(buf), dt, _lib.stream_ptr()), 'hla_vgg_pack_weights')
+        cache['key'], cache['buf'] = key, buf
+    return cache['buf']
+
+
+def vgg_forward_nhwc(module: 'VGGUnet', x: torch.Tensor, want_conf: bool = True, defer_norm: bool = False):
+    """Run the three-level extractor.  Returns (feats, confs, inv_norm): lists of NHWC fp32 tensors
+    [B,h,w,C] and [B,h,w] (or None), and inv_norm [3,B] fp64 = 1/max(||map||, 1e-12).
+    With ``defer_norm`` the maps are left un-normalised (the LM loop folds inv_norm into its sums);
+    otherwise they are L2-normalised per sample like the reference's (VGG.py:172-175)."""
     _lib.require_gpu(x, 'VGGUnet input')
     if x.dim() != 4 or x.shape[1] != 3:
         raise ValueError(f'expected [B,3,H,W], got {tuple(x.shape)}')
     lib = _lib.load()
     x = x.contiguous().float()
     B, _, H, W = x.shape
-    sd = dict(module.named_parameters())
-    prm = _lib.VggParams()
-    keep = []
-    for i, name in enumerate(_W_ORDER):
-        w = sd[name + '.weight'].detach().contiguous().float()
-        keep.append(w)
-        prm.w[i] = w.data_ptr()
-        if i < 7:
-            b = sd[name + '.bias'].detach().contiguous().float()
-            keep.append(b)
-            prm.b[i] = b.data_ptr()
     dt = _dtype_code(module.precision)
+    prm, keep, versions = _param_table(module)
+    packed = _packed_weights(module, prm, versions, dt, x.device)
     feats = [torch.empty(B, H >> (3 - l), W >> (3 - l), _CH[l], device=x.device, dtype=torch.float32) for l in range(3)]
     confs = [torch.empty(B, H >> (3 - l), W >> (3 - l), device=x.device, dtype=torch.float32) if want_conf else None
              for l in range(3)]
+    inv_norm = torch.empty(3, B, device=x.device, dtype=torch.float64)
     fp = (C.c_void_p * 4)(*[f.data_ptr() for f in feats], 0)
     cp = (C.c_void_p * 4)(*[(c.data_ptr() if c is not None else 0) for c in confs], 0)
     nbytes = lib.hla_vgg_workspace_bytes(B, H, W, 3, dt)
     ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
-    rc = lib.hla_vgg_forward(_lib.ptr(x), C.byref(prm), fp, cp, _lib.ptr(ws), nbytes, B, H, W, 3, dt,
-                             _lib.HLA_VGG_WANT_CONF if want_conf else 0, _lib.stream_ptr())
+    flags = (_lib.HLA_VGG_WANT_CONF if want_conf else 0) | (_lib.HLA_VGG_DEFER_NORM if defer_norm else 0)
+    rc = lib.hla_vgg_forward(_lib.ptr(x), C.byref(prm), _lib.ptr(packed), fp, cp, _lib.ptr(inv_norm), _lib.ptr(ws), nbytes,
+                             B, H, W, 3, dt, flags, _lib.stream_ptr())
     _lib.check(rc, 'hla_vgg_forward')
-    # ws / packed weights are only used by work already enqueued on this stream; the caching allocator
-    # keeps the block stream-ordered, so dropping the Python reference here is safe.
-    return feats, confs
+    # ws is only used by work already enqueued on this stream; the caching allocator keeps the block
+    # stream-ordered, so dropping the Python reference here is safe.
+    return feats, confs, inv_norm
 
 
 class VGGUnet(nn.Module):
@@ -91,7 +120,7 @@ class VGGUnet(nn.Module):
         self.conf3 = nn.Sequential(nn.ReLU(), c(16, 1, False), nn.Sigmoid())
 
     def forward(self, x):
-        feats, confs = vgg_forward_nhwc(self, x, want_conf=True)
+        feats, confs, _ = vgg_forward_nhwc(self, x, want_conf=True)
         sel = _LEVEL_SEL[self.level]
         # NCHW-shaped views over the NHWC storage
         return [feats[i].permute(0, 3, 1, 2) for i in sel], [confs[i].unsqueeze(1) for i in sel]

@@ -11,10 +11,11 @@ import os
 import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, 'libhla.so')
+LIB_PATH = os.environ.get('HLA_LIB') or os.path.join(HERE, 'libhla.so')   # HLA_LIB: experiment builds
 
 HLA_F32, HLA_BF16 = 0, 1
-HLA_VGG_WANT_CONF, HLA_VGG_KEEP_RAW = 1, 2
+HLA_VGG_WANT_CONF, HLA_VGG_DEFER_NORM = 1, 2
+ABI_VERSION = 2
 
 
 class HlaError(RuntimeError):
@@ -27,6 +28,7 @@ class VggParams(C.Structure):
 
 class S2GLevel(C.Structure):
     _fields_ = [('sat_feat', C.c_void_p), ('grd_feat', C.c_void_p), ('grd_conf', C.c_void_p), ('xyz', C.c_void_p),
+                ('sat_inv_norm', C.c_void_p), ('grd_inv_norm', C.c_void_p),
                 ('A', C.c_int), ('h', C.c_int), ('w', C.c_int), ('C', C.c_int), ('row0', C.c_int),
                 ('meter_per_pixel', C.c_double), ('centre', C.c_double)]
 
@@ -60,7 +62,12 @@ def load() -> C.CDLL:
     lib.hla_vgg_workspace_bytes.restype = sz
     lib.hla_vgg_workspace_bytes.argtypes = [i, i, i, i, i]
     lib.hla_vgg_forward.restype = i
-    lib.hla_vgg_forward.argtypes = [vp, C.POINTER(VggParams), C.POINTER(vp), C.POINTER(vp), vp, sz, i, i, i, i, i, i, vp]
+    lib.hla_vgg_forward.argtypes = [vp, C.POINTER(VggParams), vp, C.POINTER(vp), C.POINTER(vp), vp, vp, sz,
+                                    i, i, i, i, i, i, vp]
+    lib.hla_vgg_packed_weight_bytes.restype = sz
+    lib.hla_vgg_packed_weight_bytes.argtypes = [i]
+    lib.hla_vgg_pack_weights.restype = i
+    lib.hla_vgg_pack_weights.argtypes = [C.POINTER(VggParams), vp, i, vp]
     lib.hla_grid_sample.restype = i
     lib.hla_grid_sample.argtypes = [vp, vp, vp, vp, vp, i, i, i, i, i, i, i, vp]
     lib.hla_s2g_workspace_bytes.restype = sz

@@ -145,8 +145,10 @@ class S2GPBase(nn.Module):
             draws.append(torch.stack([ru[:, 0], rv[:, 0]], 0))
         return torch.stack(draws, 0).to(device)
 
-    def lm_solve(self, sat_feats, grd_feats, grd_confs, grd_hw, extra=None, level_first=0, init_pose=None):
-        """sat_feats/grd_feats: NHWC fp32 lists; returns trace [B,N_iters,L,3] = (shift_u, shift_v, theta)."""
+    def lm_solve(self, sat_feats, grd_feats, grd_confs, grd_hw, extra=None, level_first=0, init_pose=None,
+                 sat_inv_norm=None, grd_inv_norm=None):
+        """sat_feats/grd_feats: NHWC fp32 lists (L2-normalised, or raw together with their [L,B] fp64
+        inverse norms); returns trace [B,N_iters,L,3] = (shift_u, shift_v, theta)."""
         lib = _lib.load()
         dev = sat_feats[0].device
         B = sat_feats[0].shape[0]
@@ -161,6 +163,8 @@ class S2GPBase(nn.Module):
             lv[l].sat_feat, lv[l].grd_feat = s.data_ptr(), g.data_ptr()
             lv[l].grd_conf = grd_confs[l].data_ptr() if (self.using_weight and grd_confs[l] is not None) else 0
             lv[l].xyz = tables[l].data_ptr()
+            lv[l].sat_inv_norm = sat_inv_norm[l].data_ptr() if sat_inv_norm is not None else 0
+            lv[l].grd_inv_norm = grd_inv_norm[l].data_ptr() if grd_inv_norm is not None else 0
             lv[l].A, lv[l].h, lv[l].w, lv[l].C, lv[l].row0 = A, h, w, Cn, h // 2
             if self.ford:
                 lv[l].meter_per_pixel = float(extra['side_m']) / A          # models_ford.py:230
@@ -184,10 +188,13 @@ class S2GPBase(nn.Module):
         self.last_trace, self.last_normal_eq = trace, neq
         return trace
 
-    def _features(self, sat_map, grd_img, want_conf):
-        sat_feats, _ = vgg_forward_nhwc(self.SatFeatureNet, sat_map, want_conf=False)
-        grd_feats, grd_confs = vgg_forward_nhwc(self.GrdFeatureNet, grd_img, want_conf=want_conf)
-        return sat_feats, grd_feats, grd_confs
+    def localise(self, sat_map, grd_img, want_conf, extra, level_first, init_pose):
+        """Both feature pyramids (normalisation deferred into the LM sums) + the whole LM loop."""
+        sat_feats, _, sat_inv = vgg_forward_nhwc(self.SatFeatureNet, sat_map, want_conf=False, defer_norm=True)
+        grd_feats, grd_confs, grd_inv = vgg_forward_nhwc(self.GrdFeatureNet, grd_img, want_conf=want_conf, defer_norm=True)
+        trace = self.lm_solve(sat_feats, grd_feats, grd_confs, grd_img.shape[-2:], extra, level_first, init_pose,
+                              sat_inv, grd_inv)
+        return trace, grd_confs
 
     def _check_train_supported(self):
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):

@@ -48,7 +48,13 @@ def _resource_table(text: str) -> None:
               f"lds {r.get('LDS','?')}")
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
+def build(force: bool = False, verbose: bool = False, variant: int = 0) -> str:
+    """variant != 0 builds an experiment library libhla_v<variant>.so with -DCONV_VARIANT=<variant>
+    (select it at run time with HLA_LIB=<path>)."""
+    global LIB
+    if variant:
+        LIB = os.path.join(HERE, f'libhla_v{variant}.so')
+        force = True
     if not force and not _stale():
         return LIB
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
@@ -56,8 +62,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
     procs = []
     os.makedirs(os.path.join(HERE, 'build'), exist_ok=True)
     for s in SOURCES:
-        o = os.path.join(HERE, 'build', s.replace('.hip', '.o'))
-        cmd = [hipcc, *FLAGS, '-c', os.path.join(CSRC, s), '-o', o]
+        o = os.path.join(HERE, 'build', s.replace('.hip', f'.v{variant}.o'))
+        cmd = [hipcc, *FLAGS, f'-DCONV_VARIANT={variant}', '-c', os.path.join(CSRC, s), '-o', o]
         if verbose:
             cmd.insert(1, '-Rpass-analysis=kernel-resource-usage')
             print(' '.join(cmd), flush=True)
@@ -77,4 +83,5 @@ def build(force: bool = False, verbose: bool = False) -> str:
 
 
 if __name__ == '__main__':
-    print(build(force='--force' in sys.argv, verbose='--verbose' in sys.argv))
+    _v = [int(a.split('=')[1]) for a in sys.argv if a.startswith('--variant=')]
+    print(build(force='--force' in sys.argv, verbose='--verbose' in sys.argv, variant=_v[0] if _v else 0))

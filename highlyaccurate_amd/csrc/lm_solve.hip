@@ -153,6 +153,8 @@ __global__ __launch_bounds__(256) void lm_accum(AccumArgs a) {
 // ---------------------------------------------------------------------------------------------
 struct SolveArgs {
   const double* part;   // [B,nt,PART_N] of the step being closed, or null (init launch)
+  const double* sat_inv; // [B] or null: feature maps are stored un-normalised, sums are rescaled here
+  const double* grd_inv;
   int nt;
   float* pose;          // [B,3] running pose (shift_u, shift_v, theta), fp32 like the reference
   float* trace_out;     // &trace[0][iter][level][0] of this step (sample stride = trace_stride)
@@ -201,6 +203,11 @@ __global__ __launch_bounds__(64) void lm_solve(SolveArgs a) {
     for (int k = 0; k < 14; ++k) s[k] = wave_sum_f64(s[k]);
 
     if (lane == 0) {
+      // deferred L2_norm (VGG.py:511-514): s -> as*s, J -> as*J, g -> ag*g
+      const double as = a.sat_inv ? a.sat_inv[b] : 1.0, ag = a.grd_inv ? a.grd_inv[b] : 1.0;
+      s[0] *= as * as; s[1] *= ag * ag;
+      for (int k = 2; k < 11; ++k) s[k] *= as * as;
+      for (int k = 11; k < 14; ++k) s[k] *= as * ag;
       if (a.normal_eq) {
         for (int k = 0; k < 14; ++k) a.normal_eq[(size_t)b * 16 + k] = s[k];
         a.normal_eq[(size_t)b * 16 + 14] = 0.0; a.normal_eq[(size_t)b * 16 + 15] = 0.0;
@@ -372,7 +379,7 @@ extern "C" int hla_s2g_lm_solve(const hla_s2g_config* cfg, const hla_s2g_level* 
     else launch_accum<false>(v.C, dim3(nblk), st, aa);
     hla_prof_end(st);
 
-    sa.part = part; sa.nt = aa.nt;
+    sa.part = part; sa.nt = aa.nt; sa.sat_inv = v.sat_inv_norm; sa.grd_inv = v.grd_inv_norm;
     sa.trace_out = trace + ((size_t)it * L + l) * 3; sa.trace_stride = N * L * 3;
     sa.rand_uv = reinit ? rand_uv + (size_t)k * 2 * B : nullptr;
     sa.normal_eq = normal_eq ? normal_eq + (size_t)k * B * 16 : nullptr;

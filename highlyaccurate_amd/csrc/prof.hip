@@ -10,8 +10,8 @@ std::vector<Rec> g_recs;
 std::mutex g_mu;
 bool g_on = false;
 const char* kNames[HLA_PROF_NKERNELS] = {
-    "pack_weights_kernel", "conv0_kernel", "conv3x3_kernel<MT4,NT2>", "conv3x3_kernel<MT4,NT2,pool>",
-    "conv3x3_kernel<MT4,NT1>", "conv3x3_kernel<MT4,NT1,pool>", "conf_kernel", "l2norm_kernel",
+    "pack_weights_kernel", "conv02_kernel", "conv3x3_kernel<MT4,NT2>", "conv3x3_kernel<MT4,NT2,pool>",
+    "conv3x3_kernel<MT4,NT1>", "conv3x3_kernel<MT4,NT1,pool>", "conf_kernel", "inv_norm+scale_kernel",
     "lm_accum<256>", "lm_accum<128>", "lm_accum<64>", "lm_accum<16>", "lm_solve", "grid_sample_kernel"};
 }  // namespace
 
@@ -20,9 +20,9 @@ bool hla_prof_on() { return g_on; }
 void hla_prof_begin(int id, double flops, double bytes, hipStream_t st) {
   if (!g_on) return;
   Rec r{id, flops, bytes, nullptr, nullptr};
-  hipEventCreate(&r.a);
-  hipEventCreate(&r.b);
-  hipEventRecord(r.a, st);
+  (void)hipEventCreate(&r.a);
+  (void)hipEventCreate(&r.b);
+  (void)hipEventRecord(r.a, st);
   std::lock_guard<std::mutex> lk(g_mu);
   g_recs.push_back(r);
 }
@@ -30,7 +30,7 @@ void hla_prof_begin(int id, double flops, double bytes, hipStream_t st) {
 void hla_prof_end(hipStream_t st) {
   if (!g_on) return;
   std::lock_guard<std::mutex> lk(g_mu);
-  if (!g_recs.empty()) hipEventRecord(g_recs.back().b, st);
+  if (!g_recs.empty()) (void)hipEventRecord(g_recs.back().b, st);
 }
 
 extern "C" int hla_prof_enable(int on) {
@@ -46,10 +46,10 @@ extern "C" int hla_prof_fetch(hla_prof_record* out, int max_records, int* n_out)
   int n = 0;
   for (auto& r : g_recs) {
     float ms = 0.f;
-    if (hipEventSynchronize(r.b) == hipSuccess) hipEventElapsedTime(&ms, r.a, r.b);
+    if (hipEventSynchronize(r.b) == hipSuccess) (void)hipEventElapsedTime(&ms, r.a, r.b);
     if (out && n < max_records) { out[n].kernel_id = r.id; out[n].flops = r.flops; out[n].bytes = r.bytes; out[n].ms = ms; ++n; }
-    hipEventDestroy(r.a);
-    hipEventDestroy(r.b);
+    (void)hipEventDestroy(r.a);
+    (void)hipEventDestroy(r.b);
   }
   g_recs.clear();
   if (n_out) *n_out = n;

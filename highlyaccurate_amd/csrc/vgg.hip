@@ -1,17 +1,20 @@
 // VGG16-U-Net feature extractor on gfx950 matrix cores: VGG.py:13-203, L2_norm VGG.py:511-514.
 //
-// Layout: activations NHWC; T = bf16 (perf mode, fp32 accumulate) or float (exact-fp32 MFMA, parity mode).
+// Layout: activations NHWC; T = bf16 (throughput mode, fp32 accumulate) or float (exact-fp32 MFMA, parity mode).
 //
-// conv3x3_kernel -- implicit GEMM, D^T = W * X^T so that a lane owns one output pixel and 4 consecutive
-//   output channels per accumulator quad:
-//     M (MFMA rows)  = 32 output channels        (A operand = weight fragment, straight from global/L2,
-//                                                 pre-packed in fragment order: one coalesced 1 KiB load)
-//     N (MFMA cols)  = 32 consecutive pixels of one image row (B operand = pixel fragment from the LDS halo tile)
-//     K              = 9 taps x Cin, walked as  chunk(128 B of channels) -> tap -> 4 k-groups of 16 B
-//   The (TH+2)x34 input halo tile of one channel chunk is staged once in LDS (144-B pixel stride: conflict-free
-//   ds_read_b128) and reused by all 9 taps; the next chunk is prefetched into registers during the MFMAs.
-//   Loader handles "virtual concat + nearest 2x upsample" (VGG.py:144-151) without materialising it.
-//   Epilogue fuses bias, 2x2 max-pool, ReLU, the raw fp32 feature copy and its per-sample sum of squares.
+// conv3x3_kernel -- implicit GEMM computed as D^T = W * X^T, so a lane owns one output pixel and four
+//   consecutive output channels per accumulator quad:
+//     M (MFMA rows) = 32 output channels   A operand = weight fragment, straight from L2/L1: weights are
+//                                          pre-packed in fragment order, so a fragment is one coalesced 1 KiB load
+//     N (MFMA cols) = 32 consecutive pixels of one image row; B operand = pixel fragment from the LDS halo tile
+//     K             = 9 taps x Cin, walked as  stage (64 B of channels) -> tap -> 2 k-groups of 16 B per lane
+//   The (TH+2)x34 input halo tile of a stage is written to LDS once (80-B pixel stride: conflict-free
+//   ds_read_b128) and reused by all 9 taps; LDS is double-buffered, one barrier per stage; the next stage's
+//   tile is prefetched into registers mid-stage; weights are prefetched 1-2 taps ahead into a register ring.
+//   The loader handles "virtual concat + nearest 2x upsample" (VGG.py:144-151) without materialising it.
+//   The epilogue fuses bias, 2x2 max-pool, ReLU, the raw fp32 feature copy and its per-sample sum of squares.
+// conv02_kernel -- conv0 (3->64 on the NCHW fp32 input, K = 27 padded to 32) computed by MFMA directly into the
+//   LDS halo tile of conv2, then conv2 + pool: the 64-channel full-resolution map never touches HBM.
 #include "common.h"
 
 typedef __bf16 bf16;
@@ -57,7 +60,19 @@ struct ConvArgs {
 constexpr int HWID = 34;   // halo tile width in pixels
 constexpr int SB = 64;     // bytes of channels per pixel per pipeline stage
 constexpr int PSTR = 80;   // LDS bytes per halo pixel (64 B of channels + 16 B pad: conflict-free ds_read_b128)
+constexpr int HALO_TAP = 3;  // tap at which the next stage's halo loads are issued
+#ifndef CONV_VARIANT
+#define CONV_VARIANT 0
+#endif
+// timing ablations for tools/variants.py (results are wrong on purpose): 10 no weight loads, 11 no LDS reads,
+// 12 no halo staging, 13 = all three, 14 = 13 + no barrier
+constexpr bool ABL_ALL = (CONV_VARIANT == 13 || CONV_VARIANT == 14);
+constexpr bool ABL_NO_W = (CONV_VARIANT == 10 || ABL_ALL);
+constexpr bool ABL_NO_LDS = (CONV_VARIANT == 11 || ABL_ALL);
+constexpr bool ABL_NO_HALO = (CONV_VARIANT == 12 || ABL_ALL);
+constexpr bool ABL_NO_BAR = (CONV_VARIANT == 14);
 
+// ---------------------------------------------------------------------------------------------
 // shared epilogue: acc[i][j] holds, for lane (x = lane&31, g = lane>>5), output channels
 // cb + j*32 + 8q + 4g + {0..3} (q = r>>2) of pixel (row i, column x).
 template <typename T, int MT, int NT, bool POOL>
@@ -116,7 +131,100 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[MT][NT], const ConvA
   }
 }
 
-template <typename T, int MT, int NT, int WM, int WN, bool POOL>
+// ---------------------------------------------------------------------------------------------
+// One pipeline stage of MFMAs: 9 taps x 2 k-groups against the halo tile at `cur` (already offset to this
+// wave's first row / this lane's pixel + k-half).  Weight fragments come from global memory through a ring of
+// WD+1 register sets filled WD taps ahead; `mid(tap)` runs right after the weight loads of each tap (used to
+// issue the next stage's halo loads BEHIND them: VM loads of a wave retire in order).
+template <typename T, int MT, int NT, int WD>
+struct WeightRing {
+  static constexpr int RS = WD + 1;
+  uint4 wb[RS][2][NT];
+  const uint4* wq[NT];   // per-lane pointer to this stage's fragments of output tile j: [tap][kg][lane]
+
+  __device__ __forceinline__ void prime() {
+#pragma unroll
+    for (int d = 0; d < WD; ++d)
+#pragma unroll
+      for (int kg = 0; kg < 2; ++kg)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) wb[d][kg][j] = wq[j][(d * 2 + kg) * 64];
+  }
+  // after a stage the ring holds taps 0..WD-1 of the next stage in slots (9+d) % RS; rotate them to slot d
+  __device__ __forceinline__ void next_stage() {
+#pragma unroll
+    for (int j = 0; j < NT; ++j) wq[j] += 18 * 64;
+    if (9 % RS != 0) {
+      uint4 tmp[WD][2][NT];
+#pragma unroll
+      for (int d = 0; d < WD; ++d)
+#pragma unroll
+        for (int kg = 0; kg < 2; ++kg)
+#pragma unroll
+          for (int j = 0; j < NT; ++j) tmp[d][kg][j] = wb[(9 + d) % RS][kg][j];
+#pragma unroll
+      for (int d = 0; d < WD; ++d)
+#pragma unroll
+        for (int kg = 0; kg < 2; ++kg)
+#pragma unroll
+          for (int j = 0; j < NT; ++j) wb[d][kg][j] = tmp[d][kg][j];
+    }
+  }
+};
+
+template <typename T, int MT, int NT, int WD, bool PF_UPFRONT, typename Mid>
+__device__ __forceinline__ void stage_mma(f32x16 (&acc)[MT][NT], const char* cur, WeightRing<T, MT, NT, WD>& ring,
+                                          Mid&& mid) {
+  constexpr int RS = WD + 1;
+#pragma unroll
+  for (int tap = 0; tap < 9; ++tap) {
+    const int ky = tap / 3, kx = tap % 3;
+#pragma unroll
+    for (int kg = 0; kg < 2; ++kg)
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+        if (!ABL_NO_W) ring.wb[(tap + WD) % RS][kg][j] = ring.wq[j][((tap + WD) * 2 + kg) * 64];
+    mid(tap);
+    const char* ap = cur + (ky * HWID + kx) * PSTR;
+    if (PF_UPFRONT) {
+      // all pixel fragments of the tap are requested up front; the MFMAs then wait on counted lgkmcnt
+      uint4 pf[2][MT];
+#pragma unroll
+      for (int kg = 0; kg < 2; ++kg)
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+          if (!ABL_NO_LDS) pf[kg][i] = *(const uint4*)(ap + i * HWID * PSTR + kg * 32);
+          else pf[kg][i] = ring.wb[0][kg][0];
+        }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int kg = 0; kg < 2; ++kg)
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j) mma16<T>(acc[i][j], ring.wb[tap % RS][kg][j], pf[kg][i]);
+    } else {
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int kg = 0; kg < 2; ++kg) {
+        uint4 pf[MT];
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+          if (!ABL_NO_LDS) pf[i] = *(const uint4*)(ap + i * HWID * PSTR + kg * 32);
+          else pf[i] = ring.wb[0][kg][0];
+        }
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j) mma16<T>(acc[i][j], ring.wb[tap % RS][kg][j], pf[i]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  ring.next_stage();
+}
+
+template <typename T, int MT, int NT, int WM, int WN, bool POOL, int WD, bool PF_UPFRONT>
 __global__ __launch_bounds__(256, 2) void conv3x3_kernel(ConvArgs a) {
   static_assert(WM * WN == 4, "4 waves per block");
   constexpr int EPL = 16 / sizeof(T), KC = SB / sizeof(T);     // channels per stage: 32 (bf16) / 16 (fp32)
@@ -173,110 +281,139 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(ConvArgs a) {
   const int aoff = ((wm * MT) * HWID + x) * PSTR + g * 16;
   const int ntg0 = (blockIdx.y * WN + wn) * NT;     // first global 32-channel output tile of this wave
   // packed weights: [ntile][stage][tap][kg(2)][lane] 16-B fragments
-  const uint4* wq[NT];
+  WeightRing<T, MT, NT, WD> ring;
 #pragma unroll
-  for (int j = 0; j < NT; ++j) wq[j] = a.wpk + (size_t)(ntg0 + j) * nstage * 18 * 64 + lane;
+  for (int j = 0; j < NT; ++j) ring.wq[j] = a.wpk + (size_t)(ntg0 + j) * nstage * 18 * 64 + lane;
 
   uint4 st[NPIECE];
   load_stage(0, st);
   write_stage(lds, st);
   __syncthreads();
-  uint4 wnext[NT];
-#pragma unroll
-  for (int j = 0; j < NT; ++j) wnext[j] = wq[j][0];
+  ring.prime();
 
   for (int sg = 0; sg < nstage; ++sg) {
-    const char* cur = lds + (sg & 1) * BUF + aoff;
-    if (sg + 1 < nstage) load_stage(sg + 1, st);     // in flight during the MFMAs below
-#pragma unroll 1
-    for (int ky = 0; ky < 3; ++ky) {
-#pragma unroll 1
-      for (int kx = 0; kx < 3; ++kx) {
-        const char* ap = cur + (ky * HWID + kx) * PSTR;
-#pragma unroll
-        for (int kg = 0; kg < 2; ++kg) {
-          uint4 wcur[NT];
-#pragma unroll
-          for (int j = 0; j < NT; ++j) { wcur[j] = wnext[j]; wq[j] += 64; wnext[j] = wq[j][0]; }
-          uint4 pf[MT];
-#pragma unroll
-          for (int i = 0; i < MT; ++i) pf[i] = *(const uint4*)(ap + i * HWID * PSTR + kg * 32);
-#pragma unroll
-          for (int i = 0; i < MT; ++i)
-#pragma unroll
-            for (int j = 0; j < NT; ++j) mma16<T>(acc[i][j], wcur[j], pf[i]);
-        }
-      }
-    }
-    if (sg + 1 < nstage) write_stage(lds + ((sg + 1) & 1) * BUF, st);
-    __syncthreads();
+    const bool more = sg + 1 < nstage;
+    stage_mma<T, MT, NT, WD, PF_UPFRONT>(acc, lds + (sg & 1) * BUF + aoff, ring, [&](int tap) {
+      if (tap == HALO_TAP && more && !ABL_NO_HALO) load_stage(sg + 1, st);
+    });
+    if (more && !ABL_NO_HALO) write_stage(lds + ((sg + 1) & 1) * BUF, st);
+    if (!ABL_NO_BAR) __syncthreads();
   }
   conv_epilogue<T, MT, NT, POOL>(acc, a, b, y0 + wm * MT, x0, ntg0 * 32, red);
 }
 
 // ---------------------------------------------------------------------------------------------
-// conv0: 3 -> 64 on the NCHW fp32 network input (VGG.py:123-124), K = 27 padded to 32.
-struct Conv0Args {
-  const float* x;     // [B,3,H,W]
-  const uint4* wpk;   // [2 ntiles][NFRAG][64 lanes] fragments, k = cin*9 + tap
-  const float* bias;  // [64]
-  void* out_act;      // NHWC T [B,H,W,64], post-ReLU
+// conv0 + ReLU + conv2 + bias + 2x2 max-pool + ReLU in one kernel (VGG.py:123-128).
+struct Conv02Args {
+  const float* x;      // [B,3,H,W] NCHW fp32
+  const uint4* w0;     // conv0 fragments [2 ntiles][NFRAG][64 lanes], k = cin*9 + tap (27 padded to 32)
+  const float* b0;     // [64]
+  const uint4* w2;     // conv2 fragments, generic layout
+  const float* b2;     // [64]
+  void* out_act;       // NHWC T [B,H/2,W/2,64] = relu(pool(conv2))
   int B, H, W, tiles_x, tiles_y;
 };
 
-template <typename T>
-__global__ __launch_bounds__(256) void conv0_kernel(Conv0Args a0) {
-  constexpr int EPL = 16 / sizeof(T), NFRAG = 32 / (2 * EPL);
-  constexpr int TH = 8, MT = 2, NT = 2, LW = 36;
-  __shared__ float in[3][TH + 2][LW];
+template <typename T> constexpr int conv02_lds_bytes() {
+  return (64 * (int)sizeof(T) / SB) * (10 * HWID * PSTR) + 3 * 12 * 36 * 4;
+}
+
+template <typename T, int WD, bool PF_UPFRONT>
+__global__ __launch_bounds__(256, 2) void conv02_kernel(Conv02Args a0) {
+  constexpr int EPL = 16 / sizeof(T), KC = SB / sizeof(T), NSG = 64 / KC, NFRAG = 32 / (2 * EPL);
+  constexpr int MT = 4, NT = 1, WN = 2, TH = 8, HPIX = (TH + 2) * HWID, BUF = HPIX * PSTR, IW = 36, IH = 12;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* lds = smem;                                  // NSG halo buffers (all of conv0's 64 channels)
+  float* in = (float*)(smem + NSG * BUF);            // [3][12][36] input patch
   __shared__ float red[4];
-  const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6, wm = wv / WN, wn = wv % WN;
   int bid = blockIdx.x;
   const int tx = bid % a0.tiles_x; bid /= a0.tiles_x;
   const int ty = bid % a0.tiles_y;
   const int b = bid / a0.tiles_y;
   const int y0 = ty * TH, x0 = tx * 32;
-  for (int e = t; e < 3 * (TH + 2) * HWID; e += 256) {
-    const int c = e / ((TH + 2) * HWID), r = e % ((TH + 2) * HWID), hy = r / HWID, hx = r % HWID;
-    const int y = y0 - 1 + hy, x = x0 - 1 + hx;
-    float v = 0.f;
-    if (y >= 0 && y < a0.H && x >= 0 && x < a0.W) v = a0.x[(((size_t)b * 3 + c) * a0.H + y) * a0.W + x];
-    in[c][hy][hx] = v;
-  }
-  __syncthreads();
   const int x = lane & 31, g = lane >> 5;
-  f32x16 acc[MT][NT];
+
+  // start the first conv2 weight loads before anything else (they do not depend on the input)
+  WeightRing<T, MT, NT, WD> ring;
+  ring.wq[0] = a0.w2 + (size_t)wn * NSG * 18 * 64 + lane;
+  ring.prime();
+
+  // phase A: input patch (2-pixel border) -> LDS
+  for (int e = t; e < 3 * IH * IW; e += 256) {
+    const int c = e / (IH * IW), r = e % (IH * IW), iy = r / IW, ix = r % IW;
+    const int y = y0 - 2 + iy, xx = x0 - 2 + ix;
+    float v = 0.f;
+    if (y >= 0 && y < a0.H && xx >= 0 && xx < a0.W) v = a0.x[(((size_t)b * 3 + c) * a0.H + y) * a0.W + xx];
+    in[e] = v;
+  }
+  uint4 wf0[2][NFRAG];
 #pragma unroll
-  for (int i = 0; i < MT; ++i)
+  for (int j = 0; j < 2; ++j)
 #pragma unroll
-    for (int j = 0; j < NT; ++j)
+    for (int f = 0; f < NFRAG; ++f) wf0[j][f] = a0.w0[(j * NFRAG + f) * 64 + lane];
+  __syncthreads();
+
+  // phase B: conv0 on the 10x34 halo pixels, 32 pixels per MFMA tile, straight into the conv2 halo buffers
+  for (int m = wv; m * 32 < HPIX; m += 4) {
+    const int p = m * 32 + x, pc = p < HPIX ? p : HPIX - 1;
+    const int hy = pc / HWID, hx = pc - hy * HWID;
+    const float* ib = in + hy * IW + hx;
+    f32x16 c0[2];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    for (int j = 0; j < 2; ++j)
 #pragma unroll
-  for (int f = 0; f < NFRAG; ++f) {
-    uint4 wf[NT];
+      for (int r = 0; r < 16; ++r) c0[j][r] = 0.f;
 #pragma unroll
-    for (int j = 0; j < NT; ++j) wf[j] = a0.wpk[(j * NFRAG + f) * 64 + lane];
-#pragma unroll
-    for (int i = 0; i < MT; ++i) {
+    for (int f = 0; f < NFRAG; ++f) {
       T e[EPL];
 #pragma unroll
       for (int jj = 0; jj < EPL; ++jj) {
         const int klo = f * 2 * EPL + jj, khi = klo + EPL;   // compile-time
         float lo = 0.f, hi = 0.f;
-        if (klo < 27) lo = in[klo / 9][wv * MT + i + (klo % 9) / 3][x + (klo % 9) % 3];
-        if (khi < 27) hi = in[khi / 9][wv * MT + i + (khi % 9) / 3][x + (khi % 9) % 3];
+        if (klo < 27) lo = ib[(klo / 9) * IH * IW + ((klo % 9) / 3) * IW + (klo % 9) % 3];
+        if (khi < 27) hi = ib[(khi / 9) * IH * IW + ((khi % 9) / 3) * IW + (khi % 9) % 3];
         e[jj] = (T)(g ? hi : lo);
       }
       const uint4 pf = __builtin_bit_cast(uint4, e);
 #pragma unroll
-      for (int j = 0; j < NT; ++j) mma16<T>(acc[i][j], wf[j], pf);
+      for (int j = 0; j < 2; ++j) mma16<T>(c0[j], wf0[j][f], pf);
+    }
+    // conv2 zero-pads conv0's OUTPUT map: halo pixels outside the image are 0, not conv0 of padded input
+    const int yy = y0 - 1 + hy, xx = x0 - 1 + hx;
+    const bool inside = yy >= 0 && yy < a0.H && xx >= 0 && xx < a0.W;
+    if (p < HPIX) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int co = j * 32 + q * 8 + g * 4;
+          const float4 bb = *(const float4*)(a0.b0 + co);
+          float v0 = fmaxf(c0[j][q * 4 + 0] + bb.x, 0.f), v1 = fmaxf(c0[j][q * 4 + 1] + bb.y, 0.f);
+          float v2 = fmaxf(c0[j][q * 4 + 2] + bb.z, 0.f), v3 = fmaxf(c0[j][q * 4 + 3] + bb.w, 0.f);
+          if (!inside) v0 = v1 = v2 = v3 = 0.f;
+          store4((T*)(lds + (co / KC) * BUF + p * PSTR) + (co % KC), v0, v1, v2, v3);
+        }
     }
   }
+  __syncthreads();
+
+  // phase C: conv2 over the NSG resident stages (no further loads, no barriers)
+  f32x16 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][0][r] = 0.f;
+  const int aoff = ((wm * MT) * HWID + x) * PSTR + g * 16;
+#pragma unroll 1
+  for (int sg = 0; sg < NSG; ++sg)
+    stage_mma<T, MT, NT, WD, PF_UPFRONT>(acc, lds + sg * BUF + aoff, ring, [](int) {});
+
   ConvArgs a{};
-  a.bias = a0.bias; a.out_act = a0.out_act; a.B = a0.B; a.H = a0.H; a.W = a0.W; a.Cout = 64; a.relu_act = 1;
+  a.bias = a0.b2; a.out_act = a0.out_act; a.B = a0.B; a.H = a0.H; a.W = a0.W; a.Cout = 64; a.relu_act = 1;
   a.tiles_x = a0.tiles_x; a.tiles_y = a0.tiles_y;
-  conv_epilogue<T, MT, NT, false>(acc, a, b, y0 + wv * MT, x0, 0, red);
+  conv_epilogue<T, MT, NT, true>(acc, a, b, y0 + wm * MT, x0, wn * 32, red);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -284,7 +421,7 @@ __global__ __launch_bounds__(256) void conv0_kernel(Conv0Args a0) {
 //   generic: idx = ((((nt*nstage + sg)*9 + tap)*2 + kg)*64 + lane)*EPL + j
 //            cout = nt*32 + (lane&31), cin = sg*KC + kg*2*EPL + (lane>>5)*EPL + j      (KC = 64 B of channels)
 //   conv0:   idx = ((nt*NFRAG + f)*64 + lane)*EPL + j,  k = f*2*EPL + (lane>>5)*EPL + j  (k = cin*9+tap, <27)
-//   The tail of every layer's buffer is padded by one fragment row (the kernel prefetches one step ahead).
+//   Every layer's buffer is padded by two taps of fragments (the kernels prefetch up to 2 taps ahead).
 template <typename T>
 __global__ void pack_weights_kernel(const float* __restrict__ w, T* __restrict__ out, int Cout, int Cin, int first) {
   constexpr int EPL = 16 / sizeof(T), KC = SB / sizeof(T), NFRAG = 32 / (2 * EPL);
@@ -352,18 +489,23 @@ __global__ __launch_bounds__(256) void conf_kernel(const T* __restrict__ act, co
 }
 
 // ---------------------------------------------------------------------------------------------
-// L2_norm (VGG.py:511-514): x / max(||x||, 1e-12) per sample, in place on the raw fp32 map.
-__global__ __launch_bounds__(256) void l2norm_kernel(float* __restrict__ x, const double* __restrict__ sumsq, int np,
-                                                     size_t per_sample, int blocks_per_sample) {
+// L2_norm (VGG.py:511-514): x / max(||x||, 1e-12) per sample.
+// inv_norm_kernel: fixed-order fp64 sum of the epilogue partials -> 1/max(||x||,1e-12) per sample.
+__global__ __launch_bounds__(256) void inv_norm_kernel(const double* __restrict__ sumsq, int np, double* __restrict__ inv) {
   __shared__ double sh[4];
-  const int b = blockIdx.x / blocks_per_sample, k = blockIdx.x % blocks_per_sample;
+  const int b = blockIdx.x;
   double s = 0.0;
   for (int i = threadIdx.x; i < np; i += 256) s += sumsq[(size_t)b * np + i];
   s = wave_sum_f64(s);
   if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
   __syncthreads();
-  const double tot = (sh[0] + sh[1]) + (sh[2] + sh[3]);
-  const double scale = 1.0 / fmax(sqrt(tot), 1e-12);
+  if (threadIdx.x == 0) inv[b] = 1.0 / fmax(sqrt((sh[0] + sh[1]) + (sh[2] + sh[3])), 1e-12);
+}
+// scale_kernel: in-place x *= inv[b] (fp64 multiply, one rounding)
+__global__ __launch_bounds__(256) void scale_kernel(float* __restrict__ x, const double* __restrict__ inv, size_t per_sample,
+                                                    int blocks_per_sample) {
+  const int b = blockIdx.x / blocks_per_sample, k = blockIdx.x % blocks_per_sample;
+  const double scale = inv[b];
   float4* p = (float4*)(x + (size_t)b * per_sample);
   const size_t n4 = per_sample / 4;
   for (size_t i = (size_t)k * 256 + threadIdx.x; i < n4; i += (size_t)blocks_per_sample * 256) {
@@ -380,29 +522,54 @@ struct LayerDef { int cin, cout, has_bias; };
 static const LayerDef kLayers[13] = {
     {3, 64, 1}, {64, 64, 1}, {64, 128, 1}, {128, 128, 1}, {128, 256, 1}, {256, 256, 1}, {256, 256, 1},
     {384, 128, 0}, {128, 128, 0}, {192, 64, 0}, {64, 64, 0}, {128, 32, 0}, {32, 16, 0}};
-
-struct VggPlan {
-  size_t wpk[13];
-  size_t a0, x3, a5, x8, a10, a12, x15r, d1a, x18r, d2a, x21r;
-  size_t ss[3];
-  int np[3];
-  size_t total;
-};
+constexpr int kPackedLayers = 11;   // conv0..dec2.3 (dec3.* only feed the unused x24 at level 3)
 
 static size_t packed_bytes(int l, int dtype) {
   const size_t es = dtype == HLA_BF16 ? 2 : 4;
   if (l == 0) return (size_t)2 * 32 * 32 * es;   // 2 ntiles x 32 (padded K) x 32 couts
-  return (size_t)kLayers[l].cin * kLayers[l].cout * 9 * es + 1024;   // + one fragment row: prefetch overrun
+  return (size_t)kLayers[l].cin * kLayers[l].cout * 9 * es + 4096;   // + two taps of fragments: prefetch overrun
 }
+static size_t packed_offset(int l, int dtype) {
+  size_t o = 0;
+  for (int i = 0; i < l; ++i) o += hla_align_up(packed_bytes(i, dtype), 256);
+  return o;
+}
+
+extern "C" size_t hla_vgg_packed_weight_bytes(int dtype) { return packed_offset(kPackedLayers, dtype); }
+
+template <typename T>
+static void pack_all(const hla_vgg_params* prm, char* packed, int dtype, hipStream_t st) {
+  for (int l = 0; l < kPackedLayers; ++l) {
+    const size_t n = l == 0 ? (size_t)2 * 32 * 32 : (size_t)kLayers[l].cin * kLayers[l].cout * 9;
+    const int grid = (int)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024);
+    hla_prof_begin(K_PACK, 0, (double)n * (4 + sizeof(T)), st);
+    hipLaunchKernelGGL((pack_weights_kernel<T>), dim3(grid), dim3(256), 0, st, prm->w[l],
+                       (T*)(packed + packed_offset(l, dtype)), kLayers[l].cout, kLayers[l].cin, l == 0 ? 1 : 0);
+    hla_prof_end(st);
+  }
+}
+
+extern "C" int hla_vgg_pack_weights(const hla_vgg_params* params, void* packed, int dtype, hla_stream_t stream) {
+  HLA_REQUIRE(params && packed, "hla_vgg_pack_weights: null argument");
+  HLA_REQUIRE(dtype == HLA_F32 || dtype == HLA_BF16, "hla_vgg_pack_weights: bad dtype");
+  if (dtype == HLA_BF16) pack_all<bf16>(params, (char*)packed, dtype, (hipStream_t)stream);
+  else pack_all<float>(params, (char*)packed, dtype, (hipStream_t)stream);
+  HLA_CHECK_HIP(hipGetLastError());
+  return HLA_OK;
+}
+
+struct VggPlan {
+  size_t x3, a5, x8, a10, a12, x15r, d1a, x18r, d2a, x21r;
+  size_t ss[3], inv;
+  int np[3];
+  size_t total;
+};
 
 static void vgg_plan(int B, int H, int W, int dtype, VggPlan* p) {
   const size_t es = dtype == HLA_BF16 ? 2 : 4;
   size_t o = 0;
   auto take = [&](size_t bytes) { size_t r = o; o += hla_align_up(bytes, 256); return r; };
-  for (int l = 0; l < 11; ++l) p->wpk[l] = take(packed_bytes(l, dtype));
-  p->wpk[11] = p->wpk[12] = 0;
   const size_t P = (size_t)B * H * W;
-  p->a0 = take(P * 64 * es);
   p->x3 = take(P / 4 * 64 * es);
   p->a5 = take(P / 4 * 128 * es);
   p->x8 = take(P / 16 * 128 * es);
@@ -419,6 +586,7 @@ static void vgg_plan(int B, int H, int W, int dtype, VggPlan* p) {
   p->np[1] = tiles(H / 4, W / 4) * 1;   // dec1.3: Cout 128
   p->np[2] = tiles(H / 2, W / 2) * 1;   // dec2.3: Cout 64
   for (int i = 0; i < 3; ++i) p->ss[i] = take((size_t)B * p->np[i] * sizeof(double));
+  p->inv = take((size_t)3 * B * sizeof(double));
   p->total = o;
 }
 
@@ -438,37 +606,38 @@ static void launch_conv(hipStream_t st, ConvArgs a, bool pool) {
   const double flops = 2.0 * 9.0 * (a.C1 + a.C2) * a.Cout * (double)P;
   const double bytes = (double)P * ((a.up1 ? a.C1 / 4.0 : a.C1) + a.C2) * es + (double)Po * a.Cout * ((a.out_act ? es : 0) + (a.out_raw ? 4 : 0));
   hla_prof_begin(a.Cout >= 128 ? (pool ? K_CONV_NT2_POOL : K_CONV_NT2) : (pool ? K_CONV_NT1_POOL : K_CONV_NT1), flops, bytes, st);
+  // Cout >= 128: block = 8x32 pixels x 128 channels, waves 2(M) x 2(N), wave tile 128 px x 64 ch, weights 1 tap ahead
+  // Cout == 64 : block = 8x32 pixels x  64 channels, waves 2 x 2,       wave tile 128 px x 32 ch, weights 2 taps ahead
   if (a.Cout >= 128) {
-    if (pool) hipLaunchKernelGGL((conv3x3_kernel<T, 4, 2, 2, 2, true>), grid, dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((conv3x3_kernel<T, 4, 2, 2, 2, false>), grid, dim3(256), 0, st, a);
+    if (pool) hipLaunchKernelGGL((conv3x3_kernel<T, 4, 2, 2, 2, true, 1, false>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((conv3x3_kernel<T, 4, 2, 2, 2, false, 1, false>), grid, dim3(256), 0, st, a);
   } else {
-    if (pool) hipLaunchKernelGGL((conv3x3_kernel<T, 4, 1, 2, 2, true>), grid, dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((conv3x3_kernel<T, 4, 1, 2, 2, false>), grid, dim3(256), 0, st, a);
+    if (pool) hipLaunchKernelGGL((conv3x3_kernel<T, 4, 1, 2, 2, true, 2, true>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((conv3x3_kernel<T, 4, 1, 2, 2, false, 2, true>), grid, dim3(256), 0, st, a);
   }
   hla_prof_end(st);
 }
 
 template <typename T>
-static int vgg_forward_t(const float* x, const hla_vgg_params* prm, float* const feat[4], float* const conf[4],
-                         char* ws, const VggPlan& pl, int B, int H, int W, int flags, hipStream_t st) {
-  // 1. pack weights (parameters may have changed since the last call: training)
-  for (int l = 0; l < 11; ++l) {
-    const size_t n = l == 0 ? (size_t)2 * 32 * 32 : (size_t)kLayers[l].cin * kLayers[l].cout * 9;
-    const int grid = (int)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024);
-    hla_prof_begin(K_PACK, 0, (double)n * (4 + sizeof(T)), st);
-    hipLaunchKernelGGL((pack_weights_kernel<T>), dim3(grid), dim3(256), 0, st, prm->w[l], (T*)(ws + pl.wpk[l]),
-                       kLayers[l].cout, kLayers[l].cin, l == 0 ? 1 : 0);
-    hla_prof_end(st);
-  }
-  auto W_ = [&](int l) { return (const uint4*)(ws + pl.wpk[l]); };
-  // 2. conv0
+static int vgg_forward_t(const float* x, const hla_vgg_params* prm, const char* packed, int dtype, float* const feat[4],
+                         float* const conf[4], double* inv_norm, char* ws, const VggPlan& pl, int B, int H, int W,
+                         int flags, hipStream_t st) {
+  auto W_ = [&](int l) { return (const uint4*)(packed + packed_offset(l, dtype)); };
+  char* w = ws;
+  // conv0 + conv2 + pool fused (VGG.py:123-128): relu(x3)
   {
-    Conv0Args a{};
-    a.x = x; a.wpk = W_(0); a.bias = prm->b[0]; a.out_act = ws + pl.a0; a.B = B; a.H = H; a.W = W;
-    a.tiles_x = (W + 31) / 32; a.tiles_y = (H + 7) / 8;
+    Conv02Args a{};
+    a.x = x; a.w0 = W_(0); a.b0 = prm->b[0]; a.w2 = W_(1); a.b2 = prm->b[1]; a.out_act = w + pl.x3;
+    a.B = B; a.H = H; a.W = W; a.tiles_x = (W + 31) / 32; a.tiles_y = (H + 7) / 8;
     const double P = (double)B * H * W;
-    hla_prof_begin(K_CONV0, 2.0 * 27 * 64 * P, P * (3 * 4 + 64 * sizeof(T)), st);
-    hipLaunchKernelGGL((conv0_kernel<T>), dim3(a.tiles_x * a.tiles_y * B), dim3(256), 0, st, a);
+    constexpr int lds_bytes = conv02_lds_bytes<T>();
+    static bool attr_set = false;
+    if (!attr_set) {
+      HLA_CHECK_HIP(hipFuncSetAttribute((const void*)conv02_kernel<T, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+      attr_set = true;
+    }
+    hla_prof_begin(K_CONV02, 2.0 * 9 * (3 + 64) * 64 * P, P * (3 * 4 + 16 * sizeof(T)), st);
+    hipLaunchKernelGGL((conv02_kernel<T, 2, true>), dim3(a.tiles_x * a.tiles_y * B), dim3(256), lds_bytes, st, a);
     hla_prof_end(st);
   }
   auto conv = [&](int l, const void* s1, int C1, int H_, int W_h, void* act, int relu, bool pool, const void* s2 = nullptr,
@@ -480,9 +649,7 @@ static int vgg_forward_t(const float* x, const hla_vgg_params* prm, float* const
     a.relu_act = relu;
     launch_conv<T>(st, a, pool);
   };
-  char* w = ws;
-  // encoder (VGG.py:123-141).  ReLU commutes with max-pool, so pooled maps are stored post-ReLU.
-  conv(1, w + pl.a0, 64, H, W, w + pl.x3, 1, true);                                   // conv2 + pool -> relu(x3)
+  // encoder (VGG.py:129-141).  ReLU commutes with max-pool, so pooled maps are stored post-ReLU.
   conv(2, w + pl.x3, 64, H / 2, W / 2, w + pl.a5, 1, false);                          // conv5
   conv(3, w + pl.a5, 128, H / 2, W / 2, w + pl.x8, 1, true);                          // conv7 + pool -> relu(x8)
   conv(4, w + pl.x8, 128, H / 4, W / 4, w + pl.a10, 1, false);                        // conv10
@@ -512,16 +679,19 @@ static int vgg_forward_t(const float* x, const hla_vgg_params* prm, float* const
       hla_prof_end(st);
     }
   }
-  // L2 normalisation of the three returned maps, in place
+  // L2 normalisation: 1/||x|| per sample (always), in-place scaling unless the caller folds it downstream
   {
     const size_t per[3] = {(size_t)(H / 8) * (W / 8) * 256, (size_t)(H / 4) * (W / 4) * 128, (size_t)(H / 2) * (W / 2) * 64};
+    double* inv = inv_norm ? inv_norm : (double*)(w + pl.inv);
     for (int l = 0; l < 3; ++l) {
-      if (!feat[l]) continue;
+      hla_prof_begin(K_L2NORM, 0, (double)B * pl.np[l] * 8, st);
+      hipLaunchKernelGGL(inv_norm_kernel, dim3(B), dim3(256), 0, st, (const double*)(w + pl.ss[l]), pl.np[l], inv + (size_t)l * B);
+      hla_prof_end(st);
+      if (flags & HLA_VGG_DEFER_NORM) continue;
       int bps = (int)(per[l] / 4 / 256 / 4);
       bps = bps < 1 ? 1 : (bps > 64 ? 64 : bps);
       hla_prof_begin(K_L2NORM, 0, (double)B * per[l] * 8, st);
-      hipLaunchKernelGGL(l2norm_kernel, dim3(B * bps), dim3(256), 0, st, feat[l], (const double*)(w + pl.ss[l]),
-                         pl.np[l], per[l], bps);
+      hipLaunchKernelGGL(scale_kernel, dim3(B * bps), dim3(256), 0, st, feat[l], inv + (size_t)l * B, per[l], bps);
       hla_prof_end(st);
     }
   }
@@ -529,14 +699,16 @@ static int vgg_forward_t(const float* x, const hla_vgg_params* prm, float* const
   return HLA_OK;
 }
 
-extern "C" int hla_vgg_forward(const float* x, const hla_vgg_params* params, float* const feat[4],
-                               float* const conf[4], void* workspace, size_t workspace_bytes, int B, int H, int W,
-                               int level, int dtype, int flags, hla_stream_t stream) {
-  HLA_REQUIRE(x && params && feat && workspace, "hla_vgg_forward: null argument");
+extern "C" int hla_vgg_forward(const float* x, const hla_vgg_params* params, const void* packed_weights,
+                               float* const feat[4], float* const conf[4], double* inv_norm, void* workspace,
+                               size_t workspace_bytes, int B, int H, int W, int level, int dtype, int flags,
+                               hla_stream_t stream) {
+  HLA_REQUIRE(x && params && packed_weights && feat && workspace, "hla_vgg_forward: null argument");
   HLA_REQUIRE(dtype == HLA_F32 || dtype == HLA_BF16, "hla_vgg_forward: dtype must be HLA_F32 or HLA_BF16");
   HLA_REQUIRE(B > 0 && H >= 8 && W >= 8 && H % 8 == 0 && W % 8 == 0, "hla_vgg_forward: H and W must be multiples of 8");
   HLA_REQUIRE(level == 3, "hla_vgg_forward: only level 3 (x15,x18,x21) is built so far (got %d)", level);
   HLA_REQUIRE(feat[0] && feat[1] && feat[2], "hla_vgg_forward: level 3 needs feat[0..2]");
+  HLA_REQUIRE(!(flags & HLA_VGG_DEFER_NORM) || inv_norm, "hla_vgg_forward: HLA_VGG_DEFER_NORM needs inv_norm");
   VggPlan pl;
   vgg_plan(B, H, W, dtype, &pl);
   if (workspace_bytes < pl.total) {
@@ -544,6 +716,8 @@ extern "C" int hla_vgg_forward(const float* x, const hla_vgg_params* params, flo
     return HLA_ERR_WORKSPACE;
   }
   if (dtype == HLA_BF16)
-    return vgg_forward_t<bf16>(x, params, feat, conf, (char*)workspace, pl, B, H, W, flags, (hipStream_t)stream);
-  return vgg_forward_t<float>(x, params, feat, conf, (char*)workspace, pl, B, H, W, flags, (hipStream_t)stream);
+    return vgg_forward_t<bf16>(x, params, (const char*)packed_weights, dtype, feat, conf, inv_norm, (char*)workspace, pl,
+                               B, H, W, flags, (hipStream_t)stream);
+  return vgg_forward_t<float>(x, params, (const char*)packed_weights, dtype, feat, conf, inv_norm, (char*)workspace, pl,
+                              B, H, W, flags, (hipStream_t)stream);
 }

@@ -18,9 +18,8 @@ class LM_S2GP_Ford(S2GPBase):
         if mode == 'train':
             self._check_train_supported()
         want_conf = bool(self.using_weight) or mode == 'train'
-        sat_feats, grd_feats, grd_confs = self._features(sat_map, grd_img_left, want_conf)
         extra = dict(R_FL=R_FL, T_FL=T_FL, side_m=float(satmap_sidelength_meters))
-        trace = self.lm_solve(sat_feats, grd_feats, grd_confs, grd_img_left.shape[-2:], extra, level_first, init_pose)
+        trace, grd_confs = self.localise(sat_map, grd_img_left, want_conf, extra, level_first, init_pose)
         us, vs, thetas = trace[..., 0], trace[..., 1], trace[..., 2]
         if mode == 'train':
             a = self.args

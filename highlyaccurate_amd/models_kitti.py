@@ -22,8 +22,7 @@ class LM_S2GP(S2GPBase):
         if mode == 'train':
             self._check_train_supported()
         want_conf = bool(self.using_weight) or mode == 'train'
-        sat_feats, grd_feats, grd_confs = self._features(sat_map, grd_img_left, want_conf)
-        trace = self.lm_solve(sat_feats, grd_feats, grd_confs, grd_img_left.shape[-2:], None, level_first, init_pose)
+        trace, grd_confs = self.localise(sat_map, grd_img_left, want_conf, None, level_first, init_pose)
         shift_lons, shift_lats, thetas = trace[..., 0], trace[..., 1], trace[..., 2]   # models_kitti.py:1281-1283
         if mode == 'train':
             a = self.args

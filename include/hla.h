@@ -58,22 +58,32 @@ typedef struct hla_vgg_params {
 } hla_vgg_params;
 
 enum {
-  HLA_VGG_WANT_CONF = 1,   /* compute the confidence maps (VGG.py:160-163)            */
-  HLA_VGG_KEEP_RAW = 2     /* also keep un-normalised maps in feat_raw (for backward) */
+  HLA_VGG_WANT_CONF = 1,   /* compute the confidence maps (VGG.py:160-163)                              */
+  HLA_VGG_DEFER_NORM = 2   /* leave feat[] un-normalised and only report inv_norm (the LM loop folds the
+                              scale into its normal equations: one full read+write pass less per map)  */
 };
+
+/* Weights are re-laid-out once into MFMA fragment order (bf16 or fp32) and reused until they change.
+ * hla_vgg_pack_weights reads params->w[0..10] (conv0..conv_dec2.3) and fills `packed`
+ * (hla_vgg_packed_weight_bytes(dtype) bytes).  Call it again after an optimizer step. */
+size_t hla_vgg_packed_weight_bytes(int dtype);
+int hla_vgg_pack_weights(const hla_vgg_params* params, void* packed, int dtype, hla_stream_t stream);
 
 /* Bytes of scratch hla_vgg_forward needs for this shape. */
 size_t hla_vgg_workspace_bytes(int B, int H, int W, int level, int dtype);
 
 /* x        [B,3,H,W] NCHW fp32 (what the reference's DataLoader hands over)
- * feat[l]  [B,H/2^(3-l),W/2^(3-l),C_l] NHWC fp32, L2-normalised per sample; C = 256,128,64,16
- *          for l = 0..3 (x15,x18,x21,x24).  Entries the `level` does not return may be NULL.
+ * params   biases b[0..6] and the confidence-head weights w[13..15] are read from here
+ * packed_weights  output of hla_vgg_pack_weights for the same dtype
+ * feat[l]  [B,H/2^(3-l),W/2^(3-l),C_l] NHWC fp32, C = 256,128,64 for l = 0..2 (x15,x18,x21):
+ *          L2-normalised per sample, or raw when HLA_VGG_DEFER_NORM
  * conf[l]  [B,h_l,w_l] fp32 = sigmoid(-sigmoid(conv(relu(.)))), or NULL
- * level    the reference's VGGUnet(level): 3 -> maps 0..2, 4 -> maps 0..3 (the dead dec3/conf3
- *          work at level 3, VGG.py:153-155,163, is skipped)                                   */
-int hla_vgg_forward(const float* x, const hla_vgg_params* params, float* const feat[4], float* const conf[4],
-                    void* workspace, size_t workspace_bytes, int B, int H, int W, int level, int dtype,
-                    int flags, hla_stream_t stream);
+ * inv_norm [3][B] fp64 out: 1/max(||map_l of sample b||_2, 1e-12) (VGG.py:511-514), or NULL
+ * level    the reference's VGGUnet(level); 3 -> maps 0..2 (the dead dec3/conf3 work of VGG.py:153-155,163
+ *          is skipped).  Level 4 (x24) is not built yet.                                              */
+int hla_vgg_forward(const float* x, const hla_vgg_params* params, const void* packed_weights, float* const feat[4],
+                    float* const conf[4], double* inv_norm, void* workspace, size_t workspace_bytes, int B, int H,
+                    int W, int level, int dtype, int flags, hla_stream_t stream);
 
 /* ------------------------------------------------------------------------- *
  * jacobian.grid_sample  (jacobian.py:138-205) -- the stand-alone operator
@@ -94,6 +104,8 @@ typedef struct hla_s2g_level {
   const float* grd_conf; /* [B,h,w] fp32 or NULL (needed iff using_weight) */
   const float* xyz;      /* [h,w,3] fp32 ground-plane points in the camera frame
                             (models_kitti.py:655-682 / models_ford.py:110-155) */
+  const double* sat_inv_norm; /* [B] or NULL: sat_feat is raw, multiply by this (HLA_VGG_DEFER_NORM) */
+  const double* grd_inv_norm; /* [B] or NULL: same for grd_feat */
   int A, h, w, C;
   int row0;              /* first ground-image row that takes part (h/2 for proj=='geo') */
   double meter_per_pixel;/* metres per satellite-feature pixel at this level */

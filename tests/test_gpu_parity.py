@@ -30,8 +30,8 @@ def T(a):
 def test_library_loaded_and_exports():
     from highlyaccurate_amd import _lib
     lib = _lib.load()
-    assert lib.hla_abi_version() == 1
-    for sym in ('hla_vgg_forward', 'hla_s2g_lm_solve', 'hla_grid_sample', 'hla_vgg_workspace_bytes',
+    assert lib.hla_abi_version() == _lib.ABI_VERSION
+    for sym in ('hla_vgg_forward', 'hla_vgg_pack_weights', 'hla_s2g_lm_solve', 'hla_grid_sample', 'hla_vgg_workspace_bytes',
                 'hla_s2g_workspace_bytes', 'hla_last_error'):
         assert hasattr(lib, sym)
 
