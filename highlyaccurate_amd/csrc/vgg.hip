@@ -55,6 +55,7 @@ struct ConvArgs {
   int B, H, W, Cout;
   int relu_act;
   int tiles_x, tiles_y;
+  unsigned long long* dbg;   // CONV_VARIANT 40 only: per-wave cycle accounting
 };
 
 constexpr int HWID = 34;   // halo tile width in pixels
@@ -75,23 +76,58 @@ constexpr bool ABL_NO_BAR = (CONV_VARIANT == 14);
 // ---------------------------------------------------------------------------------------------
 // shared epilogue: acc[i][j] holds, for lane (x = lane&31, g = lane>>5), output channels
 // cb + j*32 + 8q + 4g + {0..3} (q = r>>2) of pixel (row i, column x).
+// Writing that straight to NHWC memory is 8 B per lane into 32 different 128-B lines per store instruction
+// (measured: 16-28 k cycles per wave, up to half of a block's lifetime).  Instead every wave transposes one
+// pixel row at a time through a private LDS region (`stage`, >= 32*(NT*32*4+16) bytes) and stores it as whole
+// pixel rows: 16 B per lane, consecutive lanes on consecutive addresses.
+template <typename E, int NT> struct RowStager {
+  static constexpr int CW = NT * 32, PITCH = CW * (int)sizeof(E) + 16, CPP = CW * (int)sizeof(E) / 16;
+  // lane-side write of 4 consecutive channels of pixel `px`
+  static __device__ __forceinline__ void put(char* stage, int px, int ch, float v0, float v1, float v2, float v3) {
+    store4((E*)(stage + px * PITCH) + ch, v0, v1, v2, v3);
+  }
+  // cooperative flush of `npx` pixels: dst points at channel cb of the first pixel; pixel stride = Cout elements
+  static __device__ __forceinline__ void flush(const char* stage, E* dst, int npx, int npx_valid, int Cout, int lane) {
+    const int chunks = npx * CPP;
+#pragma unroll
+    for (int c0 = 0; c0 < 32 * CPP; c0 += 64) {
+      const int c = c0 + lane;
+      if (c0 < chunks && c < chunks) {
+        const int px = c / CPP, part = c % CPP;
+        if (px < npx_valid)
+          *(uint4*)((char*)(dst + (size_t)px * Cout) + part * 16) = *(const uint4*)(stage + px * PITCH + part * 16);
+      }
+    }
+  }
+};
+
 template <typename T, int MT, int NT, bool POOL>
 __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[MT][NT], const ConvArgs& a, int b, int yrow0, int x0,
-                                              int cb, float* red) {
+                                              int cb, float* red, char* stage) {
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, x = lane & 31, g = lane >> 5;
   const int Ho = POOL ? a.H >> 1 : a.H, Wo = POOL ? a.W >> 1 : a.W;
+  constexpr int NPX = POOL ? 16 : 32;
+  float4 bias[NT][4];
+#pragma unroll
+  for (int j = 0; j < NT; ++j)
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      bias[j][q] = a.bias ? *(const float4*)(a.bias + cb + j * 32 + q * 8 + g * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+  const int xo0 = POOL ? x0 >> 1 : x0;
+  const int nvalid = min(NPX, Wo - xo0);              // pixels of this row segment inside the image
   float ss = 0.f;
 #pragma unroll
   for (int i = 0; i < MT; i += (POOL ? 2 : 1)) {
-    const int y = yrow0 + i, xg = x0 + x;
-    const bool ok = (y < a.H) && (xg < a.W) && (!POOL || !(x & 1));
-    const int yo = POOL ? y >> 1 : y, xo = POOL ? xg >> 1 : xg;
-    const size_t pix = ((size_t)b * Ho + yo) * Wo + xo;
+    const int y = yrow0 + i;
+    const int yo = POOL ? y >> 1 : y;
+    const bool row_ok = y < a.H;                      // wave-uniform
+    const bool lane_ok = row_ok && (x0 + x < a.W) && (!POOL || !(x & 1));
+    const int px = POOL ? x >> 1 : x;
+    float v[NT][4][4];
 #pragma unroll
-    for (int j = 0; j < NT; ++j) {
+    for (int j = 0; j < NT; ++j)
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        float v[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           float t = acc[i][j][q * 4 + e];
@@ -99,24 +135,35 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[MT][NT], const ConvA
             t = fmaxf(t, acc[i + 1][j][q * 4 + e]);
             t = fmaxf(t, __shfl_xor(t, 1, 64));
           }
-          v[e] = t;
+          v[j][q][e] = t;
         }
-        const int co = cb + j * 32 + q * 8 + g * 4;
-        if (a.bias) {
-          const float4 bb = *(const float4*)(a.bias + co);
-          v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
-        }
-        if (ok) {
-          if (a.out_raw) {
-            *(float4*)(a.out_raw + pix * a.Cout + co) = make_float4(v[0], v[1], v[2], v[3]);
-            ss += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
-          }
-          if (a.out_act) {
-            if (a.relu_act) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
-            store4((T*)a.out_act + pix * a.Cout + co, v[0], v[1], v[2], v[3]);
-          }
-        }
+        v[j][q][0] += bias[j][q].x; v[j][q][1] += bias[j][q].y; v[j][q][2] += bias[j][q].z; v[j][q][3] += bias[j][q].w;
       }
+    const size_t pix0 = ((size_t)b * Ho + yo) * Wo + xo0;
+    if (a.out_raw) {
+      if (!POOL || !(x & 1)) {
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            RowStager<float, NT>::put(stage, px, j * 32 + q * 8 + g * 4, v[j][q][0], v[j][q][1], v[j][q][2], v[j][q][3]);
+            if (lane_ok) ss += v[j][q][0] * v[j][q][0] + v[j][q][1] * v[j][q][1] + v[j][q][2] * v[j][q][2] + v[j][q][3] * v[j][q][3];
+          }
+      }
+      if (row_ok) RowStager<float, NT>::flush(stage, a.out_raw + pix0 * a.Cout + cb, NPX, nvalid, a.Cout, lane);
+    }
+    if (a.out_act) {
+      if (!POOL || !(x & 1)) {
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            float w0 = v[j][q][0], w1 = v[j][q][1], w2 = v[j][q][2], w3 = v[j][q][3];
+            if (a.relu_act) { w0 = fmaxf(w0, 0.f); w1 = fmaxf(w1, 0.f); w2 = fmaxf(w2, 0.f); w3 = fmaxf(w3, 0.f); }
+            RowStager<T, NT>::put(stage, px, j * 32 + q * 8 + g * 4, w0, w1, w2, w3);
+          }
+      }
+      if (row_ok) RowStager<T, NT>::flush(stage, (T*)a.out_act + pix0 * a.Cout + cb, NPX, nvalid, a.Cout, lane);
     }
   }
   if (a.sumsq) {
@@ -171,6 +218,18 @@ struct WeightRing {
     }
   }
 };
+
+// The two waves that share a SIMD (one from each co-resident workgroup) run the same instruction stream and
+// start together, so left alone they contend for the matrix pipe during their MFMA bursts and then both sit in
+// their LDS / VM waits at the same time (a convoy: measured MFMA-busy 46 %).  Giving the wave in the odd
+// hardware wave slot a higher static priority lets it run ahead, which staggers the two streams: one computes
+// while the other waits.  HW_REG_HW_ID (id 4) bits [3:0] = wave slot within the SIMD.
+__device__ __forceinline__ void stagger_priority() {
+#if CONV_VARIANT != 31
+  const unsigned slot = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4);
+  if (slot & 1) __builtin_amdgcn_s_setprio(CONV_VARIANT == 32 ? 3 : 1);
+#endif
+}
 
 template <typename T, int MT, int NT, int WD, bool PF_UPFRONT, typename Mid>
 __device__ __forceinline__ void stage_mma(f32x16 (&acc)[MT][NT], const char* cur, WeightRing<T, MT, NT, WD>& ring,
@@ -233,6 +292,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(ConvArgs a) {
   __shared__ __attribute__((aligned(16))) char lds[2 * BUF];
   __shared__ float red[4];
 
+#if CONV_VARIANT == 40
+  const unsigned long long t_begin = __builtin_readcyclecounter();
+#endif
   const int t = threadIdx.x, lane = t & 63, wv = t >> 6, wm = wv / WN, wn = wv % WN;
   int bid = blockIdx.x;
   const int tx = bid % a.tiles_x; bid /= a.tiles_x;
@@ -290,16 +352,38 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(ConvArgs a) {
   write_stage(lds, st);
   __syncthreads();
   ring.prime();
+  stagger_priority();
 
+#if CONV_VARIANT == 40   // cycle accounting per wave: [prologue, mma, halo write, barrier wait, epilogue]
+  unsigned long long tc[5] = {0, 0, 0, 0, 0};
+  unsigned long long t_prev = __builtin_readcyclecounter();
+  tc[0] = t_prev - t_begin;
+#define TICK(k) { const unsigned long long _n = __builtin_readcyclecounter(); tc[k] += _n - t_prev; t_prev = _n; }
+#else
+#define TICK(k)
+#endif
   for (int sg = 0; sg < nstage; ++sg) {
     const bool more = sg + 1 < nstage;
     stage_mma<T, MT, NT, WD, PF_UPFRONT>(acc, lds + (sg & 1) * BUF + aoff, ring, [&](int tap) {
       if (tap == HALO_TAP && more && !ABL_NO_HALO) load_stage(sg + 1, st);
     });
+    TICK(1)
     if (more && !ABL_NO_HALO) write_stage(lds + ((sg + 1) & 1) * BUF, st);
+    TICK(2)
     if (!ABL_NO_BAR) __syncthreads();
+    TICK(3)
   }
-  conv_epilogue<T, MT, NT, POOL>(acc, a, b, y0 + wm * MT, x0, ntg0 * 32, red);
+  // the loop's last barrier guarantees nobody still reads the halo buffers: reuse them as 4 wave-private stagers
+  static_assert(2 * BUF / 4 >= 32 * (NT * 32 * 4 + 16) && (2 * BUF / 4) % 16 == 0, "stager does not fit");
+  conv_epilogue<T, MT, NT, POOL>(acc, a, b, y0 + wm * MT, x0, ntg0 * 32, red, lds + wv * (2 * BUF / 4));
+#if CONV_VARIANT == 40
+  TICK(4)
+  if (a.dbg && lane == 0) {
+    unsigned long long* d = a.dbg + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 4 + wv) * 5;
+    for (int k = 0; k < 5; ++k) d[k] = tc[k];
+  }
+#endif
+#undef TICK
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -406,6 +490,7 @@ __global__ __launch_bounds__(256, 2) void conv02_kernel(Conv02Args a0) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[i][0][r] = 0.f;
   const int aoff = ((wm * MT) * HWID + x) * PSTR + g * 16;
+  stagger_priority();
 #pragma unroll 1
   for (int sg = 0; sg < NSG; ++sg)
     stage_mma<T, MT, NT, WD, PF_UPFRONT>(acc, lds + sg * BUF + aoff, ring, [](int) {});
@@ -413,7 +498,8 @@ __global__ __launch_bounds__(256, 2) void conv02_kernel(Conv02Args a0) {
   ConvArgs a{};
   a.bias = a0.b2; a.out_act = a0.out_act; a.B = a0.B; a.H = a0.H; a.W = a0.W; a.Cout = 64; a.relu_act = 1;
   a.tiles_x = a0.tiles_x; a.tiles_y = a0.tiles_y;
-  conv_epilogue<T, MT, NT, true>(acc, a, b, y0 + wm * MT, x0, wn * 32, red);
+  __syncthreads();   // all waves are done with the halo buffers; reuse them as wave-private stagers
+  conv_epilogue<T, MT, NT, true>(acc, a, b, y0 + wm * MT, x0, wn * 32, red, lds + wv * (NSG * BUF / 4));
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -605,6 +691,12 @@ static void launch_conv(hipStream_t st, ConvArgs a, bool pool) {
   const size_t es = sizeof(T), P = (size_t)a.B * a.H * a.W, Po = pool ? P / 4 : P;
   const double flops = 2.0 * 9.0 * (a.C1 + a.C2) * a.Cout * (double)P;
   const double bytes = (double)P * ((a.up1 ? a.C1 / 4.0 : a.C1) + a.C2) * es + (double)Po * a.Cout * ((a.out_act ? es : 0) + (a.out_raw ? 4 : 0));
+#if CONV_VARIANT == 40
+  static unsigned long long* dbg = nullptr;
+  static int n_reported = 0;
+  if (!dbg) (void)hipMallocManaged((void**)&dbg, (size_t)1 << 26);
+  a.dbg = dbg;
+#endif
   hla_prof_begin(a.Cout >= 128 ? (pool ? K_CONV_NT2_POOL : K_CONV_NT2) : (pool ? K_CONV_NT1_POOL : K_CONV_NT1), flops, bytes, st);
   // Cout >= 128: block = 8x32 pixels x 128 channels, waves 2(M) x 2(N), wave tile 128 px x 64 ch, weights 1 tap ahead
   // Cout == 64 : block = 8x32 pixels x  64 channels, waves 2 x 2,       wave tile 128 px x 32 ch, weights 2 taps ahead
@@ -616,6 +708,19 @@ static void launch_conv(hipStream_t st, ConvArgs a, bool pool) {
     else hipLaunchKernelGGL((conv3x3_kernel<T, 4, 1, 2, 2, false, 2, true>), grid, dim3(256), 0, st, a);
   }
   hla_prof_end(st);
+#if CONV_VARIANT == 40
+  if (n_reported++ < 40) {
+    (void)hipStreamSynchronize(st);
+    const size_t nw = (size_t)grid.x * grid.y * 4;
+    double m[5] = {0, 0, 0, 0, 0};
+    for (size_t i = 0; i < nw; ++i) for (int k = 0; k < 5; ++k) m[k] += (double)dbg[i * 5 + k];
+    const int nstage = (a.C1 + a.C2) / (int)(SB / sizeof(T));
+    fprintf(stderr, "[dbg] Cin %d Cout %d H %d pool %d stages %d | per wave cycles: prologue %.0f, mma/stage %.0f (ideal 4608 alone), "
+            "write/stage %.0f, barrier/stage %.0f, epilogue %.0f, total %.0f\n", a.C1 + a.C2, a.Cout, a.H, (int)pool, nstage,
+            m[0] / nw, m[1] / nw / nstage, m[2] / nw / nstage, m[3] / nw / nstage, m[4] / nw,
+            (m[0] + m[1] + m[2] + m[3] + m[4]) / nw);
+  }
+#endif
 }
 
 template <typename T>

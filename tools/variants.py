@@ -11,5 +11,5 @@ for lib in libs:
     except Exception:
         print(lib, 'FAILED', out.stderr[-500:]); continue
     k = d['kernels']
-    conv = {n.replace('conv3x3_kernel', 'c'): (v['avg_us'], v['tflops']) for n, v in k.items() if n.startswith('conv3x3')}
+    conv = {n.replace('conv3x3_kernel', 'c'): (v['avg_us'], v['tflops']) for n, v in k.items() if n.startswith("conv")}
     print(f"{lib:16s} {d['value']:8.1f} pairs/s {d['ms_per_step']:7.3f} ms  " + '  '.join(f'{n}:{u:.0f}us/{t:.0f}TF' for n, (u, t) in conv.items()), flush=True)
