@@ -40,6 +40,10 @@ class S2GConfig(C.Structure):
                 ('damping', C.c_double * 3)]
 
 
+class S2GLevelGrad(C.Structure):
+    _fields_ = [('d_sat_feat', C.c_void_p), ('d_grd_feat', C.c_void_p), ('d_grd_conf', C.c_void_p)]
+
+
 class ProfRecord(C.Structure):
     _fields_ = [('kernel_id', C.c_int), ('ms', C.c_float), ('flops', C.c_double), ('bytes', C.c_double)]
 
@@ -74,6 +78,11 @@ def load() -> C.CDLL:
     lib.hla_s2g_workspace_bytes.argtypes = [C.POINTER(S2GConfig), C.POINTER(S2GLevel), i]
     lib.hla_s2g_lm_solve.restype = i
     lib.hla_s2g_lm_solve.argtypes = [C.POINTER(S2GConfig), C.POINTER(S2GLevel), vp, vp, vp, vp, vp, vp, vp, sz, i, vp]
+    lib.hla_s2g_bwd_workspace_bytes.restype = sz
+    lib.hla_s2g_bwd_workspace_bytes.argtypes = [C.POINTER(S2GConfig), C.POINTER(S2GLevel), i]
+    lib.hla_s2g_lm_solve_bwd.restype = i
+    lib.hla_s2g_lm_solve_bwd.argtypes = [C.POINTER(S2GConfig), C.POINTER(S2GLevel), C.POINTER(S2GLevelGrad), vp, vp, vp, vp,
+                                         vp, vp, vp, vp, sz, i, vp]
     lib.hla_prof_enable.restype = i
     lib.hla_prof_enable.argtypes = [i]
     lib.hla_prof_kernel_name.restype = C.c_char_p

@@ -145,13 +145,8 @@ class S2GPBase(nn.Module):
             draws.append(torch.stack([ru[:, 0], rv[:, 0]], 0))
         return torch.stack(draws, 0).to(device)
 
-    def lm_solve(self, sat_feats, grd_feats, grd_confs, grd_hw, extra=None, level_first=0, init_pose=None,
-                 sat_inv_norm=None, grd_inv_norm=None):
-        """sat_feats/grd_feats: NHWC fp32 lists (L2-normalised, or raw together with their [L,B] fp64
-        inverse norms); returns trace [B,N_iters,L,3] = (shift_u, shift_v, theta)."""
-        lib = _lib.load()
+    def _lm_structs(self, sat_feats, grd_feats, grd_confs, grd_hw, extra, level_first, sat_inv_norm, grd_inv_norm):
         dev = sat_feats[0].device
-        B = sat_feats[0].shape[0]
         L = len(sat_feats)
         tables = self.xyz_tables(grd_hw[0], grd_hw[1], dev)
         cfg = self._config(L, level_first)
@@ -160,6 +155,7 @@ class S2GPBase(nn.Module):
             s, g = sat_feats[l], grd_feats[l]
             A, h, w, Cn = s.shape[1], g.shape[1], g.shape[2], g.shape[3]
             assert s.shape[2] == A and s.shape[3] == Cn and tuple(tables[l].shape) == (h, w, 3)
+            assert s.is_contiguous() and g.is_contiguous()
             lv[l].sat_feat, lv[l].grd_feat = s.data_ptr(), g.data_ptr()
             lv[l].grd_conf = grd_confs[l].data_ptr() if (self.using_weight and grd_confs[l] is not None) else 0
             lv[l].xyz = tables[l].data_ptr()
@@ -172,21 +168,61 @@ class S2GPBase(nn.Module):
             else:
                 lv[l].meter_per_pixel = utils.get_meter_per_pixel() * utils.get_process_satmap_sidelength() / A
                 lv[l].centre = A / 2.0                                      # models_kitti.py:765-767
+        R_FL = extra['R_FL'].to(dev).float().contiguous() if self.ford else None
+        T_FL = extra['T_FL'].to(dev).float().contiguous() if self.ford else None
+        return cfg, lv, R_FL, T_FL
+
+    def lm_solve(self, sat_feats, grd_feats, grd_confs, grd_hw, extra=None, level_first=0, init_pose=None,
+                 sat_inv_norm=None, grd_inv_norm=None, keep_normal_eq=None):
+        """sat_feats/grd_feats: NHWC fp32 lists (L2-normalised, or raw together with their [L,B] fp64
+        inverse norms); returns trace [B,N_iters,L,3] = (shift_u, shift_v, theta)."""
+        lib = _lib.load()
+        dev = sat_feats[0].device
+        B, L = sat_feats[0].shape[0], len(sat_feats)
+        cfg, lv, R_FL, T_FL = self._lm_structs(sat_feats, grd_feats, grd_confs, grd_hw, extra, level_first,
+                                               sat_inv_norm, grd_inv_norm)
         steps = L * self.N_iters
         reinit = self.ford or cfg.dof == 3
         rand_uv = self._draw_reinit(steps, B, dev) if reinit else None
         trace = torch.empty(B, self.N_iters, L, 3, device=dev, dtype=torch.float32)
-        neq = torch.empty(steps, B, 16, device=dev, dtype=torch.float64) if self.keep_normal_eq else None
+        want_neq = self.keep_normal_eq if keep_normal_eq is None else keep_normal_eq
+        neq = torch.empty(steps, B, 16, device=dev, dtype=torch.float64) if want_neq else None
         nbytes = lib.hla_s2g_workspace_bytes(C.byref(cfg), lv, B)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-        R_FL = extra['R_FL'].to(dev).float().contiguous() if self.ford else None
-        T_FL = extra['T_FL'].to(dev).float().contiguous() if self.ford else None
         p0 = init_pose.to(dev).float().contiguous() if init_pose is not None else None
         rc = lib.hla_s2g_lm_solve(C.byref(cfg), lv, _lib.ptr(R_FL), _lib.ptr(T_FL), _lib.ptr(p0), _lib.ptr(rand_uv),
                                   _lib.ptr(trace), _lib.ptr(neq), _lib.ptr(ws), nbytes, B, _lib.stream_ptr())
         _lib.check(rc, 'hla_s2g_lm_solve')
         self.last_trace, self.last_normal_eq = trace, neq
         return trace
+
+    def lm_backward(self, sat_feats, grd_feats, grd_confs, grd_hw, trace, normal_eq, d_trace, extra=None, level_first=0,
+                    init_pose=None, sat_inv_norm=None, grd_inv_norm=None):
+        """Backward of ``lm_solve``: d(loss)/d(trace) [B,N,L,3] -> (d_sat[l], d_grd[l], d_conf[l] or None, d_lambda[3]).
+        Map gradients are NHWC fp32 and taken w.r.t. the L2-normalised maps (inv_norm * stored map)."""
+        lib = _lib.load()
+        dev = sat_feats[0].device
+        B, L = sat_feats[0].shape[0], len(sat_feats)
+        cfg, lv, R_FL, T_FL = self._lm_structs(sat_feats, grd_feats, grd_confs, grd_hw, extra, level_first,
+                                               sat_inv_norm, grd_inv_norm)
+        d_sat = [torch.zeros_like(t) for t in sat_feats]
+        d_grd = [torch.zeros_like(t) for t in grd_feats]
+        d_conf = [torch.zeros_like(grd_confs[l]) if (self.using_weight and grd_confs[l] is not None) else None
+                  for l in range(L)]
+        gr = (_lib.S2GLevelGrad * L)()
+        for l in range(L):
+            gr[l].d_sat_feat, gr[l].d_grd_feat = d_sat[l].data_ptr(), d_grd[l].data_ptr()
+            gr[l].d_grd_conf = d_conf[l].data_ptr() if d_conf[l] is not None else 0
+        d_lambda = torch.zeros(3, device=dev, dtype=torch.float64)
+        dtr = d_trace.to(dev).float().contiguous()
+        nbytes = lib.hla_s2g_bwd_workspace_bytes(C.byref(cfg), lv, B)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        p0 = init_pose.to(dev).float().contiguous() if init_pose is not None else None
+        rc = lib.hla_s2g_lm_solve_bwd(C.byref(cfg), lv, gr, _lib.ptr(R_FL), _lib.ptr(T_FL), _lib.ptr(p0), _lib.ptr(trace),
+                                      _lib.ptr(normal_eq), _lib.ptr(dtr), _lib.ptr(d_lambda), _lib.ptr(ws), nbytes, B,
+                                      _lib.stream_ptr())
+        _lib.check(rc, 'hla_s2g_lm_solve_bwd')
+        return d_sat, d_grd, d_conf, d_lambda
 
     def localise(self, sat_map, grd_img, want_conf, extra, level_first, init_pose):
         """Both feature pyramids (normalisation deferred into the LM sums) + the whole LM loop."""

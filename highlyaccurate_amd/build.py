@@ -8,8 +8,8 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'libhla.so')
-SOURCES = ['capi.hip', 'prof.hip', 'lm_solve.hip', 'grid_sample.hip', 'vgg.hip']
-FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=fast', '-Wno-unused-result']
+SOURCES = ['capi.hip', 'prof.hip', 'lm_solve.hip', 'lm_backward.hip', 'grid_sample.hip', 'vgg.hip']
+FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=fast', '-munsafe-fp-atomics', '-Wno-unused-result']
 
 
 def _stale() -> bool:

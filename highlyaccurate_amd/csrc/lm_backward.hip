@@ -1,0 +1,356 @@
+// Backward of the LM pose loop (hla_s2g_lm_solve): given d(loss)/d(trace) for every step, walk the
+// N_iters x levels steps in reverse and accumulate d(loss)/d(sat map), d(loss)/d(grd map) [, d/d(grd conf),
+// d/d(damping)].  This is what autograd does in the reference through models_kitti.py:1176-1283 (gather values,
+// bilinear weights, both norms, J^T W J, torch.inverse, the pose->uv chain of every later step; SURVEY
+// Appendix C), restated as two kernels per step:
+//   lm_bwd_solve   one wave per sample: closes the previous (later) step -- reduces its 12 projection-
+//                  coefficient adjoints and pulls them back to the pose --, re-solves this step's damped
+//                  system from the saved sums, and turns d(loss)/d(pose_out) into adjoints of the 14 sums.
+//   lm_bwd_accum   same tiling as lm_accum: recomputes the gather, forms the per-element adjoints, scatters
+//                  d/d(sat) to the 4 taps with fp32 atomics, adds d/d(grd) in place, and reduces the adjoints
+//                  of the pixel coordinates / uv-Jacobians to 12 sums per tile.
+// Gradients are w.r.t. the L2-NORMALISED maps (inv_norm * stored map); hla_vgg_backward applies the
+// normalisation Jacobian.  d/d(sat) accumulation order is not deterministic (atomics).
+#include "lm_common.h"
+
+int hla_s2g_validate(const char* who, const hla_s2g_config* cfg, const hla_s2g_level* lv, const float* R_FL,
+                     const float* T_FL, int B);
+
+struct BwdAccumArgs {
+  const float* sat; const float* grd; const float* conf; const float* xyz;
+  const double* coef;      // [B,COEF_N] forward coefficients of this step
+  const double* adj;       // [B,16]: gS gG A00 A01 A02 A11 A12 A22 gU0 gU1 gU2 gV0 gV1 gV2
+  const double* sat_inv;   // [B] or null
+  const double* grd_inv;
+  float* d_sat; float* d_grd; float* d_conf;
+  double* part;            // [B,nt,PART_N]: 12 coefficient-adjoint sums
+  int A, h, w, row0, npix, TP, nt, B, xcd_affine;
+};
+
+template <int C, bool USE_W>
+__global__ __launch_bounds__(256) void lm_bwd_accum(BwdAccumArgs a) {
+  __shared__ PixParam pp[MAX_TP];
+  __shared__ float pixacc[MAX_TP][9];     // a_ix a_iy a_j0u a_j0v a_j1u a_j1v a_j2u a_j2v a_w
+  __shared__ double red[4][12];
+  int b, tile;
+  if (!lm_block_map(a.xcd_affine, a.nt, a.B, b, tile)) return;
+  const int t = threadIdx.x;
+  const int p0 = tile * a.TP;
+  const int np = min(a.TP, a.npix - p0);
+  const double* cf = a.coef + (size_t)b * COEF_N;
+
+  if (t < np) {
+    const int p = p0 + t;
+    const int r = a.row0 + p / a.w, c = p % a.w;
+    const float cw = USE_W ? a.conf[((size_t)b * a.h + r) * a.w + c] : 1.f;
+    pp[t] = lm_pixel<C>(cf, a.xyz + ((size_t)r * a.w + c) * 3, a.A, cw);
+  }
+  __syncthreads();
+
+  const double* ad = a.adj + (size_t)b * 16;
+  const float gS = (float)ad[0], gG = (float)ad[1];
+  const float A00 = (float)ad[2], A01 = (float)ad[3], A02 = (float)ad[4], A11 = (float)ad[5], A12 = (float)ad[6], A22 = (float)ad[7];
+  const float gU0 = (float)ad[8], gU1 = (float)ad[9], gU2 = (float)ad[10];
+  const float gV0 = (float)ad[11], gV1 = (float)ad[12], gV2 = (float)ad[13];
+  const float as = a.sat_inv ? (float)a.sat_inv[b] : 1.f, ag = a.grd_inv ? (float)a.grd_inv[b] : 1.f;
+  const float j0u = (float)cf[8], j0v = (float)cf[9], j1u = (float)cf[10], j1v = (float)cf[11];
+  constexpr int LPP = C / 4, PPW = 64 / LPP;
+  const int lane = t & 63, wave = t >> 6;
+  const int sub = lane / LPP, cl = (lane % LPP) * 4;
+  const size_t sat_base = (size_t)b * a.A * a.A * C + cl;
+  const size_t grd_base = ((size_t)b * a.h * a.w + (size_t)a.row0 * a.w + p0) * C + cl;
+
+  for (int i0 = wave * PPW; i0 < np; i0 += 4 * PPW) {
+    const int i = i0 + sub;
+    const bool live = i < np;                    // PPW divides TP, so whole waves stay converged except at a ragged end
+    float q[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    if (live) {
+      const PixParam P = pp[i];
+      const float* sp = a.sat + sat_base + P.off;
+      const float4 t00 = *(const float4*)(sp), t01 = *(const float4*)(sp + P.dxo);
+      const float4 t10 = *(const float4*)(sp + P.dyo), t11 = *(const float4*)(sp + P.dyo + P.dxo);
+      const float4 gg = *(const float4*)(a.grd + grd_base + (size_t)i * C);
+      const float v00[4] = {t00.x, t00.y, t00.z, t00.w}, v01[4] = {t01.x, t01.y, t01.z, t01.w};
+      const float v10[4] = {t10.x, t10.y, t10.z, t10.w}, v11[4] = {t11.x, t11.y, t11.z, t11.w};
+      const float vg[4] = {gg.x, gg.y, gg.z, gg.w};
+      float d00[4], d01[4], d10[4], d11[4], dg[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float V00 = v00[e] * as, V01 = v01[e] * as, V10 = v10[e] * as, V11 = v11[e] * as;
+        const float top = P.wx0 * V00 + P.wx1 * V01, bot = P.wx0 * V10 + P.wx1 * V11;
+        const float s = P.wy0 * top + P.wy1 * bot;
+        const float dsy = bot - top;
+        const float e01 = V01 - V00, e11 = V11 - V10;
+        const float dsx = P.wy0 * e01 + P.wy1 * e11;
+        const float dxy = (e11 - e01) * P.m;
+        const float g = vg[e] * ag * P.gm;
+        const float J0 = dsx * j0u + dsy * j0v, J1 = dsx * j1u + dsy * j1v, J2 = dsx * P.j2u + dsy * P.j2v;
+        const float w = USE_W ? P.wt : 1.f;
+        const float aj0 = A00 * J0 + A01 * J1 + A02 * J2, aj1 = A01 * J0 + A11 * J1 + A12 * J2, aj2 = A02 * J0 + A12 * J1 + A22 * J2;
+        const float gs = 2.f * s * gS + w * (J0 * gU0 + J1 * gU1 + J2 * gU2);
+        const float ggr = 2.f * g * gG + w * (J0 * gV0 + J1 * gV1 + J2 * gV2);
+        const float gJ0 = w * (aj0 + s * gU0 + g * gV0), gJ1 = w * (aj1 + s * gU1 + g * gV1), gJ2 = w * (aj2 + s * gU2 + g * gV2);
+        const float gdsx = gJ0 * j0u + gJ1 * j1u + gJ2 * P.j2u, gdsy = gJ0 * j0v + gJ1 * j1v + gJ2 * P.j2v;
+        q[0] += gs * dsx + gdsy * dxy; q[1] += gs * dsy + gdsx * dxy;
+        q[2] += gJ0 * dsx; q[3] += gJ0 * dsy; q[4] += gJ1 * dsx; q[5] += gJ1 * dsy; q[6] += gJ2 * dsx; q[7] += gJ2 * dsy;
+        if (USE_W) q[8] += 0.5f * (J0 * aj0 + J1 * aj1 + J2 * aj2) + s * (J0 * gU0 + J1 * gU1 + J2 * gU2) + g * (J0 * gV0 + J1 * gV1 + J2 * gV2);
+        d00[e] = gs * P.wy0 * P.wx0 - gdsx * P.wy0 - gdsy * P.wx0;
+        d01[e] = gs * P.wy0 * P.wx1 + gdsx * P.wy0 - gdsy * P.wx1;
+        d10[e] = gs * P.wy1 * P.wx0 - gdsx * P.wy1 + gdsy * P.wx0;
+        d11[e] = gs * P.wy1 * P.wx1 + gdsx * P.wy1 + gdsy * P.wx1;
+        dg[e] = ggr * P.gm;
+      }
+      if (P.m != 0.f) {
+        float* dp = a.d_sat + sat_base + P.off;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          atomicAdd(dp + e, d00[e]);
+          atomicAdd(dp + P.dxo + e, d01[e]);
+          atomicAdd(dp + P.dyo + e, d10[e]);
+          atomicAdd(dp + P.dyo + P.dxo + e, d11[e]);
+        }
+      }
+      float4* gp = (float4*)(a.d_grd + grd_base + (size_t)i * C);      // this (pixel, channels) is owned by this lane
+      float4 o = *gp;
+      o.x += dg[0]; o.y += dg[1]; o.z += dg[2]; o.w += dg[3];
+      *gp = o;
+    }
+    // reduce the per-pixel adjoints over the LPP lanes that share the pixel
+#pragma unroll
+    for (int k = 0; k < (USE_W ? 9 : 8); ++k) {
+#pragma unroll
+      for (int o = LPP >> 1; o > 0; o >>= 1) q[k] += __shfl_xor(q[k], o, 64);
+    }
+    if (live && (lane % LPP) == 0) {
+#pragma unroll
+      for (int k = 0; k < 9; ++k) pixacc[i][k] = q[k];
+    }
+  }
+  __syncthreads();
+
+  // pixel adjoints -> adjoints of the 12 projection coefficients (+ d/d(conf))
+  double c12[12];
+#pragma unroll
+  for (int k = 0; k < 12; ++k) c12[k] = 0.0;
+  if (t < np) {
+    const int p = p0 + t;
+    const int r = a.row0 + p / a.w, c = p % a.w;
+    const float* qx = a.xyz + ((size_t)r * a.w + c) * 3;
+    const double kk = cf[12];
+    const double gu = (double)pixacc[t][0] - kk * (double)pixacc[t][7];     // j2v = -k (u - ctr)
+    const double gv = (double)pixacc[t][1] + kk * (double)pixacc[t][6];     // j2u =  k (v - ctr)
+    c12[0] = gu * qx[0]; c12[1] = gu * qx[1]; c12[2] = gu * qx[2]; c12[3] = gu;
+    c12[4] = gv * qx[0]; c12[5] = gv * qx[1]; c12[6] = gv * qx[2]; c12[7] = gv;
+    c12[8] = pixacc[t][2]; c12[9] = pixacc[t][3]; c12[10] = pixacc[t][4]; c12[11] = pixacc[t][5];
+    if (USE_W && a.d_conf) a.d_conf[((size_t)b * a.h + r) * a.w + c] += pixacc[t][8] * pp[t].gm;
+  }
+#pragma unroll
+  for (int k = 0; k < 12; ++k) c12[k] = wave_sum_f64(c12[k]);
+  if (lane == 0) {
+#pragma unroll
+    for (int k = 0; k < 12; ++k) red[wave][k] = c12[k];
+  }
+  __syncthreads();
+  if (t < PART_N) {
+    double v = 0.0;
+    if (t < 12) v = (red[0][t] + red[1][t]) + (red[2][t] + red[3][t]);
+    a.part[((size_t)b * a.nt + tile) * PART_N + t] = v;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+struct BwdSolveArgs {
+  // the later step (k+1) whose accum has just run, or part_next == null
+  const double* part_next; int nt_next; LmGeom geom_next;
+  // this step k
+  const double* normal_eq;    // [B,16] forward sums of step k
+  const float* pose_in;       // pose before step k: &trace[0][..][..][0] of step k-1, or pose0, or null (zeros)
+  int pose_in_stride;
+  const float* pose_out;      // pose after step k (= pose_in of step k+1), stride = trace_stride
+  const float* d_trace;       // d(loss)/d(pose after step k), stride = trace_stride
+  int trace_stride;
+  double* gid;                // [B,3] identity-path adjoint carried between launches
+  double* adj;                // [B,16] out
+  double* coef;               // [B,COEF_N] out: forward coefficients of step k
+  double* d_lambda;           // [3] accumulated over samples and steps
+  const float* R_FL; const float* T_FL;
+  int B, reinit, first;       // first: this is the last forward step (nothing to close, gid is not read)
+  LmSolveCfg cfg; LmGeom geom;
+};
+
+__global__ __launch_bounds__(64) void lm_bwd_solve(BwdSolveArgs a) {
+  const int b = blockIdx.x, lane = threadIdx.x;
+  const float* R = a.R_FL ? a.R_FL + (size_t)b * 9 : nullptr;
+  const float* T = a.T_FL ? a.T_FL + (size_t)b * 3 : nullptr;
+  double c12[12];
+#pragma unroll
+  for (int k = 0; k < 12; ++k) c12[k] = 0.0;
+  if (a.part_next) {
+    for (int i = lane; i < a.nt_next; i += 64) {
+      const double* p = a.part_next + ((size_t)b * a.nt_next + i) * PART_N;
+#pragma unroll
+      for (int k = 0; k < 12; ++k) c12[k] += p[k];
+    }
+#pragma unroll
+    for (int k = 0; k < 12; ++k) c12[k] = wave_sum_f64(c12[k]);
+  }
+  if (lane != 0) return;
+
+  const float* po = a.pose_out + (size_t)b * a.trace_stride;
+  const float* dt = a.d_trace + (size_t)b * a.trace_stride;
+  double gout[3] = {dt[0], dt[1], dt[2]};
+  if (!a.first) {
+    double g3[3] = {0, 0, 0};
+    if (a.part_next) lm_coefficients_bwd(a.geom_next, po[0], po[1], po[2], R, T, c12, g3);
+    for (int p = 0; p < 3; ++p) gout[p] += g3[p] + a.gid[(size_t)b * 3 + p];
+  }
+  float pin[3] = {0.f, 0.f, 0.f};
+  if (a.pose_in) { const float* pi = a.pose_in + (size_t)b * a.pose_in_stride; pin[0] = pi[0]; pin[1] = pi[1]; pin[2] = pi[2]; }
+
+  const double* s = a.normal_eq + (size_t)b * 16;
+  double H[3][3], g[3], Mi[3][3], d[3], ns, ng;
+  lm_solve_step(a.cfg, s, H, g, Mi, d, ns, ng);
+  // which components survived the re-initialisation rule (models_kitti.py:1032-1033)?
+  double keep[3] = {1.0, 1.0, 1.0};
+  if (a.reinit) {
+    const float nu = (float)((double)pin[0] - d[0]), nv = (float)((double)pin[1] - d[1]);
+    if (!(nu > -2.5f && nu < 2.5f)) keep[0] = 0.0;
+    if (!(nv > -2.5f && nv < 2.5f)) keep[1] = 0.0;
+  }
+  double gnew[3], gd[3], y[3];
+  for (int p = 0; p < 3; ++p) { gnew[p] = gout[p] * keep[p]; a.gid[(size_t)b * 3 + p] = gnew[p]; gd[p] = -gnew[p]; }
+  for (int p = 0; p < 3; ++p) y[p] = Mi[p][0] * gd[0] + Mi[p][1] * gd[1] + Mi[p][2] * gd[2];
+  // d = M^-1 g  =>  g_bar = y,  M_bar = -y d^T
+  double gH[3][3];
+  for (int p = 0; p < 3; ++p) for (int q = 0; q < 3; ++q) gH[p][q] = -y[p] * d[q];
+  const int nl = a.cfg.dof == 3 ? 3 : (a.cfg.dof == 2 ? 2 : 1);
+  for (int i = 0; i < nl; ++i) {
+    const int p = a.cfg.dof == 1 ? 2 : i;
+    const double gM = gH[p][p];
+    atomicAdd(a.d_lambda + i, gM * (a.cfg.use_hessian ? H[p][p] : 1.0));
+    if (a.cfg.use_hessian) gH[p][p] += a.cfg.lam[i] * gM;
+  }
+  const double is2 = 1.0 / (ns * ns), isg = 1.0 / (ns * ng);
+  const double Hs[3][3] = {{s[2], s[3], s[4]}, {s[3], s[5], s[6]}, {s[4], s[6], s[7]}};
+  double g_is2 = 0.0, g_isg = 0.0;
+  for (int p = 0; p < 3; ++p) {
+    for (int q = 0; q < 3; ++q) g_is2 += gH[p][q] * Hs[p][q];
+    g_is2 += y[p] * s[8 + p];
+    g_isg -= y[p] * s[11 + p];
+  }
+  const double g_ns = -2.0 * g_is2 / (ns * ns * ns) - g_isg / (ns * ns * ng);
+  const double g_ng = -g_isg / (ns * ng * ng);
+  double* ad = a.adj + (size_t)b * 16;
+  ad[0] = sqrt(s[0]) > 1e-6 ? g_ns / (2.0 * ns) : 0.0;
+  ad[1] = sqrt(s[1]) > 1e-6 ? g_ng / (2.0 * ng) : 0.0;
+  ad[2] = 2.0 * is2 * gH[0][0]; ad[3] = is2 * (gH[0][1] + gH[1][0]); ad[4] = is2 * (gH[0][2] + gH[2][0]);
+  ad[5] = 2.0 * is2 * gH[1][1]; ad[6] = is2 * (gH[1][2] + gH[2][1]); ad[7] = 2.0 * is2 * gH[2][2];
+  for (int p = 0; p < 3; ++p) { ad[8 + p] = is2 * y[p]; ad[11 + p] = -isg * y[p]; }
+  ad[14] = ad[15] = 0.0;
+  lm_coefficients(a.geom, pin[0], pin[1], pin[2], R, T, a.coef + (size_t)b * COEF_N);
+}
+
+// ---------------------------------------------------------------------------------------------
+static size_t bwd_layout(const hla_s2g_config* cfg, const hla_s2g_level* lv, int B, size_t off[5]) {
+  int max_nt = 1;
+  for (int l = 0; l < cfg->n_levels; ++l) {
+    const int npix = (lv[l].h - lv[l].row0) * lv[l].w;
+    const int tp = lm_pick_tile(npix);
+    max_nt = max(max_nt, (npix + tp - 1) / tp);
+  }
+  size_t o = 0;
+  off[0] = o; o += hla_align_up((size_t)B * COEF_N * sizeof(double), 256);          // coef
+  off[1] = o; o += hla_align_up((size_t)B * 16 * sizeof(double), 256);              // adj
+  off[2] = o; o += hla_align_up((size_t)B * 3 * sizeof(double), 256);               // gid
+  off[3] = o; o += hla_align_up((size_t)B * max_nt * PART_N * sizeof(double), 256); // part
+  off[4] = o;
+  return o;
+}
+
+extern "C" size_t hla_s2g_bwd_workspace_bytes(const hla_s2g_config* cfg, const hla_s2g_level* levels, int B) {
+  size_t off[5];
+  return bwd_layout(cfg, levels, B, off);
+}
+
+template <bool W>
+static void launch_bwd_accum(int C, dim3 grid, hipStream_t st, const BwdAccumArgs& a) {
+  switch (C) {
+    case 256: hipLaunchKernelGGL((lm_bwd_accum<256, W>), grid, dim3(256), 0, st, a); break;
+    case 128: hipLaunchKernelGGL((lm_bwd_accum<128, W>), grid, dim3(256), 0, st, a); break;
+    case 64: hipLaunchKernelGGL((lm_bwd_accum<64, W>), grid, dim3(256), 0, st, a); break;
+    case 16: hipLaunchKernelGGL((lm_bwd_accum<16, W>), grid, dim3(256), 0, st, a); break;
+  }
+}
+
+extern "C" int hla_s2g_lm_solve_bwd(const hla_s2g_config* cfg, const hla_s2g_level* lv, const hla_s2g_level_grad* gr,
+                                    const float* R_FL, const float* T_FL, const float* pose0, const float* trace,
+                                    const double* normal_eq, const float* d_trace, double* d_damping, void* workspace,
+                                    size_t workspace_bytes, int B, hla_stream_t stream) {
+  HLA_REQUIRE(gr && trace && normal_eq && d_trace && d_damping && workspace, "hla_s2g_lm_solve_bwd: null argument");
+  const int rc = hla_s2g_validate("hla_s2g_lm_solve_bwd", cfg, lv, R_FL, T_FL, B);
+  if (rc) return rc;
+  for (int l = 0; l < cfg->n_levels; ++l)
+    HLA_REQUIRE(gr[l].d_sat_feat && gr[l].d_grd_feat, "hla_s2g_lm_solve_bwd: level %d gradient buffers missing", l);
+  size_t off[5];
+  const size_t need = bwd_layout(cfg, lv, B, off);
+  if (workspace_bytes < need) {
+    hla_set_error("hla_s2g_lm_solve_bwd: workspace %zu < %zu", workspace_bytes, need);
+    return HLA_ERR_WORKSPACE;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  char* ws = (char*)workspace;
+  double* coef = (double*)(ws + off[0]);
+  double* adj = (double*)(ws + off[1]);
+  double* gid = (double*)(ws + off[2]);
+  double* part = (double*)(ws + off[3]);
+  HLA_CHECK_HIP(hipMemsetAsync(d_damping, 0, 3 * sizeof(double), st));
+
+  const bool reinit = cfg->ford || cfg->dof == 3;
+  const int L = cfg->n_levels, N = cfg->n_iters, steps = L * N, tstride = N * L * 3;
+  auto step_level = [&](int k) { return cfg->level_first ? k / N : k % L; };
+  auto step_iter = [&](int k) { return cfg->level_first ? k % N : k / L; };
+  auto slot = [&](int k) { return ((size_t)step_iter(k) * L + step_level(k)) * 3; };
+  auto geom = [&](int l) {
+    LmGeom g{};
+    g.ford = cfg->ford; g.lat = cfg->shift_range_lat; g.lon = cfg->shift_range_lon; g.rot = cfg->rotation_range;
+    g.mpp = lv[l].meter_per_pixel; g.ctr = lv[l].centre;
+    return g;
+  };
+
+  int nt_prev = 0;
+  for (int k = steps - 1; k >= 0; --k) {
+    const int l = step_level(k);
+    const hla_s2g_level& v = lv[l];
+    BwdSolveArgs sa{};
+    sa.first = (k == steps - 1) ? 1 : 0;
+    if (!sa.first) { sa.part_next = part; sa.nt_next = nt_prev; sa.geom_next = geom(step_level(k + 1)); }
+    sa.normal_eq = normal_eq + (size_t)k * B * 16;
+    if (k > 0) { sa.pose_in = trace + slot(k - 1); sa.pose_in_stride = tstride; }
+    else { sa.pose_in = pose0; sa.pose_in_stride = 3; }
+    sa.pose_out = trace + slot(k); sa.d_trace = d_trace + slot(k); sa.trace_stride = tstride;
+    sa.gid = gid; sa.adj = adj; sa.coef = coef; sa.d_lambda = d_damping;
+    sa.R_FL = R_FL; sa.T_FL = T_FL; sa.B = B; sa.reinit = reinit ? 1 : 0;
+    sa.cfg.dof = cfg->dof; sa.cfg.use_hessian = cfg->use_hessian;
+    for (int i = 0; i < 3; ++i) sa.cfg.lam[i] = cfg->damping[i];
+    sa.geom = geom(l);
+    hla_prof_begin(K_LMSOLVE, 0, 0, st);
+    hipLaunchKernelGGL(lm_bwd_solve, dim3(B), dim3(64), 0, st, sa);
+    hla_prof_end(st);
+
+    BwdAccumArgs aa{};
+    aa.sat = v.sat_feat; aa.grd = v.grd_feat; aa.conf = v.grd_conf; aa.xyz = v.xyz; aa.coef = coef; aa.adj = adj;
+    aa.sat_inv = v.sat_inv_norm; aa.grd_inv = v.grd_inv_norm;
+    aa.d_sat = gr[l].d_sat_feat; aa.d_grd = gr[l].d_grd_feat; aa.d_conf = gr[l].d_grd_conf; aa.part = part;
+    aa.A = v.A; aa.h = v.h; aa.w = v.w; aa.row0 = v.row0; aa.npix = (v.h - v.row0) * v.w;
+    aa.TP = lm_pick_tile(aa.npix); aa.nt = (aa.npix + aa.TP - 1) / aa.TP; aa.B = B;
+    aa.xcd_affine = (B >= 8) ? 1 : 0;
+    const int nblk = aa.xcd_affine ? 8 * ((B + 7) / 8) * aa.nt : B * aa.nt;
+    hla_prof_begin(K_LMBWD, 0, (double)B * (5.0 * (double)v.A * v.A + 3.0 * (double)aa.npix) * v.C * 4.0, st);
+    if (cfg->using_weight) launch_bwd_accum<true>(v.C, dim3(nblk), st, aa);
+    else launch_bwd_accum<false>(v.C, dim3(nblk), st, aa);
+    hla_prof_end(st);
+    nt_prev = aa.nt;
+  }
+  HLA_CHECK_HIP(hipGetLastError());
+  return HLA_OK;
+}

@@ -12,19 +12,7 @@
 //   lm_solve     one wave per sample: fixed-order fp64 reduction of the tile partials (bitwise
 //                deterministic), 3x3/2x2/1x1 damped solve, pose update + re-initialisation rule,
 //                and the projection coefficients of the NEXT step (so no extra launch for them).
-#include "common.h"
-
-#define COEF_N 16      // doubles per sample: au[3] tu av[3] tv jsu[2] jsv[2] k centre pad pad
-#define PART_N 16      // doubles per (sample, tile): S G H00 H01 H02 H11 H12 H22 U0 U1 U2 V0 V1 V2 pad pad
-#define MAX_TP 256
-
-struct __attribute__((aligned(16))) PixParam {
-  int off, dxo, dyo;            // element offsets of the NW tap and the +x / +y neighbours
-  float wx0, wx1, wy0, wy1;     // clamped-corner bilinear weights x in-bounds x ground mask
-  float j2u, j2v;               // d(uv)/d(theta) at this pixel
-  float gm, wt;                 // ground mask (z>0), LM weight
-  int pad;
-};
+#include "lm_common.h"
 
 struct AccumArgs {
   const float* sat;   // [B,A,A,C]
@@ -40,19 +28,8 @@ template <int C, bool USE_W>
 __global__ __launch_bounds__(256) void lm_accum(AccumArgs a) {
   __shared__ PixParam pp[MAX_TP];
   __shared__ float red[4][14];
-
-  // block -> (sample, tile).  With >= 8 samples keep every tile of a sample on one XCD
-  // (blocks are dealt round-robin to the 8 XCDs) so its satellite map stays in that XCD's L2.
   int b, tile;
-  if (a.xcd_affine) {
-    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
-    b = (j / a.nt) * 8 + xcd;
-    tile = j % a.nt;
-    if (b >= a.B) return;
-  } else {
-    b = blockIdx.x / a.nt;
-    tile = blockIdx.x % a.nt;
-  }
+  if (!lm_block_map(a.xcd_affine, a.nt, a.B, b, tile)) return;
   const int t = threadIdx.x;
   const int p0 = tile * a.TP;
   const int np = min(a.TP, a.npix - p0);
@@ -61,36 +38,8 @@ __global__ __launch_bounds__(256) void lm_accum(AccumArgs a) {
   if (t < np) {
     const int p = p0 + t;
     const int r = a.row0 + p / a.w, c = p % a.w;
-    const float* q = a.xyz + ((size_t)r * a.w + c) * 3;
-    const double X = q[0], Y = q[1], Z = q[2];
-    const double u = cf[0] * X + cf[1] * Y + cf[2] * Z + cf[3];
-    const double v = cf[4] * X + cf[5] * Y + cf[6] * Z + cf[7];
-    const double lim = (double)(a.A - 1);
-    const bool gm = q[2] > 0.f;
-    const bool inb = (u >= 0.0) && (u <= lim) && (v >= 0.0) && (v <= lim);   // jacobian.py:168-170
-    PixParam o;
-    o.gm = gm ? 1.f : 0.f;
-    o.wt = 1.f;
-    if (USE_W) o.wt = a.conf[((size_t)b * a.h + r) * a.w + c] * o.gm;        // grd_conf * mask
-    o.pad = 0;
-    if (inb && gm) {
-      const double x0 = floor(u), y0 = floor(v);
-      const double x1 = fmin(x0 + 1.0, lim), y1 = fmin(y0 + 1.0, lim);       // clamped corners, 146-166
-      o.wx0 = (float)(x1 - u); o.wx1 = (float)(u - x0);
-      o.wy0 = (float)(y1 - v); o.wy1 = (float)(v - y0);
-      const int ix0 = (int)x0, iy0 = (int)y0;
-      o.off = (iy0 * a.A + ix0) * C;
-      o.dxo = ((int)x1 - ix0) * C;
-      o.dyo = ((int)y1 - iy0) * a.A * C;
-      const double k = cf[12], ctr = cf[13];
-      o.j2u = (float)(k * (v - ctr));
-      o.j2v = (float)(-k * (u - ctr));
-    } else {
-      o.wx0 = o.wx1 = o.wy0 = o.wy1 = 0.f;
-      o.off = o.dxo = o.dyo = 0;
-      o.j2u = o.j2v = 0.f;
-    }
-    pp[t] = o;
+    const float cw = USE_W ? a.conf[((size_t)b * a.h + r) * a.w + c] : 1.f;
+    pp[t] = lm_pixel<C>(cf, a.xyz + ((size_t)r * a.w + c) * 3, a.A, cw);
   }
   __syncthreads();
 
@@ -152,39 +101,22 @@ __global__ __launch_bounds__(256) void lm_accum(AccumArgs a) {
 
 // ---------------------------------------------------------------------------------------------
 struct SolveArgs {
-  const double* part;   // [B,nt,PART_N] of the step being closed, or null (init launch)
+  const double* part;    // [B,nt,PART_N] of the step being closed, or null (init launch)
   const double* sat_inv; // [B] or null: feature maps are stored un-normalised, sums are rescaled here
   const double* grd_inv;
   int nt;
-  float* pose;          // [B,3] running pose (shift_u, shift_v, theta), fp32 like the reference
-  float* trace_out;     // &trace[0][iter][level][0] of this step (sample stride = trace_stride)
+  float* pose;           // [B,3] running pose (shift_u, shift_v, theta), fp32 like the reference
+  float* trace_out;      // &trace[0][iter][level][0] of this step (sample stride = trace_stride)
   int trace_stride;
-  const float* rand_uv; // [2,B] for this step, or null
-  double* normal_eq;    // [B,16] for this step, or null
-  double* coef;         // [B,COEF_N] out for the next step, or null
-  const float* R_FL;    // [B,3,3]
-  const float* T_FL;    // [B,3]
-  int B, ford, dof, use_hessian, reinit;
-  double lat, lon, rot, lam0, lam1, lam2;
-  double next_mpp, next_ctr;
+  const float* rand_uv;  // [2,B] for this step, or null
+  double* normal_eq;     // [B,16] for this step, or null
+  double* coef;          // [B,COEF_N] out for the next step, or null
+  const float* R_FL;     // [B,3,3]
+  const float* T_FL;     // [B,3]
+  int B, reinit;
+  LmSolveCfg cfg;
+  LmGeom next;           // geometry of the level the NEXT step runs on
 };
-
-__device__ static void solve3(const double M[3][3], const double b[3], double x[3]) {
-  const double c00 = M[1][1] * M[2][2] - M[1][2] * M[2][1];
-  const double c01 = M[1][2] * M[2][0] - M[1][0] * M[2][2];
-  const double c02 = M[1][0] * M[2][1] - M[1][1] * M[2][0];
-  const double det = M[0][0] * c00 + M[0][1] * c01 + M[0][2] * c02;
-  const double id = 1.0 / det;
-  const double i00 = c00 * id, i01 = (M[0][2] * M[2][1] - M[0][1] * M[2][2]) * id,
-               i02 = (M[0][1] * M[1][2] - M[0][2] * M[1][1]) * id;
-  const double i10 = c01 * id, i11 = (M[0][0] * M[2][2] - M[0][2] * M[2][0]) * id,
-               i12 = (M[0][2] * M[1][0] - M[0][0] * M[1][2]) * id;
-  const double i20 = c02 * id, i21 = (M[0][1] * M[2][0] - M[0][0] * M[2][1]) * id,
-               i22 = (M[0][0] * M[1][1] - M[0][1] * M[1][0]) * id;
-  x[0] = i00 * b[0] + i01 * b[1] + i02 * b[2];
-  x[1] = i10 * b[0] + i11 * b[1] + i12 * b[2];
-  x[2] = i20 * b[0] + i21 * b[1] + i22 * b[2];
-}
 
 __global__ __launch_bounds__(64) void lm_solve(SolveArgs a) {
   const int b = blockIdx.x, lane = threadIdx.x;
@@ -212,29 +144,8 @@ __global__ __launch_bounds__(64) void lm_solve(SolveArgs a) {
         for (int k = 0; k < 14; ++k) a.normal_eq[(size_t)b * 16 + k] = s[k];
         a.normal_eq[(size_t)b * 16 + 14] = 0.0; a.normal_eq[(size_t)b * 16 + 15] = 0.0;
       }
-      // models_kitti.py:976-984: both norms clamped at 1e-6; J is divided by ||s|| as well
-      const double ns = fmax(sqrt(s[0]), 1e-6), ng = fmax(sqrt(s[1]), 1e-6);
-      const double is2 = 1.0 / (ns * ns), isg = 1.0 / (ns * ng);
-      double H[3][3] = {{s[2] * is2, s[3] * is2, s[4] * is2}, {s[3] * is2, s[5] * is2, s[6] * is2},
-                        {s[4] * is2, s[6] * is2, s[7] * is2}};
-      double g[3] = {s[8] * is2 - s[11] * isg, s[9] * is2 - s[12] * isg, s[10] * is2 - s[13] * isg};
-      double d[3] = {0, 0, 0};
-      if (a.dof == 3) {
-        double M[3][3];
-        for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) M[i][j] = H[i][j];
-        M[0][0] += a.lam0 * (a.use_hessian ? H[0][0] : 1.0);
-        M[1][1] += a.lam1 * (a.use_hessian ? H[1][1] : 1.0);
-        M[2][2] += a.lam2 * (a.use_hessian ? H[2][2] : 1.0);
-        solve3(M, g, d);
-      } else if (a.dof == 2) {       // rotation_range == 0: (u,v) only, models_kitti.py:954-955,1015-1018
-        const double m00 = H[0][0] + a.lam0 * (a.use_hessian ? H[0][0] : 1.0);
-        const double m11 = H[1][1] + a.lam1 * (a.use_hessian ? H[1][1] : 1.0);
-        const double m01 = H[0][1], det = m00 * m11 - m01 * m01;
-        d[0] = (m11 * g[0] - m01 * g[1]) / det;
-        d[1] = (m00 * g[1] - m01 * g[0]) / det;
-      } else {                       // shift ranges == 0: theta only, models_kitti.py:956-957,1019-1022
-        d[2] = g[2] / (H[2][2] + a.lam0 * (a.use_hessian ? H[2][2] : 1.0));
-      }
+      double H[3][3], g[3], Mi[3][3], d[3], ns, ng;
+      lm_solve_step(a.cfg, s, H, g, Mi, d, ns, ng);
       su = (float)((double)su - d[0]);
       sv = (float)((double)sv - d[1]);
       th = (float)((double)th - d[2]);
@@ -248,50 +159,18 @@ __global__ __launch_bounds__(64) void lm_solve(SolveArgs a) {
       tr[0] = su; tr[1] = sv; tr[2] = th;
     }
   }
-
-  if (a.coef && lane == 0) {
-    double* cf = a.coef + (size_t)b * COEF_N;
-    const double k = a.rot / 180.0 * 3.14159265358979323846;
-    const double ang = (double)th * k, c = cos(ang), s = sin(ang), im = 1.0 / a.next_mpp, ctr = a.next_ctr;
-    if (!a.ford) {                   // models_kitti.py:719-799
-      const double sum = (double)su * a.lon, svm = (double)sv * a.lat;
-      cf[0] = s * im; cf[1] = 0.0; cf[2] = c * im; cf[3] = (c * sum - s * svm) * im + ctr;
-      cf[4] = c * im; cf[5] = 0.0; cf[6] = -s * im; cf[7] = (-c * svm - s * sum) * im + ctr;
-      cf[8] = c * a.lon * im; cf[9] = -s * a.lon * im;
-      cf[10] = -s * a.lat * im; cf[11] = -c * a.lat * im;
-    } else {                         // models_ford.py:208-253
-      const float* R = a.R_FL + (size_t)b * 9;
-      const float* T = a.T_FL + (size_t)b * 3;
-      const double sum = (double)su * a.lat, svm = (double)sv * a.lon;
-      const double t0 = (double)T[0] + svm, t1 = (double)T[1] - sum;
-      for (int i = 0; i < 3; ++i) {
-        cf[i] = (-s * (double)R[i] + c * (double)R[3 + i]) * im;
-        cf[4 + i] = -(c * (double)R[i] + s * (double)R[3 + i]) * im;
-      }
-      cf[3] = (-s * t0 + c * t1) * im + ctr;
-      cf[7] = -(c * t0 + s * t1) * im + ctr;
-      cf[8] = -c * a.lat * im; cf[9] = s * a.lat * im;
-      cf[10] = -s * a.lon * im; cf[11] = -c * a.lon * im;
-    }
-    cf[12] = k; cf[13] = ctr; cf[14] = 0.0; cf[15] = 0.0;
-  }
+  if (a.coef && lane == 0)
+    lm_coefficients(a.next, su, sv, th, a.R_FL ? a.R_FL + (size_t)b * 9 : nullptr, a.T_FL ? a.T_FL + (size_t)b * 3 : nullptr,
+                    a.coef + (size_t)b * COEF_N);
 }
 
 // ---------------------------------------------------------------------------------------------
-// Pixels per block.  Depends on the level only, never on the batch size, so that a sample's partial-sum
-// grouping -- and therefore its pose, bit for bit -- does not depend on its batch mates.
-static int pick_tile(int npix, int /*B*/) {
-  if (npix >= 16384) return 256;
-  if (npix >= 4096) return 128;
-  return 64;
-}
-
 static size_t ws_layout(const hla_s2g_config* cfg, const hla_s2g_level* lv, int B, size_t* off_coef, size_t* off_pose,
                         size_t* off_part) {
   int max_nt = 1;
   for (int l = 0; l < cfg->n_levels; ++l) {
     const int npix = (lv[l].h - lv[l].row0) * lv[l].w;
-    const int tp = pick_tile(npix, B);
+    const int tp = lm_pick_tile(npix);
     max_nt = max(max_nt, (npix + tp - 1) / tp);
   }
   size_t o = 0;
@@ -316,22 +195,30 @@ static void launch_accum(int C, dim3 grid, hipStream_t st, const AccumArgs& a) {
   }
 }
 
+int hla_s2g_validate(const char* who, const hla_s2g_config* cfg, const hla_s2g_level* lv, const float* R_FL,
+                     const float* T_FL, int B) {
+  HLA_REQUIRE(cfg && lv, "%s: null argument", who);
+  HLA_REQUIRE(B > 0 && cfg->n_levels >= 1 && cfg->n_levels <= 4 && cfg->n_iters >= 1, "%s: bad sizes", who);
+  HLA_REQUIRE(cfg->dof >= 1 && cfg->dof <= 3, "%s: dof must be 1..3", who);
+  HLA_REQUIRE(!cfg->ford || (R_FL && T_FL), "%s: Ford mode needs R_FL and T_FL", who);
+  for (int l = 0; l < cfg->n_levels; ++l) {
+    const int C = lv[l].C;
+    HLA_REQUIRE(C == 256 || C == 128 || C == 64 || C == 16, "%s: unsupported channel count %d", who, C);
+    HLA_REQUIRE(lv[l].sat_feat && lv[l].grd_feat && lv[l].xyz, "%s: level %d has null maps", who, l);
+    HLA_REQUIRE(!cfg->using_weight || lv[l].grd_conf, "%s: using_weight needs grd_conf", who);
+    HLA_REQUIRE(lv[l].row0 >= 0 && lv[l].row0 < lv[l].h, "%s: bad row0", who);
+    HLA_REQUIRE((size_t)lv[l].A * lv[l].A * C < (1u << 31), "%s: satellite map too large", who);
+  }
+  return HLA_OK;
+}
+
 extern "C" int hla_s2g_lm_solve(const hla_s2g_config* cfg, const hla_s2g_level* lv, const float* R_FL,
                                 const float* T_FL, const float* pose0, const float* rand_uv, float* trace,
                                 double* normal_eq, void* workspace, size_t workspace_bytes, int B,
                                 hla_stream_t stream) {
-  HLA_REQUIRE(cfg && lv && trace && workspace, "hla_s2g_lm_solve: null argument");
-  HLA_REQUIRE(B > 0 && cfg->n_levels >= 1 && cfg->n_levels <= 4 && cfg->n_iters >= 1, "hla_s2g_lm_solve: bad sizes");
-  HLA_REQUIRE(cfg->dof >= 1 && cfg->dof <= 3, "hla_s2g_lm_solve: dof must be 1..3");
-  HLA_REQUIRE(!cfg->ford || (R_FL && T_FL), "hla_s2g_lm_solve: Ford mode needs R_FL and T_FL");
-  for (int l = 0; l < cfg->n_levels; ++l) {
-    const int C = lv[l].C;
-    HLA_REQUIRE(C == 256 || C == 128 || C == 64 || C == 16, "hla_s2g_lm_solve: unsupported channel count %d", C);
-    HLA_REQUIRE(lv[l].sat_feat && lv[l].grd_feat && lv[l].xyz, "hla_s2g_lm_solve: level %d has null maps", l);
-    HLA_REQUIRE(!cfg->using_weight || lv[l].grd_conf, "hla_s2g_lm_solve: using_weight needs grd_conf");
-    HLA_REQUIRE(lv[l].row0 >= 0 && lv[l].row0 < lv[l].h, "hla_s2g_lm_solve: bad row0");
-    HLA_REQUIRE((size_t)lv[l].A * lv[l].A * C < (1u << 31), "hla_s2g_lm_solve: satellite map too large");
-  }
+  HLA_REQUIRE(trace && workspace, "hla_s2g_lm_solve: null argument");
+  const int rc = hla_s2g_validate("hla_s2g_lm_solve", cfg, lv, R_FL, T_FL, B);
+  if (rc) return rc;
   const bool reinit = cfg->ford || cfg->dof == 3;
   HLA_REQUIRE(!reinit || rand_uv, "hla_s2g_lm_solve: rand_uv required");
   size_t oc, op, opart;
@@ -352,16 +239,21 @@ extern "C" int hla_s2g_lm_solve(const hla_s2g_config* cfg, const hla_s2g_level* 
   const int L = cfg->n_levels, N = cfg->n_iters, steps = L * N;
   auto step_level = [&](int k) { return cfg->level_first ? k / N : k % L; };
   auto step_iter = [&](int k) { return cfg->level_first ? k % N : k / L; };
+  auto geom = [&](int l) {
+    LmGeom g{};
+    g.ford = cfg->ford; g.lat = cfg->shift_range_lat; g.lon = cfg->shift_range_lon; g.rot = cfg->rotation_range;
+    g.mpp = lv[l].meter_per_pixel; g.ctr = lv[l].centre;
+    return g;
+  };
 
   SolveArgs sa{};
-  sa.pose = pose; sa.B = B; sa.ford = cfg->ford; sa.dof = cfg->dof; sa.use_hessian = cfg->use_hessian;
-  sa.reinit = reinit ? 1 : 0; sa.R_FL = R_FL; sa.T_FL = T_FL;
-  sa.lat = cfg->shift_range_lat; sa.lon = cfg->shift_range_lon; sa.rot = cfg->rotation_range;
-  sa.lam0 = cfg->damping[0]; sa.lam1 = cfg->damping[1]; sa.lam2 = cfg->damping[2];
+  sa.pose = pose; sa.B = B; sa.reinit = reinit ? 1 : 0; sa.R_FL = R_FL; sa.T_FL = T_FL;
+  sa.cfg.dof = cfg->dof; sa.cfg.use_hessian = cfg->use_hessian;
+  for (int i = 0; i < 3; ++i) sa.cfg.lam[i] = cfg->damping[i];
   sa.coef = coef;
 
   // init launch: coefficients of step 0
-  sa.part = nullptr; sa.next_mpp = lv[step_level(0)].meter_per_pixel; sa.next_ctr = lv[step_level(0)].centre;
+  sa.part = nullptr; sa.next = geom(step_level(0));
   hipLaunchKernelGGL(lm_solve, dim3(B), dim3(64), 0, st, sa);
 
   for (int k = 0; k < steps; ++k) {
@@ -370,7 +262,7 @@ extern "C" int hla_s2g_lm_solve(const hla_s2g_config* cfg, const hla_s2g_level* 
     AccumArgs aa{};
     aa.sat = v.sat_feat; aa.grd = v.grd_feat; aa.conf = v.grd_conf; aa.xyz = v.xyz; aa.coef = coef; aa.part = part;
     aa.A = v.A; aa.h = v.h; aa.w = v.w; aa.row0 = v.row0; aa.npix = (v.h - v.row0) * v.w;
-    aa.TP = pick_tile(aa.npix, B); aa.nt = (aa.npix + aa.TP - 1) / aa.TP; aa.B = B;
+    aa.TP = lm_pick_tile(aa.npix); aa.nt = (aa.npix + aa.TP - 1) / aa.TP; aa.B = B;
     aa.xcd_affine = (B >= 8) ? 1 : 0;
     const int nblk = aa.xcd_affine ? 8 * ((B + 7) / 8) * aa.nt : B * aa.nt;
     hla_prof_begin(v.C == 256 ? K_LM256 : v.C == 128 ? K_LM128 : v.C == 64 ? K_LM64 : K_LM16, 0,
@@ -383,11 +275,8 @@ extern "C" int hla_s2g_lm_solve(const hla_s2g_config* cfg, const hla_s2g_level* 
     sa.trace_out = trace + ((size_t)it * L + l) * 3; sa.trace_stride = N * L * 3;
     sa.rand_uv = reinit ? rand_uv + (size_t)k * 2 * B : nullptr;
     sa.normal_eq = normal_eq ? normal_eq + (size_t)k * B * 16 : nullptr;
-    if (k + 1 < steps) {
-      sa.coef = coef; sa.next_mpp = lv[step_level(k + 1)].meter_per_pixel; sa.next_ctr = lv[step_level(k + 1)].centre;
-    } else {
-      sa.coef = nullptr;
-    }
+    if (k + 1 < steps) { sa.coef = coef; sa.next = geom(step_level(k + 1)); }
+    else sa.coef = nullptr;
     hla_prof_begin(K_LMSOLVE, 0, (double)B * aa.nt * PART_N * 8.0, st);
     hipLaunchKernelGGL(lm_solve, dim3(B), dim3(64), 0, st, sa);
     hla_prof_end(st);

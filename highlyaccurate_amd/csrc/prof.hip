@@ -12,7 +12,7 @@ bool g_on = false;
 const char* kNames[HLA_PROF_NKERNELS] = {
     "pack_weights_kernel", "conv02_kernel", "conv3x3_kernel<MT4,NT2>", "conv3x3_kernel<MT4,NT2,pool>",
     "conv3x3_kernel<MT4,NT1>", "conv3x3_kernel<MT4,NT1,pool>", "conf_kernel", "inv_norm+scale_kernel",
-    "lm_accum<256>", "lm_accum<128>", "lm_accum<64>", "lm_accum<16>", "lm_solve", "grid_sample_kernel"};
+    "lm_accum<256>", "lm_accum<128>", "lm_accum<64>", "lm_accum<16>", "lm_solve", "grid_sample_kernel", "lm_bwd_accum", "wgrad_kernel", "elementwise_bwd"};
 }  // namespace
 
 bool hla_prof_on() { return g_on; }

@@ -136,11 +136,32 @@ int hla_s2g_lm_solve(const hla_s2g_config* cfg, const hla_s2g_level* levels, con
                      double* normal_eq, void* workspace, size_t workspace_bytes, int B, hla_stream_t stream);
 
 /* ------------------------------------------------------------------------- *
+ * Backward of the LM pose loop (what autograd does in the reference through models_kitti.py:1176-1283,
+ * SURVEY Appendix C): d(loss)/d(trace) -> d(loss)/d(feature maps).  Gradients are taken w.r.t. the
+ * L2-NORMALISED maps (inv_norm * stored map when the level carries inv norms); buffers are ACCUMULATED into
+ * (the caller zero-fills them), d_sat_feat with fp32 atomics.
+ * ------------------------------------------------------------------------- */
+typedef struct hla_s2g_level_grad {
+  float* d_sat_feat; /* [B,A,A,C] fp32 */
+  float* d_grd_feat; /* [B,h,w,C] fp32 */
+  float* d_grd_conf; /* [B,h,w] fp32 or NULL (only written when using_weight) */
+} hla_s2g_level_grad;
+
+size_t hla_s2g_bwd_workspace_bytes(const hla_s2g_config* cfg, const hla_s2g_level* levels, int B);
+
+/* trace, normal_eq: outputs of the forward call (normal_eq is required here);  d_trace [B,n_iters,n_levels,3] fp32
+ * d_damping [3] fp64 out: d(loss)/d(lambda_i) summed over samples and steps (for train_damping) */
+int hla_s2g_lm_solve_bwd(const hla_s2g_config* cfg, const hla_s2g_level* levels, const hla_s2g_level_grad* grads,
+                         const float* R_FL, const float* T_FL, const float* pose0, const float* trace,
+                         const double* normal_eq, const float* d_trace, double* d_damping, void* workspace,
+                         size_t workspace_bytes, int B, hla_stream_t stream);
+
+/* ------------------------------------------------------------------------- *
  * Measurement hooks (no reference counterpart; used by bench.py for the roofline numbers).
  * When enabled, every kernel launch of the entry points above is bracketed by two hipEvents
  * on its own stream; hla_prof_fetch synchronises them and returns one record per launch.
  * ------------------------------------------------------------------------- */
-#define HLA_PROF_NKERNELS 14
+#define HLA_PROF_NKERNELS 17
 typedef struct hla_prof_record {
   int kernel_id;  /* index for hla_prof_kernel_name */
   float ms;       /* event-to-event duration on the launch stream */

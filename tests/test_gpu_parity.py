@@ -358,3 +358,51 @@ def test_full_bench_config_runs_and_is_consistent():
         t5 = net.last_trace.clone()
     assert torch.isfinite(t).all()
     assert torch.equal(t[5:6], t5)
+
+
+@pytest.mark.parametrize('kw', [dict(), dict(using_weight=1), dict(use_hessian=1, damping=0.5),
+                                dict(rotation_range=0.0), dict(level_first=1)])
+def test_lm_backward_small_vs_oracle_autograd(kw):
+    """hla_s2g_lm_solve_bwd against torch autograd through the fp64 oracle's unrolled loop
+    (gather values, bilinear weights, norms, J^T W J, inverse, pose->uv chain of later steps)."""
+    from oracle import ref_cpu as O
+    from highlyaccurate_amd.models_kitti import LM_S2GP
+    d = _dev()
+    kw = dict(kw)
+    lf = kw.pop('level_first', 0)
+    args = O.default_args(**{'N_iters': 2, 'damping': 1.0, **kw})
+    B, grd_hw, sat_a = 2, (64, 256), 128
+    onet, sat, grd, conf = _oracle_small(args, 7, B, grd_hw, sat_a)
+    p0 = T(np.random.RandomState(5).uniform(-0.2, 0.2, size=(B, 3)).astype(np.float32))
+    L, N = 3, args.N_iters
+    coef = T(np.random.RandomState(6).standard_normal((B, N, L, 3)))         # loss = sum(coef * trace)
+    # oracle: leaves in fp64
+    sat64 = [s.double().requires_grad_(True) for s in sat]
+    grd64 = [g.double().requires_grad_(True) for g in grd]
+    conf64 = [c.double().requires_grad_(True) for c in conf]
+    su, sv, th = [p0[:, i:i + 1].double() for i in range(3)]
+    order = [(i, l) for l in range(L) for i in range(N)] if lf else [(i, l) for i in range(N) for l in range(L)]
+    torch.manual_seed(0)
+    loss = 0
+    for i, l in order:
+        su, sv, th = onet._step(l, sat64[l], None, grd64[l], conf64[l], su, sv, th, None)
+        loss = loss + (coef[:, i, l] * torch.cat([su, sv, th], 1)).sum()
+    loss.backward()
+    net = LM_S2GP(args).to(d)
+    nh = lambda t: t.permute(0, 2, 3, 1).contiguous().to(d)
+    feats = ([nh(s) for s in sat], [nh(g) for g in grd], [c[:, 0].contiguous().to(d) for c in conf])
+    torch.manual_seed(0)
+    trace = net.lm_solve(*feats, grd_hw, None, lf, init_pose=p0, keep_normal_eq=True)
+    d_sat, d_grd, d_conf, d_lam = net.lm_backward(*feats, grd_hw, trace, net.last_normal_eq, coef.float(), None, lf, init_pose=p0)
+    for l in range(L):
+        for name, got, ref in (('sat', d_sat[l], sat64[l].grad), ('grd', d_grd[l], grd64[l].grad)):
+            got = got.permute(0, 3, 1, 2).cpu().double().numpy()
+            e = np.abs(got - ref.numpy()).max() / max(np.abs(ref.numpy()).max(), 1e-30)
+            print(f'lm bwd {kw} lf{lf} level {l} d_{name}: rel err {e:.2e} (max |ref| {np.abs(ref.numpy()).max():.2e})')
+            assert e < 2e-4, (kw, l, name, e)
+        if args.using_weight:
+            got = d_conf[l].cpu().double().numpy()
+            ref = conf64[l].grad[:, 0].numpy()
+            e = np.abs(got - ref).max() / max(np.abs(ref).max(), 1e-30)
+            print(f'lm bwd level {l} d_conf: rel err {e:.2e}')
+            assert e < 2e-4
