@@ -64,7 +64,8 @@ def _packed_weights(module: 'VGGUnet', prm, versions, dt: int, device):
     return cache['buf']
 
 
-def vgg_forward_nhwc(module: 'VGGUnet', x: torch.Tensor, want_conf: bool = True, defer_norm: bool = False):
+def vgg_forward_nhwc(module: 'VGGUnet', x: torch.Tensor, want_conf: bool = True, defer_norm: bool = False,
+                     save_for_backward: bool = False):
     """Run the three-level extractor.  Returns (feats, confs, inv_norm): lists of NHWC fp32 tensors
     [B,h,w,C] and [B,h,w] (or None), and inv_norm [3,B] fp64 = 1/max(||map||, 1e-12).
     With ``defer_norm`` the maps are left un-normalised (the LM loop folds inv_norm into its sums);
@@ -87,12 +88,53 @@ def vgg_forward_nhwc(module: 'VGGUnet', x: torch.Tensor, want_conf: bool = True,
     nbytes = lib.hla_vgg_workspace_bytes(B, H, W, 3, dt)
     ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
     flags = (_lib.HLA_VGG_WANT_CONF if want_conf else 0) | (_lib.HLA_VGG_DEFER_NORM if defer_norm else 0)
+    if save_for_backward:
+        if not defer_norm:
+            raise ValueError('save_for_backward needs defer_norm=True (the backward works on the raw maps)')
+        flags |= _lib.HLA_VGG_SAVE_FOR_BACKWARD
     rc = lib.hla_vgg_forward(_lib.ptr(x), C.byref(prm), _lib.ptr(packed), fp, cp, _lib.ptr(inv_norm), _lib.ptr(ws), nbytes,
                              B, H, W, 3, dt, flags, _lib.stream_ptr())
     _lib.check(rc, 'hla_vgg_forward')
     # ws is only used by work already enqueued on this stream; the caching allocator keeps the block
     # stream-ordered, so dropping the Python reference here is safe.
+    if save_for_backward:
+        return feats, confs, inv_norm, dict(x=x, ws=ws, feats=feats, inv_norm=inv_norm, dt=dt)
     return feats, confs, inv_norm
+
+
+def vgg_backward_nhwc(module: 'VGGUnet', ctx: dict, d_feats):
+    """Backward of ``vgg_forward_nhwc(..., defer_norm=True, save_for_backward=True)``.
+    d_feats[l]: NHWC fp32 gradient w.r.t. the L2-normalised map l.  Returns {parameter name: gradient} for the
+    22 tensors that receive one at level 3 (conv0..conv14 weights+biases, conv_dec1/2 weights)."""
+    lib = _lib.load()
+    x, dt = ctx['x'], ctx['dt']
+    B, _, H, W = x.shape
+    prm, keep, versions = _param_table(module)
+    cache = module.__dict__.setdefault('_hla_packed_T', {})
+    key = (dt, str(x.device), versions)
+    if cache.get('key') != key:
+        buf = torch.empty(lib.hla_vgg_packed_weight_T_bytes(dt), dtype=torch.uint8, device=x.device)
+        _lib.check(lib.hla_vgg_pack_weights_T(C.byref(prm), _lib.ptr(buf), dt, _lib.stream_ptr()), 'hla_vgg_pack_weights_T')
+        cache['key'], cache['buf'] = key, buf
+    sd = dict(module.named_parameters())
+    grads, gs = {}, _lib.VggGrads()
+    for i, name in enumerate(_W_ORDER[:11]):
+        g = torch.empty_like(sd[name + '.weight'], dtype=torch.float32, memory_format=torch.contiguous_format)
+        grads[name + '.weight'] = g
+        gs.dw[i] = g.data_ptr()
+        if i < 7:
+            gb = torch.empty_like(sd[name + '.bias'], dtype=torch.float32)
+            grads[name + '.bias'] = gb
+            gs.db[i] = gb.data_ptr()
+    dfs = [d.contiguous().float() for d in d_feats]
+    fp = (C.c_void_p * 3)(*[f.data_ptr() for f in ctx['feats']])
+    dp = (C.c_void_p * 3)(*[d.data_ptr() for d in dfs])
+    nbytes = lib.hla_vgg_bwd_workspace_bytes(B, H, W, dt)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+    rc = lib.hla_vgg_backward(_lib.ptr(x), C.byref(prm), _lib.ptr(cache['buf']), _lib.ptr(ctx['ws']), fp, _lib.ptr(ctx['inv_norm']),
+                              dp, C.byref(gs), _lib.ptr(ws), nbytes, B, H, W, 3, dt, _lib.stream_ptr())
+    _lib.check(rc, 'hla_vgg_backward')
+    return grads
 
 
 class VGGUnet(nn.Module):

@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('HLA_LIB') or os.path.join(HERE, 'libhla.so')   # HLA_LIB: experiment builds
 
 HLA_F32, HLA_BF16 = 0, 1
-HLA_VGG_WANT_CONF, HLA_VGG_DEFER_NORM = 1, 2
+HLA_VGG_WANT_CONF, HLA_VGG_DEFER_NORM, HLA_VGG_SAVE_FOR_BACKWARD = 1, 2, 4
 ABI_VERSION = 2
 
 
@@ -38,6 +38,10 @@ class S2GConfig(C.Structure):
                 ('using_weight', C.c_int), ('use_hessian', C.c_int), ('dof', C.c_int),
                 ('shift_range_lat', C.c_double), ('shift_range_lon', C.c_double), ('rotation_range', C.c_double),
                 ('damping', C.c_double * 3)]
+
+
+class VggGrads(C.Structure):
+    _fields_ = [('dw', C.c_void_p * 17), ('db', C.c_void_p * 7)]
 
 
 class S2GLevelGrad(C.Structure):
@@ -72,6 +76,15 @@ def load() -> C.CDLL:
     lib.hla_vgg_packed_weight_bytes.argtypes = [i]
     lib.hla_vgg_pack_weights.restype = i
     lib.hla_vgg_pack_weights.argtypes = [C.POINTER(VggParams), vp, i, vp]
+    lib.hla_vgg_packed_weight_T_bytes.restype = sz
+    lib.hla_vgg_packed_weight_T_bytes.argtypes = [i]
+    lib.hla_vgg_pack_weights_T.restype = i
+    lib.hla_vgg_pack_weights_T.argtypes = [C.POINTER(VggParams), vp, i, vp]
+    lib.hla_vgg_bwd_workspace_bytes.restype = sz
+    lib.hla_vgg_bwd_workspace_bytes.argtypes = [i, i, i, i]
+    lib.hla_vgg_backward.restype = i
+    lib.hla_vgg_backward.argtypes = [vp, C.POINTER(VggParams), vp, vp, C.POINTER(vp), vp, C.POINTER(vp), C.POINTER(VggGrads),
+                                     vp, sz, i, i, i, i, i, vp]
     lib.hla_grid_sample.restype = i
     lib.hla_grid_sample.argtypes = [vp, vp, vp, vp, vp, i, i, i, i, i, i, i, vp]
     lib.hla_s2g_workspace_bytes.restype = sz

@@ -8,7 +8,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'libhla.so')
-SOURCES = ['capi.hip', 'prof.hip', 'lm_solve.hip', 'lm_backward.hip', 'grid_sample.hip', 'vgg.hip']
+SOURCES = ['capi.hip', 'prof.hip', 'lm_solve.hip', 'lm_backward.hip', 'grid_sample.hip', 'vgg.hip', 'vgg_backward.hip']
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=fast', '-munsafe-fp-atomics', '-Wno-unused-result']
 
 

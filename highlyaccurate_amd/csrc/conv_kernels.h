@@ -1,0 +1,729 @@
+// Device code shared by the VGG forward (vgg.hip) and backward (vgg_backward.hip) translation units.
+#pragma once
+// VGG16-U-Net feature extractor on gfx950 matrix cores: VGG.py:13-203, L2_norm VGG.py:511-514.
+//
+// Layout: activations NHWC; T = bf16 (throughput mode, fp32 accumulate) or float (exact-fp32 MFMA, parity mode).
+//
+// conv3x3_kernel -- implicit GEMM computed as D^T = W * X^T, so a lane owns one output pixel and four
+//   consecutive output channels per accumulator quad:
+//     M (MFMA rows) = 32 output channels   A operand = weight fragment, straight from L2/L1: weights are
+//                                          pre-packed in fragment order, so a fragment is one coalesced 1 KiB load
+//     N (MFMA cols) = 32 consecutive pixels of one image row; B operand = pixel fragment from the LDS halo tile
+//     K             = 9 taps x Cin, walked as  stage (64 B of channels) -> tap -> 2 k-groups of 16 B per lane
+//   The (TH+2)x34 input halo tile of a stage is written to LDS once (80-B pixel stride: conflict-free
+//   ds_read_b128) and reused by all 9 taps; LDS is double-buffered, one barrier per stage; the next stage's
+//   tile is prefetched into registers mid-stage; weights are prefetched 1-2 taps ahead into a register ring.
+//   The loader handles "virtual concat + nearest 2x upsample" (VGG.py:144-151) without materialising it.
+//   The epilogue fuses bias, 2x2 max-pool, ReLU, the raw fp32 feature copy and its per-sample sum of squares.
+// conv02_kernel -- conv0 (3->64 on the NCHW fp32 input, K = 27 padded to 32) computed by MFMA directly into the
+//   LDS halo tile of conv2, then conv2 + pool: the 64-channel full-resolution map never touches HBM.
+#include "common.h"
+
+typedef __bf16 bf16;
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+
+template <typename T> __device__ __forceinline__ void mma16(f32x16& acc, const uint4& w, const uint4& p);
+template <> __device__ __forceinline__ void mma16<bf16>(f32x16& acc, const uint4& w, const uint4& p) {
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w), __builtin_bit_cast(bf16x8, p), acc, 0, 0, 0);
+}
+template <> __device__ __forceinline__ void mma16<float>(f32x16& acc, const uint4& w, const uint4& p) {
+  // element t of both fragments: channels {8q+t (lanes 0-31), 8q+4+t (lanes 32-63)}
+  acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(w.x), __uint_as_float(p.x), acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(w.y), __uint_as_float(p.y), acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(w.z), __uint_as_float(p.z), acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(w.w), __uint_as_float(p.w), acc, 0, 0, 0);
+}
+
+__device__ __forceinline__ void store4(bf16* p, float a, float b, float c, float d) {
+  const bf16 h[4] = {(bf16)a, (bf16)b, (bf16)c, (bf16)d};
+  *(uint2*)p = __builtin_bit_cast(uint2, h);
+}
+__device__ __forceinline__ void store4(float* p, float a, float b, float c, float d) {
+  *(float4*)p = make_float4(a, b, c, d);
+}
+__device__ __forceinline__ void store4(unsigned char* p, float a, float b, float c, float d) {
+  *(unsigned*)p = (unsigned)a | ((unsigned)b << 8) | ((unsigned)c << 16) | ((unsigned)d << 24);
+}
+__device__ __forceinline__ float to_f32(bf16 v) { return (float)v; }
+__device__ __forceinline__ float to_f32(float v) { return v; }
+
+struct ConvArgs {
+  const void* src1;   // NHWC T, C1 channels; at half resolution when up1
+  const void* src2;   // NHWC T, C2 channels (virtual concat after src1), or null
+  const uint4* wpk;   // fragment-packed weights
+  const float* bias;  // [Cout] or null
+  void* out_act;      // NHWC T [B,Ho,Wo,Cout] (post-ReLU when relu_act) or null
+  float* out_raw;     // NHWC fp32 (pre-ReLU) or null
+  double* sumsq;      // [B, tiles_per_img * gridDim.y] sum of squares of out_raw, or null
+  int C1, C2, up1;
+  int B, H, W, Cout;
+  int relu_act;
+  int tiles_x, tiles_y;
+  // --- training / backward extras (all optional) ---
+  const unsigned char* unpool_idx;  // src1 is a max-pooled map's gradient at half resolution [B,H/2,W/2,C1] and this is
+                                    // the forward argmax (0..3): the loader routes it to full resolution (virtual unpool)
+  const void* mask_act;             // NHWC T, output shape: out = act > 0 ? out : 0   (ReLU backward)
+  const void* add_src;              // NHWC T, output shape: out += add                (gradient fan-in)
+  unsigned char* idx_out;           // POOL (max): argmax position 2*row+col of every pooled element (forward, training)
+  int pool_sum;                     // POOL epilogue sums the 2x2 block instead of max (backward of nearest upsample)
+  unsigned long long* dbg;          // CONV_VARIANT 40 only: per-wave cycle accounting
+};
+
+constexpr int HWID = 34;   // halo tile width in pixels
+constexpr int SB = 64;     // bytes of channels per pixel per pipeline stage
+constexpr int PSTR = 80;   // LDS bytes per halo pixel (64 B of channels + 16 B pad: conflict-free ds_read_b128)
+constexpr int HALO_TAP = 3;  // tap at which the next stage's halo loads are issued
+#ifndef CONV_VARIANT
+#define CONV_VARIANT 0
+#endif
+// timing ablations for tools/variants.py (results are wrong on purpose): 10 no weight loads, 11 no LDS reads,
+// 12 no halo staging, 13 = all three, 14 = 13 + no barrier
+constexpr bool ABL_ALL = (CONV_VARIANT == 13 || CONV_VARIANT == 14);
+constexpr bool ABL_NO_W = (CONV_VARIANT == 10 || ABL_ALL);
+constexpr bool ABL_NO_LDS = (CONV_VARIANT == 11 || ABL_ALL);
+constexpr bool ABL_NO_HALO = (CONV_VARIANT == 12 || ABL_ALL);
+constexpr bool ABL_NO_BAR = (CONV_VARIANT == 14);
+
+// ---------------------------------------------------------------------------------------------
+// shared epilogue: acc[i][j] holds, for lane (x = lane&31, g = lane>>5), output channels
+// cb + j*32 + 8q + 4g + {0..3} (q = r>>2) of pixel (row i, column x).
+// Writing that straight to NHWC memory is 8 B per lane into 32 different 128-B lines per store instruction
+// (measured: 16-28 k cycles per wave, up to half of a block's lifetime).  Instead every wave transposes one
+// pixel row at a time through a private LDS region (`stage`, >= 32*(NT*32*4+16) bytes) and stores it as whole
+// pixel rows: 16 B per lane, consecutive lanes on consecutive addresses.
+template <typename E, int NT> struct RowStager {
+  static constexpr int CW = NT * 32, PITCH = CW * (int)sizeof(E) + 16, CPP = CW * (int)sizeof(E) / 16;
+  // lane-side write of 4 consecutive channels of pixel `px`
+  static __device__ __forceinline__ void put(char* stage, int px, int ch, float v0, float v1, float v2, float v3) {
+    store4((E*)(stage + px * PITCH) + ch, v0, v1, v2, v3);
+  }
+  // cooperative flush of `npx` pixels: dst points at channel cb of the first pixel; pixel stride = Cout elements
+  // `mask` / `add` (optional) are indexed exactly like dst: v = (mask > 0 ? v : 0) + add, applied on the 16-B vectors
+  static __device__ __forceinline__ void flush(const char* stage, E* dst, int npx, int npx_valid, int Cout, int lane,
+                                               const E* mask = nullptr, const E* add = nullptr) {
+    const int chunks = npx * CPP;
+    constexpr int EPV = 16 / (int)sizeof(E);
+#pragma unroll
+    for (int c0 = 0; c0 < 32 * CPP; c0 += 64) {
+      const int c = c0 + lane;
+      if (c0 < chunks && c < chunks) {
+        const int px = c / CPP, part = c % CPP;
+        if (px < npx_valid) {
+          uint4 v = *(const uint4*)(stage + px * PITCH + part * 16);
+          const size_t off = (size_t)px * Cout * sizeof(E) + part * 16;
+          if (mask || add) {
+            E e[EPV], m[EPV], ad[EPV];
+            __builtin_memcpy(e, &v, 16);
+            if (mask) { const uint4 t = *(const uint4*)((const char*)mask + off); __builtin_memcpy(m, &t, 16); }
+            if (add) { const uint4 t = *(const uint4*)((const char*)add + off); __builtin_memcpy(ad, &t, 16); }
+#pragma unroll
+            for (int k = 0; k < EPV; ++k) {
+              float f = (float)e[k];
+              if (mask && !((float)m[k] > 0.f)) f = 0.f;
+              if (add) f += (float)ad[k];
+              e[k] = (E)f;
+            }
+            __builtin_memcpy(&v, e, 16);
+          }
+          *(uint4*)((char*)dst + off) = v;
+        }
+      }
+    }
+  }
+};
+
+template <typename T, int MT, int NT, bool POOL>
+__device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[MT][NT], const ConvArgs& a, int b, int yrow0, int x0,
+                                              int cb, float* red, char* stage) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, x = lane & 31, g = lane >> 5;
+  const int Ho = POOL ? a.H >> 1 : a.H, Wo = POOL ? a.W >> 1 : a.W;
+  constexpr int NPX = POOL ? 16 : 32;
+  float4 bias[NT][4];
+#pragma unroll
+  for (int j = 0; j < NT; ++j)
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      bias[j][q] = a.bias ? *(const float4*)(a.bias + cb + j * 32 + q * 8 + g * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+  const int xo0 = POOL ? x0 >> 1 : x0;
+  const int nvalid = min(NPX, Wo - xo0);              // pixels of this row segment inside the image
+  float ss = 0.f;
+#pragma unroll
+  for (int i = 0; i < MT; i += (POOL ? 2 : 1)) {
+    const int y = yrow0 + i;
+    const int yo = POOL ? y >> 1 : y;
+    const bool row_ok = y < a.H;                      // wave-uniform
+    const bool lane_ok = row_ok && (x0 + x < a.W) && (!POOL || !(x & 1));
+    const int px = POOL ? x >> 1 : x;
+    float v[NT][4][4], amax[NT][4][4];
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          amax[j][q][e] = 0.f;
+          float t = acc[i][j][q * 4 + e];
+          if (POOL) {
+            const float u = acc[i + 1][j][q * 4 + e];
+            if (a.pool_sum) {
+              t += u;
+              t += __shfl_xor(t, 1, 64);
+            } else {
+              const float rown = u > t ? 1.f : 0.f;               // first maximum wins, like F.max_pool2d
+              t = fmaxf(t, u);
+              const float t2 = __shfl_xor(t, 1, 64), r2 = __shfl_xor(rown, 1, 64);
+              amax[j][q][e] = t2 > t ? 2.f * r2 + 1.f : 2.f * rown;
+              t = fmaxf(t, t2);
+            }
+          }
+          v[j][q][e] = t;
+        }
+        v[j][q][0] += bias[j][q].x; v[j][q][1] += bias[j][q].y; v[j][q][2] += bias[j][q].z; v[j][q][3] += bias[j][q].w;
+      }
+    const size_t pix0 = ((size_t)b * Ho + yo) * Wo + xo0;
+    if (a.out_raw) {
+      if (!POOL || !(x & 1)) {
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            RowStager<float, NT>::put(stage, px, j * 32 + q * 8 + g * 4, v[j][q][0], v[j][q][1], v[j][q][2], v[j][q][3]);
+            if (lane_ok) ss += v[j][q][0] * v[j][q][0] + v[j][q][1] * v[j][q][1] + v[j][q][2] * v[j][q][2] + v[j][q][3] * v[j][q][3];
+          }
+      }
+      if (row_ok) RowStager<float, NT>::flush(stage, a.out_raw + pix0 * a.Cout + cb, NPX, nvalid, a.Cout, lane);
+    }
+    if (a.out_act) {
+      if (!POOL || !(x & 1)) {
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            float w0 = v[j][q][0], w1 = v[j][q][1], w2 = v[j][q][2], w3 = v[j][q][3];
+            if (a.relu_act) { w0 = fmaxf(w0, 0.f); w1 = fmaxf(w1, 0.f); w2 = fmaxf(w2, 0.f); w3 = fmaxf(w3, 0.f); }
+            RowStager<T, NT>::put(stage, px, j * 32 + q * 8 + g * 4, w0, w1, w2, w3);
+          }
+      }
+      const size_t o = pix0 * a.Cout + cb;
+      if (row_ok) RowStager<T, NT>::flush(stage, (T*)a.out_act + o, NPX, nvalid, a.Cout, lane,
+                                          a.mask_act ? (const T*)a.mask_act + o : nullptr,
+                                          a.add_src ? (const T*)a.add_src + o : nullptr);
+    }
+    if (POOL && a.idx_out) {
+      if (!(x & 1)) {
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            RowStager<unsigned char, NT>::put(stage, px, j * 32 + q * 8 + g * 4, amax[j][q][0], amax[j][q][1], amax[j][q][2], amax[j][q][3]);
+      }
+      if (row_ok) RowStager<unsigned char, NT>::flush(stage, a.idx_out + pix0 * a.Cout + cb, NPX, nvalid, a.Cout, lane);
+    }
+  }
+  if (a.sumsq) {
+    ss = wave_sum_f32(ss);
+    if (lane == 0) red[wv] = ss;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const int np = a.tiles_x * a.tiles_y * gridDim.y;
+      const int tile = (blockIdx.x % (a.tiles_x * a.tiles_y)) * gridDim.y + blockIdx.y;
+      a.sumsq[(size_t)b * np + tile] = ((double)red[0] + (double)red[1]) + ((double)red[2] + (double)red[3]);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// One pipeline stage of MFMAs: 9 taps x 2 k-groups against the halo tile at `cur` (already offset to this
+// wave's first row / this lane's pixel + k-half).  Weight fragments come from global memory through a ring of
+// WD+1 register sets filled WD taps ahead; `mid(tap)` runs right after the weight loads of each tap (used to
+// issue the next stage's halo loads BEHIND them: VM loads of a wave retire in order).
+template <typename T, int MT, int NT, int WD>
+struct WeightRing {
+  static constexpr int RS = WD + 1;
+  uint4 wb[RS][2][NT];
+  const uint4* wq[NT];   // per-lane pointer to this stage's fragments of output tile j: [tap][kg][lane]
+
+  __device__ __forceinline__ void prime() {
+#pragma unroll
+    for (int d = 0; d < WD; ++d)
+#pragma unroll
+      for (int kg = 0; kg < 2; ++kg)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) wb[d][kg][j] = wq[j][(d * 2 + kg) * 64];
+  }
+  // after a stage the ring holds taps 0..WD-1 of the next stage in slots (9+d) % RS; rotate them to slot d
+  __device__ __forceinline__ void next_stage() {
+#pragma unroll
+    for (int j = 0; j < NT; ++j) wq[j] += 18 * 64;
+    if (9 % RS != 0) {
+      uint4 tmp[WD][2][NT];
+#pragma unroll
+      for (int d = 0; d < WD; ++d)
+#pragma unroll
+        for (int kg = 0; kg < 2; ++kg)
+#pragma unroll
+          for (int j = 0; j < NT; ++j) tmp[d][kg][j] = wb[(9 + d) % RS][kg][j];
+#pragma unroll
+      for (int d = 0; d < WD; ++d)
+#pragma unroll
+        for (int kg = 0; kg < 2; ++kg)
+#pragma unroll
+          for (int j = 0; j < NT; ++j) wb[d][kg][j] = tmp[d][kg][j];
+    }
+  }
+};
+
+// The two waves that share a SIMD (one from each co-resident workgroup) run the same instruction stream and
+// start together, so left alone they contend for the matrix pipe during their MFMA bursts and then both sit in
+// their LDS / VM waits at the same time (a convoy: measured MFMA-busy 46 %).  Giving the wave in the odd
+// hardware wave slot a higher static priority lets it run ahead, which staggers the two streams: one computes
+// while the other waits.  HW_REG_HW_ID (id 4) bits [3:0] = wave slot within the SIMD.
+__device__ __forceinline__ void stagger_priority() {
+#if CONV_VARIANT != 31
+  const unsigned slot = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4);
+  if (slot & 1) __builtin_amdgcn_s_setprio(CONV_VARIANT == 32 ? 3 : 1);
+#endif
+}
+
+template <typename T, int MT, int NT, int WD, bool PF_UPFRONT, typename Mid>
+__device__ __forceinline__ void stage_mma(f32x16 (&acc)[MT][NT], const char* cur, WeightRing<T, MT, NT, WD>& ring,
+                                          Mid&& mid) {
+  constexpr int RS = WD + 1;
+#pragma unroll
+  for (int tap = 0; tap < 9; ++tap) {
+    const int ky = tap / 3, kx = tap % 3;
+#pragma unroll
+    for (int kg = 0; kg < 2; ++kg)
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+        if (!ABL_NO_W) ring.wb[(tap + WD) % RS][kg][j] = ring.wq[j][((tap + WD) * 2 + kg) * 64];
+    mid(tap);
+    const char* ap = cur + (ky * HWID + kx) * PSTR;
+    if (PF_UPFRONT) {
+      // all pixel fragments of the tap are requested up front; the MFMAs then wait on counted lgkmcnt
+      uint4 pf[2][MT];
+#pragma unroll
+      for (int kg = 0; kg < 2; ++kg)
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+          if (!ABL_NO_LDS) pf[kg][i] = *(const uint4*)(ap + i * HWID * PSTR + kg * 32);
+          else pf[kg][i] = ring.wb[0][kg][0];
+        }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int kg = 0; kg < 2; ++kg)
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j) mma16<T>(acc[i][j], ring.wb[tap % RS][kg][j], pf[kg][i]);
+    } else {
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int kg = 0; kg < 2; ++kg) {
+        uint4 pf[MT];
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+          if (!ABL_NO_LDS) pf[i] = *(const uint4*)(ap + i * HWID * PSTR + kg * 32);
+          else pf[i] = ring.wb[0][kg][0];
+        }
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j) mma16<T>(acc[i][j], ring.wb[tap % RS][kg][j], pf[i]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  ring.next_stage();
+}
+
+template <typename T, int MT, int NT, int WM, int WN, bool POOL, int WD, bool PF_UPFRONT>
+__global__ __launch_bounds__(256, 2) void conv3x3_kernel(ConvArgs a) {
+  static_assert(WM * WN == 4, "4 waves per block");
+  constexpr int EPL = 16 / sizeof(T), KC = SB / sizeof(T);     // channels per stage: 32 (bf16) / 16 (fp32)
+  constexpr int TH = WM * MT, HPIX = (TH + 2) * HWID, BUF = HPIX * PSTR;
+  constexpr int NPIECE = (HPIX * 4 + 255) / 256;               // 16-B pieces per thread per stage
+  __shared__ __attribute__((aligned(16))) char lds[2 * BUF];
+  __shared__ float red[4];
+
+#if CONV_VARIANT == 40
+  const unsigned long long t_begin = __builtin_readcyclecounter();
+#endif
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6, wm = wv / WN, wn = wv % WN;
+  int bid = blockIdx.x;
+  const int tx = bid % a.tiles_x; bid /= a.tiles_x;
+  const int ty = bid % a.tiles_y;
+  const int b = bid / a.tiles_y;
+  const int y0 = ty * TH, x0 = tx * 32;
+  const int nstage = (a.C1 + a.C2) / KC;
+  const int part = t & 3, pbase = t >> 2;   // 256 % 4 == 0: a thread always moves the same 16-B part of a pixel
+
+  auto load_stage = [&](int sg, uint4 (&st)[NPIECE]) {
+    const int c0 = sg * KC;
+    const bool first = c0 < a.C1;       // wave-uniform
+    const T* src = first ? (const T*)a.src1 : (const T*)a.src2;
+    const int Cs = first ? a.C1 : a.C2;
+    const int coff = (first ? c0 : c0 - a.C1) + part * EPL;
+    const int sh = (first && (a.up1 || a.unpool_idx)) ? 1 : 0;
+    const int Hs = a.H >> sh, Ws = a.W >> sh;
+#pragma unroll
+    for (int i = 0; i < NPIECE; ++i) {
+      const int pix = pbase + 64 * i;
+      const int hy = pix / HWID, hx = pix - hy * HWID;
+      const int y = y0 - 1 + hy, x = x0 - 1 + hx;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (pix < HPIX && y >= 0 && y < a.H && x >= 0 && x < a.W) {
+        const size_t e0 = (((size_t)b * Hs + (y >> sh)) * Ws + (x >> sh)) * Cs + coff;
+        v = *(const uint4*)(src + e0);
+        if (a.unpool_idx) {          // keep only the elements whose forward argmax is this (y&1, x&1) position
+          const unsigned pos = ((y & 1) << 1) | (x & 1);
+          T e[EPL];
+          unsigned char id[EPL];
+          __builtin_memcpy(e, &v, 16);
+          __builtin_memcpy(id, a.unpool_idx + e0, EPL);
+#pragma unroll
+          for (int k = 0; k < EPL; ++k) if (id[k] != pos) e[k] = (T)0.f;
+          __builtin_memcpy(&v, e, 16);
+        }
+      }
+      st[i] = v;
+    }
+  };
+  auto write_stage = [&](char* buf, const uint4 (&st)[NPIECE]) {
+#pragma unroll
+    for (int i = 0; i < NPIECE; ++i) {
+      const int pix = pbase + 64 * i;
+      if (pix < HPIX) *(uint4*)(buf + pix * PSTR + part * 16) = st[i];
+    }
+  };
+
+  f32x16 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int x = lane & 31, g = lane >> 5;
+  const int aoff = ((wm * MT) * HWID + x) * PSTR + g * 16;
+  const int ntg0 = (blockIdx.y * WN + wn) * NT;     // first global 32-channel output tile of this wave
+  // packed weights: [ntile][stage][tap][kg(2)][lane] 16-B fragments
+  WeightRing<T, MT, NT, WD> ring;
+#pragma unroll
+  for (int j = 0; j < NT; ++j) ring.wq[j] = a.wpk + (size_t)(ntg0 + j) * nstage * 18 * 64 + lane;
+
+  uint4 st[NPIECE];
+  load_stage(0, st);
+  write_stage(lds, st);
+  __syncthreads();
+  ring.prime();
+  stagger_priority();
+
+#if CONV_VARIANT == 40   // cycle accounting per wave: [prologue, mma, halo write, barrier wait, epilogue]
+  unsigned long long tc[5] = {0, 0, 0, 0, 0};
+  unsigned long long t_prev = __builtin_readcyclecounter();
+  tc[0] = t_prev - t_begin;
+#define TICK(k) { const unsigned long long _n = __builtin_readcyclecounter(); tc[k] += _n - t_prev; t_prev = _n; }
+#else
+#define TICK(k)
+#endif
+  for (int sg = 0; sg < nstage; ++sg) {
+    const bool more = sg + 1 < nstage;
+    stage_mma<T, MT, NT, WD, PF_UPFRONT>(acc, lds + (sg & 1) * BUF + aoff, ring, [&](int tap) {
+      if (tap == HALO_TAP && more && !ABL_NO_HALO) load_stage(sg + 1, st);
+    });
+    TICK(1)
+    if (more && !ABL_NO_HALO) write_stage(lds + ((sg + 1) & 1) * BUF, st);
+    TICK(2)
+    if (!ABL_NO_BAR) __syncthreads();
+    TICK(3)
+  }
+  // the loop's last barrier guarantees nobody still reads the halo buffers: reuse them as 4 wave-private stagers
+  static_assert(2 * BUF / 4 >= 32 * (NT * 32 * 4 + 16) && (2 * BUF / 4) % 16 == 0, "stager does not fit");
+  conv_epilogue<T, MT, NT, POOL>(acc, a, b, y0 + wm * MT, x0, ntg0 * 32, red, lds + wv * (2 * BUF / 4));
+#if CONV_VARIANT == 40
+  TICK(4)
+  if (a.dbg && lane == 0) {
+    unsigned long long* d = a.dbg + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 4 + wv) * 5;
+    for (int k = 0; k < 5; ++k) d[k] = tc[k];
+  }
+#endif
+#undef TICK
+}
+
+// ---------------------------------------------------------------------------------------------
+// conv0 + ReLU + conv2 + bias + 2x2 max-pool + ReLU in one kernel (VGG.py:123-128).
+struct Conv02Args {
+  const float* x;      // [B,3,H,W] NCHW fp32
+  const uint4* w0;     // conv0 fragments [2 ntiles][NFRAG][64 lanes], k = cin*9 + tap (27 padded to 32)
+  const float* b0;     // [64]
+  const uint4* w2;     // conv2 fragments, generic layout
+  const float* b2;     // [64]
+  void* out_act;       // NHWC T [B,H/2,W/2,64] = relu(pool(conv2))
+  void* a0_out;        // training: NHWC T [B,H,W,64] = relu(conv0), or null
+  unsigned char* idx_out;  // training: pool argmax [B,H/2,W/2,64], or null
+  int B, H, W, tiles_x, tiles_y;
+};
+
+template <typename T> constexpr int conv02_lds_bytes() {
+  return (64 * (int)sizeof(T) / SB) * (10 * HWID * PSTR) + 3 * 12 * 36 * 4;
+}
+
+template <typename T, int WD, bool PF_UPFRONT>
+__global__ __launch_bounds__(256, 2) void conv02_kernel(Conv02Args a0) {
+  constexpr int EPL = 16 / sizeof(T), KC = SB / sizeof(T), NSG = 64 / KC, NFRAG = 32 / (2 * EPL);
+  constexpr int MT = 4, NT = 1, WN = 2, TH = 8, HPIX = (TH + 2) * HWID, BUF = HPIX * PSTR, IW = 36, IH = 12;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* lds = smem;                                  // NSG halo buffers (all of conv0's 64 channels)
+  float* in = (float*)(smem + NSG * BUF);            // [3][12][36] input patch
+  __shared__ float red[4];
+
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6, wm = wv / WN, wn = wv % WN;
+  int bid = blockIdx.x;
+  const int tx = bid % a0.tiles_x; bid /= a0.tiles_x;
+  const int ty = bid % a0.tiles_y;
+  const int b = bid / a0.tiles_y;
+  const int y0 = ty * TH, x0 = tx * 32;
+  const int x = lane & 31, g = lane >> 5;
+
+  // start the first conv2 weight loads before anything else (they do not depend on the input)
+  WeightRing<T, MT, NT, WD> ring;
+  ring.wq[0] = a0.w2 + (size_t)wn * NSG * 18 * 64 + lane;
+  ring.prime();
+
+  // phase A: input patch (2-pixel border) -> LDS
+  for (int e = t; e < 3 * IH * IW; e += 256) {
+    const int c = e / (IH * IW), r = e % (IH * IW), iy = r / IW, ix = r % IW;
+    const int y = y0 - 2 + iy, xx = x0 - 2 + ix;
+    float v = 0.f;
+    if (y >= 0 && y < a0.H && xx >= 0 && xx < a0.W) v = a0.x[(((size_t)b * 3 + c) * a0.H + y) * a0.W + xx];
+    in[e] = v;
+  }
+  uint4 wf0[2][NFRAG];
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int f = 0; f < NFRAG; ++f) wf0[j][f] = a0.w0[(j * NFRAG + f) * 64 + lane];
+  __syncthreads();
+
+  // phase B: conv0 on the 10x34 halo pixels, 32 pixels per MFMA tile, straight into the conv2 halo buffers
+  for (int m = wv; m * 32 < HPIX; m += 4) {
+    const int p = m * 32 + x, pc = p < HPIX ? p : HPIX - 1;
+    const int hy = pc / HWID, hx = pc - hy * HWID;
+    const float* ib = in + hy * IW + hx;
+    f32x16 c0[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) c0[j][r] = 0.f;
+#pragma unroll
+    for (int f = 0; f < NFRAG; ++f) {
+      T e[EPL];
+#pragma unroll
+      for (int jj = 0; jj < EPL; ++jj) {
+        const int klo = f * 2 * EPL + jj, khi = klo + EPL;   // compile-time
+        float lo = 0.f, hi = 0.f;
+        if (klo < 27) lo = ib[(klo / 9) * IH * IW + ((klo % 9) / 3) * IW + (klo % 9) % 3];
+        if (khi < 27) hi = ib[(khi / 9) * IH * IW + ((khi % 9) / 3) * IW + (khi % 9) % 3];
+        e[jj] = (T)(g ? hi : lo);
+      }
+      const uint4 pf = __builtin_bit_cast(uint4, e);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) mma16<T>(c0[j], wf0[j][f], pf);
+    }
+    // conv2 zero-pads conv0's OUTPUT map: halo pixels outside the image are 0, not conv0 of padded input
+    const int yy = y0 - 1 + hy, xx = x0 - 1 + hx;
+    const bool inside = yy >= 0 && yy < a0.H && xx >= 0 && xx < a0.W;
+    if (p < HPIX) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int co = j * 32 + q * 8 + g * 4;
+          const float4 bb = *(const float4*)(a0.b0 + co);
+          float v0 = fmaxf(c0[j][q * 4 + 0] + bb.x, 0.f), v1 = fmaxf(c0[j][q * 4 + 1] + bb.y, 0.f);
+          float v2 = fmaxf(c0[j][q * 4 + 2] + bb.z, 0.f), v3 = fmaxf(c0[j][q * 4 + 3] + bb.w, 0.f);
+          if (!inside) v0 = v1 = v2 = v3 = 0.f;
+          store4((T*)(lds + (co / KC) * BUF + p * PSTR) + (co % KC), v0, v1, v2, v3);
+        }
+    }
+  }
+  __syncthreads();
+
+  if (a0.a0_out) {     // training: the backward pass needs relu(conv0) (conv2's wgrad input and ReLU mask)
+    constexpr int PPP = 64 * (int)sizeof(T) / 16;          // 16-B pieces per pixel over all stages
+    for (int e = t; e < TH * 32 * PPP; e += 256) {
+      const int pxl = e / PPP, piece = e % PPP, sgi = piece / 4, part = piece % 4;
+      const int r = pxl / 32, c = pxl % 32, yy = y0 + r, xx = x0 + c;
+      if (yy < a0.H && xx < a0.W)
+        *(uint4*)((char*)a0.a0_out + (((size_t)b * a0.H + yy) * a0.W + xx) * 64 * sizeof(T) + piece * 16) =
+            *(const uint4*)(lds + sgi * BUF + ((r + 1) * HWID + c + 1) * PSTR + part * 16);
+    }
+  }
+
+  // phase C: conv2 over the NSG resident stages (no further loads, no barriers)
+  f32x16 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][0][r] = 0.f;
+  const int aoff = ((wm * MT) * HWID + x) * PSTR + g * 16;
+  stagger_priority();
+#pragma unroll 1
+  for (int sg = 0; sg < NSG; ++sg)
+    stage_mma<T, MT, NT, WD, PF_UPFRONT>(acc, lds + sg * BUF + aoff, ring, [](int) {});
+
+  ConvArgs a{};
+  a.bias = a0.b2; a.out_act = a0.out_act; a.B = a0.B; a.H = a0.H; a.W = a0.W; a.Cout = 64; a.relu_act = 1;
+  a.tiles_x = a0.tiles_x; a.tiles_y = a0.tiles_y; a.idx_out = a0.idx_out;
+  __syncthreads();   // all waves are done with the halo buffers; reuse them as wave-private stagers
+  conv_epilogue<T, MT, NT, true>(acc, a, b, y0 + wm * MT, x0, wn * 32, red, lds + wv * (NSG * BUF / 4));
+}
+
+// ---------------------------------------------------------------------------------------------
+// weight packing: OIHW fp32 -> MFMA fragment order, T elements.
+//   generic: idx = ((((nt*nstage + sg)*9 + tap)*2 + kg)*64 + lane)*EPL + j
+//            cout = nt*32 + (lane&31), cin = sg*KC + kg*2*EPL + (lane>>5)*EPL + j      (KC = 64 B of channels)
+//   conv0:   idx = ((nt*NFRAG + f)*64 + lane)*EPL + j,  k = f*2*EPL + (lane>>5)*EPL + j  (k = cin*9+tap, <27)
+//   Every layer's buffer is padded by two taps of fragments (the kernels prefetch up to 2 taps ahead).
+//   mode 2 (dgrad): the packed conv is the transpose: Cout' = Cin_orig, Cin' = Cout_orig, taps flipped:
+//            v = w_orig[cin'][cout'][8 - tap]  with w_orig laid out [Cout_orig = Cin'][Cin_orig = Cout'][9]
+template <typename T>
+__global__ void pack_weights_kernel(const float* __restrict__ w, T* __restrict__ out, int Cout, int Cin, int first) {
+  constexpr int EPL = 16 / sizeof(T), KC = SB / sizeof(T), NFRAG = 32 / (2 * EPL);
+  const size_t total = first == 1 ? (size_t)(Cout / 32) * NFRAG * 64 * EPL : (size_t)Cout * Cin * 9;
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+    size_t r = e;
+    const int j = r % EPL; r /= EPL;
+    const int lane = r % 64; r /= 64;
+    float v = 0.f;
+    if (first == 1) {
+      const int f = r % NFRAG; r /= NFRAG;
+      const int nt = (int)r;
+      const int k = f * 2 * EPL + (lane >> 5) * EPL + j, cout = nt * 32 + (lane & 31);
+      if (k < 27) v = w[(size_t)cout * 27 + k];
+    } else {
+      const int kg = r % 2; r /= 2;
+      const int tap = r % 9; r /= 9;
+      const int nsg = Cin / KC;
+      const int sg = r % nsg; r /= nsg;
+      const int nt = (int)r;
+      const int cout = nt * 32 + (lane & 31), cin = sg * KC + kg * 2 * EPL + (lane >> 5) * EPL + j;
+      v = first == 2 ? w[((size_t)cin * Cout + cout) * 9 + (8 - tap)] : w[((size_t)cout * Cin + cin) * 9 + tap];
+    }
+    out[e] = (T)v;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// confidence head: sigmoid(-sigmoid(conv3x3(relu(x), C->1)))  VGG.py:62-81,160-163.  `act` is already ReLU'd.
+template <typename T>
+__global__ __launch_bounds__(256) void conf_kernel(const T* __restrict__ act, const float* __restrict__ w,
+                                                   float* __restrict__ out, int B, int H, int W, int C) {
+  constexpr int EPL = 16 / sizeof(T);
+  extern __shared__ float ws[];   // [9][C]
+  for (int e = threadIdx.x; e < 9 * C; e += 256) ws[(e % 9) * C + e / 9] = w[e];   // OIHW (O=1): w[c*9+tap]
+  __syncthreads();
+  const int G = C / EPL;                     // threads per pixel (8 channels bf16 / 4 fp32 each), power of 2 <= 64
+  const int ppb = 256 / G;
+  const size_t npix = (size_t)B * H * W;
+  const int gi = threadIdx.x % G;
+  for (size_t pix = (size_t)blockIdx.x * ppb + threadIdx.x / G; pix < (npix + ppb - 1) / ppb * ppb;
+       pix += (size_t)gridDim.x * ppb) {
+    float s = 0.f;
+    const bool live = pix < npix;
+    if (live) {
+      const int x = (int)(pix % W), y = (int)((pix / W) % H);
+      const size_t b = pix / ((size_t)W * H);
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        const int yy = y + tap / 3 - 1, xx = x + tap % 3 - 1;
+        if (yy < 0 || yy >= H || xx < 0 || xx >= W) continue;
+        const uint4 raw = *(const uint4*)(act + ((b * H + yy) * W + xx) * C + gi * EPL);
+        T e[EPL];
+        __builtin_memcpy(e, &raw, 16);
+#pragma unroll
+        for (int k = 0; k < EPL; ++k) s += to_f32(e[k]) * ws[tap * C + gi * EPL + k];
+      }
+    }
+    for (int o = G >> 1; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if (live && gi == 0) {
+      const float sg = 1.f / (1.f + __expf(-s));
+      out[pix] = 1.f / (1.f + __expf(sg));
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// L2_norm (VGG.py:511-514): x / max(||x||, 1e-12) per sample.
+// inv_norm_kernel: fixed-order fp64 sum of the epilogue partials -> 1/max(||x||,1e-12) per sample.
+static __global__ __launch_bounds__(256) void inv_norm_kernel(const double* __restrict__ sumsq, int np, double* __restrict__ inv) {
+  __shared__ double sh[4];
+  const int b = blockIdx.x;
+  double s = 0.0;
+  for (int i = threadIdx.x; i < np; i += 256) s += sumsq[(size_t)b * np + i];
+  s = wave_sum_f64(s);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) inv[b] = 1.0 / fmax(sqrt((sh[0] + sh[1]) + (sh[2] + sh[3])), 1e-12);
+}
+// scale_kernel: in-place x *= inv[b] (fp64 multiply, one rounding)
+static __global__ __launch_bounds__(256) void scale_kernel(float* __restrict__ x, const double* __restrict__ inv, size_t per_sample,
+                                                    int blocks_per_sample) {
+  const int b = blockIdx.x / blocks_per_sample, k = blockIdx.x % blocks_per_sample;
+  const double scale = inv[b];
+  float4* p = (float4*)(x + (size_t)b * per_sample);
+  const size_t n4 = per_sample / 4;
+  for (size_t i = (size_t)k * 256 + threadIdx.x; i < n4; i += (size_t)blocks_per_sample * 256) {
+    float4 v = p[i];
+    v.x = (float)((double)v.x * scale); v.y = (float)((double)v.y * scale);
+    v.z = (float)((double)v.z * scale); v.w = (float)((double)v.w * scale);
+    p[i] = v;
+  }
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// host: pick the tile configuration for a 3x3 conv launch (forward convs and the dgrad convs of the backward)
+template <typename T>
+static void launch_conv(hipStream_t st, ConvArgs a, bool pool) {
+  a.tiles_x = (a.W + 31) / 32;
+  a.tiles_y = (a.H + 7) / 8;
+  const dim3 grid(a.tiles_x * a.tiles_y * a.B, a.Cout >= 128 ? a.Cout / 128 : 1);
+  const size_t es = sizeof(T), P = (size_t)a.B * a.H * a.W, Po = pool ? P / 4 : P;
+  const double flops = 2.0 * 9.0 * (a.C1 + a.C2) * a.Cout * (double)P;
+  const double bytes = (double)P * ((a.up1 ? a.C1 / 4.0 : a.C1) + a.C2) * es + (double)Po * a.Cout * ((a.out_act ? es : 0) + (a.out_raw ? 4 : 0));
+#if CONV_VARIANT == 40
+  static unsigned long long* dbg = nullptr;
+  static int n_reported = 0;
+  if (!dbg) (void)hipMallocManaged((void**)&dbg, (size_t)1 << 26);
+  a.dbg = dbg;
+#endif
+  hla_prof_begin(a.Cout >= 128 ? (pool ? K_CONV_NT2_POOL : K_CONV_NT2) : (pool ? K_CONV_NT1_POOL : K_CONV_NT1), flops, bytes, st);
+  // Cout >= 128: block = 8x32 pixels x 128 channels, waves 2(M) x 2(N), wave tile 128 px x 64 ch, weights 1 tap ahead
+  // Cout == 64 : block = 8x32 pixels x  64 channels, waves 2 x 2,       wave tile 128 px x 32 ch, weights 2 taps ahead
+  if (a.Cout >= 128) {
+    if (pool) hipLaunchKernelGGL((conv3x3_kernel<T, 4, 2, 2, 2, true, 1, false>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((conv3x3_kernel<T, 4, 2, 2, 2, false, 1, false>), grid, dim3(256), 0, st, a);
+  } else {
+    if (pool) hipLaunchKernelGGL((conv3x3_kernel<T, 4, 1, 2, 2, true, 2, true>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((conv3x3_kernel<T, 4, 1, 2, 2, false, 2, true>), grid, dim3(256), 0, st, a);
+  }
+  hla_prof_end(st);
+#if CONV_VARIANT == 40
+  if (n_reported++ < 40) {
+    (void)hipStreamSynchronize(st);
+    const size_t nw = (size_t)grid.x * grid.y * 4;
+    double m[5] = {0, 0, 0, 0, 0};
+    for (size_t i = 0; i < nw; ++i) for (int k = 0; k < 5; ++k) m[k] += (double)dbg[i * 5 + k];
+    const int nstage = (a.C1 + a.C2) / (int)(SB / sizeof(T));
+    fprintf(stderr, "[dbg] Cin %d Cout %d H %d pool %d stages %d | per wave cycles: prologue %.0f, mma/stage %.0f (ideal 4608 alone), "
+            "write/stage %.0f, barrier/stage %.0f, epilogue %.0f, total %.0f\n", a.C1 + a.C2, a.Cout, a.H, (int)pool, nstage,
+            m[0] / nw, m[1] / nw / nstage, m[2] / nw / nstage, m[3] / nw / nstage, m[4] / nw,
+            (m[0] + m[1] + m[2] + m[3] + m[4]) / nw);
+  }
+#endif
+}
+

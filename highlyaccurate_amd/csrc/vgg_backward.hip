@@ -1,0 +1,476 @@
+// Backward of the VGG16-U-Net extractor (what autograd does in the reference through VGG.py:121-203):
+//   * L2_norm backward (VGG.py:511-514)
+//   * data gradients: every conv's dgrad is the SAME MFMA implicit-GEMM kernel as the forward pass, run on
+//     transposed + tap-flipped packed weights, with the ReLU mask / gradient fan-in / "sum 2x2" (nearest-upsample
+//     backward) fused into its epilogue and the max-pool routing (argmax) fused into its loader
+//   * weight gradients: wgrad_kernel, an MFMA GEMM that contracts over PIXELS.  Both operands are then "k-major"
+//     in NHWC (pixels are rows); for bf16 the fragments are fetched with gfx950's transpose read
+//     ds_read_b64_tr_b16 straight from the same [pixel][channel] LDS tiles the forward kernel uses
+//     (tools/probes/tr16_probe.hip documents the lane semantics), for fp32 a lane needs one element per MFMA
+//     so plain ds_read_b32 suffices.  Bias gradients ride along as one extra MFMA against an all-ones fragment.
+#include "conv_kernels.h"
+#include "vgg_layers.h"
+
+typedef short v4s __attribute__((ext_vector_type(4)));
+
+// fragment of a k-major LDS tile T[k = pixel][i = channel] (row stride `stride` bytes) in MFMA operand order:
+// lane l -> row i = ch0 + (l & 31), its 16 bytes = the K-step's k values of its half (see mma16<T>).
+//   bf16: K-step = 16 pixels, lane group g = l>>5 holds k = 8g..8g+7
+//   fp32: K-step =  8 pixels, element t of lane group g is k = 2t+g
+template <typename T> struct KStep;
+template <> struct KStep<bf16> { static constexpr int PX = 16; };
+template <> struct KStep<float> { static constexpr int PX = 8; };
+
+template <typename T> __device__ __forceinline__ uint4 frag_kmajor(const char* tile, int stride, int px0, int ch0, int lane);
+template <> __device__ __forceinline__ uint4 frag_kmajor<bf16>(const char* tile, int stride, int px0, int ch0, int lane) {
+  const int t = lane & 15, i0 = ch0 + 16 * ((lane >> 4) & 1), k0 = px0 + 8 * (lane >> 5);
+  const char* p = tile + (k0 + (t >> 2)) * stride + (i0 + 4 * (t & 3)) * 2;
+  const v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s*)(p));
+  const v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s*)(p + 4 * stride));
+  uint4 r;
+  __builtin_memcpy(&r.x, &lo, 8);
+  __builtin_memcpy(&r.z, &hi, 8);
+  return r;
+}
+template <> __device__ __forceinline__ uint4 frag_kmajor<float>(const char* tile, int stride, int px0, int ch0, int lane) {
+  const char* p = tile + (px0 + (lane >> 5)) * stride + (ch0 + (lane & 31)) * 4;
+  uint4 r;
+  r.x = *(const unsigned*)(p); r.y = *(const unsigned*)(p + 2 * stride);
+  r.z = *(const unsigned*)(p + 4 * stride); r.w = *(const unsigned*)(p + 6 * stride);
+  return r;
+}
+template <typename T> __device__ __forceinline__ uint4 frag_ones();
+template <> __device__ __forceinline__ uint4 frag_ones<bf16>() { return make_uint4(0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u); }
+template <> __device__ __forceinline__ uint4 frag_ones<float>() { return make_uint4(0x3F800000u, 0x3F800000u, 0x3F800000u, 0x3F800000u); }
+
+// ---------------------------------------------------------------------------------------------
+struct WgradArgs {
+  const void* x1; const void* x2;      // conv input (stored post-ReLU activations); virtual upsample+concat as forward
+  const void* g;                       // d(loss)/d(conv output) NHWC T [B,H,W,Cout], or the pooled map's gradient
+  const unsigned char* g_unpool;       //   [B,H/2,W/2,Cout] + forward argmax (virtual unpool) when non-null
+  float* part;                         // [KS][Cout][Cin][9] partial sums
+  float* bpart;                        // [KS][Cout] partial bias gradients, or null
+  int C1, C2, up1, B, H, W, Cout, Cin, tiles_x, tiles_y, ntile, KS;
+};
+
+constexpr int WG_TH = 4;                                  // pixel tile: 4 rows x 32 px
+template <typename T> constexpr int wg_stride() { return 64 * (int)sizeof(T) + 16; }
+template <typename T> constexpr int wg_lds_bytes() { return ((WG_TH + 2) * HWID + WG_TH * 32) * wg_stride<T>(); }
+
+template <typename T>
+__global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
+  constexpr int EPL = 16 / sizeof(T), STR = wg_stride<T>(), PPX = 64 * (int)sizeof(T) / 16;   // 16-B pieces per pixel
+  constexpr int XPIX = (WG_TH + 2) * HWID, GPIX = WG_TH * 32, KPX = KStep<T>::PX;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* Xs = smem;
+  char* Gs = smem + XPIX * STR;
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6, ct = wv >> 1, it = wv & 1;
+  const int ks = blockIdx.x, ci0 = blockIdx.y * 64, co0 = blockIdx.z * 64;
+  const bool first = ci0 < a.C1;
+  const T* xsrc = first ? (const T*)a.x1 : (const T*)a.x2;
+  const int Cs = first ? a.C1 : a.C2, coff = first ? ci0 : ci0 - a.C1, sh = (first && a.up1) ? 1 : 0;
+  const int Hs = a.H >> sh, Ws = a.W >> sh;
+  const int gsh = a.g_unpool ? 1 : 0, Hg = a.H >> gsh, Wg = a.W >> gsh;
+  const bool want_bias = a.bpart && blockIdx.y == 0 && it == 0;
+
+  f32x16 acc[9], accb;
+#pragma unroll
+  for (int k = 0; k < 9; ++k)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[k][r] = 0.f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) accb[r] = 0.f;
+  const uint4 ones = frag_ones<T>();
+
+  for (int tile = ks; tile < a.ntile; tile += a.KS) {
+    int q = tile;
+    const int tx = q % a.tiles_x; q /= a.tiles_x;
+    const int ty = q % a.tiles_y;
+    const int b = q / a.tiles_y;
+    const int y0 = ty * WG_TH, x0 = tx * 32;
+    __syncthreads();                                   // previous tile fully consumed
+    for (int e = t; e < XPIX * PPX; e += 256) {        // input halo tile, zero outside the image
+      const int pix = e / PPX, part = e % PPX;
+      const int hy = pix / HWID, hx = pix - hy * HWID, y = y0 - 1 + hy, x = x0 - 1 + hx;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (y >= 0 && y < a.H && x >= 0 && x < a.W)
+        v = *(const uint4*)(xsrc + (((size_t)b * Hs + (y >> sh)) * Ws + (x >> sh)) * Cs + coff + part * EPL);
+      *(uint4*)(Xs + pix * STR + part * 16) = v;
+    }
+    for (int e = t; e < GPIX * PPX; e += 256) {        // output-gradient tile (with virtual unpool)
+      const int pix = e / PPX, part = e % PPX;
+      const int y = y0 + pix / 32, x = x0 + pix % 32;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (y < a.H && x < a.W) {
+        const size_t e0 = (((size_t)b * Hg + (y >> gsh)) * Wg + (x >> gsh)) * a.Cout + co0 + part * EPL;
+        v = *(const uint4*)((const T*)a.g + e0);
+        if (a.g_unpool) {
+          const unsigned pos = ((y & 1) << 1) | (x & 1);
+          T ev[EPL];
+          unsigned char id[EPL];
+          __builtin_memcpy(ev, &v, 16);
+          __builtin_memcpy(id, a.g_unpool + e0, EPL);
+#pragma unroll
+          for (int k = 0; k < EPL; ++k) if (id[k] != pos) ev[k] = (T)0.f;
+          __builtin_memcpy(&v, ev, 16);
+        }
+      }
+      *(uint4*)(Gs + pix * STR + part * 16) = v;
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int r = 0; r < WG_TH; ++r) {
+#pragma unroll
+      for (int kk = 0; kk < 32 / KPX; ++kk) {
+        const uint4 A = frag_kmajor<T>(Gs, STR, r * 32 + kk * KPX, ct * 32, lane);
+        if (want_bias) mma16<T>(accb, A, ones);
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+          const uint4 Bf = frag_kmajor<T>(Xs, STR, (r + tap / 3) * HWID + tap % 3 + kk * KPX, it * 32, lane);
+          mma16<T>(acc[tap], A, Bf);
+        }
+      }
+    }
+  }
+  // D[i = co][j = ci]: lane -> ci = ci0 + it*32 + (lane&31); reg r -> co = co0 + ct*32 + (r&3) + 8(r>>2) + 4(lane>>5)
+  const int ci = ci0 + it * 32 + (lane & 31), g5 = lane >> 5;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int co = co0 + ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * g5;
+    float* o = a.part + (((size_t)ks * a.Cout + co) * a.Cin + ci) * 9;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) o[tap] = acc[tap][r];
+    if (want_bias && (lane & 31) == 0) a.bpart[(size_t)ks * a.Cout + co] = accb[r];
+  }
+}
+
+// conv0: dW0[co][k = c*9+tap] over the NCHW fp32 input (k padded to 32 as one "ci tile").
+struct Wgrad0Args {
+  const float* x;        // [B,3,H,W]
+  const void* g;         // d(loss)/d(conv0 pre-activation) NHWC T [B,H,W,64]
+  float* part;           // [KS][2 row-halves][64][32]
+  float* bpart;          // [KS][2][64]
+  int B, H, W, tiles_x, tiles_y, ntile, KS;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void wgrad0_kernel(Wgrad0Args a) {
+  constexpr int EPL = 16 / sizeof(T), STR = wg_stride<T>(), PPX = 64 * (int)sizeof(T) / 16, KPX = KStep<T>::PX;
+  constexpr int IW = 48;   // plane row pitch (32 + 2 halo + K-step overrun)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* Gs = smem;
+  float* in = (float*)(smem + WG_TH * 32 * STR);     // [3][WG_TH+2][IW]
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6, ct = wv & 1, half = wv >> 1;
+  const int ks = blockIdx.x;
+  f32x16 acc, accb;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { acc[r] = 0.f; accb[r] = 0.f; }
+  const uint4 ones = frag_ones<T>();
+  const int j = lane & 31, g5 = lane >> 5;            // B operand: column j = k index (c, ky, kx)
+  const int jc = j < 27 ? j / 9 : 0, jky = (j % 9) / 3, jkx = j % 3;
+  for (int tile = ks; tile < a.ntile; tile += a.KS) {
+    int q = tile;
+    const int tx = q % a.tiles_x; q /= a.tiles_x;
+    const int ty = q % a.tiles_y;
+    const int b = q / a.tiles_y;
+    const int y0 = ty * WG_TH, x0 = tx * 32;
+    __syncthreads();
+    for (int e = t; e < 3 * (WG_TH + 2) * IW; e += 256) {
+      const int c = e / ((WG_TH + 2) * IW), r = e % ((WG_TH + 2) * IW), iy = r / IW, ix = r % IW;
+      const int y = y0 - 1 + iy, x = x0 - 1 + ix;
+      float v = 0.f;
+      if (ix < HWID && y >= 0 && y < a.H && x >= 0 && x < a.W) v = a.x[(((size_t)b * 3 + c) * a.H + y) * a.W + x];
+      in[e] = v;
+    }
+    for (int e = t; e < WG_TH * 32 * PPX; e += 256) {
+      const int pix = e / PPX, part = e % PPX;
+      const int y = y0 + pix / 32, x = x0 + pix % 32;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (y < a.H && x < a.W) v = *(const uint4*)((const T*)a.g + (((size_t)b * a.H + y) * a.W + x) * 64 + part * EPL);
+      *(uint4*)(Gs + pix * STR + part * 16) = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int rr = 0; rr < WG_TH / 2; ++rr) {
+      const int r = half * (WG_TH / 2) + rr;
+#pragma unroll
+      for (int kk = 0; kk < 32 / KPX; ++kk) {
+        const uint4 A = frag_kmajor<T>(Gs, STR, r * 32 + kk * KPX, ct * 32, lane);
+        T e[EPL];
+        const float* row = in + (jc * (WG_TH + 2) + r + jky) * IW + jkx + kk * KPX;
+#pragma unroll
+        for (int jj = 0; jj < EPL; ++jj) {
+          // bf16: k = 8*g5 + jj ; fp32: k = 2*jj + g5   (pixel offset inside the K-step, see KStep)
+          const int k = sizeof(T) == 2 ? 8 * g5 + jj : 2 * jj + g5;
+          e[jj] = (T)(j < 27 ? row[k] : 0.f);
+        }
+        mma16<T>(acc, A, __builtin_bit_cast(uint4, e));
+        mma16<T>(accb, A, ones);
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int co = ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * g5;
+    a.part[(((size_t)ks * 2 + half) * 64 + co) * 32 + j] = acc[r];
+    if (j == 0) a.bpart[((size_t)ks * 2 + half) * 64 + co] = accb[r];
+  }
+}
+
+// out[i] (=) sum_k part[k][i]  (fixed order: deterministic)
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ part, float* __restrict__ out,
+                                                              size_t n, int K, int in_stride_inner, int out_inner, int in_inner) {
+  // generic 2-D gather: element i = (row, col) with col < out_inner; input row pitch in_inner (conv0: 32 -> 27)
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const size_t row = i / out_inner, col = i % out_inner;
+    const size_t src = row * in_inner + col;
+    float s = 0.f;
+    for (int k = 0; k < K; ++k) s += part[(size_t)k * in_stride_inner + src];
+    out[i] = s;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// L2_norm backward: y = a*x with a = 1/||x||  =>  dx = a*dy - a^3 * (x . dy) * x      (per sample)
+__global__ __launch_bounds__(256) void l2bwd_dot_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                        double* __restrict__ part, size_t per_sample, int nblk) {
+  __shared__ double sh[4];
+  const int b = blockIdx.x / nblk, k = blockIdx.x % nblk;
+  const float4* px = (const float4*)(x + (size_t)b * per_sample);
+  const float4* pd = (const float4*)(dy + (size_t)b * per_sample);
+  float s = 0.f;
+  double sd = 0.0;
+  int cnt = 0;
+  for (size_t i = (size_t)k * 256 + threadIdx.x; i < per_sample / 4; i += (size_t)nblk * 256) {
+    const float4 u = px[i], v = pd[i];
+    s += u.x * v.x + u.y * v.y + u.z * v.z + u.w * v.w;
+    if (++cnt == 64) { sd += (double)s; s = 0.f; cnt = 0; }
+  }
+  sd += (double)s;
+  sd = wave_sum_f64(sd);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = sd;
+  __syncthreads();
+  if (threadIdx.x == 0) part[(size_t)b * nblk + k] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void l2bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                          const double* __restrict__ part, const double* __restrict__ inv,
+                                                          T* __restrict__ out, size_t per_sample, int nblk) {
+  const int b = blockIdx.x / nblk, k = blockIdx.x % nblk;
+  double dot = 0.0;
+  for (int i = 0; i < nblk; ++i) dot += part[(size_t)b * nblk + i];
+  const double al = inv[b];
+  const float c1 = (float)al, c3 = (float)(al * al * al * dot);
+  const float4* px = (const float4*)(x + (size_t)b * per_sample);
+  const float4* pd = (const float4*)(dy + (size_t)b * per_sample);
+  T* po = out + (size_t)b * per_sample;
+  for (size_t i = (size_t)k * 256 + threadIdx.x; i < per_sample / 4; i += (size_t)nblk * 256) {
+    const float4 u = px[i], v = pd[i];
+    store4(po + i * 4, c1 * v.x - c3 * u.x, c1 * v.y - c3 * u.y, c1 * v.z - c3 * u.z, c1 * v.w - c3 * u.w);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// host
+struct BwdPlan {
+  size_t g_x21, g_d2a, g_x18, l2_18, g_d1a, g_x15, l2_15, g_a12, g_a10, g_x8, g_x8p, g_a5, g_x3, g_x3p, g_a0;
+  size_t dot, part, bpart;
+  size_t total;
+};
+
+static int wgrad_ksplit(int Cout, int Cin, int ntile) {
+  const int pairs = (Cout / 64) * (Cin / 64);
+  int ks = 1024 / (pairs > 0 ? pairs : 1);
+  if (ks < 1) ks = 1;
+  if (ks > ntile) ks = ntile;
+  return ks;
+}
+
+static void bwd_plan(int B, int H, int W, int dtype, BwdPlan* p) {
+  const size_t es = dtype == HLA_BF16 ? 2 : 4;
+  size_t o = 0;
+  auto take = [&](size_t bytes) { size_t r = o; o += hla_align_up(bytes, 256); return r; };
+  const size_t P = (size_t)B * H * W;
+  p->g_x21 = take(P / 4 * 64 * es);  p->g_d2a = take(P / 4 * 64 * es);
+  p->g_x18 = take(P / 16 * 128 * es); p->l2_18 = take(P / 16 * 128 * es); p->g_d1a = take(P / 16 * 128 * es);
+  p->g_x15 = take(P / 64 * 256 * es); p->l2_15 = take(P / 64 * 256 * es);
+  p->g_a12 = take(P / 16 * 256 * es); p->g_a10 = take(P / 16 * 256 * es);
+  p->g_x8 = take(P / 16 * 128 * es);  p->g_x8p = take(P / 16 * 128 * es);
+  p->g_a5 = take(P / 4 * 128 * es);
+  p->g_x3 = take(P / 4 * 64 * es);    p->g_x3p = take(P / 4 * 64 * es);
+  p->g_a0 = take(P * 64 * es);
+  p->dot = take((size_t)B * 64 * sizeof(double));
+  size_t maxpart = (size_t)1024 * 2 * 64 * 32 * 4;      // conv0
+  const int hs[11] = {1, 1, 2, 2, 4, 4, 4, 4, 4, 2, 2};  // resolution divisor of each layer's output
+  for (int l = 1; l < kPackedLayers; ++l) {
+    const int h = H / hs[l], w = W / hs[l];
+    const int ntile = B * ((h + WG_TH - 1) / WG_TH) * ((w + 31) / 32);
+    const size_t sz = (size_t)wgrad_ksplit(kLayers[l].cout, kLayers[l].cin, ntile) * kLayers[l].cout * kLayers[l].cin * 9 * 4;
+    if (sz > maxpart) maxpart = sz;
+  }
+  p->part = take(maxpart);
+  p->bpart = take((size_t)2048 * 256 * 4);
+  p->total = o;
+}
+
+extern "C" size_t hla_vgg_bwd_workspace_bytes(int B, int H, int W, int dtype) {
+  BwdPlan p;
+  bwd_plan(B, H, W, dtype, &p);
+  return p.total;
+}
+
+extern "C" size_t hla_vgg_packed_weight_T_bytes(int dtype) { return packed_offset(kPackedLayers, dtype); }
+
+template <typename T>
+static void pack_all_T(const hla_vgg_params* prm, char* packed, int dtype, hipStream_t st) {
+  for (int l = 1; l < kPackedLayers; ++l) {       // conv0 needs no data gradient
+    const size_t n = (size_t)kLayers[l].cin * kLayers[l].cout * 9;
+    const int grid = (int)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024);
+    // transposed conv: Cout' = cin, Cin' = cout
+    hipLaunchKernelGGL((pack_weights_kernel<T>), dim3(grid), dim3(256), 0, st, prm->w[l],
+                       (T*)(packed + packed_offset(l, dtype)), kLayers[l].cin, kLayers[l].cout, 2);
+  }
+}
+
+extern "C" int hla_vgg_pack_weights_T(const hla_vgg_params* params, void* packed, int dtype, hla_stream_t stream) {
+  HLA_REQUIRE(params && packed, "hla_vgg_pack_weights_T: null argument");
+  HLA_REQUIRE(dtype == HLA_F32 || dtype == HLA_BF16, "hla_vgg_pack_weights_T: bad dtype");
+  if (dtype == HLA_BF16) pack_all_T<bf16>(params, (char*)packed, dtype, (hipStream_t)stream);
+  else pack_all_T<float>(params, (char*)packed, dtype, (hipStream_t)stream);
+  HLA_CHECK_HIP(hipGetLastError());
+  return HLA_OK;
+}
+
+template <typename T>
+static int vgg_backward_t(const float* x, const hla_vgg_params* prm, const char* packedT, int dtype, const char* fw,
+                          const float* const feat[3], const double* inv_norm, const float* const d_feat[3],
+                          const hla_vgg_grads* gr, char* bw, const BwdPlan& bp, int B, int H, int W, hipStream_t st) {
+  VggPlan fp;
+  vgg_plan(B, H, W, dtype, true, &fp);
+  constexpr int KC = SB / (int)sizeof(T);
+  static bool attr_set = false;
+  if (!attr_set) {
+    HLA_CHECK_HIP(hipFuncSetAttribute((const void*)wgrad_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, wg_lds_bytes<T>()));
+    attr_set = true;
+  }
+  auto F = [&](size_t off) { return (const void*)(fw + off); };
+  auto G = [&](size_t off) { return (void*)(bw + off); };
+
+  // ---- L2_norm backward of the three returned maps
+  const size_t per[3] = {(size_t)(H / 8) * (W / 8) * 256, (size_t)(H / 4) * (W / 4) * 128, (size_t)(H / 2) * (W / 2) * 64};
+  void* l2out[3] = {G(bp.l2_15), G(bp.l2_18), G(bp.g_x21)};
+  for (int l = 0; l < 3; ++l) {
+    int nblk = (int)(per[l] / 4 / 256 / 8);
+    nblk = nblk < 1 ? 1 : (nblk > 64 ? 64 : nblk);
+    double* part = (double*)(bw + bp.dot);
+    hla_prof_begin(K_ELEMWISE, 0, (double)B * per[l] * 8, st);
+    hipLaunchKernelGGL(l2bwd_dot_kernel, dim3(B * nblk), dim3(256), 0, st, feat[l], d_feat[l], part, per[l], nblk);
+    hipLaunchKernelGGL((l2bwd_apply_kernel<T>), dim3(B * nblk), dim3(256), 0, st, feat[l], d_feat[l], part,
+                       inv_norm + (size_t)l * B, (T*)l2out[l], per[l], nblk);
+    hla_prof_end(st);
+  }
+
+  // ---- helpers
+  // data gradient of layer l restricted to its input channels [c0, c0+n): a forward conv on the transposed weights
+  auto dgrad = [&](int l, int c0, int n, const void* gsrc, const unsigned char* unpool, int Hout, int Wout, void* out,
+                   const void* mask, const void* add, bool pool_sum) {
+    ConvArgs a{};
+    a.src1 = gsrc; a.C1 = kLayers[l].cout; a.unpool_idx = unpool;
+    const int nstage = kLayers[l].cout / KC;
+    a.wpk = (const uint4*)(packedT + packed_offset(l, dtype)) + (size_t)(c0 / 32) * nstage * 18 * 64;
+    a.out_act = out; a.mask_act = mask; a.add_src = add; a.pool_sum = pool_sum ? 1 : 0;
+    a.B = B; a.H = Hout; a.W = Wout; a.Cout = n; a.relu_act = 0;
+    launch_conv<T>(st, a, pool_sum);
+  };
+  auto wgrad = [&](int l, const void* x1, int C1, const void* x2, int C2, int up1, const void* g, const unsigned char* unpool,
+                   int Hout, int Wout) {
+    WgradArgs a{};
+    a.x1 = x1; a.x2 = x2; a.C1 = C1; a.C2 = C2; a.up1 = up1; a.g = g; a.g_unpool = unpool;
+    a.B = B; a.H = Hout; a.W = Wout; a.Cout = kLayers[l].cout; a.Cin = kLayers[l].cin;
+    a.tiles_x = (Wout + 31) / 32; a.tiles_y = (Hout + WG_TH - 1) / WG_TH; a.ntile = B * a.tiles_x * a.tiles_y;
+    a.KS = wgrad_ksplit(a.Cout, a.Cin, a.ntile);
+    a.part = (float*)(bw + bp.part);
+    a.bpart = (kLayers[l].has_bias && gr->db[l]) ? (float*)(bw + bp.bpart) : nullptr;
+    const double P = (double)B * Hout * Wout;
+    hla_prof_begin(K_WGRAD, 2.0 * 9 * a.Cin * a.Cout * P, P * (a.Cin + a.Cout) * sizeof(T), st);
+    hipLaunchKernelGGL((wgrad_kernel<T>), dim3(a.KS, a.Cin / 64, a.Cout / 64), dim3(256), wg_lds_bytes<T>(), st, a);
+    hla_prof_end(st);
+    const size_t n = (size_t)a.Cout * a.Cin * 9;
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048)), dim3(256), 0, st,
+                       a.part, gr->dw[l], n, a.KS, (int)n, 1, 1);
+    if (a.bpart)
+      hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(256), 0, st, a.bpart, gr->db[l], (size_t)a.Cout, a.KS, a.Cout, 1, 1);
+  };
+  const unsigned char* idx3 = (const unsigned char*)(fw + fp.idx3);
+  const unsigned char* idx8 = (const unsigned char*)(fw + fp.idx8);
+  const unsigned char* idx15 = (const unsigned char*)(fw + fp.idx15);
+  const int H2 = H / 2, W2 = W / 2, H4 = H / 4, W4 = W / 4;
+
+  // ---- decoder 2 (VGG.py:148-151)
+  dgrad(10, 0, 64, G(bp.g_x21), nullptr, H2, W2, G(bp.g_d2a), F(fp.d2a), nullptr, false);
+  wgrad(10, F(fp.d2a), 64, nullptr, 0, 0, G(bp.g_x21), nullptr, H2, W2);
+  dgrad(9, 0, 128, G(bp.g_d2a), nullptr, H2, W2, G(bp.g_x18), F(fp.x18r), G(bp.l2_18), true);     // up(x18) branch
+  dgrad(9, 128, 64, G(bp.g_d2a), nullptr, H2, W2, G(bp.g_x3p), F(fp.x3), nullptr, false);          // x3 skip branch
+  wgrad(9, F(fp.x18r), 128, F(fp.x3), 64, 1, G(bp.g_d2a), nullptr, H2, W2);
+  // ---- decoder 1 (VGG.py:144-146)
+  dgrad(8, 0, 128, G(bp.g_x18), nullptr, H4, W4, G(bp.g_d1a), F(fp.d1a), nullptr, false);
+  wgrad(8, F(fp.d1a), 128, nullptr, 0, 0, G(bp.g_x18), nullptr, H4, W4);
+  dgrad(7, 0, 256, G(bp.g_d1a), nullptr, H4, W4, G(bp.g_x15), F(fp.x15r), G(bp.l2_15), true);     // up(x15) branch
+  dgrad(7, 256, 128, G(bp.g_d1a), nullptr, H4, W4, G(bp.g_x8p), F(fp.x8), nullptr, false);        // x8 skip branch
+  wgrad(7, F(fp.x15r), 256, F(fp.x8), 128, 1, G(bp.g_d1a), nullptr, H4, W4);
+  // ---- encoder block 2 (VGG.py:136-141); conv14 is followed by the pool (no ReLU in between)
+  dgrad(6, 0, 256, G(bp.g_x15), idx15, H4, W4, G(bp.g_a12), F(fp.a12), nullptr, false);
+  wgrad(6, F(fp.a12), 256, nullptr, 0, 0, G(bp.g_x15), idx15, H4, W4);
+  dgrad(5, 0, 256, G(bp.g_a12), nullptr, H4, W4, G(bp.g_a10), F(fp.a10), nullptr, false);
+  wgrad(5, F(fp.a10), 256, nullptr, 0, 0, G(bp.g_a12), nullptr, H4, W4);
+  dgrad(4, 0, 128, G(bp.g_a10), nullptr, H4, W4, G(bp.g_x8), F(fp.x8), G(bp.g_x8p), false);
+  wgrad(4, F(fp.x8), 128, nullptr, 0, 0, G(bp.g_a10), nullptr, H4, W4);
+  // ---- encoder block 1
+  dgrad(3, 0, 128, G(bp.g_x8), idx8, H2, W2, G(bp.g_a5), F(fp.a5), nullptr, false);
+  wgrad(3, F(fp.a5), 128, nullptr, 0, 0, G(bp.g_x8), idx8, H2, W2);
+  dgrad(2, 0, 64, G(bp.g_a5), nullptr, H2, W2, G(bp.g_x3), F(fp.x3), G(bp.g_x3p), false);
+  wgrad(2, F(fp.x3), 64, nullptr, 0, 0, G(bp.g_a5), nullptr, H2, W2);
+  // ---- encoder block 0
+  dgrad(1, 0, 64, G(bp.g_x3), idx3, H, W, G(bp.g_a0), F(fp.a0), nullptr, false);
+  wgrad(1, F(fp.a0), 64, nullptr, 0, 0, G(bp.g_x3), idx3, H, W);
+  {
+    Wgrad0Args a{};
+    a.x = x; a.g = G(bp.g_a0); a.B = B; a.H = H; a.W = W;
+    a.tiles_x = (W + 31) / 32; a.tiles_y = (H + WG_TH - 1) / WG_TH; a.ntile = B * a.tiles_x * a.tiles_y;
+    a.KS = a.ntile < 1024 ? a.ntile : 1024;
+    a.part = (float*)(bw + bp.part); a.bpart = (float*)(bw + bp.bpart);
+    const int lds = WG_TH * 32 * wg_stride<T>() + 3 * (WG_TH + 2) * 48 * 4;
+    const double P = (double)B * H * W;
+    hla_prof_begin(K_WGRAD, 2.0 * 27 * 64 * P, P * (12 + 64 * sizeof(T)), st);
+    hipLaunchKernelGGL((wgrad0_kernel<T>), dim3(a.KS), dim3(256), lds, st, a);
+    hla_prof_end(st);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(7), dim3(256), 0, st, a.part, gr->dw[0], (size_t)64 * 27, a.KS * 2, 64 * 32, 27, 32);
+    if (gr->db[0]) hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(256), 0, st, a.bpart, gr->db[0], (size_t)64, a.KS * 2, 64, 1, 1);
+  }
+  HLA_CHECK_HIP(hipGetLastError());
+  return HLA_OK;
+}
+
+extern "C" int hla_vgg_backward(const float* x, const hla_vgg_params* params, const void* packed_weights_T,
+                                const void* fwd_workspace, const float* const feat[3], const double* inv_norm,
+                                const float* const d_feat[3], const hla_vgg_grads* grads, void* workspace,
+                                size_t workspace_bytes, int B, int H, int W, int level, int dtype, hla_stream_t stream) {
+  HLA_REQUIRE(x && params && packed_weights_T && fwd_workspace && feat && inv_norm && d_feat && grads && workspace,
+              "hla_vgg_backward: null argument");
+  HLA_REQUIRE(dtype == HLA_F32 || dtype == HLA_BF16, "hla_vgg_backward: bad dtype");
+  HLA_REQUIRE(level == 3, "hla_vgg_backward: only level 3 is built");
+  HLA_REQUIRE(B > 0 && H % 8 == 0 && W % 8 == 0, "hla_vgg_backward: H and W must be multiples of 8");
+  for (int l = 0; l < kPackedLayers; ++l) HLA_REQUIRE(grads->dw[l], "hla_vgg_backward: dw[%d] missing", l);
+  BwdPlan bp;
+  bwd_plan(B, H, W, dtype, &bp);
+  if (workspace_bytes < bp.total) {
+    hla_set_error("hla_vgg_backward: workspace %zu < %zu", workspace_bytes, bp.total);
+    return HLA_ERR_WORKSPACE;
+  }
+  if (dtype == HLA_BF16)
+    return vgg_backward_t<bf16>(x, params, (const char*)packed_weights_T, dtype, (const char*)fwd_workspace, feat, inv_norm,
+                                d_feat, grads, (char*)workspace, bp, B, H, W, (hipStream_t)stream);
+  return vgg_backward_t<float>(x, params, (const char*)packed_weights_T, dtype, (const char*)fwd_workspace, feat, inv_norm,
+                               d_feat, grads, (char*)workspace, bp, B, H, W, (hipStream_t)stream);
+}

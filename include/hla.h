@@ -59,8 +59,10 @@ typedef struct hla_vgg_params {
 
 enum {
   HLA_VGG_WANT_CONF = 1,   /* compute the confidence maps (VGG.py:160-163)                              */
-  HLA_VGG_DEFER_NORM = 2   /* leave feat[] un-normalised and only report inv_norm (the LM loop folds the
+  HLA_VGG_DEFER_NORM = 2,  /* leave feat[] un-normalised and only report inv_norm (the LM loop folds the
                               scale into its normal equations: one full read+write pass less per map)  */
+  HLA_VGG_SAVE_FOR_BACKWARD = 4 /* training: also keep relu(conv0) and the three max-pool argmax maps in the
+                              workspace; the caller keeps the workspace alive until hla_vgg_backward   */
 };
 
 /* Weights are re-laid-out once into MFMA fragment order (bf16 or fp32) and reused until they change.
@@ -84,6 +86,31 @@ size_t hla_vgg_workspace_bytes(int B, int H, int W, int level, int dtype);
 int hla_vgg_forward(const float* x, const hla_vgg_params* params, const void* packed_weights, float* const feat[4],
                     float* const conf[4], double* inv_norm, void* workspace, size_t workspace_bytes, int B, int H,
                     int W, int level, int dtype, int flags, hla_stream_t stream);
+
+/* ------------------------------------------------------------------------- *
+ * Backward of VGGUnet (autograd through VGG.py:121-203 in the reference).
+ * ------------------------------------------------------------------------- */
+/* fp32 gradient buffers with PyTorch's layouts (OIHW weights), overwritten: dw[0..10] = conv0..conv_dec2.3
+ * (required), db[0..6] (NULL to skip).  dw[11..16] are unused at level 3 (those parameters get no gradient). */
+typedef struct hla_vgg_grads {
+  float* dw[17];
+  float* db[7];
+} hla_vgg_grads;
+
+size_t hla_vgg_packed_weight_T_bytes(int dtype);
+/* transposed + tap-flipped fragment packing used by the data-gradient convolutions */
+int hla_vgg_pack_weights_T(const hla_vgg_params* params, void* packed_T, int dtype, hla_stream_t stream);
+size_t hla_vgg_bwd_workspace_bytes(int B, int H, int W, int dtype);
+
+/* x, params        as in the forward call
+ * fwd_workspace    the workspace of the forward call made with HLA_VGG_SAVE_FOR_BACKWARD | HLA_VGG_DEFER_NORM
+ * feat[l], inv_norm  its outputs (raw maps + 1/norm)
+ * d_feat[l]        d(loss)/d(L2-normalised map l), NHWC fp32 (what hla_s2g_lm_solve_bwd produces)
+ * Confidence-head gradients (using_weight) are not built yet. */
+int hla_vgg_backward(const float* x, const hla_vgg_params* params, const void* packed_weights_T,
+                     const void* fwd_workspace, const float* const feat[3], const double* inv_norm,
+                     const float* const d_feat[3], const hla_vgg_grads* grads, void* workspace,
+                     size_t workspace_bytes, int B, int H, int W, int level, int dtype, hla_stream_t stream);
 
 /* ------------------------------------------------------------------------- *
  * jacobian.grid_sample  (jacobian.py:138-205) -- the stand-alone operator

@@ -406,3 +406,46 @@ def test_lm_backward_small_vs_oracle_autograd(kw):
             e = np.abs(got - ref).max() / max(np.abs(ref).max(), 1e-30)
             print(f'lm bwd level {l} d_conf: rel err {e:.2e}')
             assert e < 2e-4
+
+
+# bf16: the one-hop gradient (conv_dec2.3) agrees to 0.5 %; deeper layers differ by up to ~17 % in relative L2 because
+# bf16 rounding of the FORWARD flips max-pool argmax / ReLU signs of near-ties (a flipped argmax moves a gradient
+# element to a neighbouring pixel).  That is a property of bf16 training, not of the backward kernels, whose logic
+# the fp32 run pins to 2e-6; the bf16 bound below only guards against gross breakage.
+@pytest.mark.parametrize('precision,tol', [('fp32', 2e-4), ('bf16', 0.3)])
+def test_vgg_backward_small_vs_oracle_autograd(precision, tol):
+    """hla_vgg_backward (L2-norm bwd, dgrad convs with fused ReLU mask / fan-in / unpool / upsample-sum, MFMA wgrad,
+    bias grads) against torch autograd through the fp64 oracle VGGUnet."""
+    from oracle import ref_cpu as O
+    from highlyaccurate_amd.VGG import VGGUnet, vgg_forward_nhwc, vgg_backward_nhwc
+    d = _dev()
+    rs = np.random.RandomState(31)
+    sd = O.synth_vgg_state(rs, bias_scale=0.05)
+    x = T(rs.random_sample((2, 3, 32, 64)).astype(np.float32))
+    onet = O.VGGUnet(3)
+    onet.load_state_dict(sd)
+    onet = onet.double()
+    feats64, _ = onet(x.double())
+    ups = [T(rs.standard_normal(tuple(f.shape))) for f in feats64]          # d(loss)/d(normalised map), NCHW
+    loss = sum((u * f).sum() for u, f in zip(ups, feats64))
+    loss.backward()
+    ref = {k: p.grad for k, p in onet.named_parameters()}
+    net = VGGUnet(3, precision=precision)
+    net.load_state_dict(sd)
+    net = net.to(d)
+    feats, _, inv, ctx = vgg_forward_nhwc(net, x.to(d), want_conf=False, defer_norm=True, save_for_backward=True)
+    grads = vgg_backward_nhwc(net, ctx, [u.permute(0, 2, 3, 1).contiguous().float().to(d) for u in ups])
+    worst, errs = 0.0, {}
+    for k, g in grads.items():
+        r = ref[k].numpy()
+        e = np.abs(g.cpu().double().numpy() - r).max() / max(np.abs(r).max(), 1e-30)
+        worst = max(worst, e)
+        rl2 = np.linalg.norm(g.cpu().double().numpy() - r) / max(np.linalg.norm(r), 1e-30)
+        print(f'vgg bwd {precision} {k:24s} rel err max {e:.2e} l2 {rl2:.2e} (max |ref| {np.abs(r).max():.2e})')
+        errs[k] = rl2 if precision == 'bf16' else e
+    assert max(errs.values()) < tol, (precision, errs)
+    if precision == 'bf16':
+        assert errs['conv_dec2.3.weight'] < 2e-2
+    for k in ('conv_dec3.1.weight', 'conf0.1.weight'):
+        assert ref[k] is None and k not in grads        # the reference leaves these without a gradient too (SURVEY B-8)
+    print(f'vgg bwd {precision}: worst rel err {worst:.2e}')
