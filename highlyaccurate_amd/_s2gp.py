@@ -13,7 +13,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib, utils
-from .VGG import VGGUnet, vgg_forward_nhwc
+from .VGG import VGGUnet, vgg_forward_nhwc, vgg_backward_nhwc
 
 KITTI_K = [[582.9802, 0.0, 496.2420], [0.0, 482.7076, 125.0034], [0.0, 0.0, 1.0]]      # models_kitti.py:657-660
 FORD_K_FL = [945.391406, 0.0, 855.502825, 0.0, 945.668274, 566.372868, 0.0, 0.0, 1.0]   # models_ford.py:116
@@ -225,15 +225,69 @@ class S2GPBase(nn.Module):
         return d_sat, d_grd, d_conf, d_lambda
 
     def localise(self, sat_map, grd_img, want_conf, extra, level_first, init_pose):
-        """Both feature pyramids (normalisation deferred into the LM sums) + the whole LM loop."""
+        """Both feature pyramids (normalisation deferred into the LM sums) + the whole LM loop.
+        Under autograd (training) the same kernels run inside one autograd.Function whose backward is the HIP
+        backward pass (hla_s2g_lm_solve_bwd + hla_vgg_backward for both extractors)."""
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            if self.using_weight:
+                raise NotImplementedError('training with using_weight=1 needs the confidence-head backward (not built yet)')
+            names = [n for n, _ in self.named_parameters()]
+            params = [p for _, p in self.named_parameters()]
+            out = _LocaliseFn.apply(self, names, sat_map, grd_img, want_conf, extra, level_first, init_pose, *params)
+            return out[0], list(out[1:]) if want_conf else [None] * 3
         sat_feats, _, sat_inv = vgg_forward_nhwc(self.SatFeatureNet, sat_map, want_conf=False, defer_norm=True)
         grd_feats, grd_confs, grd_inv = vgg_forward_nhwc(self.GrdFeatureNet, grd_img, want_conf=want_conf, defer_norm=True)
         trace = self.lm_solve(sat_feats, grd_feats, grd_confs, grd_img.shape[-2:], extra, level_first, init_pose,
                               sat_inv, grd_inv)
         return trace, grd_confs
 
-    def _check_train_supported(self):
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            raise NotImplementedError(
-                "mode='train' with autograd enabled needs the HIP backward kernels, which are not built yet; "
-                "call under torch.no_grad() for the forward values")
+
+class _LocaliseFn(torch.autograd.Function):
+    """forward: trace [B,N,L,3] (+ the three ground confidence maps); backward: parameter gradients from HIP kernels."""
+
+    @staticmethod
+    def forward(ctx, model, names, sat_map, grd_img, want_conf, extra, level_first, init_pose, *params):
+        sat_feats, _, sat_inv, cs = vgg_forward_nhwc(model.SatFeatureNet, sat_map, want_conf=False, defer_norm=True,
+                                                     save_for_backward=True)
+        grd_feats, grd_confs, grd_inv, cg = vgg_forward_nhwc(model.GrdFeatureNet, grd_img, want_conf=want_conf,
+                                                             defer_norm=True, save_for_backward=True)
+        trace = model.lm_solve(sat_feats, grd_feats, grd_confs, grd_img.shape[-2:], extra, level_first, init_pose,
+                               sat_inv, grd_inv, keep_normal_eq=True)
+        ctx.model, ctx.names, ctx.extra, ctx.level_first, ctx.init_pose = model, names, extra, level_first, init_pose
+        ctx.state = (sat_feats, grd_feats, grd_confs, tuple(grd_img.shape[-2:]), trace, model.last_normal_eq, sat_inv, grd_inv, cs, cg)
+        outs = (trace,) + (tuple(grd_confs) if want_conf else ())
+        if want_conf:
+            ctx.mark_non_differentiable(*grd_confs)     # loss_method 0 does not read them; using_weight is gated above
+        return outs
+
+    @staticmethod
+    def backward(ctx, d_trace, *unused):
+        model = ctx.model
+        sat_feats, grd_feats, grd_confs, grd_hw, trace, neq, sat_inv, grd_inv, cs, cg = ctx.state
+        d_sat, d_grd, _, d_lam = model.lm_backward(sat_feats, grd_feats, grd_confs, grd_hw, trace, neq, d_trace, ctx.extra,
+                                                   ctx.level_first, ctx.init_pose, sat_inv, grd_inv)
+        sync = getattr(model, 'grad_sync', None)        # optional: overlap the sat-branch all-reduce with the grd backward
+        g_sat = vgg_backward_nhwc(model.SatFeatureNet, cs, d_sat)
+        h1 = sync.start({'SatFeatureNet.' + k: v for k, v in g_sat.items()}) if sync else None
+        g_grd = vgg_backward_nhwc(model.GrdFeatureNet, cg, d_grd)
+        h2 = sync.start({'GrdFeatureNet.' + k: v for k, v in g_grd.items()}) if sync else None
+        if sync:
+            sync.finish(h1)
+            sync.finish(h2)
+        grads = {'SatFeatureNet.' + k: v for k, v in g_sat.items()}
+        grads.update({'GrdFeatureNet.' + k: v for k, v in g_grd.items()})
+        if getattr(model.args, 'train_damping', 0):
+            d = model.damping.detach().double()
+            sg = torch.sigmoid(d)
+            lam = 10.0 ** (-6 + sg * 11.0)
+            dlam_dd = lam * np.log(10.0) * 11.0 * sg * (1 - sg)
+            if d.dim() == 0:
+                n = 2 if model.args.rotation_range == 0 else 1
+                grads['damping'] = (d_lam[:n].sum() * dlam_dd).float()
+            else:
+                grads['damping'] = (d_lam.view(1, 3) * dlam_dd).float()
+            if sync:
+                sync.finish(sync.start({'damping': grads['damping']}))
+        return (None,) * 8 + tuple(grads.get(n) for n in ctx.names)
+
+

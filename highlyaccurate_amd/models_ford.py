@@ -15,8 +15,6 @@ class LM_S2GP_Ford(S2GPBase):
                 file_name=None, level_first=0, loop=0, init_pose=None):
         """mode='test' -> (shift_u[B], shift_v[B], theta[B]) (models_ford.py:864-865);
         mode='train' -> 14-tuple (models_ford.py:858-862).  gt_* are [B] (float64 from the dataloader)."""
-        if mode == 'train':
-            self._check_train_supported()
         want_conf = bool(self.using_weight) or mode == 'train'
         extra = dict(R_FL=R_FL, T_FL=T_FL, side_m=float(satmap_sidelength_meters))
         trace, grd_confs = self.localise(sat_map, grd_img_left, want_conf, extra, level_first, init_pose)

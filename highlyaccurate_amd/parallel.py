@@ -1,0 +1,89 @@
+"""Data-parallel training support: one process per GPU, gradients averaged with one bucketed all-reduce per
+network branch over RCCL/xGMI (torch.distributed backend "nccl" on ROCm; "gloo" on CPU for the tests).
+
+The reference has no distributed code; this is the capability BASELINE configs 3-4 add.  The batch
+shards over ranks; the loss is a mean over the local batch, so averaging local gradients over equal shards
+reproduces the global-batch gradient exactly.  Parameters that receive no gradient under the
+current flags (damping, conv_dec3.*, conf*; SURVEY B-8) are skipped consistently on every rank.
+"""
+from __future__ import annotations
+
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_distributed(backend: str | None = None):
+    """Initialise torch.distributed from the torchrun environment.  Returns (rank, world, local_rank)."""
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        if backend is None:
+            backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+        kw = {}
+        if backend == 'nccl':
+            torch.cuda.set_device(local)
+            kw['device_id'] = torch.device('cuda', local)
+        dist.init_process_group(backend, rank=rank, world_size=world, **kw)
+    return rank, world, local
+
+
+def shard_batch(t: torch.Tensor, rank: int, world: int) -> torch.Tensor:
+    """Equal contiguous shard of the leading (batch) dimension."""
+    B = t.shape[0]
+    if B % world:
+        raise ValueError(f'batch {B} does not divide over {world} ranks')
+    n = B // world
+    return t[rank * n:(rank + 1) * n]
+
+
+class GradSync:
+    """Bucketed gradient averaging.  ``start(grads)`` flattens a {name: tensor} dict into one bucket and launches
+    an asynchronous SUM all-reduce; ``finish(handle)`` waits, divides by the world size and scatters the values
+    back into the original tensors.  Used by the model's backward (``model.grad_sync``) so that the satellite
+    branch's 9.9 MB bucket is in flight on the xGMI links while the ground branch's backward kernels run."""
+
+    def __init__(self, group=None):
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.bytes_reduced = 0
+
+    def start(self, grads: dict):
+        if self.world == 1 or not grads:
+            return None
+        names = sorted(grads)                         # identical order on every rank
+        flat = torch.cat([grads[n].reshape(-1).float() for n in names])
+        self.bytes_reduced += flat.numel() * 4
+        work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        return work, flat, names, grads
+
+    def finish(self, handle):
+        if handle is None:
+            return
+        work, flat, names, grads = handle
+        work.wait()
+        flat.div_(self.world)
+        o = 0
+        for n in names:
+            g = grads[n]
+            g.copy_(flat[o:o + g.numel()].view_as(g))
+            o += g.numel()
+
+
+def allreduce_module_grads(module: torch.nn.Module, group=None):
+    """Fallback for code that did not install ``grad_sync``: average every existing ``.grad`` after backward."""
+    gs = GradSync(group)
+    grads = {n: p.grad for n, p in module.named_parameters() if p.grad is not None}
+    gs.finish(gs.start(grads))
+    return gs.bytes_reduced
+
+
+def max_over_ranks(x: float, device) -> float:
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return x
+    t = torch.tensor([x], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())

@@ -333,8 +333,69 @@ def test_train_mode_forward_values_vs_golden():
     for i in range(1, 9):
         np.testing.assert_allclose(res[i].cpu().numpy(), ref[i], rtol=1e-3, atol=2e-3)
     assert tuple(res[13][0].shape) == (B, 1, 32, 128)
-    with pytest.raises(NotImplementedError):
-        net(sat.to(d), grd.to(d), gu.to(d), gv.to(d), gh.to(d), mode='train')
+
+
+def test_train_step_gradients_vs_reference_golden():
+    """mode='train' under autograd: loss.backward() runs the HIP backward (LM loop + both VGGs).  Gradients are checked
+    against samples recorded from the REAL reference's autograd (fp64 run), full KITTI shape, B=1."""
+    from oracle import ref_cpu as O
+    from highlyaccurate_amd.models_kitti import LM_S2GP
+    from make_idx import sample_idx
+    g = load_golden('train_kitti.npz')
+    seed, B = int(g['seed']), int(g['B'])
+    d = _dev()
+    net = LM_S2GP(O.default_args())
+    net.load_state_dict(O.synth_model_state(seed))
+    net = net.to(d).train()
+    sat, grd, gu, gv, gh = O.synth_images(seed + 100, B)
+    torch.manual_seed(seed)
+    res = net(sat.to(d), grd.to(d), gu.to(d), gv.to(d), gh.to(d), mode='train')
+    assert abs(float(res[0]) - g['tuple64'][0][0]) < 1e-3 * abs(g['tuple64'][0][0])
+    res[0].backward()
+    named = dict(net.named_parameters())
+    nograd = set(str(k) for k in g['nograd_64'])
+    for k, p in named.items():
+        assert (p.grad is None) == (k in nograd), k          # same 13 parameters without gradient as the reference (B-8)
+    keys = [k[len('grad64_'):] for k in g.files if k.startswith('grad64_')]
+    worst = 0.0
+    for k in keys:
+        ref = g['grad64_' + k]
+        gr = named[k].grad.double().reshape(-1).cpu()
+        idx = sample_idx(gr.numel(), 77)
+        got = np.concatenate([[gr.abs().sum().item(), (gr * gr).sum().item()], gr[idx].numpy()])
+        gap = np.abs(g['grad32_' + k][2:] - ref[2:]).max()        # the reference's own fp32-vs-fp64 gradient gap
+        scale = np.abs(ref[2:]).max()
+        e = np.abs(got[2:] - ref[2:]).max()
+        print(f'train grad {k:36s} max err {e:.2e} (ref fp32 gap {gap:.2e}, scale {scale:.2e}); l1 {got[0]:.4e} vs {ref[0]:.4e}')
+        # Gradients that pass through a max-pool carry "flip noise": one fp32 near-tie (relative gap < 1e-6, measured
+        # with tools/diag_argmax.py: exactly 1 window per map differs from the fp64 run) reroutes one gradient element,
+        # which moves a weight gradient by ~1/sqrt(#pixels) ~ 1e-3 relative.  The reference's own fp32-vs-fp64 gap shows
+        # the same effect.  conv_dec2.* sit above every pool in the backward order and must be tight.
+        rel_tol = 2e-4 if 'conv_dec2' in k else 5e-3
+        assert e <= max(rel_tol * scale, 3 * gap), (k, e, gap, scale)
+        # L1 norms: 1e-3 relative (fp32 rounding flips a few max-pool near-ties differently than the fp64 run does)
+        assert abs(got[0] - ref[0]) <= max(2e-3 * ref[0], 3 * abs(g['grad32_' + k][0] - ref[0]))
+        worst = max(worst, e / scale)
+    print('train grads worst rel err', worst)
+    # a second step after an optimizer update must re-pack the weights (version counters) and still run
+    opt = torch.optim.Adam(net.parameters(), lr=1e-4)
+    opt.step(); opt.zero_grad()
+    torch.manual_seed(seed)
+    res2 = net(sat.to(d), grd.to(d), gu.to(d), gv.to(d), gh.to(d), mode='train')
+    res2[0].backward()
+    assert torch.isfinite(res2[0]) and float(res2[0]) != float(res[0])
+
+
+def test_test_mode_outputs_are_differentiable():
+    """train_kitti.py:63-64 calls .backward() on the test-mode outputs."""
+    from oracle import ref_cpu as O
+    from highlyaccurate_amd.models_kitti import LM_S2GP
+    d = _dev()
+    net = LM_S2GP(O.default_args(N_iters=1)).to(d)
+    sat, grd, gu, *_ = O.synth_images(3, 1, grd_hw=(64, 256), sat_a=128)
+    lat, lon, th = net(sat.to(d), grd.to(d), mode='test')
+    torch.mean(lat - gu.to(d)[:, 0]).backward()
+    assert net.SatFeatureNet.conv0.weight.grad is not None
 
 
 def test_full_bench_config_runs_and_is_consistent():
