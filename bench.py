@@ -69,6 +69,7 @@ def main():
     ap.add_argument('--n-iters', type=int, default=5)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-timing', action='store_true')
+    ap.add_argument('--train-steps', type=int, default=4, help='extra: time this many training steps (0 = skip)')
     a = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -138,6 +139,62 @@ def main():
     if not os.environ.get('HLA_BENCH_NOCHECK'):     # timing-ablation builds (tools/variants.py) produce garbage
         assert all(torch.isfinite(o).all() for o in out)
 
+    # ---- extra: the training step (forward(train) + HIP backward + gradient all-reduce + Adam), same shapes
+    train = None
+    if a.train_steps > 0:
+      try:
+          from highlyaccurate_amd.parallel import GradSync
+          net.train()
+          if dist:
+              net.grad_sync = GradSync()
+          opt = torch.optim.Adam(net.parameters(), lr=1e-4)
+          gt = [torch.rand(B, 1, device=dev) * 2 - 1 for _ in range(3)]
+
+          def tstep():
+              opt.zero_grad(set_to_none=True)
+              r = net(sat, grd, gt[0], gt[1], gt[2], mode='train')
+              r[0].backward()
+              opt.step()
+              return r[0]
+          tstep()
+          torch.cuda.synchronize()
+          if dist:
+              dist.barrier()
+          torch.cuda.synchronize()
+          if want_kt:
+              _lib.prof_enable(True)
+          t1 = time.perf_counter()
+          for _ in range(a.train_steps):
+              lossv = tstep()
+          torch.cuda.synchronize()
+          if dist:
+              dist.barrier()
+          torch.cuda.synchronize()
+          tdt = time.perf_counter() - t1
+          trecs = []
+          if want_kt:
+              _lib.prof_enable(False)
+              trecs = _lib.prof_fetch()
+          if dist:
+              tt = torch.tensor([tdt], device=dev, dtype=torch.float64)
+              dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+              tdt = float(tt.item())
+          train = {'value': round(B * world * a.train_steps / tdt, 3), 'unit': 'pairs/s', 'steps': a.train_steps,
+                   'ms_per_step': round(tdt / a.train_steps * 1e3, 3), 'loss_finite': bool(torch.isfinite(lossv)),
+                   'what': "forward(mode='train') + HIP backward (LM loop + both VGGs) + gradient all-reduce + Adam",
+                   'allreduce_bytes_per_step': (net.grad_sync.bytes_reduced // (a.train_steps + 1)) if dist else 0}
+          if trecs:
+              tagg = {}
+              for name, ms, fl, by in trecs:
+                  e = tagg.setdefault(name, [0, 0.0, 0.0])
+                  e[0] += 1; e[1] += ms; e[2] += fl
+              tot = sum(v[1] for v in tagg.values())
+              train['kernels'] = {k: {'launches': v[0], 'avg_us': round(v[1] / v[0] * 1e3, 1), 'share': round(v[1] / tot, 3),
+                                      'tflops': round(v[2] / (v[1] * 1e-3) / 1e12, 1) if v[2] else None}
+                                  for k, v in sorted(tagg.items(), key=lambda kv: -kv[1][1])[:8]}
+      except Exception as e:      # the headline line must still be printed
+        train = {'error': repr(e)[:300]}
+
     if rank == 0:
         pairs = B * world * a.steps
         res = {
@@ -174,6 +231,8 @@ def main():
                 res['lm_roofline'] = {'kernel': 'lm_accum<*>', 'bound': 'hbm', 'achieved': round(lby / (lms * 1e-3) / 1e9, 1),
                                       'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'frac': round(lby / (lms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)}
             res['kernels'] = kern
+        if train:
+            res['train'] = train
         if not a.no_cpu_baseline:
             res['cpu_baseline'] = cpu_baseline()
         print(json.dumps(res), flush=True)

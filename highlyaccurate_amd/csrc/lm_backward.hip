@@ -60,9 +60,28 @@ __global__ __launch_bounds__(256) void lm_bwd_accum(BwdAccumArgs a) {
   const size_t sat_base = (size_t)b * a.A * a.A * C + cl;
   const size_t grd_base = ((size_t)b * a.h * a.w + (size_t)a.row0 * a.w + p0) * C + cl;
 
-  for (int i0 = wave * PPW; i0 < np; i0 += 4 * PPW) {
-    const int i = i0 + sub;
-    const bool live = i < np;                    // PPW divides TP, so whole waves stay converged except at a ragged end
+  // Every lane group walks a CONTIGUOUS run of ground pixels.  Neighbouring ground pixels oversample the satellite
+  // map (2-20x laterally at KITTI geometry), so consecutive pixels mostly fall into the same texel cell: their tap
+  // gradients are merged in registers and flushed with one set of atomics when the cell changes.
+  const int RUN = (np + 4 * PPW - 1) / (4 * PPW);
+  const int grp = wave * PPW + sub;
+  int cur_off = -1, cur_dxo = 0, cur_dyo = 0;
+  float c00[4] = {0, 0, 0, 0}, c01[4] = {0, 0, 0, 0}, c10[4] = {0, 0, 0, 0}, c11[4] = {0, 0, 0, 0};
+  auto flush_cell = [&]() {
+    if (cur_off >= 0) {
+      float* dp = a.d_sat + sat_base + cur_off;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        atomicAdd(dp + e, c00[e]);
+        atomicAdd(dp + cur_dxo + e, c01[e]);
+        atomicAdd(dp + cur_dyo + e, c10[e]);
+        atomicAdd(dp + cur_dyo + cur_dxo + e, c11[e]);
+      }
+    }
+  };
+  for (int jr = 0; jr < RUN; ++jr) {
+    const int i = grp * RUN + jr;
+    const bool live = i < np;
     float q[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     if (live) {
       const PixParam P = pp[i];
@@ -101,13 +120,14 @@ __global__ __launch_bounds__(256) void lm_bwd_accum(BwdAccumArgs a) {
         dg[e] = ggr * P.gm;
       }
       if (P.m != 0.f) {
-        float* dp = a.d_sat + sat_base + P.off;
+        if (P.off != cur_off || P.dxo != cur_dxo || P.dyo != cur_dyo) {
+          flush_cell();
+          cur_off = P.off; cur_dxo = P.dxo; cur_dyo = P.dyo;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          atomicAdd(dp + e, d00[e]);
-          atomicAdd(dp + P.dxo + e, d01[e]);
-          atomicAdd(dp + P.dyo + e, d10[e]);
-          atomicAdd(dp + P.dyo + P.dxo + e, d11[e]);
+          for (int e = 0; e < 4; ++e) { c00[e] = d00[e]; c01[e] = d01[e]; c10[e] = d10[e]; c11[e] = d11[e]; }
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { c00[e] += d00[e]; c01[e] += d01[e]; c10[e] += d10[e]; c11[e] += d11[e]; }
         }
       }
       float4* gp = (float4*)(a.d_grd + grd_base + (size_t)i * C);      // this (pixel, channels) is owned by this lane
@@ -126,6 +146,7 @@ __global__ __launch_bounds__(256) void lm_bwd_accum(BwdAccumArgs a) {
       for (int k = 0; k < 9; ++k) pixacc[i][k] = q[k];
     }
   }
+  flush_cell();
   __syncthreads();
 
   // pixel adjoints -> adjoints of the 12 projection coefficients (+ d/d(conf))
