@@ -7,6 +7,7 @@ H2D copies (the reference does ~60 syncs and ~100 small uploads per forward, SUR
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -235,8 +236,23 @@ class S2GPBase(nn.Module):
             params = [p for _, p in self.named_parameters()]
             out = _LocaliseFn.apply(self, names, sat_map, grd_img, want_conf, extra, level_first, init_pose, *params)
             return out[0], list(out[1:]) if want_conf else [None] * 3
-        sat_feats, _, sat_inv = vgg_forward_nhwc(self.SatFeatureNet, sat_map, want_conf=False, defer_norm=True)
-        grd_feats, grd_confs, grd_inv = vgg_forward_nhwc(self.GrdFeatureNet, grd_img, want_conf=want_conf, defer_norm=True)
+        if os.environ.get('HLA_TWO_STREAMS', '0') == '1':
+            # experiment (measured 2 % SLOWER on MI355X, so off by default): ground branch on a side stream so that each branch's
+            # kernel tails (the last, partially filled wave of workgroups) overlap with the other branch's work
+            cur = torch.cuda.current_stream()
+            side = self.__dict__.get('_side_stream')
+            if side is None or side.device != sat_map.device:
+                side = self.__dict__['_side_stream'] = torch.cuda.Stream(device=sat_map.device)
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                grd_feats, grd_confs, grd_inv = vgg_forward_nhwc(self.GrdFeatureNet, grd_img, want_conf=want_conf, defer_norm=True)
+            sat_feats, _, sat_inv = vgg_forward_nhwc(self.SatFeatureNet, sat_map, want_conf=False, defer_norm=True)
+            cur.wait_stream(side)
+            for t in list(grd_feats) + [c for c in grd_confs if c is not None] + [grd_inv]:
+                t.record_stream(cur)
+        else:
+            sat_feats, _, sat_inv = vgg_forward_nhwc(self.SatFeatureNet, sat_map, want_conf=False, defer_norm=True)
+            grd_feats, grd_confs, grd_inv = vgg_forward_nhwc(self.GrdFeatureNet, grd_img, want_conf=want_conf, defer_norm=True)
         trace = self.lm_solve(sat_feats, grd_feats, grd_confs, grd_img.shape[-2:], extra, level_first, init_pose,
                               sat_inv, grd_inv)
         return trace, grd_confs

@@ -155,14 +155,13 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[MT][NT], const ConvA
     const bool row_ok = y < a.H;                      // wave-uniform
     const bool lane_ok = row_ok && (x0 + x < a.W) && (!POOL || !(x & 1));
     const int px = POOL ? x >> 1 : x;
-    float v[NT][4][4], amax[NT][4][4];
+    float v[NT][4][4];
 #pragma unroll
     for (int j = 0; j < NT; ++j)
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          amax[j][q][e] = 0.f;
           float t = acc[i][j][q * 4 + e];
           if (POOL) {
             const float u = acc[i + 1][j][q * 4 + e];
@@ -170,11 +169,8 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[MT][NT], const ConvA
               t += u;
               t += __shfl_xor(t, 1, 64);
             } else {
-              const float rown = u > t ? 1.f : 0.f;               // first maximum wins, like F.max_pool2d
               t = fmaxf(t, u);
-              const float t2 = __shfl_xor(t, 1, 64), r2 = __shfl_xor(rown, 1, 64);
-              amax[j][q][e] = t2 > t ? 2.f * r2 + 1.f : 2.f * rown;
-              t = fmaxf(t, t2);
+              t = fmaxf(t, __shfl_xor(t, 1, 64));
             }
           }
           v[j][q][e] = t;
@@ -210,14 +206,22 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[MT][NT], const ConvA
                                           a.mask_act ? (const T*)a.mask_act + o : nullptr,
                                           a.add_src ? (const T*)a.add_src + o : nullptr);
     }
-    if (POOL && a.idx_out) {
-      if (!(x & 1)) {
+    if (POOL && a.idx_out) {            // training only: recompute which of the 4 window positions won (2*row+col)
 #pragma unroll
-        for (int j = 0; j < NT; ++j)
+      for (int j = 0; j < NT; ++j)
 #pragma unroll
-          for (int q = 0; q < 4; ++q)
-            RowStager<unsigned char, NT>::put(stage, px, j * 32 + q * 8 + g * 4, amax[j][q][0], amax[j][q][1], amax[j][q][2], amax[j][q][3]);
-      }
+        for (int q = 0; q < 4; ++q) {
+          float am[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float t0 = acc[i][j][q * 4 + e], u = acc[i + 1][j][q * 4 + e];
+            const float rown = u > t0 ? 1.f : 0.f;             // first maximum wins, like F.max_pool2d
+            const float t = fmaxf(t0, u);
+            const float t2 = __shfl_xor(t, 1, 64), r2 = __shfl_xor(rown, 1, 64);
+            am[e] = t2 > t ? 2.f * r2 + 1.f : 2.f * rown;
+          }
+          if (!(x & 1)) RowStager<unsigned char, NT>::put(stage, px, j * 32 + q * 8 + g * 4, am[0], am[1], am[2], am[3]);
+        }
       if (row_ok) RowStager<unsigned char, NT>::flush(stage, a.idx_out + pix0 * a.Cout + cb, NPX, nvalid, a.Cout, lane);
     }
   }
@@ -339,7 +343,7 @@ __device__ __forceinline__ void stage_mma(f32x16 (&acc)[MT][NT], const char* cur
 }
 
 template <typename T, int MT, int NT, int WM, int WN, bool POOL, int WD, bool PF_UPFRONT>
-__global__ __launch_bounds__(256, 2) void conv3x3_kernel(ConvArgs a) {
+__global__ __launch_bounds__(256, (NT == 1 && !PF_UPFRONT) ? 3 : 2) void conv3x3_kernel(ConvArgs a) {
   static_assert(WM * WN == 4, "4 waves per block");
   constexpr int EPL = 16 / sizeof(T), KC = SB / sizeof(T);     // channels per stage: 32 (bf16) / 16 (fp32)
   constexpr int TH = WM * MT, HPIX = (TH + 2) * HWID, BUF = HPIX * PSTR;
@@ -691,7 +695,13 @@ template <typename T>
 static void launch_conv(hipStream_t st, ConvArgs a, bool pool) {
   a.tiles_x = (a.W + 31) / 32;
   a.tiles_y = (a.H + 7) / 8;
-  const dim3 grid(a.tiles_x * a.tiles_y * a.B, a.Cout >= 128 ? a.Cout / 128 : 1);
+#if CONV_VARIANT == 51 || CONV_VARIANT == 52    // experiment: every layer on the 64-channel block (3 blocks per CU)
+  const bool big = false;
+  const dim3 grid(a.tiles_x * a.tiles_y * a.B, a.Cout / 64);
+#else
+  const bool big = a.Cout >= 128;
+  const dim3 grid(a.tiles_x * a.tiles_y * a.B, big ? a.Cout / 128 : 1);
+#endif
   const size_t es = sizeof(T), P = (size_t)a.B * a.H * a.W, Po = pool ? P / 4 : P;
   const double flops = 2.0 * 9.0 * (a.C1 + a.C2) * a.Cout * (double)P;
   const double bytes = (double)P * ((a.up1 ? a.C1 / 4.0 : a.C1) + a.C2) * es + (double)Po * a.Cout * ((a.out_act ? es : 0) + (a.out_raw ? 4 : 0));
@@ -704,12 +714,17 @@ static void launch_conv(hipStream_t st, ConvArgs a, bool pool) {
   hla_prof_begin(a.Cout >= 128 ? (pool ? K_CONV_NT2_POOL : K_CONV_NT2) : (pool ? K_CONV_NT1_POOL : K_CONV_NT1), flops, bytes, st);
   // Cout >= 128: block = 8x32 pixels x 128 channels, waves 2(M) x 2(N), wave tile 128 px x 64 ch, weights 1 tap ahead
   // Cout == 64 : block = 8x32 pixels x  64 channels, waves 2 x 2,       wave tile 128 px x 32 ch, weights 2 taps ahead
-  if (a.Cout >= 128) {
+#if CONV_VARIANT == 50 || CONV_VARIANT == 51
+#define SMALL_OPT 1, false     // 154 VGPRs -> 3 waves/SIMD, 3 blocks/CU (LDS 3 x 54,416 B fits the 160 KiB)
+#else
+#define SMALL_OPT 2, true
+#endif
+  if (big) {
     if (pool) hipLaunchKernelGGL((conv3x3_kernel<T, 4, 2, 2, 2, true, 1, false>), grid, dim3(256), 0, st, a);
     else hipLaunchKernelGGL((conv3x3_kernel<T, 4, 2, 2, 2, false, 1, false>), grid, dim3(256), 0, st, a);
   } else {
-    if (pool) hipLaunchKernelGGL((conv3x3_kernel<T, 4, 1, 2, 2, true, 2, true>), grid, dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((conv3x3_kernel<T, 4, 1, 2, 2, false, 2, true>), grid, dim3(256), 0, st, a);
+    if (pool) hipLaunchKernelGGL((conv3x3_kernel<T, 4, 1, 2, 2, true, SMALL_OPT>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((conv3x3_kernel<T, 4, 1, 2, 2, false, SMALL_OPT>), grid, dim3(256), 0, st, a);
   }
   hla_prof_end(st);
 #if CONV_VARIANT == 40
