@@ -221,8 +221,20 @@ def main():
             dom = max((k for k in agg if agg[k][2] > 0), key=lambda k: agg[k][1])
             n, ms, fl, by = agg[dom]
             ach = fl / (ms * 1e-3) / 1e12
+            traffic, tsrc = None, None
+            try:      # HBM bytes per launch from the committed rocprofv3 PMC passes (separate --pmc runs, gfx950 correction)
+                pm = json.load(open(os.path.join(ROOT, 'profiles', 'r01_pmc_hbm_traffic.json')))
+                sym = {'conv3x3_kernel<MT4,NT2>': 'Li4ELi2ELi2ELi2ELb0', 'conv3x3_kernel<MT4,NT2,pool>': 'Li4ELi2ELi2ELi2ELb1',
+                       'conv3x3_kernel<MT4,NT1>': 'Li4ELi1ELi2ELi2ELb0', 'conv3x3_kernel<MT4,NT1,pool>': 'Li4ELi1ELi2ELi2ELb1'}.get(dom)
+                if a.precision == 'bf16' and B == 32 and sym:
+                    for kname, v in pm.items():
+                        if sym in kname:
+                            traffic, tsrc = v['hbm_bytes_corrected'], 'profiles/r01_pmc_hbm_traffic.json'
+            except Exception:
+                pass
             res['roofline'] = {'kernel': dom, 'bound': 'mfma', 'achieved': round(ach, 2), 'peak': PEAK_TFLOPS[a.precision],
-                               'unit': 'TFLOP/s', 'frac': round(ach / PEAK_TFLOPS[a.precision], 4), 'traffic': None,
+                               'unit': 'TFLOP/s', 'frac': round(ach / PEAK_TFLOPS[a.precision], 4), 'traffic': traffic,
+                               'traffic_unit': 'bytes/launch', 'traffic_source': tsrc,
                                'launches': n, 'avg_launch_us': round(ms / n * 1e3, 2),
                                'flops_per_launch': round(fl / n / 1e9, 3), 'flops_unit': 'GFLOP'}
             lm = [k for k in agg if k.startswith('lm_accum')]

@@ -510,3 +510,15 @@ def test_vgg_backward_small_vs_oracle_autograd(precision, tol):
     for k in ('conv_dec3.1.weight', 'conf0.1.weight'):
         assert ref[k] is None and k not in grads        # the reference leaves these without a gradient too (SURVEY B-8)
     print(f'vgg bwd {precision}: worst rel err {worst:.2e}')
+
+
+def test_reference_call_pattern_harness_runs():
+    """tools/train_harness.py = the reference's train/test call pattern (train_kitti.py) on synthetic batches."""
+    import importlib.util, os
+    p = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools', 'train_harness.py')
+    spec = importlib.util.spec_from_file_location('train_harness', p)
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    log = m.main(['--batch_size', '2', '--iters_per_epoch', '2', '--N_iters', '2', '--grd_h', '64', '--grd_w', '256',
+                  '--sat_a', '128', '--precision', 'fp32', '--train_damping', '1'])
+    assert len(log) == 2 and all(np.isfinite(log))
