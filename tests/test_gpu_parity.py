@@ -422,7 +422,8 @@ def test_full_bench_config_runs_and_is_consistent():
 
 
 @pytest.mark.parametrize('kw', [dict(), dict(using_weight=1), dict(use_hessian=1, damping=0.5),
-                                dict(rotation_range=0.0), dict(level_first=1)])
+                                dict(rotation_range=0.0), dict(level_first=1), dict(train_damping=1),
+                                dict(train_damping=1, use_hessian=1)])
 def test_lm_backward_small_vs_oracle_autograd(kw):
     """hla_s2g_lm_solve_bwd against torch autograd through the fp64 oracle's unrolled loop
     (gather values, bilinear weights, norms, J^T W J, inverse, pose->uv chain of later steps)."""
@@ -434,6 +435,10 @@ def test_lm_backward_small_vs_oracle_autograd(kw):
     args = O.default_args(**{'N_iters': 2, 'damping': 1.0, **kw})
     B, grd_hw, sat_a = 2, (64, 256), 128
     onet, sat, grd, conf = _oracle_small(args, 7, B, grd_hw, sat_a)
+    dparam = torch.tensor([[0.55, 0.6, 0.5]])          # lambda = 10^(-6+11*sigmoid(.)) ~ 1 .. 3
+    if args.train_damping:
+        with torch.no_grad():
+            onet.damping.copy_(dparam.double())
     p0 = T(np.random.RandomState(5).uniform(-0.2, 0.2, size=(B, 3)).astype(np.float32))
     L, N = 3, args.N_iters
     coef = T(np.random.RandomState(6).standard_normal((B, N, L, 3)))         # loss = sum(coef * trace)
@@ -450,6 +455,9 @@ def test_lm_backward_small_vs_oracle_autograd(kw):
         loss = loss + (coef[:, i, l] * torch.cat([su, sv, th], 1)).sum()
     loss.backward()
     net = LM_S2GP(args).to(d)
+    if args.train_damping:
+        with torch.no_grad():
+            net.damping.copy_(dparam.to(d))
     nh = lambda t: t.permute(0, 2, 3, 1).contiguous().to(d)
     feats = ([nh(s) for s in sat], [nh(g) for g in grd], [c[:, 0].contiguous().to(d) for c in conf])
     torch.manual_seed(0)
@@ -467,6 +475,15 @@ def test_lm_backward_small_vs_oracle_autograd(kw):
             e = np.abs(got - ref).max() / max(np.abs(ref).max(), 1e-30)
             print(f'lm bwd level {l} d_conf: rel err {e:.2e}')
             assert e < 2e-4
+    if args.train_damping:                      # d(loss)/d(damping parameter) through lambda = 10^(-6+11*sigmoid(d))
+        dd = dparam.double()
+        sg = torch.sigmoid(dd)
+        lam = 10.0 ** (-6 + sg * 11.0)
+        got = (d_lam.cpu().view(1, 3) * lam * np.log(10.0) * 11.0 * sg * (1 - sg)).numpy()
+        ref = onet.damping.grad.numpy()
+        e = np.abs(got - ref).max() / np.abs(ref).max()
+        print(f'lm bwd d_damping: rel err {e:.2e}', got, ref)
+        assert e < 1e-5
 
 
 # bf16: the one-hop gradient (conv_dec2.3) agrees to 0.5 %; deeper layers differ by up to ~17 % in relative L2 because
@@ -522,3 +539,36 @@ def test_reference_call_pattern_harness_runs():
     log = m.main(['--batch_size', '2', '--iters_per_epoch', '2', '--N_iters', '2', '--grd_h', '64', '--grd_w', '256',
                   '--sat_a', '128', '--precision', 'fp32', '--train_damping', '1'])
     assert len(log) == 2 and all(np.isfinite(log))
+
+
+def test_ford_train_step_vs_oracle_autograd_small():
+    """Ford model, mode='train' under autograd on a reduced shape: loss and a few gradients vs the fp64 oracle."""
+    from oracle import ref_cpu as O
+    from highlyaccurate_amd.models_ford import LM_S2GP_Ford
+    d = _dev()
+    args = O.default_args(N_iters=2)
+    B, grd_hw, sat_a = 2, (64, 256), 128
+    sd = O.synth_model_state(4, bias_scale=0.02)
+    sat, grd, gu, gv, gh = O.synth_images(9, B, grd_hw=grd_hw, sat_a=sat_a)
+    R_FL = torch.tensor([[[0., 0., 1.], [1., 0., 0.], [0., 1., 0.]]]).repeat(B, 1, 1)
+    T_FL = torch.tensor([[1.7, 0.3, -1.2]]).repeat(B, 1)
+    gts = [gu[:, 0].double(), gv[:, 0].double(), gh[:, 0].double()]            # Ford passes [B] float64 (Ford_dataset.py:211)
+    on = O.LM_S2GP_Ford(args, grd_hw=grd_hw)
+    on.load_state_dict(sd)
+    on = on.double()
+    torch.manual_seed(0)
+    ro = on(sat.double(), grd.double(), 28.16, R_FL.double(), T_FL.double(), *gts, mode='train')
+    ro[0].backward()
+    net = LM_S2GP_Ford(args)
+    net.load_state_dict(sd)
+    net = net.to(d).train()
+    torch.manual_seed(0)
+    r = net(sat.to(d), grd.to(d), 28.16, R_FL.to(d), T_FL.to(d), *[g.to(d) for g in gts], mode='train')
+    r[0].backward()
+    assert abs(float(r[0]) - float(ro[0])) < 1e-4 * abs(float(ro[0]))
+    ref = dict(on.named_parameters())
+    for k in ('SatFeatureNet.conv_dec2.3.weight', 'GrdFeatureNet.conv_dec2.3.weight', 'SatFeatureNet.conv0.weight', 'GrdFeatureNet.conv5.weight'):
+        a, b = dict(net.named_parameters())[k].grad.double().cpu().numpy(), ref[k].grad.numpy()
+        e = np.linalg.norm(a - b) / np.linalg.norm(b)
+        print(f'ford train grad {k}: rel-l2 {e:.2e}')
+        assert e < (2e-4 if 'dec2' in k else 2e-2)
