@@ -288,6 +288,15 @@ __device__ __forceinline__ void stagger_priority() {
   const unsigned slot = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4);
   if (slot & 1) __builtin_amdgcn_s_setprio(CONV_VARIANT == 32 ? 3 : 1);
 #endif
+#if CONV_VARIANT >= 60 && CONV_VARIANT <= 62
+  // experiment: phase-shift the first generation of workgroups in the odd wave slots by about half a stage so that
+  // the two co-resident workgroups of a CU never run their prologue / epilogue at the same time
+  if ((slot & 1) && blockIdx.x + blockIdx.y * gridDim.x < 512) {
+    constexpr int N = CONV_VARIANT == 60 ? 1 : (CONV_VARIANT == 61 ? 2 : 4);
+#pragma unroll
+    for (int k = 0; k < N; ++k) __builtin_amdgcn_s_sleep(80);
+  }
+#endif
 }
 
 template <typename T, int MT, int NT, int WD, bool PF_UPFRONT, typename Mid>
@@ -513,6 +522,11 @@ __global__ __launch_bounds__(256, 2) void conv02_kernel(Conv02Args a0) {
   __syncthreads();
 
   // phase B: conv0 on the 10x34 halo pixels, 32 pixels per MFMA tile, straight into the conv2 halo buffers
+  float4 bias0[2][4];
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) bias0[j][q] = *(const float4*)(a0.b0 + j * 32 + q * 8 + g * 4);
   for (int m = wv; m * 32 < HPIX; m += 4) {
     const int p = m * 32 + x, pc = p < HPIX ? p : HPIX - 1;
     const int hy = pc / HWID, hx = pc - hy * HWID;
@@ -527,11 +541,14 @@ __global__ __launch_bounds__(256, 2) void conv02_kernel(Conv02Args a0) {
       T e[EPL];
 #pragma unroll
       for (int jj = 0; jj < EPL; ++jj) {
-        const int klo = f * 2 * EPL + jj, khi = klo + EPL;   // compile-time
-        float lo = 0.f, hi = 0.f;
-        if (klo < 27) lo = ib[(klo / 9) * IH * IW + ((klo % 9) / 3) * IW + (klo % 9) % 3];
-        if (khi < 27) hi = ib[(khi / 9) * IH * IW + ((khi % 9) / 3) * IW + (khi % 9) % 3];
-        e[jj] = (T)(g ? hi : lo);
+        // this lane's k is klo (lanes 0-31) or khi (lanes 32-63): select the OFFSET, then read once
+        const int kl = f * 2 * EPL + jj, kh = kl + EPL;      // compile-time
+        const int ol = kl < 27 ? (kl / 9) * IH * IW + ((kl % 9) / 3) * IW + (kl % 9) % 3 : 0;
+        const int oh = kh < 27 ? (kh / 9) * IH * IW + ((kh % 9) / 3) * IW + (kh % 9) % 3 : 0;
+        float v = ib[g ? oh : ol];
+        if (kh >= 27 && g) v = 0.f;                          // padded k (27..31) only occurs in the upper half
+        if (kl >= 27 && !g) v = 0.f;
+        e[jj] = (T)v;
       }
       const uint4 pf = __builtin_bit_cast(uint4, e);
 #pragma unroll
@@ -546,7 +563,7 @@ __global__ __launch_bounds__(256, 2) void conv02_kernel(Conv02Args a0) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const int co = j * 32 + q * 8 + g * 4;
-          const float4 bb = *(const float4*)(a0.b0 + co);
+          const float4 bb = bias0[j][q];
           float v0 = fmaxf(c0[j][q * 4 + 0] + bb.x, 0.f), v1 = fmaxf(c0[j][q * 4 + 1] + bb.y, 0.f);
           float v2 = fmaxf(c0[j][q * 4 + 2] + bb.z, 0.f), v3 = fmaxf(c0[j][q * 4 + 3] + bb.w, 0.f);
           if (!inside) v0 = v1 = v2 = v3 = 0.f;
