@@ -102,10 +102,11 @@ def vgg_forward_nhwc(module: 'VGGUnet', x: torch.Tensor, want_conf: bool = True,
     return feats, confs, inv_norm
 
 
-def vgg_backward_nhwc(module: 'VGGUnet', ctx: dict, d_feats):
+def vgg_backward_nhwc(module: 'VGGUnet', ctx: dict, d_feats, confs=None, d_confs=None):
     """Backward of ``vgg_forward_nhwc(..., defer_norm=True, save_for_backward=True)``.
     d_feats[l]: NHWC fp32 gradient w.r.t. the L2-normalised map l.  Returns {parameter name: gradient} for the
-    22 tensors that receive one at level 3 (conv0..conv14 weights+biases, conv_dec1/2 weights)."""
+    22 tensors that receive one at level 3 (conv0..conv14 weights+biases, conv_dec1/2 weights), plus conf0..2 weights
+    when ``confs`` / ``d_confs`` (the forward's confidence maps and their [B,h,w] gradients) are given."""
     lib = _lib.load()
     x, dt = ctx['x'], ctx['dt']
     B, _, H, W = x.shape
@@ -126,13 +127,23 @@ def vgg_backward_nhwc(module: 'VGGUnet', ctx: dict, d_feats):
             gb = torch.empty_like(sd[name + '.bias'], dtype=torch.float32)
             grads[name + '.bias'] = gb
             gs.db[i] = gb.data_ptr()
+    cp = dcp = None
+    if d_confs is not None:
+        dcs = [d.contiguous().float() for d in d_confs]
+        cp = (C.c_void_p * 3)(*[c.data_ptr() for c in confs])
+        dcp = (C.c_void_p * 3)(*[d.data_ptr() for d in dcs])
+        for l in range(3):
+            name = f'conf{l}.1.weight'
+            g = torch.empty_like(sd[name], dtype=torch.float32, memory_format=torch.contiguous_format)
+            grads[name] = g
+            gs.dw[13 + l] = g.data_ptr()
     dfs = [d.contiguous().float() for d in d_feats]
     fp = (C.c_void_p * 3)(*[f.data_ptr() for f in ctx['feats']])
     dp = (C.c_void_p * 3)(*[d.data_ptr() for d in dfs])
     nbytes = lib.hla_vgg_bwd_workspace_bytes(B, H, W, dt)
     ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
     rc = lib.hla_vgg_backward(_lib.ptr(x), C.byref(prm), _lib.ptr(cache['buf']), _lib.ptr(ctx['ws']), fp, _lib.ptr(ctx['inv_norm']),
-                              dp, C.byref(gs), _lib.ptr(ws), nbytes, B, H, W, 3, dt, _lib.stream_ptr())
+                              dp, cp, dcp, C.byref(gs), _lib.ptr(ws), nbytes, B, H, W, 3, dt, _lib.stream_ptr())
     _lib.check(rc, 'hla_vgg_backward')
     return grads
 

@@ -230,8 +230,6 @@ class S2GPBase(nn.Module):
         Under autograd (training) the same kernels run inside one autograd.Function whose backward is the HIP
         backward pass (hla_s2g_lm_solve_bwd + hla_vgg_backward for both extractors)."""
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            if self.using_weight:
-                raise NotImplementedError('training with using_weight=1 needs the confidence-head backward (not built yet)')
             names = [n for n, _ in self.named_parameters()]
             params = [p for _, p in self.named_parameters()]
             out = _LocaliseFn.apply(self, names, sat_map, grd_img, want_conf, extra, level_first, init_pose, *params)
@@ -273,19 +271,20 @@ class _LocaliseFn(torch.autograd.Function):
         ctx.state = (sat_feats, grd_feats, grd_confs, tuple(grd_img.shape[-2:]), trace, model.last_normal_eq, sat_inv, grd_inv, cs, cg)
         outs = (trace,) + (tuple(grd_confs) if want_conf else ())
         if want_conf:
-            ctx.mark_non_differentiable(*grd_confs)     # loss_method 0 does not read them; using_weight is gated above
+            ctx.mark_non_differentiable(*grd_confs)     # loss_method 0 does not read them; their LM-weight role is in backward()
         return outs
 
     @staticmethod
     def backward(ctx, d_trace, *unused):
         model = ctx.model
         sat_feats, grd_feats, grd_confs, grd_hw, trace, neq, sat_inv, grd_inv, cs, cg = ctx.state
-        d_sat, d_grd, _, d_lam = model.lm_backward(sat_feats, grd_feats, grd_confs, grd_hw, trace, neq, d_trace, ctx.extra,
+        d_sat, d_grd, d_conf, d_lam = model.lm_backward(sat_feats, grd_feats, grd_confs, grd_hw, trace, neq, d_trace, ctx.extra,
                                                    ctx.level_first, ctx.init_pose, sat_inv, grd_inv)
         sync = getattr(model, 'grad_sync', None)        # optional: overlap the sat-branch all-reduce with the grd backward
         g_sat = vgg_backward_nhwc(model.SatFeatureNet, cs, d_sat)
         h1 = sync.start({'SatFeatureNet.' + k: v for k, v in g_sat.items()}) if sync else None
-        g_grd = vgg_backward_nhwc(model.GrdFeatureNet, cg, d_grd)
+        use_w = model.using_weight and all(c is not None for c in d_conf)
+        g_grd = vgg_backward_nhwc(model.GrdFeatureNet, cg, d_grd, grd_confs if use_w else None, d_conf if use_w else None)
         h2 = sync.start({'GrdFeatureNet.' + k: v for k, v in g_grd.items()}) if sync else None
         if sync:
             sync.finish(h1)

@@ -272,10 +272,84 @@ __global__ __launch_bounds__(256) void l2bwd_apply_kernel(const float* __restric
 }
 
 // ---------------------------------------------------------------------------------------------
+// Confidence head backward (VGG.py:62-76,160-162):  conf = sigmoid(-s),  s = sigmoid(z),  z = conv3x3(relu(x), w)
+//   dz = -d_conf * conf*(1-conf) * s*(1-s)   with s recovered from conf:  e^s = (1-conf)/conf
+__global__ __launch_bounds__(256) void conf_dz_kernel(const float* __restrict__ conf, const float* __restrict__ d_conf,
+                                                      float* __restrict__ dz, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const float c = conf[i];
+    const float s = logf((1.f - c) / c);
+    dz[i] = -d_conf[i] * c * (1.f - c) * s * (1.f - s);
+  }
+}
+
+// One pass over relu(x) [B,H,W,C]:  gx[q,c] += (x>0) * sum_tap w[c,tap]*dz[q-off(tap)]   (data gradient, added into the
+// gradient of the raw map) and per-block partial sums of  dw[c,tap] = sum_q relu(x)[q,c]*dz[q-off(tap)].
+// G = C/EPL lanes share a pixel; the 256/G pixel slots of a block are folded with shuffles + LDS at the end.
+template <typename T>
+__global__ __launch_bounds__(256) void conf_bwd_kernel(const T* __restrict__ act, const float* __restrict__ w,
+                                                       const float* __restrict__ dz, T* __restrict__ gx,
+                                                       float* __restrict__ part, int B, int H, int W, int C) {
+  constexpr int EPL = 16 / sizeof(T);
+  extern __shared__ float sh[];   // [4][9*C]
+  const int G = C / EPL, ppb = 256 / G, gi = threadIdx.x % G;
+  float wr[9][EPL], acc[9][EPL];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int k = 0; k < EPL; ++k) { wr[t][k] = w[(gi * EPL + k) * 9 + t]; acc[t][k] = 0.f; }
+  const size_t npix = (size_t)B * H * W;
+  for (size_t pix = (size_t)blockIdx.x * ppb + threadIdx.x / G; pix < npix; pix += (size_t)gridDim.x * ppb) {
+    const int x = (int)(pix % W), y = (int)((pix / W) % H);
+    float dzm[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const int yy = y - (t / 3 - 1), xx = x - (t % 3 - 1);
+      dzm[t] = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? dz[(long)pix - ((long)(t / 3 - 1) * W + (t % 3 - 1))] : 0.f;
+    }
+    const uint4 raw = *(const uint4*)(act + pix * C + gi * EPL);
+    uint4 graw = *(const uint4*)(gx + pix * C + gi * EPL);
+    T a[EPL], g[EPL];
+    __builtin_memcpy(a, &raw, 16);
+    __builtin_memcpy(g, &graw, 16);
+#pragma unroll
+    for (int k = 0; k < EPL; ++k) {
+      const float av = to_f32(a[k]);
+      float d = 0.f;
+#pragma unroll
+      for (int t = 0; t < 9; ++t) { acc[t][k] += av * dzm[t]; d += wr[t][k] * dzm[t]; }
+      g[k] = (T)(to_f32(g[k]) + (av > 0.f ? d : 0.f));
+    }
+    __builtin_memcpy(&graw, g, 16);
+    *(uint4*)(gx + pix * C + gi * EPL) = graw;
+  }
+  // fold the pixel slots: lanes with equal gi inside a wave, then the 4 waves
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int k = 0; k < EPL; ++k) {
+      float v = acc[t][k];
+      for (int o = G; o < 64; o <<= 1) v += __shfl_xor(v, o, 64);
+      acc[t][k] = v;
+    }
+  const int wv = threadIdx.x >> 6, ln = threadIdx.x & 63;
+  if (G >= 64 ? true : ln < G) {
+    // G == 64 (fp32, C = 256): every lane of the wave owns distinct channels
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int k = 0; k < EPL; ++k) sh[wv * 9 * C + ((ln % G) * EPL + k) * 9 + t] = acc[t][k];
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < 9 * C; e += 256)
+    part[(size_t)blockIdx.x * 9 * C + e] = (sh[e] + sh[9 * C + e]) + (sh[2 * 9 * C + e] + sh[3 * 9 * C + e]);
+}
+
+// ---------------------------------------------------------------------------------------------
 // host
 struct BwdPlan {
   size_t g_x21, g_d2a, g_x18, l2_18, g_d1a, g_x15, l2_15, g_a12, g_a10, g_x8, g_x8p, g_a5, g_x3, g_x3p, g_a0;
-  size_t dot, part, bpart;
+  size_t dot, part, bpart, dz;
   size_t total;
 };
 
@@ -311,6 +385,7 @@ static void bwd_plan(int B, int H, int W, int dtype, BwdPlan* p) {
   }
   p->part = take(maxpart);
   p->bpart = take((size_t)2048 * 256 * 4);
+  p->dz = take(P / 4 * sizeof(float));
   p->total = o;
 }
 
@@ -345,7 +420,7 @@ extern "C" int hla_vgg_pack_weights_T(const hla_vgg_params* params, void* packed
 template <typename T>
 static int vgg_backward_t(const float* x, const hla_vgg_params* prm, const char* packedT, int dtype, const char* fw,
                           const float* const feat[3], const double* inv_norm, const float* const d_feat[3],
-                          const hla_vgg_grads* gr, char* bw, const BwdPlan& bp, int B, int H, int W, hipStream_t st) {
+                          const float* const conf[3], const float* const d_conf[3], const hla_vgg_grads* gr, char* bw, const BwdPlan& bp, int B, int H, int W, hipStream_t st) {
   VggPlan fp;
   vgg_plan(B, H, W, dtype, true, &fp);
   constexpr int KC = SB / (int)sizeof(T);
@@ -369,6 +444,29 @@ static int vgg_backward_t(const float* x, const hla_vgg_params* prm, const char*
     hipLaunchKernelGGL((l2bwd_apply_kernel<T>), dim3(B * nblk), dim3(256), 0, st, feat[l], d_feat[l], part,
                        inv_norm + (size_t)l * B, (T*)l2out[l], per[l], nblk);
     hla_prof_end(st);
+  }
+
+  // ---- confidence heads (only the ground branch with using_weight=1 ever has d_conf): adds into the raw-map gradients
+  if (conf && d_conf) {
+    const T* acts[3] = {(const T*)(fw + fp.x15r), (const T*)(fw + fp.x18r), (const T*)(fw + fp.x21r)};
+    const int Cs[3] = {256, 128, 64}, hs[3] = {H / 8, H / 4, H / 2}, wsz[3] = {W / 8, W / 4, W / 2};
+    for (int l = 0; l < 3; ++l) {
+      if (!d_conf[l]) continue;
+      constexpr int EPL = 16 / (int)sizeof(T);
+      const int ppb = 256 / (Cs[l] / EPL);
+      const size_t npix = (size_t)B * hs[l] * wsz[l];
+      const int grid = (int)((npix + ppb - 1) / ppb < 1024 ? (npix + ppb - 1) / ppb : 1024);
+      float* dz = (float*)(bw + bp.dz);
+      hla_prof_begin(K_ELEMWISE, 4.0 * 9 * Cs[l] * (double)npix, (double)npix * (3 * Cs[l] * sizeof(T) + 12), st);
+      hipLaunchKernelGGL(conf_dz_kernel, dim3((unsigned)((npix + 255) / 256 < 2048 ? (npix + 255) / 256 : 2048)), dim3(256), 0, st,
+                         conf[l], d_conf[l], dz, npix);
+      hipLaunchKernelGGL((conf_bwd_kernel<T>), dim3(grid), dim3(256), 4 * 9 * Cs[l] * sizeof(float), st, acts[l],
+                         prm->w[13 + l], (const float*)dz, (T*)l2out[l], (float*)(bw + bp.part), B, hs[l], wsz[l], Cs[l]);
+      const size_t n = (size_t)9 * Cs[l];
+      hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const float*)(bw + bp.part),
+                         gr->dw[13 + l], n, grid, (int)n, 1, 1);
+      hla_prof_end(st);
+    }
   }
 
   // ---- helpers
@@ -454,14 +552,19 @@ static int vgg_backward_t(const float* x, const hla_vgg_params* prm, const char*
 
 extern "C" int hla_vgg_backward(const float* x, const hla_vgg_params* params, const void* packed_weights_T,
                                 const void* fwd_workspace, const float* const feat[3], const double* inv_norm,
-                                const float* const d_feat[3], const hla_vgg_grads* grads, void* workspace,
-                                size_t workspace_bytes, int B, int H, int W, int level, int dtype, hla_stream_t stream) {
+                                const float* const d_feat[3], const float* const conf[3], const float* const d_conf[3],
+                                const hla_vgg_grads* grads, void* workspace, size_t workspace_bytes, int B, int H, int W,
+                                int level, int dtype, hla_stream_t stream) {
   HLA_REQUIRE(x && params && packed_weights_T && fwd_workspace && feat && inv_norm && d_feat && grads && workspace,
               "hla_vgg_backward: null argument");
   HLA_REQUIRE(dtype == HLA_F32 || dtype == HLA_BF16, "hla_vgg_backward: bad dtype");
   HLA_REQUIRE(level == 3, "hla_vgg_backward: only level 3 is built");
   HLA_REQUIRE(B > 0 && H % 8 == 0 && W % 8 == 0, "hla_vgg_backward: H and W must be multiples of 8");
   for (int l = 0; l < kPackedLayers; ++l) HLA_REQUIRE(grads->dw[l], "hla_vgg_backward: dw[%d] missing", l);
+  HLA_REQUIRE(!d_conf || conf, "hla_vgg_backward: d_conf given without conf");
+  if (d_conf)
+    for (int l = 0; l < 3; ++l)
+      HLA_REQUIRE(!d_conf[l] || (conf[l] && grads->dw[13 + l]), "hla_vgg_backward: d_conf[%d] needs conf[%d] and dw[%d]", l, l, 13 + l);
   BwdPlan bp;
   bwd_plan(B, H, W, dtype, &bp);
   if (workspace_bytes < bp.total) {
@@ -470,7 +573,7 @@ extern "C" int hla_vgg_backward(const float* x, const hla_vgg_params* params, co
   }
   if (dtype == HLA_BF16)
     return vgg_backward_t<bf16>(x, params, (const char*)packed_weights_T, dtype, (const char*)fwd_workspace, feat, inv_norm,
-                                d_feat, grads, (char*)workspace, bp, B, H, W, (hipStream_t)stream);
+                                d_feat, conf, d_conf, grads, (char*)workspace, bp, B, H, W, (hipStream_t)stream);
   return vgg_backward_t<float>(x, params, (const char*)packed_weights_T, dtype, (const char*)fwd_workspace, feat, inv_norm,
-                               d_feat, grads, (char*)workspace, bp, B, H, W, (hipStream_t)stream);
+                               d_feat, conf, d_conf, grads, (char*)workspace, bp, B, H, W, (hipStream_t)stream);
 }

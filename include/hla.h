@@ -91,7 +91,8 @@ int hla_vgg_forward(const float* x, const hla_vgg_params* params, const void* pa
  * Backward of VGGUnet (autograd through VGG.py:121-203 in the reference).
  * ------------------------------------------------------------------------- */
 /* fp32 gradient buffers with PyTorch's layouts (OIHW weights), overwritten: dw[0..10] = conv0..conv_dec2.3
- * (required), db[0..6] (NULL to skip).  dw[11..16] are unused at level 3 (those parameters get no gradient). */
+ * (required), db[0..6] (NULL to skip), dw[13..15] = conf0.1..conf2.1 (required iff the matching d_conf is given).
+ * dw[11], dw[12], dw[16] are unused at level 3 (those parameters get no gradient). */
 typedef struct hla_vgg_grads {
   float* dw[17];
   float* db[7];
@@ -106,11 +107,14 @@ size_t hla_vgg_bwd_workspace_bytes(int B, int H, int W, int dtype);
  * fwd_workspace    the workspace of the forward call made with HLA_VGG_SAVE_FOR_BACKWARD | HLA_VGG_DEFER_NORM
  * feat[l], inv_norm  its outputs (raw maps + 1/norm)
  * d_feat[l]        d(loss)/d(L2-normalised map l), NHWC fp32 (what hla_s2g_lm_solve_bwd produces)
- * Confidence-head gradients (using_weight) are not built yet. */
+ * conf[l], d_conf[l]  the forward's confidence maps and d(loss)/d(conf map l) [B,h_l,w_l] fp32 (what
+ *                  hla_s2g_lm_solve_bwd produces with using_weight=1, models_kitti.py:994-996); both arrays or
+ *                  single entries may be NULL: then the heads get no gradient, as in the reference's default run. */
 int hla_vgg_backward(const float* x, const hla_vgg_params* params, const void* packed_weights_T,
                      const void* fwd_workspace, const float* const feat[3], const double* inv_norm,
-                     const float* const d_feat[3], const hla_vgg_grads* grads, void* workspace,
-                     size_t workspace_bytes, int B, int H, int W, int level, int dtype, hla_stream_t stream);
+                     const float* const d_feat[3], const float* const conf[3], const float* const d_conf[3],
+                     const hla_vgg_grads* grads, void* workspace, size_t workspace_bytes, int B, int H, int W, int level,
+                     int dtype, hla_stream_t stream);
 
 /* ------------------------------------------------------------------------- *
  * jacobian.grid_sample  (jacobian.py:138-205) -- the stand-alone operator

@@ -279,9 +279,13 @@ GRAD_KEYS = ['SatFeatureNet.conv0.weight', 'SatFeatureNet.conv14.weight', 'SatFe
              'GrdFeatureNet.conv2.bias']
 
 
-def gen_train(mk, seed, B=1):
-    """Train-mode 14-tuple + gradient samples, fp64."""
-    args = O.default_args()
+CONF_KEYS = ['GrdFeatureNet.conf0.1.weight', 'GrdFeatureNet.conf1.1.weight', 'GrdFeatureNet.conf2.1.weight', 'damping']
+
+
+def gen_train(mk, seed, B=1, weighted=False):
+    """Train-mode 14-tuple + gradient samples, fp64.  weighted: using_weight=1 + train_damping=1
+    (gradients then also reach the ground branch's confidence heads and the damping parameter)."""
+    args = O.default_args(using_weight=1, train_damping=1) if weighted else O.default_args()
     out = {'seed': np.array(seed), 'B': np.array(B)}
     for dtype, tag in ((torch.float64, '64'), (torch.float32, '32')):
         net = ref_model(mk, 'LM_S2GP', args, seed, dtype)
@@ -292,13 +296,13 @@ def gen_train(mk, seed, B=1):
         out['tuple' + tag] = np.stack([np.atleast_1d(r.detach().double().numpy()) if r.dim() else
                                        np.full(3, float(r)) for r in res[:9]])
         sd = dict(net.named_parameters())
-        for k in GRAD_KEYS:
+        for k in GRAD_KEYS + (CONF_KEYS if weighted else []):
             g = sd[k].grad.double().reshape(-1)
             idx = sample_idx(g.numel(), 77)
             out[f'grad{tag}_{k}'] = np.concatenate([[g.abs().sum().item(), (g * g).sum().item()], g[idx].numpy()])
         out['nograd_' + tag] = np.array([k for k, p in sd.items() if p.grad is None])
         print('train', tag, 'loss', float(res[0]), flush=True)
-    np.savez_compressed(os.path.join(GOLD, 'train_kitti.npz'), **out)
+    np.savez_compressed(os.path.join(GOLD, 'train_kitti_w.npz' if weighted else 'train_kitti.npz'), **out)
 
 
 if __name__ == '__main__':
@@ -320,3 +324,5 @@ if __name__ == '__main__':
         gen_ford(mf, (seeds or [1])[:2])
     if a.only in ('all', 'train'):
         gen_train(mk, (seeds or [1])[0])
+    if a.only in ('all', 'trainw'):
+        gen_train(mk, (seeds or [1])[0], weighted=True)

@@ -529,6 +529,76 @@ def test_vgg_backward_small_vs_oracle_autograd(precision, tol):
     print(f'vgg bwd {precision}: worst rel err {worst:.2e}')
 
 
+def test_vgg_backward_confidence_heads_vs_oracle_autograd():
+    """Gradients arriving at the confidence maps (using_weight=1, models_kitti.py:994-996) flow through
+    sigmoid(-sigmoid(conv(relu(x)))) (VGG.py:62-76,160-162) into the head weights and into the trunk."""
+    from oracle import ref_cpu as O
+    from highlyaccurate_amd.VGG import VGGUnet, vgg_forward_nhwc, vgg_backward_nhwc
+    d = _dev()
+    rs = np.random.RandomState(37)
+    sd = O.synth_vgg_state(rs, bias_scale=0.05)
+    x = T(rs.random_sample((2, 3, 32, 64)).astype(np.float32))
+    onet = O.VGGUnet(3)
+    onet.load_state_dict(sd)
+    onet = onet.double()
+    feats64, confs64 = onet(x.double())
+    ups = [T(rs.standard_normal(tuple(f.shape))) for f in feats64]
+    cups = [T(rs.standard_normal(tuple(c.shape))) * 30.0 for c in confs64[:3]]   # comparable in size to the feature term
+    loss = sum((u * f).sum() for u, f in zip(ups, feats64)) + sum((u * c).sum() for u, c in zip(cups, confs64))
+    loss.backward()
+    ref = {k: p.grad for k, p in onet.named_parameters()}
+    net = VGGUnet(3, precision='fp32')
+    net.load_state_dict(sd)
+    net = net.to(d)
+    feats, confs, inv, ctx = vgg_forward_nhwc(net, x.to(d), want_conf=True, defer_norm=True, save_for_backward=True)
+    grads = vgg_backward_nhwc(net, ctx, [u.permute(0, 2, 3, 1).contiguous().float().to(d) for u in ups], confs,
+                              [u[:, 0].contiguous().float().to(d) for u in cups])
+    for k in ('conf0.1.weight', 'conf1.1.weight', 'conf2.1.weight'):
+        assert k in grads
+    for k, g in grads.items():
+        r = ref[k].numpy()
+        e = np.abs(g.cpu().double().numpy() - r).max() / max(np.abs(r).max(), 1e-30)
+        print(f'vgg bwd conf {k:24s} rel err max {e:.2e} (max |ref| {np.abs(r).max():.2e})')
+        assert e < 2e-4, (k, e)
+    # the heads must matter in this test: without d_conf the trunk gradient differs visibly
+    g0 = vgg_backward_nhwc(net, ctx, [u.permute(0, 2, 3, 1).contiguous().float().to(d) for u in ups])
+    assert (g0['conv14.weight'] - grads['conv14.weight']).abs().max() > 1e-3 * grads['conv14.weight'].abs().max()
+
+
+def test_train_step_using_weight_vs_reference_golden():
+    """using_weight=1 + train_damping=1, mode='train': the confidence maps weight the LM sums, so loss.backward() also
+    reaches GrdFeatureNet.conf{0,1,2} and `damping`.  Samples recorded from the REAL reference's autograd (fp64)."""
+    from oracle import ref_cpu as O
+    from highlyaccurate_amd.models_kitti import LM_S2GP
+    from make_idx import sample_idx
+    g = load_golden('train_kitti_w.npz')
+    seed, B = int(g['seed']), int(g['B'])
+    d = _dev()
+    net = LM_S2GP(O.default_args(using_weight=1, train_damping=1))
+    net.load_state_dict(O.synth_model_state(seed))
+    net = net.to(d).train()
+    sat, grd, gu, gv, gh = O.synth_images(seed + 100, B)
+    torch.manual_seed(seed)
+    res = net(sat.to(d), grd.to(d), gu.to(d), gv.to(d), gh.to(d), mode='train')
+    assert abs(float(res[0]) - g['tuple64'][0][0]) < 1e-3 * abs(g['tuple64'][0][0])
+    res[0].backward()
+    named = dict(net.named_parameters())
+    nograd = set(str(k) for k in g['nograd_64'])
+    for k, p in named.items():
+        assert (p.grad is None) == (k in nograd), k
+    for k in [k[len('grad64_'):] for k in g.files if k.startswith('grad64_')]:
+        ref = g['grad64_' + k]
+        gr = named[k].grad.double().reshape(-1).cpu()
+        idx = sample_idx(gr.numel(), 77)
+        got = np.concatenate([[gr.abs().sum().item(), (gr * gr).sum().item()], gr[idx].numpy()])
+        gap = np.abs(g['grad32_' + k][2:] - ref[2:]).max()
+        scale = np.abs(ref[2:]).max()
+        e = np.abs(got[2:] - ref[2:]).max()
+        print(f'train(w) grad {k:36s} max err {e:.2e} (ref fp32 gap {gap:.2e}, scale {scale:.2e}); l1 {got[0]:.4e} vs {ref[0]:.4e}')
+        rel_tol = 2e-4 if ('conv_dec2' in k or 'conf2' in k or k == 'damping') else 5e-3   # see the flip-noise note above
+        assert e <= max(rel_tol * scale, 3 * gap), (k, e, gap, scale)
+
+
 def test_reference_call_pattern_harness_runs():
     """tools/train_harness.py = the reference's train/test call pattern (train_kitti.py) on synthetic batches."""
     import importlib.util, os
