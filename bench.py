@@ -27,7 +27,7 @@ if ROOT not in sys.path:
 import torch  # noqa: E402
 
 # dense peaks, /opt/skills/guides/MI355X_MICROARCH.md "Chip-level parameters"
-PEAK_TFLOPS = {'bf16': 2500.0, 'fp32': 157.3}
+PEAK_TFLOPS = {'bf16': 2500.0, 'fp16': 2500.0, 'fp32': 157.3}
 PEAK_HBM_GBS = 8000.0
 # conv FLOPs per pair, forward, live outputs at level 3: 272.4 GFLOP
 GFLOP_PER_PAIR_LIVE = 272.4
@@ -65,7 +65,7 @@ def main():
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--batch', type=int, default=32, help='pairs per GPU')
-    ap.add_argument('--precision', default='bf16', choices=['bf16', 'fp32'])
+    ap.add_argument('--precision', default='bf16', choices=['bf16', 'fp16', 'fp32'])
     ap.add_argument('--n-iters', type=int, default=5)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-timing', action='store_true')

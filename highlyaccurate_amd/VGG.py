@@ -3,7 +3,7 @@ argument, ``forward(x) -> ([feat_l], [conf_l])``), computed by libhla's MFMA con
 
 Differences a caller can observe:
   * returned maps are logically [B,C,H,W] but stored channels-last (NHWC); values match the reference
-  * ``precision='fp32'`` (default) runs exact-fp32 MFMA; ``'bf16'`` is the throughput mode
+  * ``precision='fp32'`` (default) runs exact-fp32 MFMA; ``'bf16'`` / ``'fp16'`` are the throughput modes
   * pretrained torchvision weights are not downloaded here: load a state dict (keys are identical)
 """
 from __future__ import annotations
@@ -25,9 +25,11 @@ _CH = (256, 128, 64, 16)
 def _dtype_code(precision: str) -> int:
     if precision == 'bf16':
         return _lib.HLA_BF16
+    if precision == 'fp16':
+        return _lib.HLA_F16
     if precision == 'fp32':
         return _lib.HLA_F32
-    raise ValueError(f"precision must be 'fp32' or 'bf16', got {precision!r}")
+    raise ValueError(f"precision must be 'fp32', 'bf16' or 'fp16', got {precision!r}")
 
 
 def _param_table(module: 'VGGUnet'):

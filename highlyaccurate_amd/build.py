@@ -8,7 +8,9 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'libhla.so')
-SOURCES = ['capi.hip', 'prof.hip', 'lm_solve.hip', 'lm_backward.hip', 'grid_sample.hip', 'vgg.hip', 'vgg_backward.hip']
+# (source, HLA_TU_DTYPE): the conv-heavy files are compiled once per dtype (kernels) plus once as the dispatcher (-1)
+SOURCES = [('capi.hip', -1), ('prof.hip', -1), ('lm_solve.hip', -1), ('lm_backward.hip', -1), ('grid_sample.hip', -1)] + \
+          [(f, d) for f in ('vgg.hip', 'vgg_backward.hip') for d in (0, 1, 2, -1)]
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=fast', '-munsafe-fp-atomics', '-Wno-unused-result']
 
 
@@ -61,9 +63,9 @@ def build(force: bool = False, verbose: bool = False, variant: int = 0) -> str:
     objs = []
     procs = []
     os.makedirs(os.path.join(HERE, 'build'), exist_ok=True)
-    for s in SOURCES:
-        o = os.path.join(HERE, 'build', s.replace('.hip', f'.v{variant}.o'))
-        cmd = [hipcc, *FLAGS, f'-DCONV_VARIANT={variant}', '-c', os.path.join(CSRC, s), '-o', o]
+    for s, tu in SOURCES:
+        o = os.path.join(HERE, 'build', s.replace('.hip', f'.v{variant}.t{tu + 1}.o'))
+        cmd = [hipcc, *FLAGS, f'-DCONV_VARIANT={variant}', f'-DHLA_TU_DTYPE={tu}', '-c', os.path.join(CSRC, s), '-o', o]
         if verbose:
             cmd.insert(1, '-Rpass-analysis=kernel-resource-usage')
             print(' '.join(cmd), flush=True)

@@ -20,12 +20,30 @@
 #include "common.h"
 
 typedef __bf16 bf16;
+typedef _Float16 f16;
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
+
+// Every dtype's kernels are compiled in their own translation unit (build.py passes -DHLA_TU_DTYPE=0|1|2); the
+// dispatcher TU (-1, the default) only declares them.
+#ifndef HLA_TU_DTYPE
+#define HLA_TU_DTYPE -1
+#endif
+#if HLA_TU_DTYPE == 0
+typedef float TuT;
+#elif HLA_TU_DTYPE == 1
+typedef bf16 TuT;
+#elif HLA_TU_DTYPE == 2
+typedef f16 TuT;
+#endif
 
 template <typename T> __device__ __forceinline__ void mma16(f32x16& acc, const uint4& w, const uint4& p);
 template <> __device__ __forceinline__ void mma16<bf16>(f32x16& acc, const uint4& w, const uint4& p) {
   acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w), __builtin_bit_cast(bf16x8, p), acc, 0, 0, 0);
+}
+template <> __device__ __forceinline__ void mma16<f16>(f32x16& acc, const uint4& w, const uint4& p) {
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, w), __builtin_bit_cast(f16x8, p), acc, 0, 0, 0);
 }
 template <> __device__ __forceinline__ void mma16<float>(f32x16& acc, const uint4& w, const uint4& p) {
   // element t of both fragments: channels {8q+t (lanes 0-31), 8q+4+t (lanes 32-63)}
@@ -39,6 +57,10 @@ __device__ __forceinline__ void store4(bf16* p, float a, float b, float c, float
   const bf16 h[4] = {(bf16)a, (bf16)b, (bf16)c, (bf16)d};
   *(uint2*)p = __builtin_bit_cast(uint2, h);
 }
+__device__ __forceinline__ void store4(f16* p, float a, float b, float c, float d) {
+  const f16 h[4] = {(f16)a, (f16)b, (f16)c, (f16)d};
+  *(uint2*)p = __builtin_bit_cast(uint2, h);
+}
 __device__ __forceinline__ void store4(float* p, float a, float b, float c, float d) {
   *(float4*)p = make_float4(a, b, c, d);
 }
@@ -46,6 +68,7 @@ __device__ __forceinline__ void store4(unsigned char* p, float a, float b, float
   *(unsigned*)p = (unsigned)a | ((unsigned)b << 8) | ((unsigned)c << 16) | ((unsigned)d << 24);
 }
 __device__ __forceinline__ float to_f32(bf16 v) { return (float)v; }
+__device__ __forceinline__ float to_f32(f16 v) { return (float)v; }
 __device__ __forceinline__ float to_f32(float v) { return v; }
 
 struct ConvArgs {

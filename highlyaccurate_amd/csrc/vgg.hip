@@ -2,10 +2,8 @@
 #include "conv_kernels.h"
 #include "vgg_layers.h"
 
-extern "C" size_t hla_vgg_packed_weight_bytes(int dtype) { return packed_offset(kPackedLayers, dtype); }
-
 template <typename T>
-static void pack_all(const hla_vgg_params* prm, char* packed, int dtype, hipStream_t st) {
+void vgg_pack_all(const hla_vgg_params* prm, char* packed, int dtype, hipStream_t st) {
   for (int l = 0; l < kPackedLayers; ++l) {
     const size_t n = l == 0 ? (size_t)2 * 32 * 32 : (size_t)kLayers[l].cin * kLayers[l].cout * 9;
     const int grid = (int)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024);
@@ -16,24 +14,8 @@ static void pack_all(const hla_vgg_params* prm, char* packed, int dtype, hipStre
   }
 }
 
-extern "C" int hla_vgg_pack_weights(const hla_vgg_params* params, void* packed, int dtype, hla_stream_t stream) {
-  HLA_REQUIRE(params && packed, "hla_vgg_pack_weights: null argument");
-  HLA_REQUIRE(dtype == HLA_F32 || dtype == HLA_BF16, "hla_vgg_pack_weights: bad dtype");
-  if (dtype == HLA_BF16) pack_all<bf16>(params, (char*)packed, dtype, (hipStream_t)stream);
-  else pack_all<float>(params, (char*)packed, dtype, (hipStream_t)stream);
-  HLA_CHECK_HIP(hipGetLastError());
-  return HLA_OK;
-}
-
-extern "C" size_t hla_vgg_workspace_bytes(int B, int H, int W, int level, int dtype) {
-  (void)level;
-  VggPlan p;
-  vgg_plan(B, H, W, dtype, /*train=*/true, &p);   // sized for training so one buffer serves both modes
-  return p.total;
-}
-
 template <typename T>
-static int vgg_forward_t(const float* x, const hla_vgg_params* prm, const char* packed, int dtype, float* const feat[4],
+int vgg_forward_t(const float* x, const hla_vgg_params* prm, const char* packed, int dtype, float* const feat[4],
                          float* const conf[4], double* inv_norm, char* ws, const VggPlan& pl, int B, int H, int W,
                          int flags, hipStream_t st) {
   auto W_ = [&](int l) { return (const uint4*)(packed + packed_offset(l, dtype)); };
@@ -117,12 +99,42 @@ static int vgg_forward_t(const float* x, const hla_vgg_params* prm, const char* 
   return HLA_OK;
 }
 
+#if HLA_TU_DTYPE >= 0
+template void vgg_pack_all<TuT>(const hla_vgg_params* prm, char* packed, int dtype, hipStream_t st);
+template int vgg_forward_t<TuT>(const float* x, const hla_vgg_params* prm, const char* packed, int dtype, float* const feat[4],
+                              float* const conf[4], double* inv_norm, char* ws, const VggPlan& pl, int B, int H, int W,
+                              int flags, hipStream_t st);
+#else
+#define HLA_EXTERN_T(T) \
+  extern template void vgg_pack_all<T>(const hla_vgg_params* prm, char* packed, int dtype, hipStream_t st); \
+  extern template int vgg_forward_t<T>(const float* x, const hla_vgg_params* prm, const char* packed, int dtype, float* const feat[4],                               float* const conf[4], double* inv_norm, char* ws, const VggPlan& pl, int B, int H, int W,                               int flags, hipStream_t st);
+HLA_EXTERN_T(float) HLA_EXTERN_T(bf16) HLA_EXTERN_T(f16)
+
+extern "C" size_t hla_vgg_packed_weight_bytes(int dtype) { return packed_offset(kPackedLayers, dtype); }
+
+extern "C" int hla_vgg_pack_weights(const hla_vgg_params* params, void* packed, int dtype, hla_stream_t stream) {
+  HLA_REQUIRE(params && packed, "hla_vgg_pack_weights: null argument");
+  HLA_REQUIRE(hla_dtype_ok(dtype), "hla_vgg_pack_weights: bad dtype %d", dtype);
+  if (dtype == HLA_BF16) vgg_pack_all<bf16>(params, (char*)packed, dtype, (hipStream_t)stream);
+  else if (dtype == HLA_F16) vgg_pack_all<f16>(params, (char*)packed, dtype, (hipStream_t)stream);
+  else vgg_pack_all<float>(params, (char*)packed, dtype, (hipStream_t)stream);
+  HLA_CHECK_HIP(hipGetLastError());
+  return HLA_OK;
+}
+
+extern "C" size_t hla_vgg_workspace_bytes(int B, int H, int W, int level, int dtype) {
+  (void)level;
+  VggPlan p;
+  vgg_plan(B, H, W, dtype, /*train=*/true, &p);   // sized for training so one buffer serves both modes
+  return p.total;
+}
+
 extern "C" int hla_vgg_forward(const float* x, const hla_vgg_params* params, const void* packed_weights,
                                float* const feat[4], float* const conf[4], double* inv_norm, void* workspace,
                                size_t workspace_bytes, int B, int H, int W, int level, int dtype, int flags,
                                hla_stream_t stream) {
   HLA_REQUIRE(x && params && packed_weights && feat && workspace, "hla_vgg_forward: null argument");
-  HLA_REQUIRE(dtype == HLA_F32 || dtype == HLA_BF16, "hla_vgg_forward: dtype must be HLA_F32 or HLA_BF16");
+  HLA_REQUIRE(hla_dtype_ok(dtype), "hla_vgg_forward: dtype must be HLA_F32, HLA_BF16 or HLA_F16 (got %d)", dtype);
   HLA_REQUIRE(B > 0 && H >= 8 && W >= 8 && H % 8 == 0 && W % 8 == 0, "hla_vgg_forward: H and W must be multiples of 8");
   HLA_REQUIRE(level == 3, "hla_vgg_forward: only level 3 (x15,x18,x21) is built so far (got %d)", level);
   HLA_REQUIRE(feat[0] && feat[1] && feat[2], "hla_vgg_forward: level 3 needs feat[0..2]");
@@ -136,6 +148,10 @@ extern "C" int hla_vgg_forward(const float* x, const hla_vgg_params* params, con
   if (dtype == HLA_BF16)
     return vgg_forward_t<bf16>(x, params, (const char*)packed_weights, dtype, feat, conf, inv_norm, (char*)workspace, pl,
                                B, H, W, flags, (hipStream_t)stream);
+  if (dtype == HLA_F16)
+    return vgg_forward_t<f16>(x, params, (const char*)packed_weights, dtype, feat, conf, inv_norm, (char*)workspace, pl,
+                              B, H, W, flags, (hipStream_t)stream);
   return vgg_forward_t<float>(x, params, (const char*)packed_weights, dtype, feat, conf, inv_norm, (char*)workspace, pl,
                               B, H, W, flags, (hipStream_t)stream);
 }
+#endif

@@ -19,6 +19,7 @@ typedef short v4s __attribute__((ext_vector_type(4)));
 //   fp32: K-step =  8 pixels, element t of lane group g is k = 2t+g
 template <typename T> struct KStep;
 template <> struct KStep<bf16> { static constexpr int PX = 16; };
+template <> struct KStep<f16> { static constexpr int PX = 16; };
 template <> struct KStep<float> { static constexpr int PX = 8; };
 
 template <typename T> __device__ __forceinline__ uint4 frag_kmajor(const char* tile, int stride, int px0, int ch0, int lane);
@@ -32,6 +33,9 @@ template <> __device__ __forceinline__ uint4 frag_kmajor<bf16>(const char* tile,
   __builtin_memcpy(&r.z, &hi, 8);
   return r;
 }
+template <> __device__ __forceinline__ uint4 frag_kmajor<f16>(const char* tile, int stride, int px0, int ch0, int lane) {
+  return frag_kmajor<bf16>(tile, stride, px0, ch0, lane);     // same 16-bit transpose read
+}
 template <> __device__ __forceinline__ uint4 frag_kmajor<float>(const char* tile, int stride, int px0, int ch0, int lane) {
   const char* p = tile + (px0 + (lane >> 5)) * stride + (ch0 + (lane & 31)) * 4;
   uint4 r;
@@ -41,6 +45,7 @@ template <> __device__ __forceinline__ uint4 frag_kmajor<float>(const char* tile
 }
 template <typename T> __device__ __forceinline__ uint4 frag_ones();
 template <> __device__ __forceinline__ uint4 frag_ones<bf16>() { return make_uint4(0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u); }
+template <> __device__ __forceinline__ uint4 frag_ones<f16>() { return make_uint4(0x3C003C00u, 0x3C003C00u, 0x3C003C00u, 0x3C003C00u); }
 template <> __device__ __forceinline__ uint4 frag_ones<float>() { return make_uint4(0x3F800000u, 0x3F800000u, 0x3F800000u, 0x3F800000u); }
 
 // ---------------------------------------------------------------------------------------------
@@ -218,7 +223,7 @@ __global__ __launch_bounds__(256) void wgrad0_kernel(Wgrad0Args a) {
 }
 
 // out[i] (=) sum_k part[k][i]  (fixed order: deterministic)
-__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ part, float* __restrict__ out,
+static __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ part, float* __restrict__ out,
                                                               size_t n, int K, int in_stride_inner, int out_inner, int in_inner) {
   // generic 2-D gather: element i = (row, col) with col < out_inner; input row pitch in_inner (conv0: 32 -> 27)
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
@@ -232,7 +237,7 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __res
 
 // ---------------------------------------------------------------------------------------------
 // L2_norm backward: y = a*x with a = 1/||x||  =>  dx = a*dy - a^3 * (x . dy) * x      (per sample)
-__global__ __launch_bounds__(256) void l2bwd_dot_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+static __global__ __launch_bounds__(256) void l2bwd_dot_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                         double* __restrict__ part, size_t per_sample, int nblk) {
   __shared__ double sh[4];
   const int b = blockIdx.x / nblk, k = blockIdx.x % nblk;
@@ -274,7 +279,7 @@ __global__ __launch_bounds__(256) void l2bwd_apply_kernel(const float* __restric
 // ---------------------------------------------------------------------------------------------
 // Confidence head backward (VGG.py:62-76,160-162):  conf = sigmoid(-s),  s = sigmoid(z),  z = conv3x3(relu(x), w)
 //   dz = -d_conf * conf*(1-conf) * s*(1-s)   with s recovered from conf:  e^s = (1-conf)/conf
-__global__ __launch_bounds__(256) void conf_dz_kernel(const float* __restrict__ conf, const float* __restrict__ d_conf,
+static __global__ __launch_bounds__(256) void conf_dz_kernel(const float* __restrict__ conf, const float* __restrict__ d_conf,
                                                       float* __restrict__ dz, size_t n) {
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
     const float c = conf[i];
@@ -362,7 +367,7 @@ static int wgrad_ksplit(int Cout, int Cin, int ntile) {
 }
 
 static void bwd_plan(int B, int H, int W, int dtype, BwdPlan* p) {
-  const size_t es = dtype == HLA_BF16 ? 2 : 4;
+  const size_t es = dtype == HLA_F32 ? 4 : 2;
   size_t o = 0;
   auto take = [&](size_t bytes) { size_t r = o; o += hla_align_up(bytes, 256); return r; };
   const size_t P = (size_t)B * H * W;
@@ -389,16 +394,8 @@ static void bwd_plan(int B, int H, int W, int dtype, BwdPlan* p) {
   p->total = o;
 }
 
-extern "C" size_t hla_vgg_bwd_workspace_bytes(int B, int H, int W, int dtype) {
-  BwdPlan p;
-  bwd_plan(B, H, W, dtype, &p);
-  return p.total;
-}
-
-extern "C" size_t hla_vgg_packed_weight_T_bytes(int dtype) { return packed_offset(kPackedLayers, dtype); }
-
 template <typename T>
-static void pack_all_T(const hla_vgg_params* prm, char* packed, int dtype, hipStream_t st) {
+void vgg_pack_all_T(const hla_vgg_params* prm, char* packed, int dtype, hipStream_t st) {
   for (int l = 1; l < kPackedLayers; ++l) {       // conv0 needs no data gradient
     const size_t n = (size_t)kLayers[l].cin * kLayers[l].cout * 9;
     const int grid = (int)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024);
@@ -408,17 +405,8 @@ static void pack_all_T(const hla_vgg_params* prm, char* packed, int dtype, hipSt
   }
 }
 
-extern "C" int hla_vgg_pack_weights_T(const hla_vgg_params* params, void* packed, int dtype, hla_stream_t stream) {
-  HLA_REQUIRE(params && packed, "hla_vgg_pack_weights_T: null argument");
-  HLA_REQUIRE(dtype == HLA_F32 || dtype == HLA_BF16, "hla_vgg_pack_weights_T: bad dtype");
-  if (dtype == HLA_BF16) pack_all_T<bf16>(params, (char*)packed, dtype, (hipStream_t)stream);
-  else pack_all_T<float>(params, (char*)packed, dtype, (hipStream_t)stream);
-  HLA_CHECK_HIP(hipGetLastError());
-  return HLA_OK;
-}
-
 template <typename T>
-static int vgg_backward_t(const float* x, const hla_vgg_params* prm, const char* packedT, int dtype, const char* fw,
+int vgg_backward_t(const float* x, const hla_vgg_params* prm, const char* packedT, int dtype, const char* fw,
                           const float* const feat[3], const double* inv_norm, const float* const d_feat[3],
                           const float* const conf[3], const float* const d_conf[3], const hla_vgg_grads* gr, char* bw, const BwdPlan& bp, int B, int H, int W, hipStream_t st) {
   VggPlan fp;
@@ -550,6 +538,33 @@ static int vgg_backward_t(const float* x, const hla_vgg_params* prm, const char*
   return HLA_OK;
 }
 
+#if HLA_TU_DTYPE >= 0
+template void vgg_pack_all_T<TuT>(const hla_vgg_params* prm, char* packed, int dtype, hipStream_t st);
+template int vgg_backward_t<TuT>(const float* x, const hla_vgg_params* prm, const char* packedT, int dtype, const char* fw, const float* const feat[3], const double* inv_norm, const float* const d_feat[3], const float* const conf[3], const float* const d_conf[3], const hla_vgg_grads* gr, char* bw, const BwdPlan& bp, int B, int H, int W, hipStream_t st);
+#else
+#define HLA_EXTERN_T(T) \
+  extern template void vgg_pack_all_T<T>(const hla_vgg_params* prm, char* packed, int dtype, hipStream_t st); \
+  extern template int vgg_backward_t<T>(const float* x, const hla_vgg_params* prm, const char* packedT, int dtype, const char* fw, const float* const feat[3], const double* inv_norm, const float* const d_feat[3], const float* const conf[3], const float* const d_conf[3], const hla_vgg_grads* gr, char* bw, const BwdPlan& bp, int B, int H, int W, hipStream_t st);
+HLA_EXTERN_T(float) HLA_EXTERN_T(bf16) HLA_EXTERN_T(f16)
+
+extern "C" size_t hla_vgg_bwd_workspace_bytes(int B, int H, int W, int dtype) {
+  BwdPlan p;
+  bwd_plan(B, H, W, dtype, &p);
+  return p.total;
+}
+
+extern "C" size_t hla_vgg_packed_weight_T_bytes(int dtype) { return packed_offset(kPackedLayers, dtype); }
+
+extern "C" int hla_vgg_pack_weights_T(const hla_vgg_params* params, void* packed, int dtype, hla_stream_t stream) {
+  HLA_REQUIRE(params && packed, "hla_vgg_pack_weights_T: null argument");
+  HLA_REQUIRE(hla_dtype_ok(dtype), "hla_vgg_pack_weights_T: bad dtype %d", dtype);
+  if (dtype == HLA_BF16) vgg_pack_all_T<bf16>(params, (char*)packed, dtype, (hipStream_t)stream);
+  else if (dtype == HLA_F16) vgg_pack_all_T<f16>(params, (char*)packed, dtype, (hipStream_t)stream);
+  else vgg_pack_all_T<float>(params, (char*)packed, dtype, (hipStream_t)stream);
+  HLA_CHECK_HIP(hipGetLastError());
+  return HLA_OK;
+}
+
 extern "C" int hla_vgg_backward(const float* x, const hla_vgg_params* params, const void* packed_weights_T,
                                 const void* fwd_workspace, const float* const feat[3], const double* inv_norm,
                                 const float* const d_feat[3], const float* const conf[3], const float* const d_conf[3],
@@ -557,7 +572,7 @@ extern "C" int hla_vgg_backward(const float* x, const hla_vgg_params* params, co
                                 int level, int dtype, hla_stream_t stream) {
   HLA_REQUIRE(x && params && packed_weights_T && fwd_workspace && feat && inv_norm && d_feat && grads && workspace,
               "hla_vgg_backward: null argument");
-  HLA_REQUIRE(dtype == HLA_F32 || dtype == HLA_BF16, "hla_vgg_backward: bad dtype");
+  HLA_REQUIRE(hla_dtype_ok(dtype), "hla_vgg_backward: bad dtype %d", dtype);
   HLA_REQUIRE(level == 3, "hla_vgg_backward: only level 3 is built");
   HLA_REQUIRE(B > 0 && H % 8 == 0 && W % 8 == 0, "hla_vgg_backward: H and W must be multiples of 8");
   for (int l = 0; l < kPackedLayers; ++l) HLA_REQUIRE(grads->dw[l], "hla_vgg_backward: dw[%d] missing", l);
@@ -574,6 +589,10 @@ extern "C" int hla_vgg_backward(const float* x, const hla_vgg_params* params, co
   if (dtype == HLA_BF16)
     return vgg_backward_t<bf16>(x, params, (const char*)packed_weights_T, dtype, (const char*)fwd_workspace, feat, inv_norm,
                                 d_feat, conf, d_conf, grads, (char*)workspace, bp, B, H, W, (hipStream_t)stream);
+  if (dtype == HLA_F16)
+    return vgg_backward_t<f16>(x, params, (const char*)packed_weights_T, dtype, (const char*)fwd_workspace, feat, inv_norm,
+                               d_feat, conf, d_conf, grads, (char*)workspace, bp, B, H, W, (hipStream_t)stream);
   return vgg_backward_t<float>(x, params, (const char*)packed_weights_T, dtype, (const char*)fwd_workspace, feat, inv_norm,
                                d_feat, conf, d_conf, grads, (char*)workspace, bp, B, H, W, (hipStream_t)stream);
 }
+#endif

@@ -10,7 +10,7 @@ static const LayerDef kLayers[13] = {
 constexpr int kPackedLayers = 11;   // conv0..dec2.3 (dec3.* only feed the unused x24 at level 3)
 
 static inline size_t packed_bytes(int l, int dtype) {
-  const size_t es = dtype == HLA_BF16 ? 2 : 4;
+  const size_t es = dtype == HLA_F32 ? 4 : 2;
   if (l == 0) return (size_t)2 * 32 * 32 * es;   // 2 ntiles x 32 (padded K) x 32 couts
   return (size_t)kLayers[l].cin * kLayers[l].cout * 9 * es + 4096;   // + two taps of fragments: prefetch overrun
 }
@@ -30,7 +30,7 @@ struct VggPlan {
 };
 
 static inline void vgg_plan(int B, int H, int W, int dtype, bool train, VggPlan* p) {
-  const size_t es = dtype == HLA_BF16 ? 2 : 4;
+  const size_t es = dtype == HLA_F32 ? 4 : 2;
   size_t o = 0;
   auto take = [&](size_t bytes) { size_t r = o; o += hla_align_up(bytes, 256); return r; };
   const size_t P = (size_t)B * H * W;

@@ -37,7 +37,9 @@ typedef enum hla_status {
 
 typedef enum hla_dtype {
   HLA_F32 = 0,  /* exact-fp32 MFMA (v_mfma_f32_32x32x2_f32): the parity mode      */
-  HLA_BF16 = 1  /* bf16 MFMA (v_mfma_f32_32x32x16_bf16), fp32 accumulate: perf mode */
+  HLA_BF16 = 1, /* bf16 MFMA (v_mfma_f32_32x32x16_bf16), fp32 accumulate: perf mode */
+  HLA_F16 = 2   /* fp16 MFMA (v_mfma_f32_32x32x16_f16), fp32 accumulate: same speed, 3 more mantissa bits,
+                   narrower range -- fine for inference on [0,1] images, not recommended for the backward pass */
 } hla_dtype;
 
 const char* hla_last_error(void);

@@ -192,9 +192,14 @@ def gen_kat(mk, mf, jac, VGG):
     print('kat_small.npz written,', len(out), 'arrays')
 
 
-def run_e2e(mod, cls, args, seed, B, dtype, extra=None, level_first=0, bias_scale=0.0):
+def run_e2e(mod, cls, args, seed, B, dtype, extra=None, level_first=0, bias_scale=0.0, grd_hw=(256, 1024), sat_a=512):
     net = ref_model(mod, cls, args, seed, dtype, bias_scale)
-    sat, grd, gu, gv, gh = O.synth_images(seed + 100, B)
+    if tuple(grd_hw) != (256, 1024):
+        # the reference hard-codes its ground-plane tables for a 256x1024 input (models_kitti.py:622); rebuild them with
+        # its OWN grd_img2cam for the actual level sizes, K still calibrated at 256x1024
+        net.xyz_grds = [tuple(t.to(dtype) if t.is_floating_point() else t for t in
+                              net.grd_img2cam(grd_hw[0] / 2 ** (3 - l), grd_hw[1] / 2 ** (3 - l), 256, 1024)) for l in range(4)]
+    sat, grd, gu, gv, gh = O.synth_images(seed + 100, B, grd_hw=grd_hw, sat_a=sat_a)
     sat, grd = sat.to(dtype), grd.to(dtype)
     torch.manual_seed(seed)
     # capture per-step poses through the train-mode return path: run test mode and
@@ -254,6 +259,20 @@ def gen_e2e(mk, seeds, B=2):
         out[f'trace64_{tag}'], out[f'trace32_{tag}'] = t64, t32
         print(f'kitti {tag}: gap {np.abs(t32 - t64).max():.2e}', flush=True)
     np.savez_compressed(os.path.join(GOLD, 'e2e_kitti.npz'), **out)
+
+
+def gen_hires(mk, seed=1, B=1):
+    """BASELINE config 5: grd 512x2048, sat 1024x1024, 10 LM iterations."""
+    args = O.default_args(N_iters=10)
+    out = {'seed': np.array(seed), 'B': np.array(B)}
+    for dtype, tag in ((torch.float32, '32'), (torch.float64, '64')):
+        t, f, sf, gf = run_e2e(mk, 'LM_S2GP', args, seed, B, dtype, grd_hw=(512, 2048), sat_a=1024)
+        out['trace' + tag], out['final' + tag] = t, f
+        if tag == '64':
+            for l in range(3):
+                out[f'satfeat64_l{l}'], out[f'grdfeat64_l{l}'] = sf[l], gf[l]
+    print(f"hires: gap {np.abs(out['trace32'] - out['trace64']).max():.2e} final {out['final64'].tolist()}", flush=True)
+    np.savez_compressed(os.path.join(GOLD, 'e2e_kitti_hires.npz'), **out)
 
 
 def ford_extra(B):
@@ -324,5 +343,7 @@ if __name__ == '__main__':
         gen_ford(mf, (seeds or [1])[:2])
     if a.only in ('all', 'train'):
         gen_train(mk, (seeds or [1])[0])
+    if a.only in ('all', 'hires'):
+        gen_hires(mk, (seeds or [1])[0])
     if a.only in ('all', 'trainw'):
         gen_train(mk, (seeds or [1])[0], weighted=True)
