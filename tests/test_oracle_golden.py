@@ -122,3 +122,65 @@ def test_state_dict_keys_and_sizes():
     assert sd['damping'].shape == (1, 3)
     assert sd['SatFeatureNet.conv_dec1.1.weight'].shape == (128, 384, 3, 3)
     assert sd['GrdFeatureNet.conf3.1.weight'].shape == (1, 16, 3, 3)
+
+
+def _oracle_trace(net, level_first=0):
+    """[B,N,L] x3 -> [B,steps,3] = (u, v, theta) in execution order, as make_golden.py logged.
+    KITTI stores (lat=v, lon=u, theta) (models_kitti.py:1281-1283), Ford (u, v, theta) (models_ford.py:837-839)."""
+    a, b, th = net.trace
+    t = torch.stack([a, b, th] if net.ford else [b, a, th], -1)   # [B,N,L,3]
+    B, N, L, _ = t.shape
+    t = t.permute(0, 2, 1, 3) if level_first else t
+    return t.reshape(B, N * L, 3).double().numpy()
+
+
+def test_oracle_e2e_kitti_matches_reference_golden():
+    """The restatement's whole forward (both extractors + 15 LM steps, full KITTI shape) against the pose trace
+    recorded from the REAL reference in fp64 (oracle/make_golden.py gen_e2e)."""
+    g = load_golden('e2e_kitti.npz')
+    seed, B = int(g['seeds'][0]), int(g['B'])
+    net = O.build('kitti', O.default_args(), seed, torch.float64)
+    sat, grd, *_ = O.synth_images(seed + 100, B)
+    torch.manual_seed(seed)
+    with torch.no_grad():
+        net(sat.double(), grd.double(), mode='test')
+    err = np.abs(_oracle_trace(net) - g[f'trace64_{seed}']).max()
+    print('oracle vs reference, kitti e2e fp64: max pose err', err)
+    assert err < 1e-7      # fp64 both sides; only the summation order differs
+
+
+def test_oracle_e2e_ford_matches_reference_golden():
+    g = load_golden('e2e_ford.npz')
+    seed, B = int(g['seeds'][0]), int(g['B'])
+    net = O.build('ford', O.default_args(N_iters=10), seed, torch.float64)
+    sat, grd, *_ = O.synth_images(seed + 100, B)
+    R_FL = torch.tensor([[[0., 0., 1.], [1., 0., 0.], [0., 1., 0.]]], dtype=torch.float64).repeat(B, 1, 1)
+    T_FL = torch.tensor([[1.7, 0.3, -1.2]], dtype=torch.float64).repeat(B, 1)
+    torch.manual_seed(seed)
+    with torch.no_grad():
+        net(sat.double(), grd.double(), 112.64, R_FL, T_FL, mode='test')
+    err = np.abs(_oracle_trace(net) - g[f'trace64_{seed}']).max()
+    print('oracle vs reference, ford e2e fp64: max pose err', err)
+    assert err < 1e-7      # fp64 both sides; only the summation order differs
+
+
+def test_oracle_train_step_matches_reference_autograd_golden():
+    """mode='train' (using_weight=1, train_damping=1): the 14-tuple's values and gradient samples of 11 parameters
+    (incl. the confidence heads and `damping`) against the REAL reference's autograd, fp64, full KITTI shape."""
+    from make_idx import sample_idx
+    g = load_golden('train_kitti_w.npz')
+    seed, B = int(g['seed']), int(g['B'])
+    net = O.build('kitti', O.default_args(using_weight=1, train_damping=1), seed, torch.float64)
+    sat, grd, gu, gv, gh = O.synth_images(seed + 100, B)
+    torch.manual_seed(seed)
+    res = net(sat.double(), grd.double(), gu.double(), gv.double(), gh.double(), mode='train')
+    got = np.stack([np.atleast_1d(r.detach().numpy()) if r.dim() else np.full(3, float(r)) for r in res[:9]])
+    np.testing.assert_allclose(got, g['tuple64'], rtol=1e-5, atol=1e-8)   # fp32 geometry tables on both sides
+    res[0].backward()
+    named = dict(net.named_parameters())
+    assert set(k for k, p in named.items() if p.grad is None) == set(str(k) for k in g['nograd_64'])
+    for k in [k[len('grad64_'):] for k in g.files if k.startswith('grad64_')]:
+        gr = named[k].grad.reshape(-1)
+        ref = g['grad64_' + k]
+        got = np.concatenate([[gr.abs().sum().item(), (gr * gr).sum().item()], gr[sample_idx(gr.numel(), 77)].numpy()])
+        np.testing.assert_allclose(got, ref, rtol=1e-5, atol=1e-7 * np.abs(ref).max(), err_msg=k)
