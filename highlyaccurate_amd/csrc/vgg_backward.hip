@@ -87,53 +87,127 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
   for (int r = 0; r < 16; ++r) accb[r] = 0.f;
   const uint4 ones = frag_ones<T>();
 
-  for (int tile = ks; tile < a.ntile; tile += a.KS) {
+  // Register-staged tile loads: all of a tile's 16-B pieces are requested back to back (memory-level parallelism), and
+  // for the 16-bit types the NEXT tile's requests are issued before the current tile's MFMA phase so that they are in
+  // flight behind it (fp32 would need 84 staging registers: it loads inside the load phase instead).
+  constexpr int NX = (XPIX * PPX + 255) / 256, NG = GPIX * PPX / 256, PSTEP = 256 / PPX;
+  constexpr bool PREFETCH = sizeof(T) == 2 && CONV_VARIANT == 73;
+  const int part = t % PPX, pix0 = t / PPX;
+  uint4 xr[NX], gr[NG];
+  unsigned long long gid[NG];
+  auto tile_origin = [&](int tile, int& b, int& y0, int& x0) {
     int q = tile;
-    const int tx = q % a.tiles_x; q /= a.tiles_x;
-    const int ty = q % a.tiles_y;
-    const int b = q / a.tiles_y;
-    const int y0 = ty * WG_TH, x0 = tx * 32;
-    __syncthreads();                                   // previous tile fully consumed
-    for (int e = t; e < XPIX * PPX; e += 256) {        // input halo tile, zero outside the image
-      const int pix = e / PPX, part = e % PPX;
+    x0 = (q % a.tiles_x) * 32; q /= a.tiles_x;
+    y0 = (q % a.tiles_y) * WG_TH;
+    b = q / a.tiles_y;
+  };
+  auto load_x = [&](int tile, int lo, int hi) {
+    int b, y0, x0;
+    tile_origin(tile, b, y0, x0);
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {                     // input halo tile, zero outside the image
+      if (i < lo || i >= hi) continue;
+      const int pix = pix0 + i * PSTEP;
       const int hy = pix / HWID, hx = pix - hy * HWID, y = y0 - 1 + hy, x = x0 - 1 + hx;
       uint4 v = make_uint4(0, 0, 0, 0);
-      if (y >= 0 && y < a.H && x >= 0 && x < a.W)
+      if (pix < XPIX && y >= 0 && y < a.H && x >= 0 && x < a.W)
         v = *(const uint4*)(xsrc + (((size_t)b * Hs + (y >> sh)) * Ws + (x >> sh)) * Cs + coff + part * EPL);
-      *(uint4*)(Xs + pix * STR + part * 16) = v;
+      xr[i] = v;
     }
-    for (int e = t; e < GPIX * PPX; e += 256) {        // output-gradient tile (with virtual unpool)
-      const int pix = e / PPX, part = e % PPX;
+  };
+  auto load_g = [&](int tile, int lo, int hi) {
+    int b, y0, x0;
+    tile_origin(tile, b, y0, x0);
+#pragma unroll
+    for (int i = 0; i < NG; ++i) {                     // output-gradient tile (virtual unpool: + the forward argmax)
+      if (i < lo || i >= hi) continue;
+      const int pix = pix0 + i * PSTEP;
       const int y = y0 + pix / 32, x = x0 + pix % 32;
       uint4 v = make_uint4(0, 0, 0, 0);
+      unsigned long long id = 0;
       if (y < a.H && x < a.W) {
         const size_t e0 = (((size_t)b * Hg + (y >> gsh)) * Wg + (x >> gsh)) * a.Cout + co0 + part * EPL;
         v = *(const uint4*)((const T*)a.g + e0);
-        if (a.g_unpool) {
-          const unsigned pos = ((y & 1) << 1) | (x & 1);
-          T ev[EPL];
-          unsigned char id[EPL];
-          __builtin_memcpy(ev, &v, 16);
-          __builtin_memcpy(id, a.g_unpool + e0, EPL);
+        if (a.g_unpool) __builtin_memcpy(&id, a.g_unpool + e0, EPL);
+      }
+      gr[i] = v; gid[i] = id;
+    }
+  };
+  auto store_x = [&](int lo, int hi) {
 #pragma unroll
-          for (int k = 0; k < EPL; ++k) if (id[k] != pos) ev[k] = (T)0.f;
-          __builtin_memcpy(&v, ev, 16);
-        }
+    for (int i = 0; i < NX; ++i) {
+      if (i < lo || i >= hi) continue;
+      const int pix = pix0 + i * PSTEP;
+      if (pix < XPIX) *(uint4*)(Xs + pix * STR + part * 16) = xr[i];
+    }
+  };
+  auto store_g = [&](int tile, int lo, int hi) {
+    int b, y0, x0;
+    tile_origin(tile, b, y0, x0);
+#pragma unroll
+    for (int i = 0; i < NG; ++i) {
+      if (i < lo || i >= hi) continue;
+      const int pix = pix0 + i * PSTEP;
+      uint4 v = gr[i];
+      if (a.g_unpool) {                                // keep the elements whose forward argmax is this (y&1, x&1)
+        const unsigned pos = (((y0 + pix / 32) & 1) << 1) | ((x0 + pix % 32) & 1);
+        T ev[EPL];
+        unsigned char id[8];
+        __builtin_memcpy(ev, &v, 16);
+        __builtin_memcpy(id, &gid[i], 8);
+#pragma unroll
+        for (int k = 0; k < EPL; ++k) if (id[k] != pos) ev[k] = (T)0.f;
+        __builtin_memcpy(&v, ev, 16);
       }
       *(uint4*)(Gs + pix * STR + part * 16) = v;
     }
+  };
+
+  if (PREFETCH && ks < a.ntile) { load_x(ks, 0, NX); load_g(ks, 0, NG); }
+  for (int tile = ks; tile < a.ntile; tile += a.KS) {
+    const bool ld = !PREFETCH && !(CONV_VARIANT == 70 && tile != ks);        // (ablation 70: loads for the first tile only)
+    if (sizeof(T) == 2) {
+      if (ld) { load_x(tile, 0, NX); load_g(tile, 0, NG); }
+      __syncthreads();                                 // previous tile fully consumed
+      store_x(0, NX);
+      store_g(tile, 0, NG);
+    } else {                                           // fp32 (parity mode): batches of 4 pieces = 16 staging registers
+      __syncthreads();
+#pragma unroll
+      for (int lo = 0; lo < NX; lo += 4) { if (ld) load_x(tile, lo, lo + 4); store_x(lo, lo + 4); }
+#pragma unroll
+      for (int lo = 0; lo < NG; lo += 4) { if (ld) load_g(tile, lo, lo + 4); store_g(tile, lo, lo + 4); }
+    }
     __syncthreads();
+    if (PREFETCH && tile + a.KS < a.ntile) { load_x(tile + a.KS, 0, NX); load_g(tile + a.KS, 0, NG); }
+    // G fragments of the whole tile stay in registers; every X fragment (halo row rho, column shift kx, K-step kk) is
+    // fetched ONCE and feeds the up to three taps ky with r = rho - ky inside the tile  (halves the LDS reads per MFMA)
+    // (K-steps are taken two at a time so that the resident G fragments cost 32 VGPRs for every dtype)
 #pragma unroll 1
-    for (int r = 0; r < WG_TH; ++r) {
+    for (int kk0 = 0; kk0 < (CONV_VARIANT == 71 ? 0 : 32 / KPX); kk0 += 2) {   // (ablation 71: no MFMA phase)
+      uint4 Af[WG_TH][2];
 #pragma unroll
-      for (int kk = 0; kk < 32 / KPX; ++kk) {
-        const uint4 A = frag_kmajor<T>(Gs, STR, r * 32 + kk * KPX, ct * 32, lane);
-        if (want_bias) mma16<T>(accb, A, ones);
+      for (int r = 0; r < WG_TH; ++r)
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-          const uint4 Bf = frag_kmajor<T>(Xs, STR, (r + tap / 3) * HWID + tap % 3 + kk * KPX, it * 32, lane);
-          mma16<T>(acc[tap], A, Bf);
+        for (int kk = 0; kk < 2; ++kk) {
+          Af[r][kk] = frag_kmajor<T>(Gs, STR, r * 32 + (kk0 + kk) * KPX, ct * 32, lane);
+          if (want_bias) mma16<T>(accb, Af[r][kk], ones);
         }
+#pragma unroll
+      for (int rho = 0; rho < WG_TH + 2; ++rho) {
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+          for (int kk = 0; kk < 2; ++kk) {
+            const uint4 Bf = CONV_VARIANT == 72 ? Af[rho % WG_TH][kk]      // (ablation 72: no X-fragment LDS reads)
+                                                : frag_kmajor<T>(Xs, STR, rho * HWID + kx + (kk0 + kk) * KPX, it * 32, lane);
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+              const int r = rho - ky;
+              if (r >= 0 && r < WG_TH) mma16<T>(acc[ky * 3 + kx], Af[r][kk], Bf);
+            }
+          }
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
   }
@@ -231,6 +305,30 @@ static __global__ __launch_bounds__(256) void reduce_partials_kernel(const float
     const size_t src = row * in_inner + col;
     float s = 0.f;
     for (int k = 0; k < K; ++k) s += part[(size_t)k * in_stride_inner + src];
+    out[i] = s;
+  }
+}
+
+// contiguous case, n % 4 == 0: 32 float4 columns x 8 k-lanes per block; each k-lane sums its rows in order, the 8 lane
+// sums are then added in order (deterministic), with 8x more loads in flight than the generic kernel
+static __global__ __launch_bounds__(256) void reduce_partials4_kernel(const float4* __restrict__ part, float4* __restrict__ out,
+                                                                      size_t n4, int K) {
+  __shared__ float4 sh[8][32];
+  const int col = threadIdx.x & 31, kl = threadIdx.x >> 5;
+  const size_t i = (size_t)blockIdx.x * 32 + col;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (i < n4) {
+#pragma unroll 4
+    for (int k = kl; k < K; k += 8) {
+      const float4 v = part[(size_t)k * n4 + i];
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+  }
+  sh[kl][col] = s;
+  __syncthreads();
+  if (kl == 0 && i < n4) {
+#pragma unroll
+    for (int k = 1; k < 8; ++k) { const float4 v = sh[k][col]; s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w; }
     out[i] = s;
   }
 }
@@ -360,7 +458,7 @@ struct BwdPlan {
 
 static int wgrad_ksplit(int Cout, int Cin, int ntile) {
   const int pairs = (Cout / 64) * (Cin / 64);
-  int ks = 1024 / (pairs > 0 ? pairs : 1);
+  int ks = 512 / (pairs > 0 ? pairs : 1);          // 512 workgroups = one resident generation (2 per CU)
   if (ks < 1) ks = 1;
   if (ks > ntile) ks = ntile;
   return ks;
@@ -483,8 +581,10 @@ int vgg_backward_t(const float* x, const hla_vgg_params* prm, const char* packed
     hipLaunchKernelGGL((wgrad_kernel<T>), dim3(a.KS, a.Cin / 64, a.Cout / 64), dim3(256), wg_lds_bytes<T>(), st, a);
     hla_prof_end(st);
     const size_t n = (size_t)a.Cout * a.Cin * 9;
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048)), dim3(256), 0, st,
-                       a.part, gr->dw[l], n, a.KS, (int)n, 1, 1);
+    hla_prof_begin(K_ELEMWISE, 0, (double)n * 4 * (a.KS + 1), st);
+    hipLaunchKernelGGL(reduce_partials4_kernel, dim3((unsigned)((n / 4 + 31) / 32)), dim3(256), 0, st, (const float4*)a.part,
+                       (float4*)gr->dw[l], n / 4, a.KS);
+    hla_prof_end(st);
     if (a.bpart)
       hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(256), 0, st, a.bpart, gr->db[l], (size_t)a.Cout, a.KS, a.Cout, 1, 1);
   };
