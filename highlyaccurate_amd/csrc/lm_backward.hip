@@ -56,7 +56,9 @@ __global__ __launch_bounds__(256) void lm_bwd_accum(BwdAccumArgs a) {
   const float j0u = (float)cf[8], j0v = (float)cf[9], j1u = (float)cf[10], j1v = (float)cf[11];
   constexpr int LPP = C / 4, PPW = 64 / LPP;
   const int lane = t & 63, wave = t >> 6;
-  const int sub = lane / LPP, cl = (lane % LPP) * 4;
+  // lane j of a pixel's LPP lanes owns channels j, j+LPP, j+2LPP, j+3LPP: every load / atomic instruction then covers
+  // LPP consecutive floats per pixel (whole cache lines) -- atomics are processed per touched line in L2
+  const int sub = lane / LPP, cl = lane % LPP;
   const size_t sat_base = (size_t)b * a.A * a.A * C + cl;
   const size_t grd_base = ((size_t)b * a.h * a.w + (size_t)a.row0 * a.w + p0) * C + cl;
 
@@ -68,14 +70,14 @@ __global__ __launch_bounds__(256) void lm_bwd_accum(BwdAccumArgs a) {
   int cur_off = -1, cur_dxo = 0, cur_dyo = 0;
   float c00[4] = {0, 0, 0, 0}, c01[4] = {0, 0, 0, 0}, c10[4] = {0, 0, 0, 0}, c11[4] = {0, 0, 0, 0};
   auto flush_cell = [&]() {
-    if (cur_off >= 0) {
+    if (cur_off >= 0 && CONV_VARIANT != 80) {          // (ablation 80: no d_sat atomics)
       float* dp = a.d_sat + sat_base + cur_off;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        atomicAdd(dp + e, c00[e]);
-        atomicAdd(dp + cur_dxo + e, c01[e]);
-        atomicAdd(dp + cur_dyo + e, c10[e]);
-        atomicAdd(dp + cur_dyo + cur_dxo + e, c11[e]);
+        atomicAdd(dp + e * LPP, c00[e]);
+        atomicAdd(dp + cur_dxo + e * LPP, c01[e]);
+        atomicAdd(dp + cur_dyo + e * LPP, c10[e]);
+        atomicAdd(dp + cur_dyo + cur_dxo + e * LPP, c11[e]);
       }
     }
   };
@@ -86,12 +88,14 @@ __global__ __launch_bounds__(256) void lm_bwd_accum(BwdAccumArgs a) {
     if (live) {
       const PixParam P = pp[i];
       const float* sp = a.sat + sat_base + P.off;
-      const float4 t00 = *(const float4*)(sp), t01 = *(const float4*)(sp + P.dxo);
-      const float4 t10 = *(const float4*)(sp + P.dyo), t11 = *(const float4*)(sp + P.dyo + P.dxo);
-      const float4 gg = *(const float4*)(a.grd + grd_base + (size_t)i * C);
-      const float v00[4] = {t00.x, t00.y, t00.z, t00.w}, v01[4] = {t01.x, t01.y, t01.z, t01.w};
-      const float v10[4] = {t10.x, t10.y, t10.z, t10.w}, v11[4] = {t11.x, t11.y, t11.z, t11.w};
-      const float vg[4] = {gg.x, gg.y, gg.z, gg.w};
+      const float* gq = a.grd + grd_base + (size_t)i * C;
+      float v00[4], v01[4], v10[4], v11[4], vg[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        v00[e] = sp[e * LPP]; v01[e] = sp[P.dxo + e * LPP];
+        v10[e] = sp[P.dyo + e * LPP]; v11[e] = sp[P.dyo + P.dxo + e * LPP];
+        vg[e] = gq[e * LPP];
+      }
       float d00[4], d01[4], d10[4], d11[4], dg[4];
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
@@ -130,10 +134,9 @@ __global__ __launch_bounds__(256) void lm_bwd_accum(BwdAccumArgs a) {
           for (int e = 0; e < 4; ++e) { c00[e] += d00[e]; c01[e] += d01[e]; c10[e] += d10[e]; c11[e] += d11[e]; }
         }
       }
-      float4* gp = (float4*)(a.d_grd + grd_base + (size_t)i * C);      // this (pixel, channels) is owned by this lane
-      float4 o = *gp;
-      o.x += dg[0]; o.y += dg[1]; o.z += dg[2]; o.w += dg[3];
-      *gp = o;
+      float* gp = a.d_grd + grd_base + (size_t)i * C;                  // this (pixel, channels) is owned by this lane
+#pragma unroll
+      for (int e = 0; e < 4; ++e) gp[e * LPP] += dg[e];
     }
     // reduce the per-pixel adjoints over the LPP lanes that share the pixel
 #pragma unroll
