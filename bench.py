@@ -69,7 +69,7 @@ def main():
     ap.add_argument('--n-iters', type=int, default=5)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-timing', action='store_true')
-    ap.add_argument('--train-steps', type=int, default=4, help='extra: time this many training steps (0 = skip)')
+    ap.add_argument('--train-steps', type=int, default=6, help='extra: time this many training steps (0 = skip)')
     a = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -156,7 +156,8 @@ def main():
               r[0].backward()
               opt.step()
               return r[0]
-          tstep()
+          for _ in range(2):          # warm-up: Adam state, caching-allocator segments for the backward workspaces
+              tstep()
           torch.cuda.synchronize()
           if dist:
               dist.barrier()
@@ -182,7 +183,7 @@ def main():
           train = {'value': round(B * world * a.train_steps / tdt, 3), 'unit': 'pairs/s', 'steps': a.train_steps,
                    'ms_per_step': round(tdt / a.train_steps * 1e3, 3), 'loss_finite': bool(torch.isfinite(lossv)),
                    'what': "forward(mode='train') + HIP backward (LM loop + both VGGs) + gradient all-reduce + Adam",
-                   'allreduce_bytes_per_step': (net.grad_sync.bytes_reduced // (a.train_steps + 1)) if dist else 0}
+                   'allreduce_bytes_per_step': (net.grad_sync.bytes_reduced // (a.train_steps + 2)) if dist else 0}
           if trecs:
               tagg = {}
               for name, ms, fl, by in trecs:
