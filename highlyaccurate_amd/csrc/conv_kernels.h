@@ -550,7 +550,7 @@ __global__ __launch_bounds__(256, 2) void conv02_kernel(Conv02Args a0) {
   for (int j = 0; j < 2; ++j)
 #pragma unroll
     for (int q = 0; q < 4; ++q) bias0[j][q] = *(const float4*)(a0.b0 + j * 32 + q * 8 + g * 4);
-  for (int m = wv; m * 32 < HPIX; m += 4) {
+  for (int m = wv; m * 32 < (CONV_VARIANT == 95 ? 0 : HPIX); m += 4) {   // (ablation 95: no conv0 phase)
     const int p = m * 32 + x, pc = p < HPIX ? p : HPIX - 1;
     const int hy = pc / HWID, hx = pc - hy * HWID;
     const float* ib = in + hy * IW + hx;
@@ -616,7 +616,7 @@ __global__ __launch_bounds__(256, 2) void conv02_kernel(Conv02Args a0) {
   const int aoff = ((wm * MT) * HWID + x) * PSTR + g * 16;
   stagger_priority();
 #pragma unroll 1
-  for (int sg = 0; sg < NSG; ++sg)
+  for (int sg = 0; sg < (CONV_VARIANT == 96 ? 0 : NSG); ++sg)   // (ablation 96: no conv2 MFMA loop)
     stage_mma<T, MT, NT, WD, PF_UPFRONT>(acc, lds + sg * BUF + aoff, ring, [](int) {});
 
   ConvArgs a{};
