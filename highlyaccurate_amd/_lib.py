@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get('HLA_LIB') or os.path.join(HERE, 'libhla.so')   # HLA_
 
 HLA_F32, HLA_BF16, HLA_F16 = 0, 1, 2
 HLA_VGG_WANT_CONF, HLA_VGG_DEFER_NORM, HLA_VGG_SAVE_FOR_BACKWARD = 1, 2, 4
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 class HlaError(RuntimeError):
@@ -29,7 +29,7 @@ class VggParams(C.Structure):
 class S2GLevel(C.Structure):
     _fields_ = [('sat_feat', C.c_void_p), ('grd_feat', C.c_void_p), ('grd_conf', C.c_void_p), ('xyz', C.c_void_p),
                 ('sat_inv_norm', C.c_void_p), ('grd_inv_norm', C.c_void_p),
-                ('A', C.c_int), ('h', C.c_int), ('w', C.c_int), ('C', C.c_int), ('row0', C.c_int),
+                ('A', C.c_int), ('h', C.c_int), ('w', C.c_int), ('C', C.c_int), ('row0', C.c_int), ('grd_row_skip', C.c_int),
                 ('meter_per_pixel', C.c_double), ('centre', C.c_double)]
 
 

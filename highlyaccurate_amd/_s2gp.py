@@ -154,15 +154,18 @@ class S2GPBase(nn.Module):
         lv = (_lib.S2GLevel * L)()
         for l in range(L):
             s, g = sat_feats[l], grd_feats[l]
-            A, h, w, Cn = s.shape[1], g.shape[1], g.shape[2], g.shape[3]
+            A, w, Cn = s.shape[1], g.shape[2], g.shape[3]
+            h = tables[l].shape[0]                     # the level's full map height; g may hold only its last rows
+            skip = h - g.shape[1]
             assert s.shape[2] == A and s.shape[3] == Cn and tuple(tables[l].shape) == (h, w, 3)
+            assert 0 <= skip <= h // 2, (h, g.shape)
             assert s.is_contiguous() and g.is_contiguous()
             lv[l].sat_feat, lv[l].grd_feat = s.data_ptr(), g.data_ptr()
             lv[l].grd_conf = grd_confs[l].data_ptr() if (self.using_weight and grd_confs[l] is not None) else 0
             lv[l].xyz = tables[l].data_ptr()
             lv[l].sat_inv_norm = sat_inv_norm[l].data_ptr() if sat_inv_norm is not None else 0
             lv[l].grd_inv_norm = grd_inv_norm[l].data_ptr() if grd_inv_norm is not None else 0
-            lv[l].A, lv[l].h, lv[l].w, lv[l].C, lv[l].row0 = A, h, w, Cn, h // 2
+            lv[l].A, lv[l].h, lv[l].w, lv[l].C, lv[l].row0, lv[l].grd_row_skip = A, h, w, Cn, h // 2, skip
             if self.ford:
                 lv[l].meter_per_pixel = float(extra['side_m']) / A          # models_ford.py:230
                 lv[l].centre = float(A // 2)                                # models_ford.py:231
@@ -225,8 +228,10 @@ class S2GPBase(nn.Module):
         _lib.check(rc, 'hla_s2g_lm_solve_bwd')
         return d_sat, d_grd, d_conf, d_lambda
 
-    def localise(self, sat_map, grd_img, want_conf, extra, level_first, init_pose):
+    def localise(self, sat_map, grd_img, want_conf, extra, level_first, init_pose, return_confs=True):
         """Both feature pyramids (normalisation deferred into the LM sums) + the whole LM loop.
+        return_confs=False (mode='test'): the caller does not need full-size confidence maps, so the ground extractor
+        only runs on the image rows that can influence the bottom half of its maps (``dead_ground_rows``).
         Under autograd (training) the same kernels run inside one autograd.Function whose backward is the HIP
         backward pass (hla_s2g_lm_solve_bwd + hla_vgg_backward for both extractors)."""
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
@@ -250,10 +255,25 @@ class S2GPBase(nn.Module):
                 t.record_stream(cur)
         else:
             sat_feats, _, sat_inv = vgg_forward_nhwc(self.SatFeatureNet, sat_map, want_conf=False, defer_norm=True)
-            grd_feats, grd_confs, grd_inv = vgg_forward_nhwc(self.GrdFeatureNet, grd_img, want_conf=want_conf, defer_norm=True)
+            grd_in = grd_img
+            skip = dead_ground_rows(grd_img.shape[-2]) if (not return_confs and os.environ.get('HLA_GRD_CROP', '1') != '0') else 0
+            if skip:
+                grd_in = grd_img[:, :, skip:, :].contiguous()
+            grd_feats, grd_confs, grd_inv = vgg_forward_nhwc(self.GrdFeatureNet, grd_in, want_conf=want_conf, defer_norm=True)
         trace = self.lm_solve(sat_feats, grd_feats, grd_confs, grd_img.shape[-2:], extra, level_first, init_pose,
                               sat_inv, grd_inv)
         return trace, grd_confs
+
+
+def dead_ground_rows(H: int) -> int:
+    """Rows at the top of the ground image that cannot influence anything the LM loop reads.
+    The loop only reads rows h_l/2.. of each ground map (models_kitti.py:1194-1199, models_ford.py:739-743) and the
+    per-sample L2_norm scale cancels in LM_update's own renormalisation (models_kitti.py:982-990).  Walking the
+    receptive field back through VGGUnet.forward (x21 <- dec2.3 <- dec2.1 <- {up(x18), x3}, x18 <- dec1.3 <- dec1.1 <-
+    {up(x15), x8}, x15 <- pool(conv14 <- conv12 <- conv10 <- x8), x8 <- pool(conv7 <- conv5 <- x3),
+    x3 <- pool(conv2 <- conv0 <- image)) the first input row needed is H/2 - 34; rounding down to a multiple of 8 keeps
+    the three 2x2 pools aligned.  The rows that ARE computed are bit-identical to the full-image run."""
+    return max(0, ((H // 2 - 34) // 8) * 8)
 
 
 class _LocaliseFn(torch.autograd.Function):

@@ -25,6 +25,7 @@ struct BwdAccumArgs {
   float* d_sat; float* d_grd; float* d_conf;
   double* part;            // [B,nt,PART_N]: 12 coefficient-adjoint sums
   int A, h, w, row0, npix, TP, nt, B, xcd_affine;
+  int hs, rskip;      // stored rows of grd/conf (h - grd_row_skip) and the skip itself
 };
 
 template <int C, bool USE_W>
@@ -42,7 +43,7 @@ __global__ __launch_bounds__(256) void lm_bwd_accum(BwdAccumArgs a) {
   if (t < np) {
     const int p = p0 + t;
     const int r = a.row0 + p / a.w, c = p % a.w;
-    const float cw = USE_W ? a.conf[((size_t)b * a.h + r) * a.w + c] : 1.f;
+    const float cw = USE_W ? a.conf[((size_t)b * a.hs + (r - a.rskip)) * a.w + c] : 1.f;
     pp[t] = lm_pixel<C>(cf, a.xyz + ((size_t)r * a.w + c) * 3, a.A, cw);
   }
   __syncthreads();
@@ -60,7 +61,7 @@ __global__ __launch_bounds__(256) void lm_bwd_accum(BwdAccumArgs a) {
   // LPP consecutive floats per pixel (whole cache lines) -- atomics are processed per touched line in L2
   const int sub = lane / LPP, cl = lane % LPP;
   const size_t sat_base = (size_t)b * a.A * a.A * C + cl;
-  const size_t grd_base = ((size_t)b * a.h * a.w + (size_t)a.row0 * a.w + p0) * C + cl;
+  const size_t grd_base = ((size_t)b * a.hs * a.w + (size_t)(a.row0 - a.rskip) * a.w + p0) * C + cl;
 
   // Every lane group walks a CONTIGUOUS run of ground pixels.  Neighbouring ground pixels oversample the satellite
   // map (2-20x laterally at KITTI geometry), so consecutive pixels mostly fall into the same texel cell: their tap
@@ -166,7 +167,7 @@ __global__ __launch_bounds__(256) void lm_bwd_accum(BwdAccumArgs a) {
     c12[0] = gu * qx[0]; c12[1] = gu * qx[1]; c12[2] = gu * qx[2]; c12[3] = gu;
     c12[4] = gv * qx[0]; c12[5] = gv * qx[1]; c12[6] = gv * qx[2]; c12[7] = gv;
     c12[8] = pixacc[t][2]; c12[9] = pixacc[t][3]; c12[10] = pixacc[t][4]; c12[11] = pixacc[t][5];
-    if (USE_W && a.d_conf) a.d_conf[((size_t)b * a.h + r) * a.w + c] += pixacc[t][8] * pp[t].gm;
+    if (USE_W && a.d_conf) a.d_conf[((size_t)b * a.hs + (r - a.rskip)) * a.w + c] += pixacc[t][8] * pp[t].gm;
   }
 #pragma unroll
   for (int k = 0; k < 12; ++k) c12[k] = wave_sum_f64(c12[k]);
@@ -366,6 +367,7 @@ extern "C" int hla_s2g_lm_solve_bwd(const hla_s2g_config* cfg, const hla_s2g_lev
     aa.sat_inv = v.sat_inv_norm; aa.grd_inv = v.grd_inv_norm;
     aa.d_sat = gr[l].d_sat_feat; aa.d_grd = gr[l].d_grd_feat; aa.d_conf = gr[l].d_grd_conf; aa.part = part;
     aa.A = v.A; aa.h = v.h; aa.w = v.w; aa.row0 = v.row0; aa.npix = (v.h - v.row0) * v.w;
+    aa.hs = v.h - v.grd_row_skip; aa.rskip = v.grd_row_skip;
     aa.TP = lm_pick_tile(aa.npix); aa.nt = (aa.npix + aa.TP - 1) / aa.TP; aa.B = B;
     aa.xcd_affine = (B >= 8) ? 1 : 0;
     const int nblk = aa.xcd_affine ? 8 * ((B + 7) / 8) * aa.nt : B * aa.nt;

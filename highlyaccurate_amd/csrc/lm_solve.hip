@@ -22,6 +22,7 @@ struct AccumArgs {
   const double* coef; // [B,COEF_N]
   double* part;       // [B,nt,PART_N]
   int A, h, w, row0, npix, TP, nt, B, xcd_affine;
+  int hs, rskip;      // stored rows of grd/conf (h - grd_row_skip) and the skip itself
 };
 
 template <int C, bool USE_W>
@@ -38,7 +39,7 @@ __global__ __launch_bounds__(256) void lm_accum(AccumArgs a) {
   if (t < np) {
     const int p = p0 + t;
     const int r = a.row0 + p / a.w, c = p % a.w;
-    const float cw = USE_W ? a.conf[((size_t)b * a.h + r) * a.w + c] : 1.f;
+    const float cw = USE_W ? a.conf[((size_t)b * a.hs + (r - a.rskip)) * a.w + c] : 1.f;
     pp[t] = lm_pixel<C>(cf, a.xyz + ((size_t)r * a.w + c) * 3, a.A, cw);
   }
   __syncthreads();
@@ -49,7 +50,7 @@ __global__ __launch_bounds__(256) void lm_accum(AccumArgs a) {
   const int lane = t & 63, wave = t >> 6;
   const int sub = lane / LPP, cl = (lane % LPP) * 4;
   const float* satb = a.sat + (size_t)b * a.A * a.A * C + cl;
-  const float* grdb = a.grd + ((size_t)b * a.h * a.w + (size_t)a.row0 * a.w + p0) * C + cl;
+  const float* grdb = a.grd + ((size_t)b * a.hs * a.w + (size_t)(a.row0 - a.rskip) * a.w + p0) * C + cl;
 
   float aS = 0, aG = 0, h00 = 0, h01 = 0, h02 = 0, h11 = 0, h12 = 0, h22 = 0;
   float u0 = 0, u1 = 0, u2 = 0, v0 = 0, v1 = 0, v2 = 0;
@@ -207,6 +208,7 @@ int hla_s2g_validate(const char* who, const hla_s2g_config* cfg, const hla_s2g_l
     HLA_REQUIRE(lv[l].sat_feat && lv[l].grd_feat && lv[l].xyz, "%s: level %d has null maps", who, l);
     HLA_REQUIRE(!cfg->using_weight || lv[l].grd_conf, "%s: using_weight needs grd_conf", who);
     HLA_REQUIRE(lv[l].row0 >= 0 && lv[l].row0 < lv[l].h, "%s: bad row0", who);
+    HLA_REQUIRE(lv[l].grd_row_skip >= 0 && lv[l].grd_row_skip <= lv[l].row0, "%s: grd_row_skip must be in [0,row0]", who);
     HLA_REQUIRE((size_t)lv[l].A * lv[l].A * C < (1u << 31), "%s: satellite map too large", who);
   }
   return HLA_OK;
@@ -262,6 +264,7 @@ extern "C" int hla_s2g_lm_solve(const hla_s2g_config* cfg, const hla_s2g_level* 
     AccumArgs aa{};
     aa.sat = v.sat_feat; aa.grd = v.grd_feat; aa.conf = v.grd_conf; aa.xyz = v.xyz; aa.coef = coef; aa.part = part;
     aa.A = v.A; aa.h = v.h; aa.w = v.w; aa.row0 = v.row0; aa.npix = (v.h - v.row0) * v.w;
+    aa.hs = v.h - v.grd_row_skip; aa.rskip = v.grd_row_skip;
     aa.TP = lm_pick_tile(aa.npix); aa.nt = (aa.npix + aa.TP - 1) / aa.TP; aa.B = B;
     aa.xcd_affine = (B >= 8) ? 1 : 0;
     const int nblk = aa.xcd_affine ? 8 * ((B + 7) / 8) * aa.nt : B * aa.nt;

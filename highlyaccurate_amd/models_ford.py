@@ -17,7 +17,8 @@ class LM_S2GP_Ford(S2GPBase):
         mode='train' -> 14-tuple (models_ford.py:858-862).  gt_* are [B] (float64 from the dataloader)."""
         want_conf = bool(self.using_weight) or mode == 'train'
         extra = dict(R_FL=R_FL, T_FL=T_FL, side_m=float(satmap_sidelength_meters))
-        trace, grd_confs = self.localise(sat_map, grd_img_left, want_conf, extra, level_first, init_pose)
+        trace, grd_confs = self.localise(sat_map, grd_img_left, want_conf, extra, level_first, init_pose,
+                                          return_confs=(mode == 'train'))
         us, vs, thetas = trace[..., 0], trace[..., 1], trace[..., 2]
         if mode == 'train':
             a = self.args

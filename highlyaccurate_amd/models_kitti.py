@@ -20,7 +20,8 @@ class LM_S2GP(S2GPBase):
         mode='train' -> the reference's 14-tuple                 (models_kitti.py:1312-1314)
         ``init_pose`` [B,3] (shift_u, shift_v, heading) is an extension; the reference always starts at 0."""
         want_conf = bool(self.using_weight) or mode == 'train'
-        trace, grd_confs = self.localise(sat_map, grd_img_left, want_conf, None, level_first, init_pose)
+        trace, grd_confs = self.localise(sat_map, grd_img_left, want_conf, None, level_first, init_pose,
+                                          return_confs=(mode == 'train'))
         shift_lons, shift_lats, thetas = trace[..., 0], trace[..., 1], trace[..., 2]   # models_kitti.py:1281-1283
         if mode == 'train':
             a = self.args

@@ -133,14 +133,17 @@ int hla_grid_sample(const float* image, const float* optical, const float* jac, 
  * ------------------------------------------------------------------------- */
 typedef struct hla_s2g_level {
   const float* sat_feat; /* [B,A,A,C]  NHWC fp32 */
-  const float* grd_feat; /* [B,h,w,C]  NHWC fp32 */
-  const float* grd_conf; /* [B,h,w] fp32 or NULL (needed iff using_weight) */
+  const float* grd_feat; /* [B,h-grd_row_skip,w,C]  NHWC fp32 (rows grd_row_skip..h-1 of the level's map) */
+  const float* grd_conf; /* [B,h-grd_row_skip,w] fp32 or NULL (needed iff using_weight) */
   const float* xyz;      /* [h,w,3] fp32 ground-plane points in the camera frame
                             (models_kitti.py:655-682 / models_ford.py:110-155) */
   const double* sat_inv_norm; /* [B] or NULL: sat_feat is raw, multiply by this (HLA_VGG_DEFER_NORM) */
   const double* grd_inv_norm; /* [B] or NULL: same for grd_feat */
   int A, h, w, C;
   int row0;              /* first ground-image row that takes part (h/2 for proj=='geo') */
+  int grd_row_skip;      /* rows [0,grd_row_skip) of the ground map are not stored (<= row0): only the bottom half is
+                            ever read (models_kitti.py:1194-1199), so a caller may extract features for the rows whose
+                            receptive field reaches it and nothing above -- see DESIGN.md "dead rows"; 0 = full map */
   double meter_per_pixel;/* metres per satellite-feature pixel at this level */
   double centre;         /* A/2 (KITTI, float) or A//2 (Ford, integer) */
 } hla_s2g_level;

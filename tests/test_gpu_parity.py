@@ -673,3 +673,37 @@ def test_ford_train_step_vs_oracle_autograd_small():
         e = np.linalg.norm(a - b) / np.linalg.norm(b)
         print(f'ford train grad {k}: rel-l2 {e:.2e}')
         assert e < (2e-4 if 'dec2' in k else 2e-2)
+
+
+def test_dead_ground_rows_elimination_is_exact(monkeypatch):
+    """mode='test' extracts ground features only for image rows >= dead_ground_rows(H) (88 at H=256): every row of the
+    three maps that the LM loop reads (h_l/2..) must be BIT-identical to the full-image run, and the pose trace equal up
+    to the rounding of the (mathematically cancelling) per-sample L2_norm scale."""
+    from oracle import ref_cpu as O
+    from highlyaccurate_amd._s2gp import dead_ground_rows
+    from highlyaccurate_amd.VGG import VGGUnet, vgg_forward_nhwc
+    assert dead_ground_rows(256) == 88 and dead_ground_rows(512) == 216 and dead_ground_rows(64) == 0
+    d = _dev()
+    for precision in ('fp32', 'bf16'):
+        net = VGGUnet(3, precision=precision)
+        net.load_state_dict(O.synth_vgg_state(np.random.RandomState(5), bias_scale=0.05))
+        net = net.to(d)
+        x = torch.rand(2, 3, 256, 1024, device=d)
+        full, cfull, _ = vgg_forward_nhwc(net, x, want_conf=True, defer_norm=True)
+        crop, ccrop, _ = vgg_forward_nhwc(net, x[:, :, 88:].contiguous(), want_conf=True, defer_norm=True)
+        for l in range(3):
+            h = full[l].shape[1]
+            skip = 88 >> (3 - l)
+            assert crop[l].shape[1] == h - skip
+            assert torch.equal(full[l][:, h // 2:], crop[l][:, h // 2 - skip:]), (precision, l)
+            assert torch.equal(cfull[l][:, h // 2:], ccrop[l][:, h // 2 - skip:]), (precision, l)
+    g = load_golden('e2e_kitti.npz')
+    seed, B = int(g['seeds'][0]), int(g['B'])
+    for kw in (dict(), dict(using_weight=1)):
+        monkeypatch.setenv('HLA_GRD_CROP', '0')
+        net0, _ = _run_kitti(seed, B, **kw)
+        monkeypatch.setenv('HLA_GRD_CROP', '1')
+        net1, _ = _run_kitti(seed, B, **kw)
+        dev = (net0.last_trace - net1.last_trace).abs().max().item()
+        print(f'dead-row elimination {kw}: max pose deviation {dev:.2e}')
+        assert dev < 2e-6
