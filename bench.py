@@ -94,7 +94,7 @@ def main():
                            train_damping=0, dropout=0, use_hessian=0, use_gt_depth=0, visualize=0,
                            coe_shift_lat=100.0, coe_shift_lon=100.0, coe_heading=100.0, coe_L1=100.0, coe_L2=100.0,
                            coe_L3=100.0, coe_L4=100.0, estimate_depth=0, precision=a.precision)
-    torch.manual_seed(1234 + rank)
+    torch.manual_seed(1234)                  # identical replicas on every rank (data-parallel training needs that) ...
     net = LM_S2GP(args)
     # random-init weights of the reference architecture: Kaiming-normal(fan_out), zero bias (torchvision's
     # non-pretrained VGG init; there is no network for the pretrained checkpoint)
@@ -104,6 +104,7 @@ def main():
             if m.bias is not None:
                 torch.nn.init.zeros_(m.bias)
     net = net.to(dev).eval()
+    torch.manual_seed(1234 + rank)           # ... and a different synthetic shard per rank (also decorrelates the re-init draws)
     B = a.batch
     sat = torch.rand(B, 3, 512, 512, device=dev)
     grd = torch.rand(B, 3, 256, 1024, device=dev)
