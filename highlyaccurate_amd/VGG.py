@@ -158,6 +158,7 @@ class VGGUnet(nn.Module):
         if level not in _LEVEL_SEL:
             raise NotImplementedError(f'VGGUnet level {level}: levels -1,-2,-3,2,3 are built (level 4 = x24 is not yet)')
         self.level = level
+        _dtype_code(precision)          # validate now, not at the first forward
         self.precision = precision
 
         def c(ci, co, bias):

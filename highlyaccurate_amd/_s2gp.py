@@ -157,9 +157,11 @@ class S2GPBase(nn.Module):
             A, w, Cn = s.shape[1], g.shape[2], g.shape[3]
             h = tables[l].shape[0]                     # the level's full map height; g may hold only its last rows
             skip = h - g.shape[1]
-            assert s.shape[2] == A and s.shape[3] == Cn and tuple(tables[l].shape) == (h, w, 3)
-            assert 0 <= skip <= h // 2, (h, g.shape)
-            assert s.is_contiguous() and g.is_contiguous()
+            if not (s.shape[2] == A and s.shape[3] == Cn and tuple(tables[l].shape) == (h, w, 3) and 0 <= skip <= h // 2
+                    and g.shape[0] == s.shape[0] and s.is_contiguous() and g.is_contiguous()
+                    and s.dtype == torch.float32 and g.dtype == torch.float32):
+                raise ValueError(f'level {l}: inconsistent feature maps sat {tuple(s.shape)} / grd {tuple(g.shape)} '
+                                 f'for a {tuple(grd_hw)} ground image')
             lv[l].sat_feat, lv[l].grd_feat = s.data_ptr(), g.data_ptr()
             lv[l].grd_conf = grd_confs[l].data_ptr() if (self.using_weight and grd_confs[l] is not None) else 0
             lv[l].xyz = tables[l].data_ptr()
@@ -234,6 +236,10 @@ class S2GPBase(nn.Module):
         only runs on the image rows that can influence the bottom half of its maps (``dead_ground_rows``).
         Under autograd (training) the same kernels run inside one autograd.Function whose backward is the HIP
         backward pass (hla_s2g_lm_solve_bwd + hla_vgg_backward for both extractors)."""
+        if sat_map.dim() != 4 or grd_img.dim() != 4 or sat_map.shape[0] != grd_img.shape[0] or sat_map.shape[1] != 3 \
+                or grd_img.shape[1] != 3 or sat_map.shape[2] != sat_map.shape[3]:
+            raise ValueError(f'expected sat_map [B,3,A,A] and grd_img [B,3,H,W] with one B, got {tuple(sat_map.shape)} '
+                             f'and {tuple(grd_img.shape)}')
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
             names = [n for n, _ in self.named_parameters()]
             params = [p for _, p in self.named_parameters()]

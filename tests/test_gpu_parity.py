@@ -707,3 +707,55 @@ def test_dead_ground_rows_elimination_is_exact(monkeypatch):
         dev = (net0.last_trace - net1.last_trace).abs().max().item()
         print(f'dead-row elimination {kw}: max pose deviation {dev:.2e}')
         assert dev < 2e-6
+
+
+@pytest.mark.parametrize('B,grd_hw,sat_a', [(3, (72, 264), 136), (1, (64, 256), 128), (5, (88, 200), 104)])
+def test_e2e_ragged_shapes_vs_oracle(B, grd_hw, sat_a):
+    """Sizes that are multiples of 8 but not of the 8x32 conv tile / the LM pixel tile, odd batch sizes, B = 1:
+    whole forward (fp32 mode) against the fp64 oracle."""
+    from oracle import ref_cpu as O
+    from highlyaccurate_amd.models_kitti import LM_S2GP
+    d = _dev()
+    args = O.default_args(N_iters=2)
+    sd = O.synth_model_state(3, bias_scale=0.02)
+    sat, grd, *_ = O.synth_images(11, B, grd_hw=grd_hw, sat_a=sat_a)
+    onet = O.LM_S2GP(args, grd_hw=grd_hw)
+    onet.load_state_dict(sd)
+    onet = onet.double()
+    torch.manual_seed(0)
+    with torch.no_grad():
+        ref = torch.stack(onet(sat.double(), grd.double(), mode='test'), -1).numpy()
+    net = LM_S2GP(args)
+    net.load_state_dict(sd)
+    net = net.to(d)
+    torch.manual_seed(0)
+    with torch.no_grad():
+        res = torch.stack(net(sat.to(d), grd.to(d), mode='test'), -1).cpu().numpy()
+    err = np.abs(res - ref).max()
+    print(f'ragged B={B} grd {grd_hw} sat {sat_a}: max pose err {err:.2e} (range {np.abs(ref).max():.2e})')
+    assert np.isfinite(res).all() and err < 2e-4
+
+
+def test_bad_arguments_raise():
+    """Error behaviour at the boundary: every misuse is a Python exception carrying hla_last_error(), never a crash."""
+    from oracle import ref_cpu as O
+    from highlyaccurate_amd import _lib
+    from highlyaccurate_amd.VGG import VGGUnet
+    from highlyaccurate_amd.models_kitti import LM_S2GP
+    d = _dev()
+    net = VGGUnet(3).to(d)
+    with pytest.raises(_lib.HlaError, match='multiples of 8'):
+        net(torch.zeros(1, 3, 36, 64, device=d))
+    with pytest.raises(ValueError):
+        VGGUnet(3, precision='int8')
+    with pytest.raises(NotImplementedError):
+        VGGUnet(4)
+    with pytest.raises(NotImplementedError):
+        LM_S2GP(O.default_args(Optimizer='SGD'))
+    m = LM_S2GP(O.default_args(N_iters=1)).to(d)
+    with pytest.raises(Exception):                       # sat / grd batch mismatch
+        with torch.no_grad():
+            m(torch.zeros(2, 3, 128, 128, device=d), torch.zeros(1, 3, 64, 256, device=d), mode='test')
+    lib = _lib.load()
+    assert lib.hla_vgg_forward(None, None, None, None, None, None, None, 0, 1, 8, 8, 3, 0, 0, None) != 0
+    assert b'null' in lib.hla_last_error()
