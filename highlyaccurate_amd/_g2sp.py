@@ -1,0 +1,104 @@
+"""``LM_G2SP`` -- the ground->satellite variant of the KITTI model (``models_kitti.py:22-499``, ``proj='geo'``): the
+ground feature map is projected onto the satellite plane with the per-sample camera intrinsics and the LM update
+runs on the satellite grid.  Same module surface as the reference (ctor argument, ``forward(sat_map, grd_img_left,
+left_camera_k, gt_shift_u, gt_shift_v, gt_heading, mode, ...)``, state-dict keys).  Forward only so far: the HIP
+backward of this direction is not built, so calling it with autograd enabled raises."""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+from torch import nn
+
+from . import _lib, utils
+from ._s2gp import loss_func
+from .VGG import VGGUnet, vgg_forward_nhwc
+
+
+class LM_G2SP(nn.Module):
+    def __init__(self, args):
+        super().__init__()
+        self.args = args
+        self.level = args.level
+        self.N_iters = args.N_iters
+        self.using_weight = args.using_weight
+        self.loss_method = args.loss_method
+        if args.level != 3:
+            raise NotImplementedError('only args.level == 3 (x15, x18, x21) is built so far')
+        if getattr(args, 'proj', 'geo') != 'geo':
+            raise NotImplementedError("only proj='geo' is built (proj='nn' needs VGGUnet_G2S, VGG.py:206-350)")
+        precision = getattr(args, 'precision', 'fp32')
+        self.SatFeatureNet = VGGUnet(self.level, precision=precision)
+        self.GrdFeatureNet = VGGUnet(self.level, precision=precision)
+        self.damping = nn.Parameter(args.damping * torch.ones(size=(1, 3), dtype=torch.float32))   # models_kitti.py:41
+        self.meters_per_pixel = [utils.get_meter_per_pixel() * (2 ** (3 - l)) for l in range(4)]
+        self.last_trace = None
+        self.last_normal_eq = None
+        self.keep_normal_eq = False
+
+    def lm_solve(self, sat_feats, grd_feats, grd_confs, camera_k, ori_hw, init_pose=None, sat_inv_norm=None,
+                 grd_inv_norm=None):
+        """NHWC fp32 feature lists (raw + [L,B] fp64 inverse norms, or already normalised) -> trace [B,N_iters,L,3]."""
+        lib = _lib.load()
+        dev = sat_feats[0].device
+        a = self.args
+        B, L = sat_feats[0].shape[0], len(sat_feats)
+        cfg = _lib.S2GConfig()
+        cfg.ford, cfg.n_levels, cfg.n_iters, cfg.level_first = 0, L, self.N_iters, 0
+        cfg.using_weight, cfg.use_hessian, cfg.dof = (1 if self.using_weight else 0), 0, 3
+        cfg.shift_range_lat, cfg.shift_range_lon = float(a.shift_range_lat), float(a.shift_range_lon)
+        cfg.rotation_range = float(a.rotation_range)
+        lam = self.damping.detach().double().reshape(-1).tolist() if getattr(a, 'train_damping', 0) else [float(a.damping)] * 3
+        for i in range(3):
+            cfg.damping[i] = lam[i]
+        lv = (_lib.S2GLevel * L)()
+        for l in range(L):
+            s, g = sat_feats[l], grd_feats[l]
+            A, Cn = s.shape[1], s.shape[3]
+            if not (s.shape[2] == A and g.shape[0] == B and g.shape[3] == Cn and s.is_contiguous() and g.is_contiguous()
+                    and s.dtype == torch.float32 and g.dtype == torch.float32):
+                raise ValueError(f'level {l}: inconsistent feature maps sat {tuple(s.shape)} / grd {tuple(g.shape)}')
+            lv[l].sat_feat, lv[l].grd_feat = s.data_ptr(), g.data_ptr()
+            lv[l].grd_conf = grd_confs[l].data_ptr() if (self.using_weight and grd_confs[l] is not None) else 0
+            lv[l].sat_inv_norm = sat_inv_norm[l].data_ptr() if sat_inv_norm is not None else 0
+            lv[l].grd_inv_norm = grd_inv_norm[l].data_ptr() if grd_inv_norm is not None else 0
+            lv[l].A, lv[l].h, lv[l].w, lv[l].C, lv[l].row0, lv[l].grd_row_skip = A, g.shape[1], g.shape[2], Cn, 0, 0
+            lv[l].meter_per_pixel = utils.get_meter_per_pixel() * utils.get_process_satmap_sidelength() / A   # 71-72
+            lv[l].centre = float(A // 2)
+        K = camera_k.to(dev).float().contiguous()
+        if tuple(K.shape) != (B, 3, 3):
+            raise ValueError(f'left_camera_k must be [B,3,3], got {tuple(K.shape)}')
+        trace = torch.empty(B, self.N_iters, L, 3, device=dev, dtype=torch.float32)
+        neq = torch.empty(L * self.N_iters, B, 16, device=dev, dtype=torch.float64) if self.keep_normal_eq else None
+        nbytes = lib.hla_g2s_workspace_bytes(C.byref(cfg), lv, B)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        p0 = init_pose.to(dev).float().contiguous() if init_pose is not None else None
+        rc = lib.hla_g2s_lm_solve(C.byref(cfg), lv, _lib.ptr(K), int(ori_hw[0]), int(ori_hw[1]), _lib.ptr(p0), _lib.ptr(trace),
+                                  _lib.ptr(neq), _lib.ptr(ws), nbytes, B, _lib.stream_ptr())
+        _lib.check(rc, 'hla_g2s_lm_solve')
+        self.last_trace, self.last_normal_eq = trace, neq
+        return trace
+
+    def forward(self, sat_map, grd_img_left, left_camera_k, gt_shift_u=None, gt_shift_v=None, gt_heading=None,
+                mode='train', file_name=None, gt_depth=None, init_pose=None):
+        """mode='test' -> (shift_lat[B], shift_lon[B], theta[B]) (models_kitti.py:498-499);
+        mode='train' -> the 14-tuple (486-496) -- values only: no backward for this direction yet."""
+        if sat_map.dim() != 4 or grd_img_left.dim() != 4 or sat_map.shape[0] != grd_img_left.shape[0] \
+                or sat_map.shape[2] != sat_map.shape[3]:
+            raise ValueError(f'expected sat_map [B,3,A,A] and grd_img [B,3,H,W], got {tuple(sat_map.shape)} and '
+                             f'{tuple(grd_img_left.shape)}')
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            raise NotImplementedError('LM_G2SP: the HIP backward of the ground->satellite loop is not built yet; '
+                                      'call under torch.no_grad()')
+        want_conf = bool(self.using_weight) or mode == 'train'
+        sat_feats, _, sat_inv = vgg_forward_nhwc(self.SatFeatureNet, sat_map, want_conf=False, defer_norm=True)
+        grd_feats, grd_confs, grd_inv = vgg_forward_nhwc(self.GrdFeatureNet, grd_img_left, want_conf=want_conf, defer_norm=True)
+        trace = self.lm_solve(sat_feats, grd_feats, grd_confs, left_camera_k, grd_img_left.shape[-2:], init_pose, sat_inv, grd_inv)
+        shift_lons, shift_lats, thetas = trace[..., 0], trace[..., 1], trace[..., 2]        # models_kitti.py:470-472
+        if mode == 'train':
+            a = self.args
+            out = loss_func(self.loss_method, None, None, None, shift_lats, shift_lons, thetas,
+                            gt_shift_v[:, 0], gt_shift_u[:, 0], gt_heading[:, 0], None, None,
+                            a.coe_shift_lat, a.coe_shift_lon, a.coe_heading, a.coe_L1, a.coe_L2, a.coe_L3, a.coe_L4)
+            return (*out, [c.unsqueeze(1) for c in grd_confs])
+        return shift_lats[:, -1, -1], shift_lons[:, -1, -1], thetas[:, -1, -1]

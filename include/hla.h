@@ -177,6 +177,22 @@ int hla_s2g_lm_solve(const hla_s2g_config* cfg, const hla_s2g_level* levels, con
  * L2-NORMALISED maps (inv_norm * stored map when the level carries inv norms); buffers are ACCUMULATED into
  * (the caller zero-fills them), d_sat_feat with fp32 atomics.
  * ------------------------------------------------------------------------- */
+/* ------------------------------------------------------------------------- *
+ * The same loop in the ground -> satellite direction: LM_G2SP (models_kitti.py:22-499, proj == 'geo')
+ *   get_warp_sat2real 53-84, seq_warp_real2camera 86-161, project_grd_to_map 163-303, LM_update 333-379,
+ *   loop 415-468.  Every satellite-map pixel samples the ground map where it projects to in the camera.
+ * cfg        ford = 0, dof = 3, level_first = 0, use_hessian = 0 (the reference has no such variants here);
+ *            damping[3] = the `damping` parameter (train_damping) or args.damping
+ * levels[l]  sat_feat [B,A,A,C], grd_feat [B,h,w,C] (whole map: grd_row_skip = 0), grd_conf [B,h,w] iff using_weight,
+ *            meter_per_pixel; xyz / row0 / centre are not read (the satellite grid is implicit, centre = A/2 integer)
+ * camera_k   [B,3,3] fp32 intrinsics of the ori_h x ori_w ground IMAGE (left_camera_k, train_kitti.py:47)
+ * trace      [B,N_iters,L,3] = (shift_u, shift_v, heading) after every step; no re-initialisation rule here.
+ * Forward only in this ABI version (the backward of this direction is not built yet). */
+size_t hla_g2s_workspace_bytes(const hla_s2g_config* cfg, const hla_s2g_level* levels, int B);
+int hla_g2s_lm_solve(const hla_s2g_config* cfg, const hla_s2g_level* levels, const float* camera_k, int ori_h, int ori_w,
+                     const float* pose0, float* trace, double* normal_eq, void* workspace, size_t workspace_bytes,
+                     int B, hla_stream_t stream);
+
 typedef struct hla_s2g_level_grad {
   float* d_sat_feat; /* [B,A,A,C] fp32 */
   float* d_grd_feat; /* [B,h,w,C] fp32 */

@@ -275,6 +275,48 @@ def gen_hires(mk, seed=1, B=1):
     np.savez_compressed(os.path.join(GOLD, 'e2e_kitti_hires.npz'), **out)
 
 
+def gen_g2s(mk, seeds, B=1):
+    """LM_G2SP (ground -> satellite direction), full KITTI shape.  The class calls .cuda() on a few
+    helper tensors (models_kitti.py:59,68,73); here those calls are made no-ops so that the unmodified code runs on the
+    CPU.  It mixes hard-coded float32 tensors into its matmuls (124-133), so it can only run in fp32."""
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    args = O.default_args()
+    out = {'seeds': np.array(seeds), 'B': np.array(B), 'K': np.array(O.KITTI_K)}
+    for seed in seeds:
+        net = mk.LM_G2SP(args)
+        torch.autograd.set_detect_anomaly(False)
+        sd = O.synth_model_state(seed)
+        sd['damping'] = args.damping * torch.ones(1, 3)
+        net.load_state_dict(sd)
+        sat, grd, gu, gv, gh = O.synth_images(seed + 100, B)
+        K = torch.tensor([O.KITTI_K], dtype=torch.float32).repeat(B, 1, 1)
+        log = []
+        orig = net.LM_update
+
+        def wrap(*a, **k):
+            r = orig(*a, **k)
+            log.append(torch.stack([x.detach()[:, 0] for x in r], -1))
+            return r
+        net.LM_update = wrap
+        with torch.no_grad():
+            res = net(sat, grd, K, mode='test')
+        out[f'trace32_{seed}'] = torch.stack(log, 1).double().numpy()          # [B, steps, 3] = (u, v, theta)
+        out[f'final32_{seed}'] = torch.stack([r.detach() for r in res], -1).double().numpy()
+        # the same with confidence weighting
+        net.using_weight = 1
+        log.clear()
+        with torch.no_grad():
+            net(sat, grd, K, mode='test')
+        out[f'trace32w_{seed}'] = torch.stack(log, 1).double().numpy()
+        net.using_weight = 0
+        # train-mode tuple
+        res = net(sat, grd, K, gu, gv, gh, mode='train')
+        out[f'tuple32_{seed}'] = np.stack([np.atleast_1d(r.detach().double().numpy()) if r.dim() else
+                                           np.full(3, float(r)) for r in res[:9]])
+        print(f'g2s seed {seed}: final {out[f"final32_{seed}"].tolist()} range {np.abs(out[f"trace32_{seed}"]).max():.3f}', flush=True)
+    np.savez_compressed(os.path.join(GOLD, 'e2e_kitti_g2s.npz'), **out)
+
+
 def ford_extra(B):
     R_FL = torch.tensor([[[0., 0., 1.], [1., 0., 0.], [0., 1., 0.]]]).repeat(B, 1, 1)
     T_FL = torch.tensor([[1.7, 0.3, -1.2]]).repeat(B, 1)
@@ -343,6 +385,8 @@ if __name__ == '__main__':
         gen_ford(mf, (seeds or [1])[:2])
     if a.only in ('all', 'train'):
         gen_train(mk, (seeds or [1])[0])
+    if a.only in ('all', 'g2s'):
+        gen_g2s(mk, seeds or [1, 2])
     if a.only in ('all', 'hires'):
         gen_hires(mk, (seeds or [1])[0])
     if a.only in ('all', 'trainw'):

@@ -496,6 +496,115 @@ class LM_S2GP(_S2GPBase):
         return shift_lats[:, -1, -1], shift_lons[:, -1, -1], thetas[:, -1, -1]
 
 
+# ----------------------------------------------------------------------------
+# ground -> satellite direction (LM_G2SP, models_kitti.py:22-499), proj == 'geo'
+# ----------------------------------------------------------------------------
+def g2s_pose_to_uv(args, A, shift_u, shift_v, heading, camera_k, grd_h, grd_w, ori_h, ori_w, require_jac=True):
+    """get_warp_sat2real (models_kitti.py:53-84) + seq_warp_real2camera (86-161): for every pixel of an A x A
+    satellite map, the ground-image coordinates (at the grd_h x grd_w feature resolution) it projects to, and their
+    derivatives w.r.t. (shift_u, shift_v, heading).  Returns uv [B,A,A,2], (du, dv, dtheta) each [B,A,A,2], mask [B,A,A,1]."""
+    dt = shift_u.dtype
+    B = shift_u.shape[0]
+    i = torch.arange(A)
+    ii, jj = torch.meshgrid(i, i, indexing='ij')
+    uvc = torch.stack([jj, ii], -1).to(dt) - (A // 2)                      # (u, v) from the centre, 66-68
+    mpp = meter_per_pixel() * SATMAP_PROCESS_SIDELENGTH / A                # 71-72
+    X, Z = mpp * uvc[..., 1], mpp * uvc[..., 0]                            # R = [[0,1],[1,0]]: v -> X, u -> Z   (73-78)
+    XYZ1 = torch.stack([X, torch.zeros_like(X), Z, torch.ones_like(X)], -1)    # [A,A,4]
+    su_m = args.shift_range_lon * shift_u
+    sv_m = args.shift_range_lat * shift_v
+    k = args.rotation_range / 180 * np.pi
+    ang = heading * k
+    c, s = torch.cos(-ang), torch.sin(-ang)
+    z, o = torch.zeros_like(c), torch.ones_like(c)
+    R = torch.cat([c, z, -s, z, o, z, s, z, c], -1).view(B, 3, 3)          # 99
+    T = torch.cat([sv_m, CAMERA_HEIGHT * o, -su_m], -1).unsqueeze(-1)      # 105-106
+    K = camera_k.to(dt).clone()
+    K[:, :1, :] = camera_k[:, :1, :].to(dt) * grd_w / ori_w               # 111-113
+    K[:, 1:2, :] = camera_k[:, 1:2, :].to(dt) * grd_h / ori_h
+    P = K @ torch.cat([R, T], -1)                                          # [B,3,4]
+    uv1 = (P[:, None, None] * XYZ1[None, :, :, None, :]).sum(-1)           # [B,A,A,3]
+    last = torch.maximum(uv1[..., 2:], torch.full_like(uv1[..., 2:], 1e-6))
+    uv = uv1[..., :2] / last
+    mask = last > 1e-6
+    if not require_jac:
+        return uv, None, mask
+    dT_dx = args.shift_range_lon * torch.tensor([0.0, 0.0, -1.0], dtype=dt).view(1, 3, 1).expand(B, 3, 1)
+    dT_dy = args.shift_range_lat * torch.tensor([1.0, 0.0, 0.0], dtype=dt).view(1, 3, 1).expand(B, 3, 1)
+    dR = k * torch.cat([s, z, c, z, z, z, -c, z, s], -1).view(B, 3, 3)     # 130
+    Z3, Z1 = torch.zeros(B, 3, 3, dtype=dt), torch.zeros(B, 3, 1, dtype=dt)
+    jac = []
+    for dP in (K @ torch.cat([Z3, dT_dx], -1), K @ torch.cat([Z3, dT_dy], -1), K @ torch.cat([dR, Z1], -1)):
+        d1 = (dP[:, None, None] * XYZ1[None, :, :, None, :]).sum(-1)
+        d = d1[..., :2] / last - uv1[..., :2] * d1[..., 2:] / last ** 2    # 143-145
+        jac.append(torch.where(mask, d, torch.zeros_like(d)))
+    return uv, tuple(jac), mask
+
+
+def lm_update_g2s(args, damping_param, shift_u, shift_v, heading, grd_feat_proj, grd_conf_proj, sat_feat, dfeat_dpose,
+                  using_weight):
+    """LM_G2SP.LM_update (models_kitti.py:333-379): no renormalisation, no re-initialisation, always 3-DoF,
+    lambda = the `damping` parameter itself when train_damping else args.damping."""
+    N, B, C, H, W = dfeat_dpose.shape
+    dt = sat_feat.dtype
+    r = (grd_feat_proj - sat_feat).reshape(B, -1, 1)
+    lam = (damping_param if args.train_damping else args.damping * torch.ones(1, 3)).to(dt)
+    Jb = dfeat_dpose.flatten(2).permute(1, 2, 0)                           # [B,D,3]
+    JtW = Jb.transpose(1, 2)
+    if using_weight:
+        JtW = JtW * grd_conf_proj.expand(B, C, H, W).reshape(B, 1, -1)
+    Hm = JtW @ Jb
+    delta = -torch.inverse(Hm + lam * torch.eye(3, dtype=dt)) @ JtW @ r
+    return shift_u + delta[:, 0:1, 0], shift_v + delta[:, 1:2, 0], heading + delta[:, 2:, 0]
+
+
+class LM_G2SP(nn.Module):
+    """KITTI model, ground -> satellite projection (models_kitti.py:22-499), proj == 'geo'."""
+
+    def __init__(self, args):
+        super().__init__()
+        self.args = args
+        self.level = args.level
+        self.N_iters = args.N_iters
+        self.using_weight = args.using_weight
+        self.SatFeatureNet = VGGUnet(self.level)
+        self.GrdFeatureNet = VGGUnet(self.level)
+        self.damping = nn.Parameter(args.damping * torch.ones(1, 3))       # models_kitti.py:41
+        self.trace = None
+
+    def project_grd_to_map(self, grd_f, grd_c, su, sv, th, camera_k, A, ori_h, ori_w):
+        """models_kitti.py:163-303: features are NOT multiplied by the z>0 mask (only the Jacobian is)."""
+        h, w = grd_f.shape[-2:]
+        uv, jac, _ = g2s_pose_to_uv(self.args, A, su, sv, th, camera_k, h, w, ori_h, ori_w)
+        f, new_jac = grid_sample(grd_f, uv, torch.stack(jac, 0))
+        c = grid_sample(grd_c, uv)[0] if grd_c is not None else None
+        return f, c, new_jac
+
+    def forward(self, sat_map, grd_img_left, left_camera_k, gt_shift_u=None, gt_shift_v=None, gt_heading=None,
+                mode='train', file_name=None, gt_depth=None):
+        B, _, ori_h, ori_w = grd_img_left.shape
+        sat_feats, _ = self.SatFeatureNet(sat_map)
+        grd_feats, grd_confs = self.GrdFeatureNet(grd_img_left)
+        dt = sat_map.dtype
+        su, sv, th = (torch.zeros(B, 1, dtype=dt) for _ in range(3))
+        us, vs, ts = [], [], []
+        for _ in range(self.N_iters):
+            u_, v_, t_ = [], [], []
+            for l in range(len(sat_feats)):
+                A = sat_feats[l].shape[-1]
+                f, c, jac = self.project_grd_to_map(grd_feats[l], grd_confs[l], su, sv, th, left_camera_k, A, ori_h, ori_w)
+                su, sv, th = lm_update_g2s(self.args, self.damping, su, sv, th, f, c, sat_feats[l], jac, self.using_weight)
+                u_.append(su[:, 0]); v_.append(sv[:, 0]); t_.append(th[:, 0])
+            us.append(torch.stack(u_, 1)); vs.append(torch.stack(v_, 1)); ts.append(torch.stack(t_, 1))
+        shift_lats, shift_lons, thetas = torch.stack(vs, 1), torch.stack(us, 1), torch.stack(ts, 1)   # 470-472
+        self.trace = (shift_lats, shift_lons, thetas)
+        if mode == 'train':
+            out = loss_func(shift_lats, shift_lons, thetas, gt_shift_v[:, 0], gt_shift_u[:, 0], gt_heading[:, 0],
+                            self.args.coe_shift_lat, self.args.coe_shift_lon, self.args.coe_heading)
+            return (*out, grd_confs)
+        return shift_lats[:, -1, -1], shift_lons[:, -1, -1], thetas[:, -1, -1]
+
+
 class LM_S2GP_Ford(_S2GPBase):
     """Ford model, models_ford.py:21-1036 (estimate_depth=0 path)."""
     ford = True

@@ -759,3 +759,47 @@ def test_bad_arguments_raise():
     lib = _lib.load()
     assert lib.hla_vgg_forward(None, None, None, None, None, None, None, 0, 1, 8, 8, 3, 0, 0, None) != 0
     assert b'null' in lib.hla_last_error()
+
+
+def test_g2s_e2e_vs_reference_golden_and_oracle():
+    """LM_G2SP (ground -> satellite direction), full KITTI shape, fp32 mode.  The reference itself only
+    runs in fp32, so the gate is |hip - oracle_fp64| <= max(tol, 2*|ref_fp32 - oracle_fp64|) per component, and
+    additionally |hip - ref_fp32| is reported."""
+    from oracle import ref_cpu as O
+    from highlyaccurate_amd.models_kitti import LM_G2SP
+    g = load_golden('e2e_kitti_g2s.npz')
+    B = int(g['B'])
+    d = _dev()
+    for seed in [int(s) for s in g['seeds']]:
+        for uw, key in ((0, f'trace32_{seed}'), (1, f'trace32w_{seed}')):
+            args = O.default_args(using_weight=uw)
+            sd = O.synth_model_state(seed)
+            sd['damping'] = args.damping * torch.ones(1, 3)
+            onet = O.LM_G2SP(args)
+            onet.load_state_dict(sd)
+            onet = onet.double()
+            sat, grd, gu, gv, gh = O.synth_images(seed + 100, B)
+            K = torch.tensor([O.KITTI_K], dtype=torch.float32).repeat(B, 1, 1)
+            with torch.no_grad():
+                onet(sat.double(), grd.double(), K, mode='test')
+            lat, lon, th = onet.trace
+            o64 = torch.stack([lon, lat, th], -1).reshape(B, -1, 3).numpy()
+            net = LM_G2SP(args)
+            net.load_state_dict(sd)
+            net = net.to(d)
+            with torch.no_grad():
+                res = net(sat.to(d), grd.to(d), K.to(d), mode='test')
+            got = net.last_trace.reshape(B, -1, 3).cpu().numpy().astype(np.float64)
+            _pose_gate(got, o64, g[key], f'g2s seed {seed} using_weight={uw}')
+            print(f'   |hip - reference_fp32| max {np.abs(got - g[key]).max():.2e}')
+            np.testing.assert_array_equal(torch.stack(res, -1).cpu().numpy()[:, [1, 0, 2]], got[:, -1].astype(np.float32))
+    # train-mode tuple (values), bf16 mode finite
+    with torch.no_grad():
+        tup = net(sat.to(d), grd.to(d), K.to(d), gu.to(d), gv.to(d), gh.to(d), mode='train')
+    assert len(tup) == 14 and tup[13][2].shape == (B, 1, 128, 512)
+    nb = LM_G2SP(O.default_args(precision='bf16')).to(d)
+    with torch.no_grad():
+        r = nb(sat.to(d), grd.to(d), K.to(d), mode='test')
+    assert all(torch.isfinite(x).all() for x in r)
+    with pytest.raises(NotImplementedError):
+        net(sat.to(d), grd.to(d), K.to(d), gu.to(d), gv.to(d), gh.to(d), mode='train')

@@ -184,3 +184,35 @@ def test_oracle_train_step_matches_reference_autograd_golden():
         ref = g['grad64_' + k]
         got = np.concatenate([[gr.abs().sum().item(), (gr * gr).sum().item()], gr[sample_idx(gr.numel(), 77)].numpy()])
         np.testing.assert_allclose(got, ref, rtol=1e-5, atol=1e-7 * np.abs(ref).max(), err_msg=k)
+
+
+def _g2s_oracle(seed, B, dtype, using_weight=0):
+    args = O.default_args(using_weight=using_weight)
+    net = O.LM_G2SP(args)
+    sd = O.synth_model_state(seed)
+    sd['damping'] = args.damping * torch.ones(1, 3)
+    net.load_state_dict(sd)
+    net = net.to(dtype)
+    sat, grd, gu, gv, gh = O.synth_images(seed + 100, B)
+    K = torch.tensor([O.KITTI_K], dtype=torch.float32).repeat(B, 1, 1)
+    return net, sat.to(dtype), grd.to(dtype), K, (gu.to(dtype), gv.to(dtype), gh.to(dtype))
+
+
+def test_oracle_g2s_matches_reference_golden():
+    """LM_G2SP (ground -> satellite direction): the restatement against the pose trace of the REAL reference (which can
+    only run in fp32: models_kitti.py:124-133 mixes hard-coded float32 tensors into its matmuls), full KITTI shape."""
+    g = load_golden('e2e_kitti_g2s.npz')
+    seed, B = int(g['seeds'][0]), int(g['B'])
+    for uw, key in ((0, f'trace32_{seed}'), (1, f'trace32w_{seed}')):
+        net, sat, grd, K, gt = _g2s_oracle(seed, B, torch.float32, uw)
+        with torch.no_grad():
+            net(sat, grd, K, mode='test')
+        lat, lon, th = net.trace
+        got = torch.stack([lon, lat, th], -1).reshape(B, -1, 3).double().numpy()      # (u, v, theta) per step
+        err = np.abs(got - g[key]).max()
+        print(f'oracle vs reference, g2s using_weight={uw} fp32: max pose err {err:.2e} (range {np.abs(g[key]).max():.2e})')
+        assert err < 2e-5
+    net, sat, grd, K, gt = _g2s_oracle(seed, B, torch.float32)
+    res = net(sat, grd, K, *gt, mode='train')
+    got = np.stack([np.atleast_1d(r.detach().double().numpy()) if r.dim() else np.full(3, float(r)) for r in res[:9]])
+    np.testing.assert_allclose(got, g[f'tuple32_{seed}'], rtol=2e-3, atol=2e-4)
