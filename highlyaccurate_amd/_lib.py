@@ -93,6 +93,11 @@ def load() -> C.CDLL:
     lib.hla_g2s_workspace_bytes.argtypes = [C.POINTER(S2GConfig), C.POINTER(S2GLevel), i]
     lib.hla_g2s_lm_solve.restype = i
     lib.hla_g2s_lm_solve.argtypes = [C.POINTER(S2GConfig), C.POINTER(S2GLevel), vp, i, i, vp, vp, vp, vp, sz, i, vp]
+    lib.hla_g2s_bwd_workspace_bytes.restype = sz
+    lib.hla_g2s_bwd_workspace_bytes.argtypes = [C.POINTER(S2GConfig), C.POINTER(S2GLevel), i]
+    lib.hla_g2s_lm_solve_bwd.restype = i
+    lib.hla_g2s_lm_solve_bwd.argtypes = [C.POINTER(S2GConfig), C.POINTER(S2GLevel), C.POINTER(S2GLevelGrad), vp, i, i, vp, vp,
+                                         vp, vp, vp, vp, sz, i, vp]
     lib.hla_s2g_lm_solve.restype = i
     lib.hla_s2g_lm_solve.argtypes = [C.POINTER(S2GConfig), C.POINTER(S2GLevel), vp, vp, vp, vp, vp, vp, vp, sz, i, vp]
     lib.hla_s2g_bwd_workspace_bytes.restype = sz

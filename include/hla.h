@@ -187,7 +187,7 @@ int hla_s2g_lm_solve(const hla_s2g_config* cfg, const hla_s2g_level* levels, con
  *            meter_per_pixel; xyz / row0 / centre are not read (the satellite grid is implicit, centre = A/2 integer)
  * camera_k   [B,3,3] fp32 intrinsics of the ori_h x ori_w ground IMAGE (left_camera_k, train_kitti.py:47)
  * trace      [B,N_iters,L,3] = (shift_u, shift_v, heading) after every step; no re-initialisation rule here.
- * Forward only in this ABI version (the backward of this direction is not built yet). */
+ * normal_eq  [steps,B,16] or NULL: the 12 sums of every step in slots 2..13 (slots 0,1 = 1), needed by the backward */
 size_t hla_g2s_workspace_bytes(const hla_s2g_config* cfg, const hla_s2g_level* levels, int B);
 int hla_g2s_lm_solve(const hla_s2g_config* cfg, const hla_s2g_level* levels, const float* camera_k, int ori_h, int ori_w,
                      const float* pose0, float* trace, double* normal_eq, void* workspace, size_t workspace_bytes,
@@ -207,6 +207,17 @@ int hla_s2g_lm_solve_bwd(const hla_s2g_config* cfg, const hla_s2g_level* levels,
                          const float* R_FL, const float* T_FL, const float* pose0, const float* trace,
                          const double* normal_eq, const float* d_trace, double* d_damping, void* workspace,
                          size_t workspace_bytes, int B, hla_stream_t stream);
+
+/* Backward of hla_g2s_lm_solve (autograd through the same reference lines).  grads[l]: d_sat_feat [B,A,A,C] and
+ * d_grd_feat [B,h,w,C] are ACCUMULATED into (zero them first), likewise d_grd_conf [B,h,w] iff using_weight;
+ * d_damping[3] (fp64) is overwritten with d(loss)/d(lambda) -- in this direction lambda IS the `damping` parameter
+ * (models_kitti.py:41,358).  Gradients are w.r.t. the L2-normalised maps, as hla_vgg_backward expects. */
+size_t hla_g2s_bwd_workspace_bytes(const hla_s2g_config* cfg, const hla_s2g_level* levels, int B);
+int hla_g2s_lm_solve_bwd(const hla_s2g_config* cfg, const hla_s2g_level* levels, const hla_s2g_level_grad* grads,
+                         const float* camera_k, int ori_h, int ori_w, const float* pose0, const float* trace,
+                         const double* normal_eq, const float* d_trace, double* d_damping, void* workspace,
+                         size_t workspace_bytes, int B, hla_stream_t stream);
+
 
 /* ------------------------------------------------------------------------- *
  * Measurement hooks (no reference counterpart; used by bench.py for the roofline numbers).

@@ -803,3 +803,99 @@ def test_g2s_e2e_vs_reference_golden_and_oracle():
     assert all(torch.isfinite(x).all() for x in r)
     with pytest.raises(NotImplementedError):
         net(sat.to(d), grd.to(d), K.to(d), gu.to(d), gv.to(d), gh.to(d), mode='train')
+
+
+@pytest.mark.parametrize('kw', [dict(), dict(using_weight=1), dict(train_damping=1, using_weight=1)])
+def test_g2s_lm_backward_small_vs_oracle_autograd(kw):
+    """hla_g2s_lm_solve_bwd on random feature pyramids against torch autograd through the fp64 oracle's
+    project_grd_to_map + LM_update chain (perspective projection, projected-confidence weights, lambda = parameter)."""
+    from oracle import ref_cpu as O
+    from highlyaccurate_amd.models_kitti import LM_G2SP
+    d = _dev()
+    args = O.default_args(N_iters=2, damping=0.5, **kw)
+    B, grd_hw, sat_a = 2, (64, 256), 128
+    rs = np.random.RandomState(17)
+    Cs, L = (256, 128, 64), 3
+    sat = [T(rs.standard_normal((B, Cs[l], sat_a >> (2 - l), sat_a >> (2 - l))).astype(np.float32) * 0.02) for l in range(L)]
+    grd = [T(rs.standard_normal((B, Cs[l], grd_hw[0] >> (3 - l), grd_hw[1] >> (3 - l))).astype(np.float32) * 0.02) for l in range(L)]
+    conf = [T(rs.uniform(0.27, 0.5, size=(B, 1, grd_hw[0] >> (3 - l), grd_hw[1] >> (3 - l))).astype(np.float32)) for l in range(L)]
+    K = (torch.tensor([O.KITTI_K]) * torch.tensor([[grd_hw[1] / 1024.0], [grd_hw[0] / 256.0], [1.0]])).float().repeat(B, 1, 1)
+    p0 = T(rs.uniform(-0.2, 0.2, size=(B, 3)).astype(np.float32))
+    coef = T(rs.standard_normal((B, args.N_iters, L, 3)))
+    onet = O.LM_G2SP(args).double()
+    dpar = torch.tensor([[0.4, 0.7, 0.55]])
+    with torch.no_grad():
+        onet.damping.copy_(dpar.double())
+    sat64 = [s.double().requires_grad_(True) for s in sat]
+    grd64 = [g.double().requires_grad_(True) for g in grd]
+    conf64 = [c.double().requires_grad_(True) for c in conf]
+    su, sv, th = (p0[:, i:i + 1].double() for i in range(3))
+    loss = 0.0
+    for it in range(args.N_iters):
+        for l in range(L):
+            f, c, jac = onet.project_grd_to_map(grd64[l], conf64[l], su, sv, th, K, sat64[l].shape[-1], *grd_hw)
+            su, sv, th = O.lm_update_g2s(args, onet.damping, su, sv, th, f, c, sat64[l], jac, args.using_weight)
+            loss = loss + (coef[:, it, l] * torch.cat([su, sv, th], 1)).sum()
+    loss.backward()
+    net = LM_G2SP(args).to(d)
+    with torch.no_grad():
+        net.damping.copy_(dpar.to(d))
+    nh = lambda t: t.permute(0, 2, 3, 1).contiguous().to(d)
+    feats = ([nh(s) for s in sat], [nh(g) for g in grd], [c[:, 0].contiguous().to(d) for c in conf])
+    trace = net.lm_solve(*feats, K.to(d), grd_hw, init_pose=p0, keep_normal_eq=True)
+    ref_last = torch.cat([su, sv, th], 1).detach().numpy()
+    assert np.abs(trace[:, -1, -1].cpu().numpy() - ref_last).max() < 1e-5
+    d_sat, d_grd, d_conf, d_lam = net.lm_backward(*feats, K.to(d), grd_hw, trace, net.last_normal_eq, coef.float().to(d), init_pose=p0)
+    for l in range(L):
+        for name, got, ref in (('sat', d_sat[l], sat64[l].grad), ('grd', d_grd[l], grd64[l].grad)):
+            got = got.permute(0, 3, 1, 2).cpu().double().numpy()
+            e = np.abs(got - ref.numpy()).max() / max(np.abs(ref.numpy()).max(), 1e-30)
+            print(f'g2s lm bwd {kw} level {l} d_{name}: rel err {e:.2e} (max |ref| {np.abs(ref.numpy()).max():.2e})')
+            assert e < 2e-4, (kw, l, name, e)
+        if args.using_weight:
+            got = d_conf[l].cpu().double().numpy()
+            ref = conf64[l].grad[:, 0].numpy()
+            e = np.abs(got - ref).max() / max(np.abs(ref).max(), 1e-30)
+            print(f'g2s lm bwd level {l} d_conf: rel err {e:.2e}')
+            assert e < 2e-4
+    if args.train_damping:
+        ref = onet.damping.grad.numpy()
+        e = np.abs(d_lam.cpu().view(1, 3).numpy() - ref).max() / np.abs(ref).max()
+        print(f'g2s lm bwd d_damping: rel err {e:.2e}')
+        assert e < 1e-5
+
+
+def test_g2s_train_step_vs_oracle_autograd_small():
+    """LM_G2SP mode='train' under autograd on a reduced shape: loss and parameter gradients vs the fp64 oracle."""
+    from oracle import ref_cpu as O
+    from highlyaccurate_amd.models_kitti import LM_G2SP
+    d = _dev()
+    args = O.default_args(N_iters=2, using_weight=1, train_damping=1)
+    B, grd_hw, sat_a = 2, (64, 256), 128
+    sd = O.synth_model_state(4, bias_scale=0.02)
+    sd['damping'] = torch.tensor([[0.1, 0.2, 0.15]])
+    sat, grd, gu, gv, gh = O.synth_images(9, B, grd_hw=grd_hw, sat_a=sat_a)
+    K = (torch.tensor([O.KITTI_K]) * torch.tensor([[grd_hw[1] / 1024.0], [grd_hw[0] / 256.0], [1.0]])).float().repeat(B, 1, 1)
+    on = O.LM_G2SP(args)
+    on.load_state_dict(sd)
+    on = on.double()
+    ro = on(sat.double(), grd.double(), K, gu.double(), gv.double(), gh.double(), mode='train')
+    ro[0].backward()
+    ref = {k: p.grad for k, p in on.named_parameters()}
+    net = LM_G2SP(args)
+    net.load_state_dict(sd)
+    net = net.to(d).train()
+    r = net(sat.to(d), grd.to(d), K.to(d), gu.to(d), gv.to(d), gh.to(d), mode='train')
+    assert abs(float(r[0]) - float(ro[0])) < 1e-4 * abs(float(ro[0]))
+    r[0].backward()
+    worst = 0.0
+    for k, p in net.named_parameters():
+        assert (p.grad is None) == (ref[k] is None), k
+        if p.grad is None:
+            continue
+        rr = ref[k].numpy()
+        e = np.abs(p.grad.cpu().double().numpy() - rr).max() / max(np.abs(rr).max(), 1e-30)
+        worst = max(worst, e)
+        print(f'g2s train grad {k:36s} rel err {e:.2e} (max |ref| {np.abs(rr).max():.2e})')
+        assert e < 5e-3, (k, e)
+    print('g2s train grads worst rel err', worst)
