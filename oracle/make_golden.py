@@ -313,6 +313,21 @@ def gen_g2s(mk, seeds, B=1):
         res = net(sat, grd, K, gu, gv, gh, mode='train')
         out[f'tuple32_{seed}'] = np.stack([np.atleast_1d(r.detach().double().numpy()) if r.dim() else
                                            np.full(3, float(r)) for r in res[:9]])
+        if seed == seeds[0]:          # gradient samples from the reference's own autograd (fp32), using_weight=1 + train_damping=1
+            net.using_weight = 1
+            net.args.train_damping = 1
+            net.zero_grad()
+            res = net(sat, grd, K, gu, gv, gh, mode='train')
+            res[0].backward()
+            out['wtuple32'] = np.stack([np.atleast_1d(r.detach().double().numpy()) if r.dim() else
+                                        np.full(3, float(r)) for r in res[:9]])
+            sdp = dict(net.named_parameters())
+            for k in GRAD_KEYS + CONF_KEYS:
+                gq = sdp[k].grad.double().reshape(-1)
+                out[f'grad32_{k}'] = np.concatenate([[gq.abs().sum().item(), (gq * gq).sum().item()], gq[sample_idx(gq.numel(), 77)].numpy()])
+            out['nograd_32'] = np.array([k for k, p in sdp.items() if p.grad is None])
+            net.using_weight = 0
+            net.args.train_damping = 0
         print(f'g2s seed {seed}: final {out[f"final32_{seed}"].tolist()} range {np.abs(out[f"trace32_{seed}"]).max():.3f}', flush=True)
     np.savez_compressed(os.path.join(GOLD, 'e2e_kitti_g2s.npz'), **out)
 
