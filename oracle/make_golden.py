@@ -328,6 +328,19 @@ def gen_g2s(mk, seeds, B=1):
             out['nograd_32'] = np.array([k for k, p in sdp.items() if p.grad is None])
             net.using_weight = 0
             net.args.train_damping = 0
+            # the reference class cannot run in fp64 (see the docstring); the fp64 column therefore comes from the
+            # RESTATEMENT (oracle/ref_cpu.py, equal to the reference in fp32 to 1e-6 on these very samples) and only
+            # serves to measure how much of |hip - reference_fp32| is the reference's own fp32 rounding
+            oa = O.default_args(using_weight=1, train_damping=1)
+            on = O.LM_G2SP(oa)
+            on.load_state_dict(sd)
+            on = on.double()
+            ro = on(sat.double(), grd.double(), K, gu.double(), gv.double(), gh.double(), mode='train')
+            ro[0].backward()
+            sdo = dict(on.named_parameters())
+            for k in GRAD_KEYS + CONF_KEYS:
+                gq = sdo[k].grad.double().reshape(-1)
+                out[f'ograd64_{k}'] = np.concatenate([[gq.abs().sum().item(), (gq * gq).sum().item()], gq[sample_idx(gq.numel(), 77)].numpy()])
         print(f'g2s seed {seed}: final {out[f"final32_{seed}"].tolist()} range {np.abs(out[f"trace32_{seed}"]).max():.3f}', flush=True)
     np.savez_compressed(os.path.join(GOLD, 'e2e_kitti_g2s.npz'), **out)
 

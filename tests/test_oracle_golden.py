@@ -216,3 +216,24 @@ def test_oracle_g2s_matches_reference_golden():
     res = net(sat, grd, K, *gt, mode='train')
     got = np.stack([np.atleast_1d(r.detach().double().numpy()) if r.dim() else np.full(3, float(r)) for r in res[:9]])
     np.testing.assert_allclose(got, g[f'tuple32_{seed}'], rtol=2e-3, atol=2e-4)
+
+
+def test_oracle_g2s_train_gradients_match_reference_autograd():
+    """LM_G2SP mode='train' (using_weight=1, train_damping=1): gradient samples of 11 parameters recorded from the REAL
+    reference's autograd (fp32 -- the only precision that class runs in) vs the restatement's autograd in fp32."""
+    from make_idx import sample_idx
+    g = load_golden('e2e_kitti_g2s.npz')
+    seed, B = int(g['seeds'][0]), int(g['B'])
+    net, sat, grd, K, gt = _g2s_oracle(seed, B, torch.float32, using_weight=1)
+    net.args.train_damping = 1
+    res = net(sat, grd, K, *gt, mode='train')
+    res[0].backward()
+    named = dict(net.named_parameters())
+    assert set(k for k, p in named.items() if p.grad is None) == set(str(k) for k in g['nograd_32'])
+    for k in [k[len('grad32_'):] for k in g.files if k.startswith('grad32_')]:
+        gr = named[k].grad.double().reshape(-1)
+        ref = g['grad32_' + k]
+        got = np.concatenate([[gr.abs().sum().item(), (gr * gr).sum().item()], gr[sample_idx(gr.numel(), 77)].numpy()])
+        e = np.abs(got[2:] - ref[2:]).max() / np.abs(ref[2:]).max()
+        print(f'oracle vs reference autograd, g2s {k:36s} rel err {e:.2e}')
+        assert e < 2e-3, (k, e)          # both sides fp32; max-pool near-ties may route differently (see DESIGN 6)
