@@ -1,0 +1,50 @@
+"""Evaluation metrics of the reference's test loops (``train_kitti.py:77-170`` test1/test2, ``train_ford.py:77-180``):
+distance / lateral / longitudinal / heading recall at {1, 3, 5} (metres, degrees) for the predictions and for the
+initial pose, with the same text lines the reference prints and appends to ``Test*_results.txt``.  Plain numpy."""
+from __future__ import annotations
+
+import numpy as np
+
+METRICS = (1, 3, 5)     # metres
+ANGLES = (1, 3, 5)      # degrees
+
+
+def localisation_metrics(pred_shifts, pred_headings, gt_shifts, gt_headings, shift_range_lat, shift_range_lon,
+                         rotation_range):
+    """All inputs in the model's normalised units: pred_shifts / gt_shifts [N,2] = (lat, lon), headings [N,1].
+    Returns (result, stats dict, text lines).  ``result`` is the reference's model-selection score: the percentage of
+    samples within 1 m AND 1 degree (train_kitti.py:160)."""
+    scale = np.array([shift_range_lat, shift_range_lon], dtype=np.float64).reshape(1, 2)
+    ps, gs = np.asarray(pred_shifts, np.float64) * scale, np.asarray(gt_shifts, np.float64) * scale      # 77-80
+    ph, gh = np.asarray(pred_headings, np.float64) * rotation_range, np.asarray(gt_headings, np.float64) * rotation_range
+    distance = np.sqrt(np.sum((ps - gs) ** 2, axis=1))
+    angle_diff = np.remainder(np.abs(ph - gh), 360)
+    angle_diff = np.where(angle_diff > 180, 360 - angle_diff, angle_diff)
+    init_dis = np.sqrt(np.sum(gs ** 2, axis=1))
+    init_angle = np.abs(gh)
+    diff = np.abs(ps - gs)
+    n = float(distance.shape[0])
+    stats = {'init_distance_mean': float(np.mean(init_dis)), 'pred_distance_mean': float(np.mean(distance)),
+             'init_angle_mean': float(np.mean(init_angle)), 'pred_angle_mean': float(np.mean(angle_diff))}
+    lines = []
+    for m in METRICS:
+        stats[f'distance@{m}'] = (np.sum(distance < m) / n * 100, np.sum(init_dis < m) / n * 100)
+        lines.append(f'distance within {m} meters (pred, init): {stats[f"distance@{m}"][0]} {stats[f"distance@{m}"][1]}')
+    lines.append('------------------------')
+    for m in METRICS:
+        stats[f'lateral@{m}'] = (np.sum(diff[:, 0] < m) / n * 100, np.sum(np.abs(gs[:, 0]) < m) / n * 100)
+        stats[f'longitudinal@{m}'] = (np.sum(diff[:, 1] < m) / n * 100, np.sum(np.abs(gs[:, 1]) < m) / n * 100)
+        lines.append(f'lateral      within {m} meters (pred, init): {stats[f"lateral@{m}"][0]} {stats[f"lateral@{m}"][1]}')
+        lines.append(f'longitudinal within {m} meters (pred, init): {stats[f"longitudinal@{m}"][0]} {stats[f"longitudinal@{m}"][1]}')
+    lines.append('------------------------')
+    for a in ANGLES:
+        stats[f'angle@{a}'] = (np.sum(angle_diff < a) / n * 100, np.sum(init_angle < a) / n * 100)
+        lines.append(f'angle within {a} degrees (pred, init): {stats[f"angle@{a}"][0]} {stats[f"angle@{a}"][1]}')
+    lines.append('------------------------')
+    for m, a in zip(METRICS, ANGLES):
+        p = np.sum((angle_diff[:, 0] < a) & (diff[:, 0] < m)) / n * 100
+        i = np.sum((init_angle[:, 0] < a) & (np.abs(gs[:, 0]) < m)) / n * 100
+        stats[f'lat@{m}&angle@{a}'] = (p, i)
+        lines.append(f'lat within {m} & angle within {a} (pred, init): {p} {i}')
+    result = float(np.sum((distance < METRICS[0]) & (angle_diff[:, 0] < ANGLES[0])) / n * 100)
+    return result, stats, lines

@@ -237,3 +237,27 @@ def test_oracle_g2s_train_gradients_match_reference_autograd():
         e = np.abs(got[2:] - ref[2:]).max() / np.abs(ref[2:]).max()
         print(f'oracle vs reference autograd, g2s {k:36s} rel err {e:.2e}')
         assert e < 2e-3, (k, e)          # both sides fp32; max-pool near-ties may route differently
+
+
+def test_evaluation_metrics_match_the_reference_formulas():
+    """highlyaccurate_amd.metrics against a direct transcription of the arithmetic of train_kitti.py:77-160 on random data
+    (the reference's test1() itself needs the KITTI data loader, so its arithmetic is restated inline here)."""
+    from highlyaccurate_amd.metrics import localisation_metrics
+    rs = np.random.RandomState(3)
+    N = 500
+    ps, gs = rs.uniform(-1, 1, (N, 2)) * 0.3, rs.uniform(-1, 1, (N, 2))
+    ps = gs + ps * rs.uniform(0, 1, (N, 1))
+    ph, gh = rs.uniform(-1, 1, (N, 1)), rs.uniform(-1, 1, (N, 1))
+    ph = gh + (ph - gh) * 0.2
+    result, stats, lines = localisation_metrics(ps, ph, gs, gh, 20.0, 20.0, 10.0)
+    P, G = ps * np.array([[20.0, 20.0]]), gs * np.array([[20.0, 20.0]])
+    distance = np.sqrt(np.sum((P - G) ** 2, axis=1))
+    ad = np.remainder(np.abs(ph * 10.0 - gh * 10.0), 360)
+    ad[ad > 180] = 360 - ad[ad > 180]
+    assert result == np.sum((distance < 1) & (ad[:, 0] < 1)) / N * 100
+    for m in (1, 3, 5):
+        assert stats[f'distance@{m}'][0] == np.sum(distance < m) / N * 100
+        assert stats[f'lateral@{m}'][0] == np.sum(np.abs(P - G)[:, 0] < m) / N * 100
+        assert stats[f'longitudinal@{m}'][1] == np.sum(np.abs(G[:, 1]) < m) / N * 100
+        assert stats[f'angle@{m}'][0] == np.sum(ad < m) / N * 100
+    assert len(lines) == 3 + 1 + 6 + 1 + 3 + 1 + 3 and lines[0].startswith('distance within 1 meters (pred, init): ')

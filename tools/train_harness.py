@@ -102,10 +102,16 @@ def main(argv=None):
         shifts_lat, shifts_lon, theta = net(sat_map, grd_left_imgs, mode='test')
         loss = torch.mean(shifts_lat - gt_shift_u)
         loss.backward()
-        pred_u = shifts_lon.data.cpu().numpy() * args.shift_range_lon       # train_kitti.py:77-80
-        pred_v = shifts_lat.data.cpu().numpy() * args.shift_range_lat
+        from highlyaccurate_amd.metrics import localisation_metrics
+        shifts = torch.stack([shifts_lat, shifts_lon], dim=-1).data.cpu().numpy()          # train_kitti.py:55-70
+        gt_shift = torch.cat([gt_shift_v, gt_shift_u], dim=-1).data.cpu().numpy()
+        result, stats, lines = localisation_metrics(shifts, theta.unsqueeze(-1).data.cpu().numpy(), gt_shift,
+                                                    gt_heading.data.cpu().numpy(), args.shift_range_lat, args.shift_range_lon,
+                                                    args.rotation_range)                      # train_kitti.py:77-160
         if rank == 0:
-            print('test batch: mean |lat| %.3f m, mean |lon| %.3f m' % (abs(pred_v).mean(), abs(pred_u).mean()), flush=True)
+            print('\n'.join(['====================================', '       EPOCH: ' + str(epoch), 'Validation results:',
+                             'Init distance average:  %s' % stats['init_distance_mean'],
+                             'Pred distance average:  %s' % stats['pred_distance_mean']] + lines), flush=True)
     return log
 
 
