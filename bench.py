@@ -39,7 +39,7 @@ def cpu_baseline(max_seconds=30.0):
     B=1 KITTI-shape forward(mode='test'), no_grad, fp32, all cores.  Bounded sample."""
     from oracle import ref_cpu as O
     # measured on the MI355X host (256 logical CPUs): B=1 forward takes 1.40 / 1.21 / 1.29 / 2.58 / 204 s with
-    # 8 / 16 / 32 / 64 / 256 torch threads (tools/cpu_threads.py) -- oversubscription kills it, 16 is the best
+    # 8 / 16 / 32 / 64 / 256 torch threads (tests/diag/cpu_threads.py) -- oversubscription kills it, 16 is the best
     cores = min(os.cpu_count() or 1, int(os.environ.get('HLA_CPU_THREADS', '16')))
     torch.set_num_threads(cores)
     net = O.build('kitti', O.default_args(), seed=1)

@@ -1,6 +1,6 @@
 """How does the CPU oracle scale with torch threads on this host?  (Informs bench.py's cpu_baseline.)"""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from oracle import ref_cpu as O
 net = O.build('kitti', O.default_args(), seed=1)

@@ -1,6 +1,6 @@
 """Compare the max-pool argmax maps saved by the HIP forward with torch's (fp64 oracle) on the same input."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch, torch.nn.functional as F
 from oracle import ref_cpu as O
 from highlyaccurate_amd.VGG import VGGUnet, vgg_forward_nhwc

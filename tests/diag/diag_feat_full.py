@@ -1,6 +1,6 @@
 """Diagnostic: full-map comparison of the HIP extractor's outputs with the fp64 oracle at full KITTI shape."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from oracle import ref_cpu as O
 from highlyaccurate_amd.VGG import VGGUnet

@@ -1,6 +1,6 @@
 """Diagnostic: G2S LM backward with raw maps + deferred inverse norms (A) vs explicitly normalised maps (B)."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from oracle import ref_cpu as O
 from highlyaccurate_amd.models_kitti import LM_G2SP

@@ -1,7 +1,7 @@
 """Diagnostic: where do the 1e-3-level G2S full-shape gradient deviations come from?  Feed the ORACLE's exact d(loss)/d(feature
 map) into (a) the HIP VGG backward and (b) torch-CPU fp32 autograd of the oracle extractor, compare both with fp64."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from oracle import ref_cpu as O
 from highlyaccurate_amd.VGG import VGGUnet, vgg_forward_nhwc, vgg_backward_nhwc

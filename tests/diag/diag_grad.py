@@ -1,6 +1,6 @@
 """Full-shape B=1 training step: HIP gradients vs the fp64 CPU oracle's autograd, every parameter tensor."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from oracle import ref_cpu as O
 from highlyaccurate_amd.models_kitti import LM_S2GP

@@ -1,6 +1,6 @@
 """VGG backward alone at a mid-size non-square shape vs the fp64 oracle (multi-tile in x and y at every level)."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from oracle import ref_cpu as O
 from highlyaccurate_amd.VGG import VGGUnet, vgg_forward_nhwc, vgg_backward_nhwc

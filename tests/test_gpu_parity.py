@@ -399,7 +399,7 @@ def test_train_step_gradients_vs_reference_golden():
         e = np.abs(got[2:] - ref[2:]).max()
         print(f'train grad {k:36s} max err {e:.2e} (ref fp32 gap {gap:.2e}, scale {scale:.2e}); l1 {got[0]:.4e} vs {ref[0]:.4e}')
         # Gradients that pass through a max-pool carry "flip noise": one fp32 near-tie (relative gap < 1e-6, measured
-        # with tools/diag_argmax.py: exactly 1 window per map differs from the fp64 run) reroutes one gradient element,
+        # with tests/diag/diag_argmax.py: exactly 1 window per map differs from the fp64 run) reroutes one gradient element,
         # which moves a weight gradient by ~1/sqrt(#pixels) ~ 1e-3 relative.  The reference's own fp32-vs-fp64 gap shows
         # the same effect.  conv_dec2.* sit above every pool in the backward order and must be tight.
         rel_tol = 2e-4 if 'conv_dec2' in k else 5e-3
@@ -932,8 +932,8 @@ def test_g2s_train_step_vs_reference_autograd_golden():
         e, e64, gap = np.abs(got - ref[2:]).max(), np.abs(got - o64).max(), np.abs(ref[2:] - o64).max()
         print(f'g2s train grad {k:36s} |hip-ref32| {e / scale:.2e}  |hip-oracle64| {e64 / scale:.2e}  |ref32-oracle64| '
               f'{gap / scale:.2e} (scale {scale:.2e})')
-        # Every stage is exact for the inputs it sees (tools/diag_g2s_e2e.py: LM backward 2e-7 against the oracle evaluated
-        # on the HIP feature maps; VGG backward 5e-7 given the oracle's upstream gradients, tools/diag_g2s_vgg.py), but this
+        # Every stage is exact for the inputs it sees (tests/diag/diag_g2s_e2e.py: LM backward 2e-7 against the oracle evaluated
+        # on the HIP feature maps; VGG backward 5e-7 given the oracle's upstream gradients, tests/diag/diag_g2s_vgg.py), but this
         # direction has no renormalisation and its Jacobian is built from differences of neighbouring texels of nearly
         # constant level-2 maps, so the 2e-6 (of max-abs) feature deviation of the fp32-MFMA extractor is amplified to a few
         # 1e-3 in the parameter gradients (the reference's own fp32-vs-fp64 gap on the same quantity is 1e-4).

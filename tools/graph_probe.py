@@ -2,12 +2,16 @@
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from oracle import ref_cpu as O
+from types import SimpleNamespace
 from highlyaccurate_amd.models_kitti import LM_S2GP
 
 d = torch.device('cuda:0')
 B = 32
-net = LM_S2GP(O.default_args(precision='bf16')).to(d).eval()
+args = SimpleNamespace(level=3, N_iters=5, using_weight=0, loss_method=0, proj='geo', Optimizer='LM', rotation_range=10.0,
+                       shift_range_lat=20.0, shift_range_lon=20.0, damping=0.1, train_damping=0, dropout=0, use_hessian=0,
+                       use_gt_depth=0, visualize=0, coe_shift_lat=100.0, coe_shift_lon=100.0, coe_heading=100.0, coe_L1=100.0,
+                       coe_L2=100.0, coe_L3=100.0, coe_L4=100.0, estimate_depth=0, precision='bf16')
+net = LM_S2GP(args).to(d).eval()
 sat, grd = torch.rand(B, 3, 512, 512, device=d), torch.rand(B, 3, 256, 1024, device=d)
 fixed = net._draw_reinit(15, B, d)
 net._draw_reinit = lambda n, b, dev: fixed        # static device buffer instead of CPU draws + H2D inside the capture
