@@ -119,6 +119,19 @@ int hla_vgg_backward(const float* x, const hla_vgg_params* params, const void* p
                      int dtype, hla_stream_t stream);
 
 /* ------------------------------------------------------------------------- *
+ * Dataset-side satellite tile: KITTI_dataset.py:128-157, Ford_dataset.py:185-209
+ *   four Pillow resampling stages (NEAREST rotations in 16.16 fixed point, BILINEAR shifts in double with uint8
+ *   truncation), TF.center_crop and ToTensor, evaluated lazily per output pixel; bit-identical to Pillow 12.2.
+ * ------------------------------------------------------------------------- */
+/* src     [B,S,S,3] uint8 (HWC) satellite images
+ * stages  [B,4,8] fp64: per stage {kind (0 nearest / 1 bilinear), c0..c5, pad}.  For a nearest stage c[] are the
+ *         16.16 fixed-point integers FIX(m0), FIX(m1), FIX(m2 + m0/2 + m1/2), FIX(m3), FIX(m4), FIX(m5 + m3/2 + m4/2),
+ *         FIX(v) = floor(v*65536 + 0.5), of Image.rotate's matrix; for a bilinear stage the six AFFINE coefficients
+ *         (highlyaccurate_amd/input_pipeline.py builds both)
+ * out     [B,3,crop,crop] fp32 in [0,1] */
+int hla_sat_tile(const unsigned char* src, const double* stages, float* out, int B, int S, int crop, hla_stream_t stream);
+
+/* ------------------------------------------------------------------------- *
  * jacobian.grid_sample  (jacobian.py:138-205) -- the stand-alone operator
  * ------------------------------------------------------------------------- */
 /* image   [N,IH,IW,C] NHWC fp32;  optical [N,H,W,2] pixel coords (x,y)
