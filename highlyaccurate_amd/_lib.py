@@ -85,6 +85,8 @@ def load() -> C.CDLL:
     lib.hla_vgg_backward.restype = i
     lib.hla_vgg_backward.argtypes = [vp, C.POINTER(VggParams), vp, vp, C.POINTER(vp), vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(VggGrads),
                                      vp, sz, i, i, i, i, i, vp]
+    lib.hla_resize_bilinear.restype = i
+    lib.hla_resize_bilinear.argtypes = [vp, vp, vp, i, vp, vp, i, vp, vp, i, i, i, i, i, vp]
     lib.hla_sat_tile.restype = i
     lib.hla_sat_tile.argtypes = [vp, vp, vp, i, i, i, vp]
     lib.hla_grid_sample.restype = i

@@ -89,3 +89,75 @@ extern "C" int hla_sat_tile(const unsigned char* src, const double* stages, floa
   HLA_CHECK_HIP(hipGetLastError());
   return HLA_OK;
 }
+
+// ---------------------------------------------------------------------------------------------
+// Ground image: torchvision Resize([256,1024]) + ToTensor (KITTI_dataset.py:300-311, Ford_dataset.py:141-155) =
+// Pillow's antialiased bilinear resample: two separable passes with integer taps scaled by 2^22 and a uint8 intermediate.
+struct ResampleArgs {
+  const unsigned char* src;   // pass 1: [B,H,W,3]; pass 2: [B,H,ow,3] (the intermediate)
+  unsigned char* mid;         // pass 1 output, or null
+  float* out;                 // pass 2 output [B,3,oh,ow] = value / 255, or null
+  const int* bounds;          // [n_out][2] first input index, tap count
+  const int* taps;            // [n_out][ksize]
+  int B, H, W, n_out, ksize;
+};
+
+__global__ __launch_bounds__(256) void resample_h_kernel(ResampleArgs a) {
+  const size_t n = (size_t)a.B * a.H * a.n_out;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const int xx = (int)(i % a.n_out);
+    const size_t row = i / a.n_out;                       // b*H + y
+    const int x0 = a.bounds[xx * 2], cnt = a.bounds[xx * 2 + 1];
+    const unsigned char* p = a.src + (row * a.W + x0) * 3;
+    long long s0 = 1 << 21, s1 = 1 << 21, s2 = 1 << 21;
+    for (int k = 0; k < cnt; ++k) {
+      const long long w = a.taps[xx * a.ksize + k];
+      s0 += w * p[k * 3]; s1 += w * p[k * 3 + 1]; s2 += w * p[k * 3 + 2];
+    }
+    unsigned char* o = a.mid + i * 3;
+    o[0] = (unsigned char)min(max(s0 >> 22, 0LL), 255LL);
+    o[1] = (unsigned char)min(max(s1 >> 22, 0LL), 255LL);
+    o[2] = (unsigned char)min(max(s2 >> 22, 0LL), 255LL);
+  }
+}
+
+__global__ __launch_bounds__(256) void resample_v_kernel(ResampleArgs a) {
+  // a.W = intermediate width (= final width), a.H = input height, a.n_out = output height
+  const size_t n = (size_t)a.B * a.n_out * a.W;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const int x = (int)(i % a.W), yy = (int)((i / a.W) % a.n_out), b = (int)(i / ((size_t)a.W * a.n_out));
+    const int y0 = a.bounds[yy * 2], cnt = a.bounds[yy * 2 + 1];
+    const unsigned char* p = a.src + (((size_t)b * a.H + y0) * a.W + x) * 3;
+    long long s0 = 1 << 21, s1 = 1 << 21, s2 = 1 << 21;
+    for (int k = 0; k < cnt; ++k) {
+      const long long w = a.taps[yy * a.ksize + k];
+      const unsigned char* q = p + (size_t)k * a.W * 3;
+      s0 += w * q[0]; s1 += w * q[1]; s2 += w * q[2];
+    }
+    const size_t plane = (size_t)a.n_out * a.W;
+    float* o = a.out + (size_t)b * 3 * plane + (size_t)yy * a.W + x;
+    o[0] = (float)min(max(s0 >> 22, 0LL), 255LL) / 255.0f;
+    o[plane] = (float)min(max(s1 >> 22, 0LL), 255LL) / 255.0f;
+    o[2 * plane] = (float)min(max(s2 >> 22, 0LL), 255LL) / 255.0f;
+  }
+}
+
+extern "C" int hla_resize_bilinear(const unsigned char* src, const int* hbounds, const int* htaps, int hksize,
+                                   const int* vbounds, const int* vtaps, int vksize, unsigned char* mid, float* out, int B,
+                                   int H, int W, int out_h, int out_w, hla_stream_t stream) {
+  HLA_REQUIRE(src && hbounds && htaps && vbounds && vtaps && mid && out, "hla_resize_bilinear: null argument");
+  HLA_REQUIRE(B > 0 && H > 0 && W > 0 && out_h > 0 && out_w > 0 && hksize > 0 && vksize > 0, "hla_resize_bilinear: bad sizes");
+  hipStream_t st = (hipStream_t)stream;
+  ResampleArgs a{};
+  a.src = src; a.mid = mid; a.bounds = hbounds; a.taps = htaps; a.B = B; a.H = H; a.W = W; a.n_out = out_w; a.ksize = hksize;
+  size_t n = (size_t)B * H * out_w;
+  hla_prof_begin(K_ELEMWISE, 0, (double)B * H * ((double)W + out_w) * 3, st);
+  hipLaunchKernelGGL(resample_h_kernel, dim3((unsigned)((n + 255) / 256 < 65535 ? (n + 255) / 256 : 65535)), dim3(256), 0, st, a);
+  ResampleArgs v{};
+  v.src = mid; v.out = out; v.bounds = vbounds; v.taps = vtaps; v.B = B; v.H = H; v.W = out_w; v.n_out = out_h; v.ksize = vksize;
+  n = (size_t)B * out_h * out_w;
+  hipLaunchKernelGGL(resample_v_kernel, dim3((unsigned)((n + 255) / 256 < 65535 ? (n + 255) / 256 : 65535)), dim3(256), 0, st, v);
+  hla_prof_end(st);
+  HLA_CHECK_HIP(hipGetLastError());
+  return HLA_OK;
+}

@@ -79,3 +79,50 @@ def sat_tile_ford(sat_u8, b_delta_u, b_delta_v, yaw_deg, gt_shift_u, gt_shift_v,
         st[b, 2] = _bilinear(float(gt_shift_u[b]) * shift_range_pixels_lat, float(gt_shift_v[b]) * shift_range_pixels_lon)
         st[b, 3] = _nearest(_rotate_matrix(S, S, float(theta[b]) * rotation_range))
     return _run(sat_u8, st, crop)
+
+
+def _resample_tables(insize: int, outsize: int, device):
+    """Pillow's antialiased triangle filter as integer taps scaled by 2^22: (bounds [n,2], taps [n,ksize], ksize)."""
+    scale = insize / outsize
+    filterscale = max(scale, 1.0)
+    support = filterscale
+    ksize = int(math.ceil(support)) * 2 + 1
+    bounds = np.zeros((outsize, 2), np.int32)
+    taps = np.zeros((outsize, ksize), np.int32)
+    for xx in range(outsize):
+        center = (xx + 0.5) * scale
+        xmin = max(int(center - support + 0.5), 0)
+        cnt = min(int(center + support + 0.5), insize) - xmin
+        k = []
+        for x in range(cnt):
+            v = abs((x + xmin - center + 0.5) / filterscale)
+            k.append(1.0 - v if v < 1.0 else 0.0)
+        ww = sum(k)
+        if ww != 0.0:
+            k = [w / ww for w in k]
+        bounds[xx] = (xmin, cnt)
+        taps[xx, :cnt] = [int(w * (1 << 22) + 0.5) for w in k]
+    return torch.from_numpy(bounds).to(device), torch.from_numpy(taps).to(device), ksize
+
+
+_table_cache = {}
+
+
+def grd_resize(grd_u8: torch.Tensor, out_h: int = 256, out_w: int = 1024) -> torch.Tensor:
+    """grd_u8 [B,H,W,3] uint8 on the GPU (e.g. the 375x1242 KITTI frames) -> [B,3,out_h,out_w] fp32 in [0,1]:
+    ``transforms.Resize([out_h, out_w])`` + ``ToTensor`` (KITTI_dataset.py:300-311), bit-identical to Pillow."""
+    lib = _lib.load()
+    _lib.require_gpu(grd_u8, 'grd_u8')
+    if grd_u8.dtype != torch.uint8 or grd_u8.dim() != 4 or grd_u8.shape[3] != 3:
+        raise ValueError(f'expected uint8 [B,H,W,3] images, got {grd_u8.dtype} {tuple(grd_u8.shape)}')
+    B, H, W = grd_u8.shape[:3]
+    key = (H, W, out_h, out_w, str(grd_u8.device))
+    if key not in _table_cache:
+        _table_cache[key] = _resample_tables(W, out_w, grd_u8.device) + _resample_tables(H, out_h, grd_u8.device)
+    hb, ht, hk, vb, vt, vk = _table_cache[key]
+    mid = torch.empty(B, H, out_w, 3, device=grd_u8.device, dtype=torch.uint8)
+    out = torch.empty(B, 3, out_h, out_w, device=grd_u8.device, dtype=torch.float32)
+    rc = lib.hla_resize_bilinear(_lib.ptr(grd_u8.contiguous()), _lib.ptr(hb), _lib.ptr(ht), hk, _lib.ptr(vb), _lib.ptr(vt), vk,
+                                 _lib.ptr(mid), _lib.ptr(out), B, H, W, out_h, out_w, _lib.stream_ptr())
+    _lib.check(rc, 'hla_resize_bilinear')
+    return out

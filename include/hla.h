@@ -131,6 +131,14 @@ int hla_vgg_backward(const float* x, const hla_vgg_params* params, const void* p
  * out     [B,3,crop,crop] fp32 in [0,1] */
 int hla_sat_tile(const unsigned char* src, const double* stages, float* out, int B, int S, int crop, hla_stream_t stream);
 
+/* Ground image: torchvision Resize([out_h,out_w]) + ToTensor (KITTI_dataset.py:300-311, Ford_dataset.py:141-155) =
+ * Pillow's antialiased BILINEAR resample: horizontal pass, uint8 intermediate, vertical pass, integer taps scaled by 2^22.
+ * src [B,H,W,3] uint8; {h,v}bounds [n_out][2] = first input index, tap count; {h,v}taps [n_out][ksize] int32
+ * (highlyaccurate_amd/input_pipeline.py builds them); mid [B,H,out_w,3] uint8 scratch; out [B,3,out_h,out_w] fp32 in [0,1] */
+int hla_resize_bilinear(const unsigned char* src, const int* hbounds, const int* htaps, int hksize, const int* vbounds,
+                        const int* vtaps, int vksize, unsigned char* mid, float* out, int B, int H, int W, int out_h,
+                        int out_w, hla_stream_t stream);
+
 /* ------------------------------------------------------------------------- *
  * jacobian.grid_sample  (jacobian.py:138-205) -- the stand-alone operator
  * ------------------------------------------------------------------------- */

@@ -127,3 +127,48 @@ def ford_stages(S: int, b_delta_u: float, b_delta_v: float, yaw_deg: float, gt_s
             Stage('N', rotate_matrix(S, S, yaw_deg)),
             Stage('B', (1, 0, gt_shift_u * shift_range_pixels_lat, 0, 1, gt_shift_v * shift_range_pixels_lon)),
             Stage('N', rotate_matrix(S, S, theta * rotation_range))]
+
+
+# ---- ground image: torchvision Resize([256,1024]) == Image.resize(BILINEAR) (KITTI_dataset.py:300-311) ---------------
+RESAMPLE_PRECISION_BITS = 32 - 8 - 2
+
+
+def resample_coeffs(insize: int, outsize: int):
+    """Pillow's antialiased bilinear (triangle) filter: per output index the first input index, the tap count and the
+    taps as integers scaled by 2^22 (rounded half away from zero)."""
+    scale = insize / outsize
+    filterscale = max(scale, 1.0)
+    support = 1.0 * filterscale
+    bounds, taps = [], []
+    for xx in range(outsize):
+        center = (xx + 0.5) * scale
+        xmin = max(int(center - support + 0.5), 0)
+        xmax = min(int(center + support + 0.5), insize) - xmin
+        k = []
+        for x in range(xmax):
+            v = abs((x + xmin - center + 0.5) / filterscale)
+            k.append(1.0 - v if v < 1.0 else 0.0)
+        ww = sum(k)
+        k = [w / ww for w in k] if ww != 0.0 else k
+        taps.append([int(w * (1 << RESAMPLE_PRECISION_BITS) + 0.5) for w in k])
+        bounds.append((xmin, xmax))
+    return bounds, taps
+
+
+def _resample_axis1(a: np.ndarray, outw: int) -> np.ndarray:
+    H, W, C = a.shape
+    bounds, taps = resample_coeffs(W, outw)
+    out = np.zeros((H, outw, C), np.uint8)
+    for xx in range(outw):
+        xmin, n = bounds[xx]
+        ss = np.full((H, C), 1 << (RESAMPLE_PRECISION_BITS - 1), np.int64)
+        for x in range(n):
+            ss += a[:, xmin + x].astype(np.int64) * taps[xx][x]
+        out[:, xx] = np.clip(ss >> RESAMPLE_PRECISION_BITS, 0, 255)
+    return out
+
+
+def resize_bilinear(a: np.ndarray, out_h: int, out_w: int) -> np.ndarray:
+    """Image.resize((out_w, out_h), BILINEAR): horizontal pass, uint8 intermediate, vertical pass."""
+    t = _resample_axis1(a, out_w)
+    return _resample_axis1(t.transpose(1, 0, 2), out_h).transpose(1, 0, 2)

@@ -89,3 +89,22 @@ def test_hip_sat_tile_matches_pillow_and_oracle_bit_for_bit(S, crop, B):
         ref = _pil_chain(a[b], [('shift', du[b], dv[b]), ('rotate', yaw[b]), ('shift', sx[b] * 90.9, sy[b] * 90.9),
                                 ('rotate', th[b] * 10.0)], crop)
         assert np.array_equal(got[b], RP.to_tensor(ref)), ('ford', b, int((got[b] != RP.to_tensor(ref)).sum()))
+
+
+@pytest.mark.parametrize('H,W,oh,ow', [(75, 124, 52, 100), (375, 1242, 256, 1024), (86, 165, 26, 100), (64, 64, 100, 90)])
+def test_oracle_resize_matches_pillow_bit_for_bit(H, W, oh, ow):
+    a = np.random.RandomState(H).randint(0, 256, (H, W, 3), dtype=np.uint8)
+    ref = np.array(Image.fromarray(a).resize((ow, oh), Image.BILINEAR))
+    assert np.array_equal(RP.resize_bilinear(a, oh, ow), ref)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('H,W,oh,ow,B', [(375, 1242, 256, 1024, 2), (860, 1656, 256, 1024, 1), (75, 124, 52, 100, 3)])
+def test_hip_grd_resize_matches_pillow_bit_for_bit(H, W, oh, ow, B):
+    from highlyaccurate_amd.input_pipeline import grd_resize
+    d = torch.device('cuda:0')
+    a = np.random.RandomState(W).randint(0, 256, (B, H, W, 3), dtype=np.uint8)
+    got = grd_resize(torch.from_numpy(a).to(d), oh, ow).cpu().numpy()
+    for b in range(B):
+        ref = np.array(Image.fromarray(a[b]).resize((ow, oh), Image.BILINEAR))
+        assert np.array_equal(got[b], RP.to_tensor(ref)), (b, int((got[b] != RP.to_tensor(ref)).sum()))
