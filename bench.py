@@ -183,13 +183,15 @@ def main():
           torch.cuda.synchronize()
           tdt = time.perf_counter() - t1
           trecs = []
-          if want_kt:                 # per-kernel table from two extra, instrumented steps (not part of the timing)
-              _lib.prof_enable(True)
+          if not a.no_kernel_timing:  # per-kernel table from two extra steps (not part of the timing).  EVERY rank runs them --
+              if want_kt:             # a training step contains the gradient all-reduce -- but only rank 0 is instrumented
+                  _lib.prof_enable(True)
               for _ in range(2):
                   tstep()
               torch.cuda.synchronize()
-              _lib.prof_enable(False)
-              trecs = _lib.prof_fetch()
+              if want_kt:
+                  _lib.prof_enable(False)
+                  trecs = _lib.prof_fetch()
           if dist:
               dist.barrier()
           if dist:
