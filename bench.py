@@ -67,11 +67,15 @@ def main():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--batch', type=int, default=32, help='pairs per GPU')
     ap.add_argument('--precision', default='bf16', choices=['bf16', 'fp16', 'fp32'])
-    ap.add_argument('--n-iters', type=int, default=5)
+    ap.add_argument('--n-iters', type=int, default=None, help='LM iterations (default 5; 10 for --model ford = BASELINE configs[3])')
+    ap.add_argument('--model', default='kitti', choices=['kitti', 'ford', 'g2sp'],
+                    help='kitti = LM_S2GP (the headline, BASELINE configs[1]); ford = LM_S2GP_Ford; g2sp = LM_G2SP')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-timing', action='store_true')
     ap.add_argument('--train-steps', type=int, default=6, help='extra: time this many training steps (0 = skip)')
     a = ap.parse_args()
+    if a.n_iters is None:
+        a.n_iters = 10 if a.model == 'ford' else 5
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
@@ -87,7 +91,8 @@ def main():
 
     from types import SimpleNamespace
     from highlyaccurate_amd import _lib
-    from highlyaccurate_amd.models_kitti import LM_S2GP
+    from highlyaccurate_amd.models_kitti import LM_G2SP, LM_S2GP
+    from highlyaccurate_amd.models_ford import LM_S2GP_Ford
     _lib.load()
     args = SimpleNamespace(level=3, N_iters=a.n_iters, using_weight=0, loss_method=0, proj='geo', Optimizer='LM',
                            rotation_range=10.0, shift_range_lat=20.0, shift_range_lon=20.0, damping=0.1,
@@ -95,7 +100,7 @@ def main():
                            coe_shift_lat=100.0, coe_shift_lon=100.0, coe_heading=100.0, coe_L1=100.0, coe_L2=100.0,
                            coe_L3=100.0, coe_L4=100.0, estimate_depth=0, precision=a.precision)
     torch.manual_seed(1234)                  # identical replicas on every rank (data-parallel training needs that) ...
-    net = LM_S2GP(args)
+    net = {'kitti': LM_S2GP, 'ford': LM_S2GP_Ford, 'g2sp': LM_G2SP}[a.model](args)
     # random-init weights of the reference architecture: Kaiming-normal(fan_out), zero bias (torchvision's
     # non-pretrained VGG init; there is no network for the pretrained checkpoint)
     for m in net.modules():
@@ -109,9 +114,17 @@ def main():
     sat = torch.rand(B, 3, 512, 512, device=dev)
     grd = torch.rand(B, 3, 256, 1024, device=dev)
 
+    if a.model == 'ford':       # BASELINE configs[3] / SURVEY 8(d): fixed camera-to-body rotation, 112.64 m tile
+        extra = (112.64, torch.tensor([[[0., 0., 1.], [1., 0., 0.], [0., 1., 0.]]], device=dev).repeat(B, 1, 1),
+                 torch.tensor([[1.7, 0.3, -1.2]], device=dev).repeat(B, 1))
+    elif a.model == 'g2sp':     # left_camera_k of the 256x1024 frame (models_kitti.py:657-660 values)
+        extra = (torch.tensor([[[582.9802, 0., 496.2420], [0., 482.7076, 125.0034], [0., 0., 1.]]], device=dev).repeat(B, 1, 1),)
+    else:
+        extra = ()
+
     def step():
         with torch.no_grad():
-            return net(sat, grd, mode='test')
+            return net(sat, grd, *extra, mode='test')
 
     for _ in range(a.warmup):
         step()
@@ -161,10 +174,12 @@ def main():
               net.grad_sync = GradSync()
           opt = torch.optim.Adam(net.parameters(), lr=1e-4)
           gt = [torch.rand(B, 1, device=dev) * 2 - 1 for _ in range(3)]
+          if a.model == 'ford':      # Ford_dataset.py:211 collates python floats: [B] float64
+              gt = [g[:, 0].double() for g in gt]
 
           def tstep():
               opt.zero_grad(set_to_none=True)
-              r = net(sat, grd, gt[0], gt[1], gt[2], mode='train')
+              r = net(sat, grd, *extra, gt[0], gt[1], gt[2], mode='train')
               r[0].backward()
               opt.step()
               return r[0]
@@ -221,7 +236,8 @@ def main():
             'value': round(pairs / dt, 3), 'unit': 'pairs/s', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
             'ms_per_step': round(dt / a.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': a.precision, 'data': 'synthetic',
-            'config': {'workload': "BASELINE configs[1]: LM_S2GP.forward(mode='test'), KITTI shapes (sat 512x512, grd 256x1024), "
+            'config': {'workload': {'kitti': "BASELINE configs[1]: LM_S2GP", 'ford': "BASELINE configs[3] shapes: LM_S2GP_Ford",
+                                    'g2sp': "SURVEY 8(f).2: LM_G2SP"}[a.model] + ".forward(mode='test'), KITTI shapes (sat 512x512, grd 256x1024), "
                                    f"VGG-16 two-branch, level 3, {a.n_iters} LM iters x 3 levels, 3-DoF, random-init weights",
                        'pairs_per_gpu': B, 'global_batch': B * world, 'parallelism': f'batch-sharded x{world}, no collective',
                        'dead_work_skipped': 'dec3/conf3 (VGG.py:153-155,163: computed and dropped by the reference at level 3); '
