@@ -363,6 +363,17 @@ def test_determinism_and_batch_independence():
     with torch.no_grad():
         n1(sat[1:2].to(d), grd[1:2].to(d), mode='test')
     assert torch.equal(t1[1:2], n1.last_trace)
+    # B >= 8 switches the LM kernels to the XCD-affine block map (a sample's tiles stay on one XCD; B = 11 leaves idle
+    # blocks in the last group of 8): still bitwise equal to the same samples run alone, in forward AND in training mode
+    sat, grd, gu, gv, gh = O.synth_images(77, 11, grd_hw=(64, 256), sat_a=128)
+    with torch.no_grad():
+        n1(sat.to(d), grd.to(d), mode='test')
+        big = n1.last_trace.clone()
+        n1(sat[9:11].to(d), grd[9:11].to(d), mode='test')
+    assert torch.equal(big[9:11], n1.last_trace)
+    n1.zero_grad()
+    n1(sat.to(d), grd.to(d), gu.to(d), gv.to(d), gh.to(d), mode='train')[0].backward()
+    assert all(torch.isfinite(p.grad).all() for p in n1.parameters() if p.grad is not None)
 
 
 def test_train_mode_forward_values_vs_golden():
