@@ -46,3 +46,25 @@ def test_ctypes_layer_binds_every_declared_symbol_and_rejects_cpu_tensors():
     from highlyaccurate_amd.VGG import VGGUnet
     with pytest.raises(_lib.HlaError):                # the product path has no CPU fallback
         VGGUnet(3)(torch.zeros(1, 3, 32, 64))
+
+
+def test_header_is_plain_c_and_links_from_a_c_program(tmp_path):
+    """The boundary is a C ABI: include/hla.h must compile as C99 (no C++ or torch types) and a C program must link
+    against libhla.so and call a non-compute entry point."""
+    import shutil
+    import subprocess
+    gcc = shutil.which('gcc')
+    if gcc is None:
+        pytest.skip('no gcc')
+    hdr = os.path.join(ROOT, 'include', 'hla.h')
+    subprocess.run([gcc, '-std=c99', '-pedantic', '-Wall', '-Werror', '-fsyntax-only', '-x', 'c', hdr], check=True)
+    from highlyaccurate_amd import build as B
+    lib_dir = os.path.dirname(B.build())
+    src = tmp_path / 'user.c'
+    src.write_text('#include "hla.h"\n'
+                   'int main(void) { hla_s2g_config c; hla_s2g_level l[3]; hla_vgg_params p; (void)c; (void)l; (void)p;\n'
+                   '  return (hla_abi_version() > 0 && hla_last_error() != 0) ? 0 : 1; }\n')
+    exe = tmp_path / 'user'
+    subprocess.run([gcc, '-std=c99', '-Wall', '-I', os.path.join(ROOT, 'include'), str(src), '-L', lib_dir, '-l:libhla.so',
+                    f'-Wl,-rpath,{lib_dir}', '-o', str(exe)], check=True)
+    assert subprocess.run([str(exe)]).returncode == 0
