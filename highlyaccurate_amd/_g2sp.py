@@ -83,7 +83,9 @@ class LM_G2SP(nn.Module):
         rc = lib.hla_g2s_lm_solve(C.byref(cfg), lv, _lib.ptr(K), int(ori_hw[0]), int(ori_hw[1]), _lib.ptr(p0), _lib.ptr(trace),
                                   _lib.ptr(neq), _lib.ptr(ws), nbytes, B, _lib.stream_ptr())
         _lib.check(rc, 'hla_g2s_lm_solve')
-        self.last_trace, self.last_normal_eq = trace, neq
+        # a detached alias: under autograd `trace` becomes the Function's output (grad_fn -> ctx), and ctx/model must not hold it
+        # or every step's ctx (8.5 GB of saved workspaces at B = 32) lives in a reference cycle until the cyclic GC runs
+        self.last_trace, self.last_normal_eq = trace.detach(), neq
         return trace
 
     def lm_backward(self, sat_feats, grd_feats, grd_confs, camera_k, ori_hw, trace, normal_eq, d_trace, init_pose=None,
@@ -152,7 +154,7 @@ class _G2sFn(torch.autograd.Function):
         trace = model.lm_solve(sat_feats, grd_feats, grd_confs, camera_k, grd_img.shape[-2:], init_pose, sat_inv, grd_inv,
                                keep_normal_eq=True)
         ctx.model, ctx.names, ctx.init_pose = model, names, init_pose
-        ctx.state = (sat_feats, grd_feats, grd_confs, camera_k, tuple(grd_img.shape[-2:]), trace, model.last_normal_eq,
+        ctx.state = (sat_feats, grd_feats, grd_confs, camera_k, tuple(grd_img.shape[-2:]), trace.detach(), model.last_normal_eq,
                      sat_inv, grd_inv, cs, cg)
         outs = (trace,) + (tuple(grd_confs) if want_conf else ())
         if want_conf:
@@ -180,4 +182,5 @@ class _G2sFn(torch.autograd.Function):
             grads['damping'] = d_lam.view(1, 3).float()
             if sync:
                 sync.finish(sync.start({'damping': grads['damping']}))
+        ctx.state = None            # release the saved workspaces now, not when the loss tensor dies
         return (None,) * 7 + tuple(grads.get(n) for n in ctx.names)

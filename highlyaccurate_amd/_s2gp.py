@@ -199,7 +199,9 @@ class S2GPBase(nn.Module):
         rc = lib.hla_s2g_lm_solve(C.byref(cfg), lv, _lib.ptr(R_FL), _lib.ptr(T_FL), _lib.ptr(p0), _lib.ptr(rand_uv),
                                   _lib.ptr(trace), _lib.ptr(neq), _lib.ptr(ws), nbytes, B, _lib.stream_ptr())
         _lib.check(rc, 'hla_s2g_lm_solve')
-        self.last_trace, self.last_normal_eq = trace, neq
+        # a detached alias: under autograd `trace` becomes the Function's output (grad_fn -> ctx), and ctx/model must not hold it
+        # or every step's ctx (8.5 GB of saved workspaces at B = 32) lives in a reference cycle until the cyclic GC runs
+        self.last_trace, self.last_normal_eq = trace.detach(), neq
         return trace
 
     def lm_backward(self, sat_feats, grd_feats, grd_confs, grd_hw, trace, normal_eq, d_trace, extra=None, level_first=0,
@@ -294,7 +296,7 @@ class _LocaliseFn(torch.autograd.Function):
         trace = model.lm_solve(sat_feats, grd_feats, grd_confs, grd_img.shape[-2:], extra, level_first, init_pose,
                                sat_inv, grd_inv, keep_normal_eq=True)
         ctx.model, ctx.names, ctx.extra, ctx.level_first, ctx.init_pose = model, names, extra, level_first, init_pose
-        ctx.state = (sat_feats, grd_feats, grd_confs, tuple(grd_img.shape[-2:]), trace, model.last_normal_eq, sat_inv, grd_inv, cs, cg)
+        ctx.state = (sat_feats, grd_feats, grd_confs, tuple(grd_img.shape[-2:]), trace.detach(), model.last_normal_eq, sat_inv, grd_inv, cs, cg)
         outs = (trace,) + (tuple(grd_confs) if want_conf else ())
         if want_conf:
             ctx.mark_non_differentiable(*grd_confs)     # loss_method 0 does not read them; their LM-weight role is in backward()
@@ -329,6 +331,7 @@ class _LocaliseFn(torch.autograd.Function):
                 grads['damping'] = (d_lam.view(1, 3) * dlam_dd).float()
             if sync:
                 sync.finish(sync.start({'damping': grads['damping']}))
+        ctx.state = None            # release the saved workspaces now, not when the loss tensor dies
         return (None,) * 8 + tuple(grads.get(n) for n in ctx.names)
 
 

@@ -63,7 +63,7 @@ template <typename T> constexpr int wg_stride() { return 64 * (int)sizeof(T) + 1
 template <typename T> constexpr int wg_lds_bytes() { return ((WG_TH + 2) * HWID + WG_TH * 32) * wg_stride<T>(); }
 
 template <typename T>
-__global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
+__global__ __launch_bounds__(256, CONV_VARIANT == 73 ? 1 : 2) void wgrad_kernel(WgradArgs a) {
   constexpr int EPL = 16 / sizeof(T), STR = wg_stride<T>(), PPX = 64 * (int)sizeof(T) / 16;   // 16-B pieces per pixel
   constexpr int XPIX = (WG_TH + 2) * HWID, GPIX = WG_TH * 32, KPX = KStep<T>::PX;
   extern __shared__ __attribute__((aligned(16))) char smem[];
