@@ -970,3 +970,30 @@ def test_g2s_train_step_vs_reference_autograd_golden():
         # constant level-2 maps, so the 2e-6 (of max-abs) feature deviation of the fp32-MFMA extractor is amplified to a few
         # 1e-3 in the parameter gradients (the reference's own fp32-vs-fp64 gap on the same quantity is 1e-4).
         assert e64 <= max(1.5e-2 * scale, 3 * gap), (k, e64, gap, scale)
+
+
+def test_training_steps_do_not_accumulate_memory():
+    """Regression: the autograd context must not sit in a reference cycle (ctx -> saved trace -> grad_fn -> ctx); every step's
+    saved workspaces (8.5 GB at the bench shape) would then live until the cyclic GC happens to run."""
+    import gc
+    from oracle import ref_cpu as O
+    from highlyaccurate_amd.models_kitti import LM_G2SP, LM_S2GP
+    d = _dev()
+    sat, grd, gu, gv, gh = O.synth_images(3, 2, grd_hw=(64, 256), sat_a=128)
+    K = (torch.tensor([O.KITTI_K]) * torch.tensor([[0.25], [0.25], [1.0]])).float().repeat(2, 1, 1).to(d)
+    gc.collect()
+    gc.disable()
+    try:
+        for cls, extra in ((LM_S2GP, ()), (LM_G2SP, (K,))):
+            net = cls(O.default_args(N_iters=2)).to(d).train()
+            used = []
+            for _ in range(5):
+                net.zero_grad(set_to_none=True)
+                r = net(sat.to(d), grd.to(d), *extra, gu.to(d), gv.to(d), gh.to(d), mode='train')
+                r[0].backward()
+                del r
+                torch.cuda.synchronize()
+                used.append(torch.cuda.memory_allocated())
+            assert used[-1] <= used[1] + (1 << 20), (cls.__name__, used)
+    finally:
+        gc.enable()
