@@ -68,6 +68,8 @@ def main():
     ap.add_argument('--batch', type=int, default=32, help='pairs per GPU')
     ap.add_argument('--precision', default='bf16', choices=['bf16', 'fp16', 'fp32'])
     ap.add_argument('--n-iters', type=int, default=None, help='LM iterations (default 5; 10 for --model ford = BASELINE configs[3])')
+    ap.add_argument('--grd-hw', type=int, nargs=2, default=[256, 1024], help='ground image size (BASELINE configs[4]: 512 2048)')
+    ap.add_argument('--sat-a', type=int, default=512, help='satellite image side (BASELINE configs[4]: 1024)')
     ap.add_argument('--model', default='kitti', choices=['kitti', 'ford', 'g2sp'],
                     help='kitti = LM_S2GP (the headline, BASELINE configs[1]); ford = LM_S2GP_Ford; g2sp = LM_G2SP')
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -111,8 +113,8 @@ def main():
     net = net.to(dev).eval()
     torch.manual_seed(1234 + rank)           # ... and a different synthetic shard per rank (also decorrelates the re-init draws)
     B = a.batch
-    sat = torch.rand(B, 3, 512, 512, device=dev)
-    grd = torch.rand(B, 3, 256, 1024, device=dev)
+    sat = torch.rand(B, 3, a.sat_a, a.sat_a, device=dev)
+    grd = torch.rand(B, 3, a.grd_hw[0], a.grd_hw[1], device=dev)
 
     if a.model == 'ford':       # BASELINE configs[3] / SURVEY 8(d): fixed camera-to-body rotation, 112.64 m tile
         extra = (112.64, torch.tensor([[[0., 0., 1.], [1., 0., 0.], [0., 1., 0.]]], device=dev).repeat(B, 1, 1),
@@ -236,8 +238,8 @@ def main():
             'value': round(pairs / dt, 3), 'unit': 'pairs/s', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
             'ms_per_step': round(dt / a.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': a.precision, 'data': 'synthetic',
-            'config': {'workload': {'kitti': "BASELINE configs[1]: LM_S2GP", 'ford': "BASELINE configs[3] shapes: LM_S2GP_Ford",
-                                    'g2sp': "SURVEY 8(f).2: LM_G2SP"}[a.model] + ".forward(mode='test'), KITTI shapes (sat 512x512, grd 256x1024), "
+            'config': {'workload': {'kitti': ("BASELINE configs[1]: LM_S2GP" if (a.sat_a, tuple(a.grd_hw)) == (512, (256, 1024)) else "BASELINE configs[4] sizes: LM_S2GP"), 'ford': "BASELINE configs[3] shapes: LM_S2GP_Ford",
+                                    'g2sp': "SURVEY 8(f).2: LM_G2SP"}[a.model] + f".forward(mode='test'), sat {a.sat_a}x{a.sat_a}, grd {a.grd_hw[0]}x{a.grd_hw[1]}, "
                                    f"VGG-16 two-branch, level 3, {a.n_iters} LM iters x 3 levels, 3-DoF, random-init weights",
                        'pairs_per_gpu': B, 'global_batch': B * world, 'parallelism': f'batch-sharded x{world}, no collective',
                        'dead_work_skipped': 'dec3/conf3 (VGG.py:153-155,163: computed and dropped by the reference at level 3); '
