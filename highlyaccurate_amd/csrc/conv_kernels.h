@@ -71,6 +71,18 @@ __device__ __forceinline__ float to_f32(bf16 v) { return (float)v; }
 __device__ __forceinline__ float to_f32(f16 v) { return (float)v; }
 __device__ __forceinline__ float to_f32(float v) { return v; }
 
+// Workgroups are dealt round-robin to the 8 XCDs (each with its own L2).  Remap the linear id so that every XCD works on
+// a CONTIGUOUS run of tiles: vertically adjacent tiles, which share two halo rows, then hit the same L2.  Bijective for
+// any grid size (cdna_hip_programming.md "XCD swizzle must be bijective").  Measured: +1 % in one A/B, within noise in the next.
+__device__ __forceinline__ int xcd_contiguous(int bid, int nb) {
+#if CONV_VARIANT == 111
+  return bid;
+#else
+  const int q = nb >> 3, r = nb & 7, xcd = bid & 7;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+#endif
+}
+
 struct ConvArgs {
   const void* src1;   // NHWC T, C1 channels; at half resolution when up1
   const void* src2;   // NHWC T, C2 channels (virtual concat after src1), or null
@@ -254,7 +266,7 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[MT][NT], const ConvA
     __syncthreads();
     if (threadIdx.x == 0) {
       const int np = a.tiles_x * a.tiles_y * gridDim.y;
-      const int tile = (blockIdx.x % (a.tiles_x * a.tiles_y)) * gridDim.y + blockIdx.y;
+      const int tile = (xcd_contiguous(blockIdx.x, gridDim.x) % (a.tiles_x * a.tiles_y)) * gridDim.y + blockIdx.y;
       a.sumsq[(size_t)b * np + tile] = ((double)red[0] + (double)red[1]) + ((double)red[2] + (double)red[3]);
     }
   }
@@ -393,7 +405,7 @@ __global__ __launch_bounds__(256, (NT == 1 && !PF_UPFRONT) ? 3 : 2) void conv3x3
   const unsigned long long t_begin = __builtin_readcyclecounter();
 #endif
   const int t = threadIdx.x, lane = t & 63, wv = t >> 6, wm = wv / WN, wn = wv % WN;
-  int bid = blockIdx.x;
+  int bid = xcd_contiguous(blockIdx.x, gridDim.x);
   const int tx = bid % a.tiles_x; bid /= a.tiles_x;
   const int ty = bid % a.tiles_y;
   const int b = bid / a.tiles_y;
@@ -514,7 +526,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_lw_kernel(ConvArgs a) {
   char* wl = lds + 2 * BUF;
 
   const int t = threadIdx.x, lane = t & 63, wv = t >> 6, wm = wv / WN, wn = wv % WN;
-  int bid = blockIdx.x;
+  int bid = xcd_contiguous(blockIdx.x, gridDim.x);
   const int tx = bid % a.tiles_x; bid /= a.tiles_x;
   const int ty = bid % a.tiles_y;
   const int b = bid / a.tiles_y;
@@ -692,7 +704,7 @@ __global__ __launch_bounds__(256, 2) void conv02_kernel(Conv02Args a0) {
   __shared__ float red[4];
 
   const int t = threadIdx.x, lane = t & 63, wv = t >> 6, wm = wv / WN, wn = wv % WN;
-  int bid = blockIdx.x;
+  int bid = blockIdx.x;                    // (the XCD-contiguous order measured 2-3 % slower for this kernel)
   const int tx = bid % a0.tiles_x; bid /= a0.tiles_x;
   const int ty = bid % a0.tiles_y;
   const int b = bid / a0.tiles_y;
