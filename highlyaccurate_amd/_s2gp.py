@@ -80,8 +80,8 @@ class S2GPBase(nn.Module):
             raise NotImplementedError("only proj='geo' is in scope")
         if getattr(args, 'Optimizer', 'LM') != 'LM':
             raise NotImplementedError("only Optimizer='LM' is in scope (SURVEY section 2)")
-        if getattr(args, 'dropout', 0) or getattr(args, 'use_gt_depth', 0) or getattr(args, 'estimate_depth', 0):
-            raise NotImplementedError('dropout / use_gt_depth / estimate_depth are out of scope')
+        if getattr(args, 'use_gt_depth', 0) or getattr(args, 'estimate_depth', 0):
+            raise NotImplementedError('use_gt_depth / estimate_depth are out of scope')
         precision = getattr(args, 'precision', 'fp32')
         self.SatFeatureNet = VGGUnet(self.level, precision=precision)
         self.GrdFeatureNet = VGGUnet(self.level, precision=precision)
@@ -93,6 +93,7 @@ class S2GPBase(nn.Module):
         self._tables = {}
         self.last_trace = None       # [B, N_iters, Level, 3] (shift_u, shift_v, theta) of the last forward
         self.last_normal_eq = None
+        self.last_keep = None
         self.keep_normal_eq = False
 
     # -- geometry tables ---------------------------------------------------------------------
@@ -146,6 +147,21 @@ class S2GPBase(nn.Module):
             draws.append(torch.stack([ru[:, 0], rv[:, 0]], 0))
         return torch.stack(draws, 0).to(device)
 
+    def _draw_dropout(self, lv, level_first, device):
+        """args.dropout > 0 (models_kitti.py:968-974, models_ford.py:406-412): every LM step keeps a random half of the
+        pixels, ``np.random.permutation(H*W)[:H*W//2]`` from numpy's GLOBAL generator, one draw per step in execution
+        order.  Returns a uint8 [steps, stride] keep mask on the device (or None)."""
+        if not getattr(self.args, 'dropout', 0):
+            return None
+        L, N = len(lv), self.N_iters
+        order = [l for l in range(L) for _ in range(N)] if level_first else [l for _ in range(N) for l in range(L)]
+        npix = [(lv[l].h - lv[l].row0) * lv[l].w for l in range(L)]
+        keep = np.zeros((len(order), max(npix)), np.uint8)
+        for k, l in enumerate(order):
+            inds = np.random.permutation(np.arange(npix[l]))[: npix[l] // 2]
+            keep[k, inds] = 1
+        return torch.from_numpy(keep).to(device)
+
     def _lm_structs(self, sat_feats, grd_feats, grd_confs, grd_hw, extra, level_first, sat_inv_norm, grd_inv_norm):
         dev = sat_feats[0].device
         L = len(sat_feats)
@@ -190,6 +206,9 @@ class S2GPBase(nn.Module):
         steps = L * self.N_iters
         reinit = self.ford or cfg.dof == 3
         rand_uv = self._draw_reinit(steps, B, dev) if reinit else None
+        self.last_keep = self._draw_dropout(lv, level_first, dev)
+        if self.last_keep is not None:
+            cfg.keep, cfg.keep_stride = self.last_keep.data_ptr(), self.last_keep.shape[1]
         trace = torch.empty(B, self.N_iters, L, 3, device=dev, dtype=torch.float32)
         want_neq = self.keep_normal_eq if keep_normal_eq is None else keep_normal_eq
         neq = torch.empty(steps, B, 16, device=dev, dtype=torch.float64) if want_neq else None
@@ -205,14 +224,17 @@ class S2GPBase(nn.Module):
         return trace
 
     def lm_backward(self, sat_feats, grd_feats, grd_confs, grd_hw, trace, normal_eq, d_trace, extra=None, level_first=0,
-                    init_pose=None, sat_inv_norm=None, grd_inv_norm=None):
+                    init_pose=None, sat_inv_norm=None, grd_inv_norm=None, keep=None):
         """Backward of ``lm_solve``: d(loss)/d(trace) [B,N,L,3] -> (d_sat[l], d_grd[l], d_conf[l] or None, d_lambda[3]).
+        ``keep``: the forward's dropout mask (``self.last_keep``), if args.dropout.
         Map gradients are NHWC fp32 and taken w.r.t. the L2-normalised maps (inv_norm * stored map)."""
         lib = _lib.load()
         dev = sat_feats[0].device
         B, L = sat_feats[0].shape[0], len(sat_feats)
         cfg, lv, R_FL, T_FL = self._lm_structs(sat_feats, grd_feats, grd_confs, grd_hw, extra, level_first,
                                                sat_inv_norm, grd_inv_norm)
+        if keep is not None:
+            cfg.keep, cfg.keep_stride = keep.data_ptr(), keep.shape[1]
         d_sat = [torch.zeros_like(t) for t in sat_feats]
         d_grd = [torch.zeros_like(t) for t in grd_feats]
         d_conf = [torch.zeros_like(grd_confs[l]) if (self.using_weight and grd_confs[l] is not None) else None
@@ -296,7 +318,8 @@ class _LocaliseFn(torch.autograd.Function):
         trace = model.lm_solve(sat_feats, grd_feats, grd_confs, grd_img.shape[-2:], extra, level_first, init_pose,
                                sat_inv, grd_inv, keep_normal_eq=True)
         ctx.model, ctx.names, ctx.extra, ctx.level_first, ctx.init_pose = model, names, extra, level_first, init_pose
-        ctx.state = (sat_feats, grd_feats, grd_confs, tuple(grd_img.shape[-2:]), trace.detach(), model.last_normal_eq, sat_inv, grd_inv, cs, cg)
+        ctx.state = (sat_feats, grd_feats, grd_confs, tuple(grd_img.shape[-2:]), trace.detach(), model.last_normal_eq, sat_inv, grd_inv, cs, cg,
+                     model.last_keep)
         outs = (trace,) + (tuple(grd_confs) if want_conf else ())
         if want_conf:
             ctx.mark_non_differentiable(*grd_confs)     # loss_method 0 does not read them; their LM-weight role is in backward()
@@ -305,9 +328,9 @@ class _LocaliseFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, d_trace, *unused):
         model = ctx.model
-        sat_feats, grd_feats, grd_confs, grd_hw, trace, neq, sat_inv, grd_inv, cs, cg = ctx.state
+        sat_feats, grd_feats, grd_confs, grd_hw, trace, neq, sat_inv, grd_inv, cs, cg, keep = ctx.state
         d_sat, d_grd, d_conf, d_lam = model.lm_backward(sat_feats, grd_feats, grd_confs, grd_hw, trace, neq, d_trace, ctx.extra,
-                                                   ctx.level_first, ctx.init_pose, sat_inv, grd_inv)
+                                                   ctx.level_first, ctx.init_pose, sat_inv, grd_inv, keep)
         sync = getattr(model, 'grad_sync', None)        # optional: overlap the sat-branch all-reduce with the grd backward
         g_sat = vgg_backward_nhwc(model.SatFeatureNet, cs, d_sat)
         h1 = sync.start({'SatFeatureNet.' + k: v for k, v in g_sat.items()}) if sync else None

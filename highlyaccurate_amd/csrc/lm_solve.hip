@@ -23,6 +23,7 @@ struct AccumArgs {
   double* part;       // [B,nt,PART_N]
   int A, h, w, row0, npix, TP, nt, B, xcd_affine;
   int hs, rskip;      // stored rows of grd/conf (h - grd_row_skip) and the skip itself
+  const unsigned char* keep;   // dropout: [npix] of this step, 1 = pixel takes part; or null
 };
 
 template <int C, bool USE_W>
@@ -40,7 +41,11 @@ __global__ __launch_bounds__(256) void lm_accum(AccumArgs a) {
     const int p = p0 + t;
     const int r = a.row0 + p / a.w, c = p % a.w;
     const float cw = USE_W ? a.conf[((size_t)b * a.hs + (r - a.rskip)) * a.w + c] : 1.f;
-    pp[t] = lm_pixel<C>(cf, a.xyz + ((size_t)r * a.w + c) * 3, a.A, cw);
+    PixParam P = lm_pixel<C>(cf, a.xyz + ((size_t)r * a.w + c) * 3, a.A, cw);
+    if (a.keep && !a.keep[p]) {          // dropped by args.dropout: the pixel leaves every sum (models_kitti.py:968-974)
+      P.wx0 = P.wx1 = P.wy0 = P.wy1 = 0.f; P.off = P.dxo = P.dyo = 0; P.j2u = P.j2v = 0.f; P.gm = P.wt = P.m = 0.f;
+    }
+    pp[t] = P;
   }
   __syncthreads();
 
@@ -265,6 +270,7 @@ extern "C" int hla_s2g_lm_solve(const hla_s2g_config* cfg, const hla_s2g_level* 
     aa.sat = v.sat_feat; aa.grd = v.grd_feat; aa.conf = v.grd_conf; aa.xyz = v.xyz; aa.coef = coef; aa.part = part;
     aa.A = v.A; aa.h = v.h; aa.w = v.w; aa.row0 = v.row0; aa.npix = (v.h - v.row0) * v.w;
     aa.hs = v.h - v.grd_row_skip; aa.rskip = v.grd_row_skip;
+    aa.keep = cfg->keep ? cfg->keep + (size_t)k * cfg->keep_stride : nullptr;
     aa.TP = lm_pick_tile(aa.npix); aa.nt = (aa.npix + aa.TP - 1) / aa.TP; aa.B = B;
     aa.xcd_affine = (B >= 8) ? 1 : 0;
     const int nblk = aa.xcd_affine ? 8 * ((B + 7) / 8) * aa.nt : B * aa.nt;

@@ -178,6 +178,9 @@ typedef struct hla_s2g_config {
   int dof;                /* 3: (u,v,theta); 2: rotation_range==0; 1: shift ranges == 0 (KITTI only) */
   double shift_range_lat, shift_range_lon, rotation_range; /* metres, metres, degrees */
   double damping[3];      /* lambda per pose component (already 10^(-6+11*sigmoid) if trained) */
+  const unsigned char* keep;  /* args.dropout (models_kitti.py:968-974): [steps][keep_stride] bytes in execution order, 1 = the
+                                 pixel (index within the rows row0..h-1 of that step's level) takes part; NULL = no dropout */
+  size_t keep_stride;
 } hla_s2g_config;
 
 size_t hla_s2g_workspace_bytes(const hla_s2g_config* cfg, const hla_s2g_level* levels, int B);

@@ -202,6 +202,7 @@ def run_e2e(mod, cls, args, seed, B, dtype, extra=None, level_first=0, bias_scal
     sat, grd, gu, gv, gh = O.synth_images(seed + 100, B, grd_hw=grd_hw, sat_a=sat_a)
     sat, grd = sat.to(dtype), grd.to(dtype)
     torch.manual_seed(seed)
+    np.random.seed(seed)                  # args.dropout (models_kitti.py:969) draws from numpy's global generator
     # capture per-step poses through the train-mode return path: run test mode and
     # recover the full [B,N,L] traces by re-running the loop pieces is intrusive; instead
     # monkey-patch loss_func-free access: call train mode with gt to get nothing extra, so
@@ -252,7 +253,8 @@ def gen_e2e(mk, seeds, B=2):
     # level-first ordering and the option flags, one seed, B=1
     seed = seeds[0]
     for tag, kw, lf in (('levelfirst', {}, 1), ('weight', dict(using_weight=1), 0),
-                        ('hess', dict(use_hessian=1, damping=0.5), 0), ('rot0', dict(rotation_range=0.0), 0)):
+                        ('hess', dict(use_hessian=1, damping=0.5), 0), ('rot0', dict(rotation_range=0.0), 0),
+                        ('dropout', dict(dropout=1), 0)):
         a = O.default_args(**kw)
         t64, f64, _, _ = run_e2e(mk, 'LM_S2GP', a, seed, 1, torch.float64, level_first=lf)
         t32, f32, _, _ = run_e2e(mk, 'LM_S2GP', a, seed, 1, torch.float32, level_first=lf)

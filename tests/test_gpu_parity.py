@@ -118,7 +118,8 @@ def _oracle_normal_eq(onet, sat, grd, conf, pose, level, using_weight, extra=Non
 
 @pytest.mark.parametrize('kw', [dict(), dict(using_weight=1), dict(use_hessian=1, damping=0.5),
                                 dict(rotation_range=0.0), dict(shift_range_lat=0.0, shift_range_lon=0.0),
-                                dict(level_first=1), dict(N_iters=2, damping=10.0)])
+                                dict(level_first=1), dict(N_iters=2, damping=10.0), dict(dropout=1),
+                                dict(dropout=1, using_weight=1, level_first=1)])
 def test_lm_solve_small_vs_oracle(kw):
     """The fused projection+Jacobian+normal-equation+solve loop on random feature pyramids:
     first-step normal equations (tight) and the whole pose trace."""
@@ -135,16 +136,19 @@ def test_lm_solve_small_vs_oracle(kw):
     net.keep_normal_eq = True
     nh = lambda t: t.permute(0, 2, 3, 1).contiguous().to(d)
     torch.manual_seed(0)
+    np.random.seed(0)                      # args.dropout draws its pixel subsets from numpy's global generator
     trace = net.lm_solve([nh(s) for s in sat], [nh(g) for g in grd], [c[:, 0].contiguous().to(d) for c in conf],
                          grd_hw, None, lf, init_pose=p0).cpu().numpy()
     neq = net.last_normal_eq[0, :, :14].cpu().numpy()
     pose = [p0[:, i:i + 1].double() for i in range(3)]
-    ref_neq = _oracle_normal_eq(onet, sat, grd, conf, pose, 0, args.using_weight)
-    e_neq = np.abs(neq - ref_neq).max(0) / np.abs(ref_neq).max(0).clip(1e-30)
-    print('normal-eq rel err per sum:', np.array2string(e_neq, precision=1))
-    assert e_neq.max() < 2e-6, e_neq
+    if not args.dropout:
+        ref_neq = _oracle_normal_eq(onet, sat, grd, conf, pose, 0, args.using_weight)
+        e_neq = np.abs(neq - ref_neq).max(0) / np.abs(ref_neq).max(0).clip(1e-30)
+        print('normal-eq rel err per sum:', np.array2string(e_neq, precision=1))
+        assert e_neq.max() < 2e-6, e_neq
     # whole trace: restart the oracle from the same pose by running its loop manually
     torch.manual_seed(0)
+    np.random.seed(0)
     su, sv, th = pose
     L, N = 3, args.N_iters
     order = [(i, l) for l in range(L) for i in range(N)] if lf else [(i, l) for i in range(N) for l in range(L)]
@@ -201,6 +205,7 @@ def _run_kitti(seed, B, precision='fp32', level_first=0, grd_hw=(256, 1024), sat
     net = net.to(d)
     sat, grd, gu, gv, gh = O.synth_images(seed + 100, B, grd_hw=grd_hw, sat_a=sat_a)
     torch.manual_seed(seed)
+    np.random.seed(seed)
     with torch.no_grad():
         res = net(sat.to(d), grd.to(d), mode='test', level_first=level_first)
     return net, res
@@ -256,7 +261,7 @@ def test_e2e_kitti_features_vs_golden():
 
 @pytest.mark.parametrize('tag,kw,lf', [('levelfirst', {}, 1), ('weight', dict(using_weight=1), 0),
                                        ('hess', dict(use_hessian=1, damping=0.5), 0),
-                                       ('rot0', dict(rotation_range=0.0), 0)])
+                                       ('rot0', dict(rotation_range=0.0), 0), ('dropout', dict(dropout=1), 0)])
 def test_e2e_kitti_variants_vs_golden(tag, kw, lf):
     g = load_golden('e2e_kitti.npz')
     seed = int(g['seeds'][0])
@@ -486,7 +491,7 @@ def test_full_bench_config_runs_and_is_consistent():
 
 @pytest.mark.parametrize('kw', [dict(), dict(using_weight=1), dict(use_hessian=1, damping=0.5),
                                 dict(rotation_range=0.0), dict(level_first=1), dict(train_damping=1),
-                                dict(train_damping=1, use_hessian=1)])
+                                dict(train_damping=1, use_hessian=1), dict(dropout=1, using_weight=1)])
 def test_lm_backward_small_vs_oracle_autograd(kw):
     """hla_s2g_lm_solve_bwd against torch autograd through the fp64 oracle's unrolled loop
     (gather values, bilinear weights, norms, J^T W J, inverse, pose->uv chain of later steps)."""
@@ -512,6 +517,7 @@ def test_lm_backward_small_vs_oracle_autograd(kw):
     su, sv, th = [p0[:, i:i + 1].double() for i in range(3)]
     order = [(i, l) for l in range(L) for i in range(N)] if lf else [(i, l) for i in range(N) for l in range(L)]
     torch.manual_seed(0)
+    np.random.seed(0)
     loss = 0
     for i, l in order:
         su, sv, th = onet._step(l, sat64[l], None, grd64[l], conf64[l], su, sv, th, None)
@@ -524,8 +530,10 @@ def test_lm_backward_small_vs_oracle_autograd(kw):
     nh = lambda t: t.permute(0, 2, 3, 1).contiguous().to(d)
     feats = ([nh(s) for s in sat], [nh(g) for g in grd], [c[:, 0].contiguous().to(d) for c in conf])
     torch.manual_seed(0)
+    np.random.seed(0)
     trace = net.lm_solve(*feats, grd_hw, None, lf, init_pose=p0, keep_normal_eq=True)
-    d_sat, d_grd, d_conf, d_lam = net.lm_backward(*feats, grd_hw, trace, net.last_normal_eq, coef.float(), None, lf, init_pose=p0)
+    d_sat, d_grd, d_conf, d_lam = net.lm_backward(*feats, grd_hw, trace, net.last_normal_eq, coef.float(), None, lf, init_pose=p0,
+                                                  keep=net.last_keep)
     for l in range(L):
         for name, got, ref in (('sat', d_sat[l], sat64[l].grad), ('grd', d_grd[l], grd64[l].grad)):
             got = got.permute(0, 3, 1, 2).cpu().double().numpy()
