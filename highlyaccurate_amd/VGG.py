@@ -18,7 +18,7 @@ from . import _lib
 _W_ORDER = ['conv0', 'conv2', 'conv5', 'conv7', 'conv10', 'conv12', 'conv14',
             'conv_dec1.1', 'conv_dec1.3', 'conv_dec2.1', 'conv_dec2.3', 'conv_dec3.1', 'conv_dec3.3',
             'conf0.1', 'conf1.1', 'conf2.1', 'conf3.1']
-_LEVEL_SEL = {-1: [0], -2: [1], -3: [2], 2: [1, 2], 3: [0, 1, 2]}
+_LEVEL_SEL = {-1: [0], -2: [1], -3: [2], 2: [1, 2], 3: [0, 1, 2], 4: [0, 1, 2, 3]}
 _CH = (256, 128, 64, 16)
 
 
@@ -36,10 +36,17 @@ def _param_table(module: 'VGGUnet'):
     sd = dict(module.named_parameters())
     prm = _lib.VggParams()
     keep, versions = [], []
+    pad = {11: (64, 128), 12: (64, 64), 16: (1, 64)}       # level 4: conv_dec3.1/3 and conf3 run zero-padded to 64 channels
     for i, name in enumerate(_W_ORDER):
         w = sd[name + '.weight']
         versions.append((w.data_ptr(), w._version))
         w = w.detach().contiguous().float()
+        if i in pad:
+            if module.level != 4:
+                continue
+            wp = torch.zeros(pad[i][0], pad[i][1], 3, 3, device=w.device, dtype=torch.float32)
+            wp[:w.shape[0], :w.shape[1]] = w
+            w = wp
         keep.append(w)
         prm.w[i] = w.data_ptr()
         if i < 7:
@@ -81,13 +88,18 @@ def vgg_forward_nhwc(module: 'VGGUnet', x: torch.Tensor, want_conf: bool = True,
     dt = _dtype_code(module.precision)
     prm, keep, versions = _param_table(module)
     packed = _packed_weights(module, prm, versions, dt, x.device)
-    feats = [torch.empty(B, H >> (3 - l), W >> (3 - l), _CH[l], device=x.device, dtype=torch.float32) for l in range(3)]
+    L = 4 if module.level == 4 else 3
+    if L == 4 and save_for_backward:
+        raise NotImplementedError('VGGUnet level 4 is forward-only (the backward of conv_dec3 / conf3 is not built)')
+    # level 4: x24 is stored with 64 channels, the 16 real ones first, zeros behind them (see include/hla.h)
+    feats = [torch.empty(B, H >> (3 - l), W >> (3 - l), 64 if l == 3 else _CH[l], device=x.device, dtype=torch.float32)
+             for l in range(L)]
     confs = [torch.empty(B, H >> (3 - l), W >> (3 - l), device=x.device, dtype=torch.float32) if want_conf else None
-             for l in range(3)]
-    inv_norm = torch.empty(3, B, device=x.device, dtype=torch.float64)
-    fp = (C.c_void_p * 4)(*[f.data_ptr() for f in feats], 0)
-    cp = (C.c_void_p * 4)(*[(c.data_ptr() if c is not None else 0) for c in confs], 0)
-    nbytes = lib.hla_vgg_workspace_bytes(B, H, W, 3, dt)
+             for l in range(L)]
+    inv_norm = torch.empty(L, B, device=x.device, dtype=torch.float64)
+    fp = (C.c_void_p * 4)(*([f.data_ptr() for f in feats] + [0] * (4 - L)))
+    cp = (C.c_void_p * 4)(*([(c.data_ptr() if c is not None else 0) for c in confs] + [0] * (4 - L)))
+    nbytes = lib.hla_vgg_workspace_bytes(B, H, W, L, dt)
     ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
     flags = (_lib.HLA_VGG_WANT_CONF if want_conf else 0) | (_lib.HLA_VGG_DEFER_NORM if defer_norm else 0)
     if save_for_backward:
@@ -95,7 +107,7 @@ def vgg_forward_nhwc(module: 'VGGUnet', x: torch.Tensor, want_conf: bool = True,
             raise ValueError('save_for_backward needs defer_norm=True (the backward works on the raw maps)')
         flags |= _lib.HLA_VGG_SAVE_FOR_BACKWARD
     rc = lib.hla_vgg_forward(_lib.ptr(x), C.byref(prm), _lib.ptr(packed), fp, cp, _lib.ptr(inv_norm), _lib.ptr(ws), nbytes,
-                             B, H, W, 3, dt, flags, _lib.stream_ptr())
+                             B, H, W, L, dt, flags, _lib.stream_ptr())
     _lib.check(rc, 'hla_vgg_forward')
     # ws is only used by work already enqueued on this stream; the caching allocator keeps the block
     # stream-ordered, so dropping the Python reference here is safe.
@@ -156,7 +168,7 @@ class VGGUnet(nn.Module):
         if estimate_depth:
             raise NotImplementedError('estimate_depth=1 (Ford height heads, VGG.py:85-118) is out of scope')
         if level not in _LEVEL_SEL:
-            raise NotImplementedError(f'VGGUnet level {level}: levels -1,-2,-3,2,3 are built (level 4 = x24 is not yet)')
+            raise NotImplementedError(f'VGGUnet level {level}: the reference defines -1, -2, -3, 2, 3, 4')
         self.level = level
         _dtype_code(precision)          # validate now, not at the first forward
         self.precision = precision
@@ -179,7 +191,8 @@ class VGGUnet(nn.Module):
         feats, confs, _ = vgg_forward_nhwc(self, x, want_conf=True)
         sel = _LEVEL_SEL[self.level]
         # NCHW-shaped views over the NHWC storage
-        return [feats[i].permute(0, 3, 1, 2) for i in sel], [confs[i].unsqueeze(1) for i in sel]
+        view = lambda i: (feats[i][..., :_CH[i]] if i == 3 else feats[i]).permute(0, 3, 1, 2)   # x24: 16 real of 64 stored channels
+        return [view(i) for i in sel], [confs[i].unsqueeze(1) for i in sel]
 
 
 def L2_norm(x):

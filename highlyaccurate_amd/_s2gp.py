@@ -74,8 +74,8 @@ class S2GPBase(nn.Module):
         self.N_iters = args.N_iters
         self.using_weight = args.using_weight
         self.loss_method = args.loss_method
-        if args.level != 3:
-            raise NotImplementedError('only args.level == 3 (x15, x18, x21) is built so far')
+        if args.level not in (3, 4):
+            raise NotImplementedError('args.level must be 3 (x15, x18, x21) or 4 (+ x24, inference only)')
         if getattr(args, 'proj', 'geo') != 'geo':
             raise NotImplementedError("only proj='geo' is in scope")
         if getattr(args, 'Optimizer', 'LM') != 'LM':
@@ -105,7 +105,7 @@ class S2GPBase(nn.Module):
         if key not in self._tables:
             K = ford_K_network_input() if self.ford else KITTI_K
             self._tables[key] = [ground_plane_table(K, grd_H / 2 ** (3 - l), grd_W / 2 ** (3 - l), 256, 1024).to(device)
-                                 for l in range(3)]
+                                 for l in range(4)]
         return self._tables[key]
 
     # -- LM options -> C structs -------------------------------------------------------------
@@ -265,6 +265,8 @@ class S2GPBase(nn.Module):
             raise ValueError(f'expected sat_map [B,3,A,A] and grd_img [B,3,H,W] with one B, got {tuple(sat_map.shape)} '
                              f'and {tuple(grd_img.shape)}')
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            if self.level == 4:
+                raise NotImplementedError('args.level == 4 is inference-only: the backward of conv_dec3 / conf3 is not built')
             names = [n for n, _ in self.named_parameters()]
             params = [p for _, p in self.named_parameters()]
             out = _LocaliseFn.apply(self, names, sat_map, grd_img, want_conf, extra, level_first, init_pose, *params)
@@ -286,7 +288,8 @@ class S2GPBase(nn.Module):
         else:
             sat_feats, _, sat_inv = vgg_forward_nhwc(self.SatFeatureNet, sat_map, want_conf=False, defer_norm=True)
             grd_in = grd_img
-            skip = dead_ground_rows(grd_img.shape[-2]) if (not return_confs and os.environ.get('HLA_GRD_CROP', '1') != '0') else 0
+            skip = dead_ground_rows(grd_img.shape[-2]) if (not return_confs and self.level == 3
+                                                           and os.environ.get('HLA_GRD_CROP', '1') != '0') else 0
             if skip:
                 grd_in = grd_img[:, :, skip:, :].contiguous()
             grd_feats, grd_confs, grd_inv = vgg_forward_nhwc(self.GrdFeatureNet, grd_in, want_conf=want_conf, defer_norm=True)

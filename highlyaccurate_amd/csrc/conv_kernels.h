@@ -522,6 +522,7 @@ struct Conv02Args {
   void* out_act;       // NHWC T [B,H/2,W/2,64] = relu(pool(conv2))
   void* a0_out;        // training: NHWC T [B,H,W,64] = relu(conv0), or null
   unsigned char* idx_out;  // training: pool argmax [B,H/2,W/2,64], or null
+  void* a2_out;        // level 4: NHWC T [B,H,W,64] = relu(conv2) before the pool (the skip input of conv_dec3), or null
   int B, H, W, tiles_x, tiles_y;
 };
 
@@ -645,6 +646,11 @@ __global__ __launch_bounds__(256, 2) void conv02_kernel(Conv02Args a0) {
   a.bias = a0.b2; a.out_act = a0.out_act; a.B = a0.B; a.H = a0.H; a.W = a0.W; a.Cout = 64; a.relu_act = 1;
   a.tiles_x = a0.tiles_x; a.tiles_y = a0.tiles_y; a.idx_out = a0.idx_out;
   __syncthreads();   // all waves are done with the halo buffers; reuse them as wave-private stagers
+  if (a0.a2_out) {   // the epilogue only reads the accumulators: run it twice, un-pooled first
+    ConvArgs f = a;
+    f.out_act = a0.a2_out; f.idx_out = nullptr;
+    conv_epilogue<T, MT, NT, false>(acc, f, b, y0 + wm * MT, x0, wn * 32, red, lds + wv * (NSG * BUF / 4));
+  }
   conv_epilogue<T, MT, NT, true>(acc, a, b, y0 + wm * MT, x0, wn * 32, red, lds + wv * (NSG * BUF / 4));
 }
 

@@ -4,7 +4,8 @@
 
 template <typename T>
 void vgg_pack_all(const hla_vgg_params* prm, char* packed, int dtype, hipStream_t st) {
-  for (int l = 0; l < kPackedLayers; ++l) {
+  for (int l = 0; l < kAllLayers; ++l) {
+    if (l >= kPackedLayers && !prm->w[l]) continue;        // conv_dec3.* only when the caller supplies its padded weights
     const size_t n = l == 0 ? (size_t)2 * 32 * 32 : (size_t)kLayers[l].cin * kLayers[l].cout * 9;
     const int grid = (int)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024);
     hla_prof_begin(K_PACK, 0, (double)n * (4 + sizeof(T)), st);
@@ -18,6 +19,8 @@ template <typename T>
 int vgg_forward_t(const float* x, const hla_vgg_params* prm, const char* packed, int dtype, float* const feat[4],
                          float* const conf[4], double* inv_norm, char* ws, const VggPlan& pl, int B, int H, int W,
                          int flags, hipStream_t st) {
+  const bool level4 = pl.x2r != 0;
+  const int NL = level4 ? 4 : 3;
   auto W_ = [&](int l) { return (const uint4*)(packed + packed_offset(l, dtype)); };
   char* w = ws;
   // conv0 + conv2 + pool fused (VGG.py:123-128): relu(x3)
@@ -25,6 +28,7 @@ int vgg_forward_t(const float* x, const hla_vgg_params* prm, const char* packed,
     Conv02Args a{};
     a.x = x; a.w0 = W_(0); a.b0 = prm->b[0]; a.w2 = W_(1); a.b2 = prm->b[1]; a.out_act = w + pl.x3;
     if (flags & HLA_VGG_SAVE_FOR_BACKWARD) { a.a0_out = w + pl.a0; a.idx_out = (unsigned char*)(w + pl.idx3); }
+    if (level4) a.a2_out = w + pl.x2r;
     a.B = B; a.H = H; a.W = W; a.tiles_x = (W + 31) / 32; a.tiles_y = (H + 7) / 8;
     const double P = (double)B * H * W;
     constexpr int lds_bytes = conv02_lds_bytes<T>();
@@ -63,11 +67,16 @@ int vgg_forward_t(const float* x, const hla_vgg_params* prm, const char* packed,
   conv(9, w + pl.x18r, 128, H / 2, W / 2, w + pl.d2a, 1, false, w + pl.x3, 64, 1);    // dec2.1
   conv(10, w + pl.d2a, 64, H / 2, W / 2, w + pl.x21r, 1, false, nullptr, 0, 0, feat[2],
        (double*)(w + pl.ss[2]));                                                      // dec2.3 -> x21
+  if (level4) {      // VGG.py:153-155: conv_dec3 on cat(up(x21), x2), zero-padded to 64 channels (vgg_layers.h)
+    conv(11, w + pl.x21r, 64, H, W, w + pl.d3a, 1, false, w + pl.x2r, 64, 1);          // dec3.1
+    conv(12, w + pl.d3a, 64, H, W, w + pl.x24r, 1, false, nullptr, 0, 0, feat[3],
+         (double*)(w + pl.ss[3]));                                                     // dec3.3 -> x24 (16 real channels)
+  }
   // confidence heads on the ReLU'd maps
   if ((flags & HLA_VGG_WANT_CONF) && conf) {
-    const T* acts[3] = {(const T*)(w + pl.x15r), (const T*)(w + pl.x18r), (const T*)(w + pl.x21r)};
-    const int Cs[3] = {256, 128, 64}, hs[3] = {H / 8, H / 4, H / 2}, wsz[3] = {W / 8, W / 4, W / 2};
-    for (int l = 0; l < 3; ++l) {
+    const T* acts[4] = {(const T*)(w + pl.x15r), (const T*)(w + pl.x18r), (const T*)(w + pl.x21r), (const T*)(w + pl.x24r)};
+    const int Cs[4] = {256, 128, 64, 64}, hs[4] = {H / 8, H / 4, H / 2, H}, wsz[4] = {W / 8, W / 4, W / 2, W};
+    for (int l = 0; l < NL; ++l) {
       if (!conf[l]) continue;
       constexpr int EPL = 16 / sizeof(T);
       const int ppb = 256 / (Cs[l] / EPL);
@@ -81,9 +90,10 @@ int vgg_forward_t(const float* x, const hla_vgg_params* prm, const char* packed,
   }
   // L2 normalisation: 1/||x|| per sample (always), in-place scaling unless the caller folds it downstream
   {
-    const size_t per[3] = {(size_t)(H / 8) * (W / 8) * 256, (size_t)(H / 4) * (W / 4) * 128, (size_t)(H / 2) * (W / 2) * 64};
+    const size_t per[4] = {(size_t)(H / 8) * (W / 8) * 256, (size_t)(H / 4) * (W / 4) * 128, (size_t)(H / 2) * (W / 2) * 64,
+                           (size_t)H * W * 64};
     double* inv = inv_norm ? inv_norm : (double*)(w + pl.inv);
-    for (int l = 0; l < 3; ++l) {
+    for (int l = 0; l < NL; ++l) {
       hla_prof_begin(K_L2NORM, 0, (double)B * pl.np[l] * 8, st);
       hipLaunchKernelGGL(inv_norm_kernel, dim3(B), dim3(256), 0, st, (const double*)(w + pl.ss[l]), pl.np[l], inv + (size_t)l * B);
       hla_prof_end(st);
@@ -110,7 +120,7 @@ template int vgg_forward_t<TuT>(const float* x, const hla_vgg_params* prm, const
   extern template int vgg_forward_t<T>(const float* x, const hla_vgg_params* prm, const char* packed, int dtype, float* const feat[4],                               float* const conf[4], double* inv_norm, char* ws, const VggPlan& pl, int B, int H, int W,                               int flags, hipStream_t st);
 HLA_EXTERN_T(float) HLA_EXTERN_T(bf16) HLA_EXTERN_T(f16)
 
-extern "C" size_t hla_vgg_packed_weight_bytes(int dtype) { return packed_offset(kPackedLayers, dtype); }
+extern "C" size_t hla_vgg_packed_weight_bytes(int dtype) { return packed_offset(kAllLayers, dtype); }
 
 extern "C" int hla_vgg_pack_weights(const hla_vgg_params* params, void* packed, int dtype, hla_stream_t stream) {
   HLA_REQUIRE(params && packed, "hla_vgg_pack_weights: null argument");
@@ -123,9 +133,8 @@ extern "C" int hla_vgg_pack_weights(const hla_vgg_params* params, void* packed, 
 }
 
 extern "C" size_t hla_vgg_workspace_bytes(int B, int H, int W, int level, int dtype) {
-  (void)level;
   VggPlan p;
-  vgg_plan(B, H, W, dtype, /*train=*/true, &p);   // sized for training so one buffer serves both modes
+  vgg_plan(B, H, W, dtype, /*train=*/true, &p, level == 4);   // sized for training so one buffer serves both modes
   return p.total;
 }
 
@@ -136,11 +145,15 @@ extern "C" int hla_vgg_forward(const float* x, const hla_vgg_params* params, con
   HLA_REQUIRE(x && params && packed_weights && feat && workspace, "hla_vgg_forward: null argument");
   HLA_REQUIRE(hla_dtype_ok(dtype), "hla_vgg_forward: dtype must be HLA_F32, HLA_BF16 or HLA_F16 (got %d)", dtype);
   HLA_REQUIRE(B > 0 && H >= 8 && W >= 8 && H % 8 == 0 && W % 8 == 0, "hla_vgg_forward: H and W must be multiples of 8");
-  HLA_REQUIRE(level == 3, "hla_vgg_forward: only level 3 (x15,x18,x21) is built so far (got %d)", level);
-  HLA_REQUIRE(feat[0] && feat[1] && feat[2], "hla_vgg_forward: level 3 needs feat[0..2]");
+  HLA_REQUIRE(level == 3 || level == 4, "hla_vgg_forward: level must be 3 (x15,x18,x21) or 4 (+x24), got %d", level);
+  HLA_REQUIRE(feat[0] && feat[1] && feat[2], "hla_vgg_forward: feat[0..2] are required");
+  HLA_REQUIRE(level == 3 || (feat[3] && params->w[11] && params->w[12] && !(flags & HLA_VGG_SAVE_FOR_BACKWARD)),
+              "hla_vgg_forward: level 4 needs feat[3] ([B,H,W,64], 16 real channels), the zero-padded conv_dec3 weights in w[11], w[12], "
+              "and is forward-only");
+  HLA_REQUIRE(level == 3 || !(flags & HLA_VGG_WANT_CONF) || !conf || !conf[3] || params->w[16], "hla_vgg_forward: conf[3] needs w[16]");
   HLA_REQUIRE(!(flags & HLA_VGG_DEFER_NORM) || inv_norm, "hla_vgg_forward: HLA_VGG_DEFER_NORM needs inv_norm");
   VggPlan pl;
-  vgg_plan(B, H, W, dtype, (flags & HLA_VGG_SAVE_FOR_BACKWARD) != 0, &pl);
+  vgg_plan(B, H, W, dtype, (flags & HLA_VGG_SAVE_FOR_BACKWARD) != 0, &pl, level == 4);
   if (workspace_bytes < pl.total) {
     hla_set_error("hla_vgg_forward: workspace %zu < %zu", workspace_bytes, pl.total);
     return HLA_ERR_WORKSPACE;

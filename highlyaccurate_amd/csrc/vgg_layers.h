@@ -6,8 +6,12 @@ struct LayerDef { int cin, cout, has_bias; };
 // state-dict order (VGG.py:23-56): conv0,2,5,7,10,12,14, dec1.1, dec1.3, dec2.1, dec2.3, dec3.1, dec3.3
 static const LayerDef kLayers[13] = {
     {3, 64, 1}, {64, 64, 1}, {64, 128, 1}, {128, 128, 1}, {128, 256, 1}, {256, 256, 1}, {256, 256, 1},
-    {384, 128, 0}, {128, 128, 0}, {192, 64, 0}, {64, 64, 0}, {128, 32, 0}, {32, 16, 0}};
-constexpr int kPackedLayers = 11;   // conv0..dec2.3 (dec3.* only feed the unused x24 at level 3)
+    {384, 128, 0}, {128, 128, 0}, {192, 64, 0}, {64, 64, 0},
+    // conv_dec3.1 (128 -> 32) and conv_dec3.3 (32 -> 16) are run on ZERO-PADDED weights (the host pads them to 64 output /
+    // 64 input channels), so every kernel keeps its 64-channel granularity; the padded channels are exactly zero
+    {128, 64, 0}, {64, 64, 0}};
+constexpr int kPackedLayers = 11;   // conv0..dec2.3: what level 3 and the backward pass use
+constexpr int kAllLayers = 13;      // + conv_dec3.1/3 (level 4, forward only)
 
 static inline size_t packed_bytes(int l, int dtype) {
   const size_t es = dtype == HLA_F32 ? 4 : 2;
@@ -23,13 +27,14 @@ static inline size_t packed_offset(int l, int dtype) {
 // Forward workspace: every activation a later layer (or the backward pass) reads.  All maps NHWC, T elements.
 struct VggPlan {
   size_t x3, a5, x8, a10, a12, x15r, d1a, x18r, d2a, x21r;   // post-ReLU activations
-  size_t ss[3], inv;                                         // sum-of-squares partials, 1/norm
+  size_t x2r, d3a, x24r;                                     // level 4 only: relu(conv2) at full resolution, dec3 maps
+  size_t ss[4], inv;                                         // sum-of-squares partials, 1/norm
   size_t a0, idx3, idx8, idx15;                              // training only: conv0 output, pool argmax (u8)
-  int np[3];
+  int np[4];
   size_t total;
 };
 
-static inline void vgg_plan(int B, int H, int W, int dtype, bool train, VggPlan* p) {
+static inline void vgg_plan(int B, int H, int W, int dtype, bool train, VggPlan* p, bool level4 = false) {
   const size_t es = dtype == HLA_F32 ? 4 : 2;
   size_t o = 0;
   auto take = [&](size_t bytes) { size_t r = o; o += hla_align_up(bytes, 256); return r; };
@@ -49,8 +54,15 @@ static inline void vgg_plan(int B, int H, int W, int dtype, bool train, VggPlan*
   p->np[0] = tiles(H / 4, W / 4) * 2;   // conv14: Cout 256 in blocks of 128
   p->np[1] = tiles(H / 4, W / 4) * 1;   // dec1.3: Cout 128
   p->np[2] = tiles(H / 2, W / 2) * 1;   // dec2.3: Cout 64
-  for (int i = 0; i < 3; ++i) p->ss[i] = take((size_t)B * p->np[i] * sizeof(double));
-  p->inv = take((size_t)3 * B * sizeof(double));
+  p->np[3] = tiles(H, W) * 1;           // dec3.3: Cout 16 (padded to 64)
+  for (int i = 0; i < 4; ++i) p->ss[i] = take((size_t)B * p->np[i] * sizeof(double));
+  p->inv = take((size_t)4 * B * sizeof(double));
+  p->x2r = p->d3a = p->x24r = 0;
+  if (level4) {
+    p->x2r = take(P * 64 * es);
+    p->d3a = take(P * 64 * es);
+    p->x24r = take(P * 64 * es);
+  }
   p->a0 = p->idx3 = p->idx8 = p->idx15 = 0;
   if (train) {
     p->a0 = take(P * 64 * es);

@@ -83,7 +83,10 @@ size_t hla_vgg_workspace_bytes(int B, int H, int W, int level, int dtype);
  *          L2-normalised per sample, or raw when HLA_VGG_DEFER_NORM
  * conf[l]  [B,h_l,w_l] fp32 = sigmoid(-sigmoid(conv(relu(.)))), or NULL
  * inv_norm [3][B] fp64 out: 1/max(||map_l of sample b||_2, 1e-12) (VGG.py:511-514), or NULL
- * level    the reference's VGGUnet(level); 3 -> maps 0..2 (the dead dec3/conf3 work of VGG.py:153-155,163
+ * level    the reference's VGGUnet(level); 4 additionally computes x24 / conf3 (forward only): feat[3] is [B,H,W,64] with the
+ *          16 real channels first and zeros behind them, and params->w[11], w[12], w[16] must point at conv_dec3.1 /
+ *          conv_dec3.3 / conf3.1 weights ZERO-PADDED to [64,128,3,3], [64,64,3,3], [1,64,3,3]; inv_norm is [4,B].
+ *          3 -> maps 0..2 (the dead dec3/conf3 work of VGG.py:153-155,163
  *          is skipped).  Level 4 (x24) is not built yet.                                              */
 int hla_vgg_forward(const float* x, const hla_vgg_params* params, const void* packed_weights, float* const feat[4],
                     float* const conf[4], double* inv_norm, void* workspace, size_t workspace_bytes, int B, int H,

@@ -263,6 +263,17 @@ def gen_e2e(mk, seeds, B=2):
     np.savez_compressed(os.path.join(GOLD, 'e2e_kitti.npz'), **out)
 
 
+def gen_level4(mk, seed=1, B=1):
+    """args.level = 4: the LM loop also runs on the full-resolution 16-channel map x24 (20 steps)."""
+    args = O.default_args(level=4)
+    out = {'seed': np.array(seed), 'B': np.array(B)}
+    for dtype, tag in ((torch.float32, '32'), (torch.float64, '64')):
+        t, f, _, _ = run_e2e(mk, 'LM_S2GP', args, seed, B, dtype)
+        out['trace' + tag], out['final' + tag] = t, f
+    print(f"level4: gap {np.abs(out['trace32'] - out['trace64']).max():.2e} final {out['final64'].tolist()}", flush=True)
+    np.savez_compressed(os.path.join(GOLD, 'e2e_kitti_level4.npz'), **out)
+
+
 def gen_hires(mk, seed=1, B=1):
     """BASELINE config 5: grd 512x2048, sat 1024x1024, 10 LM iterations."""
     args = O.default_args(N_iters=10)
@@ -425,6 +436,8 @@ if __name__ == '__main__':
         gen_train(mk, (seeds or [1])[0])
     if a.only in ('all', 'g2s'):
         gen_g2s(mk, seeds or [1, 2])
+    if a.only in ('all', 'level4'):
+        gen_level4(mk, (seeds or [1])[0])
     if a.only in ('all', 'hires'):
         gen_hires(mk, (seeds or [1])[0])
     if a.only in ('all', 'trainw'):

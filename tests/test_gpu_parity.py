@@ -81,6 +81,34 @@ def test_vgg_small_vs_golden(kat, precision, tol):
         assert ec < max(tol, 2e-6), (precision, l, ec)
 
 
+@pytest.mark.parametrize('precision,tol', [('fp32', 1e-5), ('bf16', 3e-2)])
+def test_vgg_level4_vs_golden(kat, precision, tol):
+    """VGGUnet(level=4): the fourth map x24 (conv_dec3 on cat(up(x21), x2), 16 channels at full resolution) and conf3
+    against the reference's fp64 maps; the first three maps must be bit-identical to the level-3 run."""
+    from oracle import ref_cpu as O
+    from highlyaccurate_amd.VGG import VGGUnet
+    d = _dev()
+    rs = np.random.RandomState(21)
+    sd = O.synth_vgg_state(rs, bias_scale=0.05)
+    x = T(rs.random_sample((2, 3, 32, 64)).astype(np.float32))
+    net = VGGUnet(4, precision=precision)
+    net.load_state_dict(sd)
+    net = net.to(d)
+    feats, confs = net(x.to(d))
+    assert len(feats) == 4 and tuple(feats[3].shape) == (2, 16, 32, 64) and tuple(confs[3].shape) == (2, 1, 32, 64)
+    for l in range(4):
+        e = _rel(feats[l].cpu().numpy(), kat[f'vgg_feat64_l{l}'])
+        ec = _rel(confs[l].cpu().numpy(), kat[f'vgg_conf64_l{l}'])
+        print(f'vgg level4 {precision} map {l}: feat rel {e:.2e} conf rel {ec:.2e}')
+        assert e < tol and ec < max(tol, 2e-6), (precision, l, e, ec)
+    net3 = VGGUnet(3, precision=precision)
+    net3.load_state_dict(sd)
+    f3, _ = net3.to(d)(x.to(d))
+    if precision == 'fp32':
+        for l in range(3):
+            assert torch.allclose(f3[l], feats[l], rtol=0, atol=0) or _rel(f3[l].cpu().numpy(), feats[l].cpu().numpy()) < 1e-6
+
+
 def _oracle_small(args, seed, B, grd_hw, sat_a, dtype=torch.float64, ford=False):
     """Random NHWC feature pyramids + the oracle's solve on them."""
     from oracle import ref_cpu as O
@@ -323,6 +351,19 @@ def test_reduced_precision_pose_deviation_reported(precision):
     err = np.abs(trace - g[f'trace64_{seed}'])
     print(f'{precision} mode pose deviation vs fp64 reference: shift {err[..., :2].max():.3e} yaw {err[..., 2].max():.3e} (normalised)')
     assert np.isfinite(trace).all() and err.max() < (0.2 if precision == 'bf16' else 0.05)
+
+
+def test_e2e_kitti_level4_vs_golden():
+    """args.level = 4 (inference): 4 levels x 5 iterations = 20 LM steps, the last level on the full-resolution x24 map."""
+    g = load_golden('e2e_kitti_level4.npz')
+    seed, B = int(g['seed']), int(g['B'])
+    net, res = _run_kitti(seed, B, level=4)
+    trace = _exec_order(net.last_trace, 0).cpu().numpy().astype(np.float64)
+    assert trace.shape == g['trace64'].shape == (B, 20, 3)
+    _pose_gate(trace, g['trace64'], g['trace32'], 'kitti level 4')
+    with pytest.raises(NotImplementedError):
+        net.train()(torch.zeros(1, 3, 64, 64, device=_dev()), torch.zeros(1, 3, 64, 256, device=_dev()),
+                    torch.zeros(1, 1), torch.zeros(1, 1), torch.zeros(1, 1), mode='train')
 
 
 def test_e2e_hires_config5_vs_golden():
@@ -789,7 +830,7 @@ def test_bad_arguments_raise():
     with pytest.raises(ValueError):
         VGGUnet(3, precision='int8')
     with pytest.raises(NotImplementedError):
-        VGGUnet(4)
+        VGGUnet(5)
     with pytest.raises(NotImplementedError):
         LM_S2GP(O.default_args(Optimizer='SGD'))
     m = LM_S2GP(O.default_args(N_iters=1)).to(d)

@@ -261,3 +261,17 @@ def test_evaluation_metrics_match_the_reference_formulas():
         assert stats[f'longitudinal@{m}'][1] == np.sum(np.abs(G[:, 1]) < m) / N * 100
         assert stats[f'angle@{m}'][0] == np.sum(ad < m) / N * 100
     assert len(lines) == 3 + 1 + 6 + 1 + 3 + 1 + 3 and lines[0].startswith('distance within 1 meters (pred, init): ')
+
+
+def test_oracle_level4_matches_reference_golden():
+    """args.level = 4: 20 LM steps, the fourth level on the full-resolution x24 map."""
+    g = load_golden('e2e_kitti_level4.npz')
+    seed, B = int(g['seed']), int(g['B'])
+    net = O.build('kitti', O.default_args(level=4), seed, torch.float64)
+    sat, grd, *_ = O.synth_images(seed + 100, B)
+    torch.manual_seed(seed)
+    with torch.no_grad():
+        net(sat.double(), grd.double(), mode='test')
+    err = np.abs(_oracle_trace(net) - g['trace64']).max()
+    print('oracle vs reference, kitti level 4 fp64: max pose err', err)
+    assert err < 1e-7
