@@ -89,8 +89,6 @@ def vgg_forward_nhwc(module: 'VGGUnet', x: torch.Tensor, want_conf: bool = True,
     prm, keep, versions = _param_table(module)
     packed = _packed_weights(module, prm, versions, dt, x.device)
     L = 4 if module.level == 4 else 3
-    if L == 4 and save_for_backward:
-        raise NotImplementedError('VGGUnet level 4 is forward-only (the backward of conv_dec3 / conf3 is not built)')
     # level 4: x24 is stored with 64 channels, the 16 real ones first, zeros behind them (see include/hla.h)
     feats = [torch.empty(B, H >> (3 - l), W >> (3 - l), 64 if l == 3 else _CH[l], device=x.device, dtype=torch.float32)
              for l in range(L)]
@@ -112,15 +110,16 @@ def vgg_forward_nhwc(module: 'VGGUnet', x: torch.Tensor, want_conf: bool = True,
     # ws is only used by work already enqueued on this stream; the caching allocator keeps the block
     # stream-ordered, so dropping the Python reference here is safe.
     if save_for_backward:
-        return feats, confs, inv_norm, dict(x=x, ws=ws, feats=feats, inv_norm=inv_norm, dt=dt)
+        return feats, confs, inv_norm, dict(x=x, ws=ws, feats=feats, inv_norm=inv_norm, dt=dt, L=L)
     return feats, confs, inv_norm
 
 
 def vgg_backward_nhwc(module: 'VGGUnet', ctx: dict, d_feats, confs=None, d_confs=None):
     """Backward of ``vgg_forward_nhwc(..., defer_norm=True, save_for_backward=True)``.
     d_feats[l]: NHWC fp32 gradient w.r.t. the L2-normalised map l.  Returns {parameter name: gradient} for the
-    22 tensors that receive one at level 3 (conv0..conv14 weights+biases, conv_dec1/2 weights), plus conf0..2 weights
-    when ``confs`` / ``d_confs`` (the forward's confidence maps and their [B,h,w] gradients) are given."""
+    22 tensors that receive one at level 3 (conv0..conv14 weights+biases, conv_dec1/2 weights), plus the conf head weights
+    when ``confs`` / ``d_confs`` (the forward's confidence maps and their [B,h,w] gradients) are given, plus conv_dec3.* at
+    level 4 (d_feats[3] is [B,H,W,64]: the gradient w.r.t. the zero-padded x24)."""
     lib = _lib.load()
     x, dt = ctx['x'], ctx['dt']
     B, _, H, W = x.shape
@@ -141,24 +140,38 @@ def vgg_backward_nhwc(module: 'VGGUnet', ctx: dict, d_feats, confs=None, d_confs
             gb = torch.empty_like(sd[name + '.bias'], dtype=torch.float32)
             grads[name + '.bias'] = gb
             gs.db[i] = gb.data_ptr()
+    L = ctx.get('L', 3)
+    padded = {}                         # level 4: gradients of the zero-padded weights; their leading blocks are the real ones
+    if L == 4:
+        for i, name, shape in ((11, 'conv_dec3.1', (64, 128, 3, 3)), (12, 'conv_dec3.3', (64, 64, 3, 3))):
+            g = torch.empty(shape, device=x.device, dtype=torch.float32)
+            padded[name + '.weight'] = g
+            gs.dw[i] = g.data_ptr()
     cp = dcp = None
     if d_confs is not None:
         dcs = [d.contiguous().float() for d in d_confs]
-        cp = (C.c_void_p * 3)(*[c.data_ptr() for c in confs])
-        dcp = (C.c_void_p * 3)(*[d.data_ptr() for d in dcs])
-        for l in range(3):
+        cp = (C.c_void_p * 4)(*([c.data_ptr() for c in confs] + [0] * (4 - L)))
+        dcp = (C.c_void_p * 4)(*([d.data_ptr() for d in dcs] + [0] * (4 - L)))
+        for l in range(L):
             name = f'conf{l}.1.weight'
-            g = torch.empty_like(sd[name], dtype=torch.float32, memory_format=torch.contiguous_format)
-            grads[name] = g
+            if l == 3:
+                g = torch.empty(1, 64, 3, 3, device=x.device, dtype=torch.float32)
+                padded[name] = g
+            else:
+                g = torch.empty_like(sd[name], dtype=torch.float32, memory_format=torch.contiguous_format)
+                grads[name] = g
             gs.dw[13 + l] = g.data_ptr()
     dfs = [d.contiguous().float() for d in d_feats]
-    fp = (C.c_void_p * 3)(*[f.data_ptr() for f in ctx['feats']])
-    dp = (C.c_void_p * 3)(*[d.data_ptr() for d in dfs])
-    nbytes = lib.hla_vgg_bwd_workspace_bytes(B, H, W, dt)
+    fp = (C.c_void_p * 4)(*([f.data_ptr() for f in ctx['feats']] + [0] * (4 - L)))
+    dp = (C.c_void_p * 4)(*([d.data_ptr() for d in dfs] + [0] * (4 - L)))
+    nbytes = lib.hla_vgg_bwd_workspace_bytes(B, H, W, L, dt)
     ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
     rc = lib.hla_vgg_backward(_lib.ptr(x), C.byref(prm), _lib.ptr(cache['buf']), _lib.ptr(ctx['ws']), fp, _lib.ptr(ctx['inv_norm']),
-                              dp, cp, dcp, C.byref(gs), _lib.ptr(ws), nbytes, B, H, W, 3, dt, _lib.stream_ptr())
+                              dp, cp, dcp, C.byref(gs), _lib.ptr(ws), nbytes, B, H, W, L, dt, _lib.stream_ptr())
     _lib.check(rc, 'hla_vgg_backward')
+    for name, g in padded.items():
+        co, ci = sd[name].shape[:2]
+        grads[name] = g[:co, :ci].contiguous()
     return grads
 
 

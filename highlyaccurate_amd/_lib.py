@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get('HLA_LIB') or os.path.join(HERE, 'libhla.so')   # HLA_
 
 HLA_F32, HLA_BF16, HLA_F16 = 0, 1, 2
 HLA_VGG_WANT_CONF, HLA_VGG_DEFER_NORM, HLA_VGG_SAVE_FOR_BACKWARD = 1, 2, 4
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 
 class HlaError(RuntimeError):
@@ -81,7 +81,7 @@ def load() -> C.CDLL:
     lib.hla_vgg_pack_weights_T.restype = i
     lib.hla_vgg_pack_weights_T.argtypes = [C.POINTER(VggParams), vp, i, vp]
     lib.hla_vgg_bwd_workspace_bytes.restype = sz
-    lib.hla_vgg_bwd_workspace_bytes.argtypes = [i, i, i, i]
+    lib.hla_vgg_bwd_workspace_bytes.argtypes = [i, i, i, i, i]
     lib.hla_vgg_backward.restype = i
     lib.hla_vgg_backward.argtypes = [vp, C.POINTER(VggParams), vp, vp, C.POINTER(vp), vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(VggGrads),
                                      vp, sz, i, i, i, i, i, vp]

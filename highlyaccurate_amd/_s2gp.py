@@ -75,7 +75,7 @@ class S2GPBase(nn.Module):
         self.using_weight = args.using_weight
         self.loss_method = args.loss_method
         if args.level not in (3, 4):
-            raise NotImplementedError('args.level must be 3 (x15, x18, x21) or 4 (+ x24, inference only)')
+            raise NotImplementedError('args.level must be 3 (x15, x18, x21) or 4 (+ x24)')
         if getattr(args, 'proj', 'geo') != 'geo':
             raise NotImplementedError("only proj='geo' is in scope")
         if getattr(args, 'Optimizer', 'LM') != 'LM':
@@ -265,12 +265,10 @@ class S2GPBase(nn.Module):
             raise ValueError(f'expected sat_map [B,3,A,A] and grd_img [B,3,H,W] with one B, got {tuple(sat_map.shape)} '
                              f'and {tuple(grd_img.shape)}')
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            if self.level == 4:
-                raise NotImplementedError('args.level == 4 is inference-only: the backward of conv_dec3 / conf3 is not built')
             names = [n for n, _ in self.named_parameters()]
             params = [p for _, p in self.named_parameters()]
             out = _LocaliseFn.apply(self, names, sat_map, grd_img, want_conf, extra, level_first, init_pose, *params)
-            return out[0], list(out[1:]) if want_conf else [None] * 3
+            return out[0], list(out[1:]) if want_conf else [None] * self.level
         if os.environ.get('HLA_TWO_STREAMS', '0') == '1':
             # experiment (measured 2 % SLOWER on MI355X, so off by default): ground branch on a side stream so that each branch's
             # kernel tails (the last, partially filled wave of workgroups) overlap with the other branch's work

@@ -147,9 +147,8 @@ extern "C" int hla_vgg_forward(const float* x, const hla_vgg_params* params, con
   HLA_REQUIRE(B > 0 && H >= 8 && W >= 8 && H % 8 == 0 && W % 8 == 0, "hla_vgg_forward: H and W must be multiples of 8");
   HLA_REQUIRE(level == 3 || level == 4, "hla_vgg_forward: level must be 3 (x15,x18,x21) or 4 (+x24), got %d", level);
   HLA_REQUIRE(feat[0] && feat[1] && feat[2], "hla_vgg_forward: feat[0..2] are required");
-  HLA_REQUIRE(level == 3 || (feat[3] && params->w[11] && params->w[12] && !(flags & HLA_VGG_SAVE_FOR_BACKWARD)),
-              "hla_vgg_forward: level 4 needs feat[3] ([B,H,W,64], 16 real channels), the zero-padded conv_dec3 weights in w[11], w[12], "
-              "and is forward-only");
+  HLA_REQUIRE(level == 3 || (feat[3] && params->w[11] && params->w[12]),
+              "hla_vgg_forward: level 4 needs feat[3] ([B,H,W,64], 16 real channels) and the zero-padded conv_dec3 weights in w[11], w[12]");
   HLA_REQUIRE(level == 3 || !(flags & HLA_VGG_WANT_CONF) || !conf || !conf[3] || params->w[16], "hla_vgg_forward: conf[3] needs w[16]");
   HLA_REQUIRE(!(flags & HLA_VGG_DEFER_NORM) || inv_norm, "hla_vgg_forward: HLA_VGG_DEFER_NORM needs inv_norm");
   VggPlan pl;

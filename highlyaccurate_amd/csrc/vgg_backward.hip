@@ -374,6 +374,31 @@ __global__ __launch_bounds__(256) void l2bwd_apply_kernel(const float* __restric
   }
 }
 
+// level 4: gradient w.r.t. the conv2 output = unpool(gradient of the pooled map, forward argmax) + gradient arriving through
+// the conv_dec3 skip connection (already ReLU-masked).  One pass at full resolution, 16 B per thread.
+template <typename T>
+__global__ __launch_bounds__(256) void unpool_add_kernel(const T* __restrict__ gp, const unsigned char* __restrict__ idx,
+                                                         const T* __restrict__ skip, T* __restrict__ out, int B, int H, int W) {
+  constexpr int EPL = 16 / sizeof(T), C = 64, PPX = C / EPL;
+  const size_t n = (size_t)B * H * W * PPX;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const int part = (int)(i % PPX);
+    const size_t pix = i / PPX;
+    const int x = (int)(pix % W), y = (int)((pix / W) % H);
+    const size_t b = pix / ((size_t)W * H);
+    const size_t e0 = ((b * (H / 2) + (y >> 1)) * (W / 2) + (x >> 1)) * C + part * EPL;
+    const unsigned pos = ((y & 1) << 1) | (x & 1);
+    uint4 g = *(const uint4*)(gp + e0), sk = *(const uint4*)(skip + pix * C + part * EPL);
+    T ge[EPL], se[EPL];
+    unsigned char id[EPL];
+    __builtin_memcpy(ge, &g, 16); __builtin_memcpy(se, &sk, 16); __builtin_memcpy(id, idx + e0, EPL);
+#pragma unroll
+    for (int k = 0; k < EPL; ++k) ge[k] = (T)((id[k] == pos ? to_f32(ge[k]) : 0.f) + to_f32(se[k]));
+    __builtin_memcpy(&g, ge, 16);
+    *(uint4*)(out + pix * C + part * EPL) = g;
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Confidence head backward (VGG.py:62-76,160-162):  conf = sigmoid(-s),  s = sigmoid(z),  z = conv3x3(relu(x), w)
 //   dz = -d_conf * conf*(1-conf) * s*(1-s)   with s recovered from conf:  e^s = (1-conf)/conf
@@ -453,6 +478,7 @@ __global__ __launch_bounds__(256) void conf_bwd_kernel(const T* __restrict__ act
 struct BwdPlan {
   size_t g_x21, g_d2a, g_x18, l2_18, g_d1a, g_x15, l2_15, g_a12, g_a10, g_x8, g_x8p, g_a5, g_x3, g_x3p, g_a0;
   size_t dot, part, bpart, dz;
+  size_t g_x24, g_d3a, g_x2p, g_c2, l2_21;      // level 4 only
   size_t total;
 };
 
@@ -464,7 +490,7 @@ static int wgrad_ksplit(int Cout, int Cin, int ntile) {
   return ks;
 }
 
-static void bwd_plan(int B, int H, int W, int dtype, BwdPlan* p) {
+static void bwd_plan(int B, int H, int W, int dtype, BwdPlan* p, bool level4 = false) {
   const size_t es = dtype == HLA_F32 ? 4 : 2;
   size_t o = 0;
   auto take = [&](size_t bytes) { size_t r = o; o += hla_align_up(bytes, 256); return r; };
@@ -480,21 +506,28 @@ static void bwd_plan(int B, int H, int W, int dtype, BwdPlan* p) {
   p->dot = take((size_t)B * 64 * sizeof(double));
   size_t maxpart = (size_t)1024 * 2 * 64 * 32 * 4;      // conv0
   const int hs[11] = {1, 1, 2, 2, 4, 4, 4, 4, 4, 2, 2};  // resolution divisor of each layer's output
-  for (int l = 1; l < kPackedLayers; ++l) {
-    const int h = H / hs[l], w = W / hs[l];
+  for (int l = 1; l < (level4 ? kAllLayers : kPackedLayers); ++l) {
+    const int div = l < 11 ? hs[l] : 1;
+    const int h = H / div, w = W / div;
     const int ntile = B * ((h + WG_TH - 1) / WG_TH) * ((w + 31) / 32);
     const size_t sz = (size_t)wgrad_ksplit(kLayers[l].cout, kLayers[l].cin, ntile) * kLayers[l].cout * kLayers[l].cin * 9 * 4;
     if (sz > maxpart) maxpart = sz;
   }
   p->part = take(maxpart);
   p->bpart = take((size_t)2048 * 256 * 4);
-  p->dz = take(P / 4 * sizeof(float));
+  p->dz = take((level4 ? P : P / 4) * sizeof(float));
+  p->g_x24 = p->g_d3a = p->g_x2p = p->g_c2 = p->l2_21 = 0;
+  if (level4) {
+    p->g_x24 = take(P * 64 * es); p->g_d3a = take(P * 64 * es); p->g_x2p = take(P * 64 * es); p->g_c2 = take(P * 64 * es);
+    p->l2_21 = take(P / 4 * 64 * es);
+  }
   p->total = o;
 }
 
 template <typename T>
 void vgg_pack_all_T(const hla_vgg_params* prm, char* packed, int dtype, hipStream_t st) {
-  for (int l = 1; l < kPackedLayers; ++l) {       // conv0 needs no data gradient
+  for (int l = 1; l < kAllLayers; ++l) {          // conv0 needs no data gradient
+    if (l >= kPackedLayers && !prm->w[l]) continue;
     const size_t n = (size_t)kLayers[l].cin * kLayers[l].cout * 9;
     const int grid = (int)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024);
     // transposed conv: Cout' = cin, Cin' = cout
@@ -505,10 +538,12 @@ void vgg_pack_all_T(const hla_vgg_params* prm, char* packed, int dtype, hipStrea
 
 template <typename T>
 int vgg_backward_t(const float* x, const hla_vgg_params* prm, const char* packedT, int dtype, const char* fw,
-                          const float* const feat[3], const double* inv_norm, const float* const d_feat[3],
-                          const float* const conf[3], const float* const d_conf[3], const hla_vgg_grads* gr, char* bw, const BwdPlan& bp, int B, int H, int W, hipStream_t st) {
+                          const float* const feat[4], const double* inv_norm, const float* const d_feat[4],
+                          const float* const conf[4], const float* const d_conf[4], const hla_vgg_grads* gr, char* bw, const BwdPlan& bp, int B, int H, int W, hipStream_t st) {
+  const bool level4 = bp.g_x24 != 0;
+  const int NL = level4 ? 4 : 3;
   VggPlan fp;
-  vgg_plan(B, H, W, dtype, true, &fp);
+  vgg_plan(B, H, W, dtype, true, &fp, level4);
   constexpr int KC = SB / (int)sizeof(T);
   static bool attr_set = false;
   if (!attr_set) {
@@ -519,9 +554,11 @@ int vgg_backward_t(const float* x, const hla_vgg_params* prm, const char* packed
   auto G = [&](size_t off) { return (void*)(bw + off); };
 
   // ---- L2_norm backward of the three returned maps
-  const size_t per[3] = {(size_t)(H / 8) * (W / 8) * 256, (size_t)(H / 4) * (W / 4) * 128, (size_t)(H / 2) * (W / 2) * 64};
-  void* l2out[3] = {G(bp.l2_15), G(bp.l2_18), G(bp.g_x21)};
-  for (int l = 0; l < 3; ++l) {
+  const size_t per[4] = {(size_t)(H / 8) * (W / 8) * 256, (size_t)(H / 4) * (W / 4) * 128, (size_t)(H / 2) * (W / 2) * 64,
+                         (size_t)H * W * 64};
+  // at level 4 x21 also feeds conv_dec3, so its L2-norm gradient goes to a side buffer and is merged by that dgrad's epilogue
+  void* l2out[4] = {G(bp.l2_15), G(bp.l2_18), level4 ? G(bp.l2_21) : G(bp.g_x21), G(bp.g_x24)};
+  for (int l = 0; l < NL; ++l) {
     int nblk = (int)(per[l] / 4 / 256 / 8);
     nblk = nblk < 1 ? 1 : (nblk > 64 ? 64 : nblk);
     double* part = (double*)(bw + bp.dot);
@@ -534,9 +571,9 @@ int vgg_backward_t(const float* x, const hla_vgg_params* prm, const char* packed
 
   // ---- confidence heads (only the ground branch with using_weight=1 ever has d_conf): adds into the raw-map gradients
   if (conf && d_conf) {
-    const T* acts[3] = {(const T*)(fw + fp.x15r), (const T*)(fw + fp.x18r), (const T*)(fw + fp.x21r)};
-    const int Cs[3] = {256, 128, 64}, hs[3] = {H / 8, H / 4, H / 2}, wsz[3] = {W / 8, W / 4, W / 2};
-    for (int l = 0; l < 3; ++l) {
+    const T* acts[4] = {(const T*)(fw + fp.x15r), (const T*)(fw + fp.x18r), (const T*)(fw + fp.x21r), (const T*)(fw + fp.x24r)};
+    const int Cs[4] = {256, 128, 64, 64}, hs[4] = {H / 8, H / 4, H / 2, H}, wsz[4] = {W / 8, W / 4, W / 2, W};
+    for (int l = 0; l < NL; ++l) {
       if (!d_conf[l]) continue;
       constexpr int EPL = 16 / (int)sizeof(T);
       const int ppb = 256 / (Cs[l] / EPL);
@@ -593,6 +630,14 @@ int vgg_backward_t(const float* x, const hla_vgg_params* prm, const char* packed
   const unsigned char* idx15 = (const unsigned char*)(fw + fp.idx15);
   const int H2 = H / 2, W2 = W / 2, H4 = H / 4, W4 = W / 4;
 
+  // ---- decoder 3 (VGG.py:153-155, level 4 only; zero-padded to 64 channels, the host slices the weight gradients)
+  if (level4) {
+    dgrad(12, 0, 64, G(bp.g_x24), nullptr, H, W, G(bp.g_d3a), F(fp.d3a), nullptr, false);
+    wgrad(12, F(fp.d3a), 64, nullptr, 0, 0, G(bp.g_x24), nullptr, H, W);
+    dgrad(11, 0, 64, G(bp.g_d3a), nullptr, H, W, G(bp.g_x21), F(fp.x21r), G(bp.l2_21), true);     // up(x21) branch
+    dgrad(11, 64, 64, G(bp.g_d3a), nullptr, H, W, G(bp.g_x2p), F(fp.x2r), nullptr, false);         // x2 skip branch
+    wgrad(11, F(fp.x21r), 64, F(fp.x2r), 64, 1, G(bp.g_d3a), nullptr, H, W);
+  }
   // ---- decoder 2 (VGG.py:148-151)
   dgrad(10, 0, 64, G(bp.g_x21), nullptr, H2, W2, G(bp.g_d2a), F(fp.d2a), nullptr, false);
   wgrad(10, F(fp.d2a), 64, nullptr, 0, 0, G(bp.g_x21), nullptr, H2, W2);
@@ -618,8 +663,18 @@ int vgg_backward_t(const float* x, const hla_vgg_params* prm, const char* packed
   dgrad(2, 0, 64, G(bp.g_a5), nullptr, H2, W2, G(bp.g_x3), F(fp.x3), G(bp.g_x3p), false);
   wgrad(2, F(fp.x3), 64, nullptr, 0, 0, G(bp.g_a5), nullptr, H2, W2);
   // ---- encoder block 0
-  dgrad(1, 0, 64, G(bp.g_x3), idx3, H, W, G(bp.g_a0), F(fp.a0), nullptr, false);
-  wgrad(1, F(fp.a0), 64, nullptr, 0, 0, G(bp.g_x3), idx3, H, W);
+  if (level4) {      // the conv2 output also fed conv_dec3: materialise unpool(g_x3) + skip gradient once
+    const size_t n = (size_t)B * H * W * (64 * sizeof(T) / 16);
+    hla_prof_begin(K_ELEMWISE, 0, (double)B * H * W * 64 * sizeof(T) * 2.25, st);
+    hipLaunchKernelGGL((unpool_add_kernel<T>), dim3((unsigned)((n + 255) / 256 < 65535 ? (n + 255) / 256 : 65535)), dim3(256), 0, st,
+                       (const T*)G(bp.g_x3), idx3, (const T*)G(bp.g_x2p), (T*)G(bp.g_c2), B, H, W);
+    hla_prof_end(st);
+    dgrad(1, 0, 64, G(bp.g_c2), nullptr, H, W, G(bp.g_a0), F(fp.a0), nullptr, false);
+    wgrad(1, F(fp.a0), 64, nullptr, 0, 0, G(bp.g_c2), nullptr, H, W);
+  } else {
+    dgrad(1, 0, 64, G(bp.g_x3), idx3, H, W, G(bp.g_a0), F(fp.a0), nullptr, false);
+    wgrad(1, F(fp.a0), 64, nullptr, 0, 0, G(bp.g_x3), idx3, H, W);
+  }
   {
     Wgrad0Args a{};
     a.x = x; a.g = G(bp.g_a0); a.B = B; a.H = H; a.W = W;
@@ -647,13 +702,13 @@ template int vgg_backward_t<TuT>(const float* x, const hla_vgg_params* prm, cons
   extern template int vgg_backward_t<T>(const float* x, const hla_vgg_params* prm, const char* packedT, int dtype, const char* fw, const float* const feat[3], const double* inv_norm, const float* const d_feat[3], const float* const conf[3], const float* const d_conf[3], const hla_vgg_grads* gr, char* bw, const BwdPlan& bp, int B, int H, int W, hipStream_t st);
 HLA_EXTERN_T(float) HLA_EXTERN_T(bf16) HLA_EXTERN_T(f16)
 
-extern "C" size_t hla_vgg_bwd_workspace_bytes(int B, int H, int W, int dtype) {
+extern "C" size_t hla_vgg_bwd_workspace_bytes(int B, int H, int W, int level, int dtype) {
   BwdPlan p;
-  bwd_plan(B, H, W, dtype, &p);
+  bwd_plan(B, H, W, dtype, &p, level == 4);
   return p.total;
 }
 
-extern "C" size_t hla_vgg_packed_weight_T_bytes(int dtype) { return packed_offset(kPackedLayers, dtype); }
+extern "C" size_t hla_vgg_packed_weight_T_bytes(int dtype) { return packed_offset(kAllLayers, dtype); }
 
 extern "C" int hla_vgg_pack_weights_T(const hla_vgg_params* params, void* packed, int dtype, hla_stream_t stream) {
   HLA_REQUIRE(params && packed, "hla_vgg_pack_weights_T: null argument");
@@ -666,22 +721,26 @@ extern "C" int hla_vgg_pack_weights_T(const hla_vgg_params* params, void* packed
 }
 
 extern "C" int hla_vgg_backward(const float* x, const hla_vgg_params* params, const void* packed_weights_T,
-                                const void* fwd_workspace, const float* const feat[3], const double* inv_norm,
-                                const float* const d_feat[3], const float* const conf[3], const float* const d_conf[3],
+                                const void* fwd_workspace, const float* const feat[4], const double* inv_norm,
+                                const float* const d_feat[4], const float* const conf[4], const float* const d_conf[4],
                                 const hla_vgg_grads* grads, void* workspace, size_t workspace_bytes, int B, int H, int W,
                                 int level, int dtype, hla_stream_t stream) {
   HLA_REQUIRE(x && params && packed_weights_T && fwd_workspace && feat && inv_norm && d_feat && grads && workspace,
               "hla_vgg_backward: null argument");
   HLA_REQUIRE(hla_dtype_ok(dtype), "hla_vgg_backward: bad dtype %d", dtype);
-  HLA_REQUIRE(level == 3, "hla_vgg_backward: only level 3 is built");
+  HLA_REQUIRE(level == 3 || level == 4, "hla_vgg_backward: level must be 3 or 4");
+  const int NLc = level == 4 ? 4 : 3;
   HLA_REQUIRE(B > 0 && H % 8 == 0 && W % 8 == 0, "hla_vgg_backward: H and W must be multiples of 8");
   for (int l = 0; l < kPackedLayers; ++l) HLA_REQUIRE(grads->dw[l], "hla_vgg_backward: dw[%d] missing", l);
   HLA_REQUIRE(!d_conf || conf, "hla_vgg_backward: d_conf given without conf");
   if (d_conf)
-    for (int l = 0; l < 3; ++l)
+    for (int l = 0; l < NLc; ++l)
       HLA_REQUIRE(!d_conf[l] || (conf[l] && grads->dw[13 + l]), "hla_vgg_backward: d_conf[%d] needs conf[%d] and dw[%d]", l, l, 13 + l);
+  if (level == 4)
+    HLA_REQUIRE(feat[3] && d_feat[3] && params->w[11] && params->w[12] && grads->dw[11] && grads->dw[12],
+                "hla_vgg_backward: level 4 needs feat[3], d_feat[3], the padded conv_dec3 weights and dw[11], dw[12] ([64,128,3,3], [64,64,3,3])");
   BwdPlan bp;
-  bwd_plan(B, H, W, dtype, &bp);
+  bwd_plan(B, H, W, dtype, &bp, level == 4);
   if (workspace_bytes < bp.total) {
     hla_set_error("hla_vgg_backward: workspace %zu < %zu", workspace_bytes, bp.total);
     return HLA_ERR_WORKSPACE;

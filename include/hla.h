@@ -83,7 +83,7 @@ size_t hla_vgg_workspace_bytes(int B, int H, int W, int level, int dtype);
  *          L2-normalised per sample, or raw when HLA_VGG_DEFER_NORM
  * conf[l]  [B,h_l,w_l] fp32 = sigmoid(-sigmoid(conv(relu(.)))), or NULL
  * inv_norm [3][B] fp64 out: 1/max(||map_l of sample b||_2, 1e-12) (VGG.py:511-514), or NULL
- * level    the reference's VGGUnet(level); 4 additionally computes x24 / conf3 (forward only): feat[3] is [B,H,W,64] with the
+ * level    the reference's VGGUnet(level); 4 additionally computes x24 / conf3: feat[3] is [B,H,W,64] with the
  *          16 real channels first and zeros behind them, and params->w[11], w[12], w[16] must point at conv_dec3.1 /
  *          conv_dec3.3 / conf3.1 weights ZERO-PADDED to [64,128,3,3], [64,64,3,3], [1,64,3,3]; inv_norm is [4,B].
  *          3 -> maps 0..2 (the dead dec3/conf3 work of VGG.py:153-155,163
@@ -96,8 +96,9 @@ int hla_vgg_forward(const float* x, const hla_vgg_params* params, const void* pa
  * Backward of VGGUnet (autograd through VGG.py:121-203 in the reference).
  * ------------------------------------------------------------------------- */
 /* fp32 gradient buffers with PyTorch's layouts (OIHW weights), overwritten: dw[0..10] = conv0..conv_dec2.3
- * (required), db[0..6] (NULL to skip), dw[13..15] = conf0.1..conf2.1 (required iff the matching d_conf is given).
- * dw[11], dw[12], dw[16] are unused at level 3 (those parameters get no gradient). */
+ * (required), db[0..6] (NULL to skip), dw[13..16] = conf0.1..conf3.1 (required iff the matching d_conf is given).
+ * Level 4: dw[11], dw[12] (required) and dw[16] have the ZERO-PADDED shapes [64,128,3,3], [64,64,3,3], [1,64,3,3]; the real
+ * gradients are their leading [32,128], [16,32], [1,16] blocks.  At level 3 these three get no gradient. */
 typedef struct hla_vgg_grads {
   float* dw[17];
   float* db[7];
@@ -106,7 +107,7 @@ typedef struct hla_vgg_grads {
 size_t hla_vgg_packed_weight_T_bytes(int dtype);
 /* transposed + tap-flipped fragment packing used by the data-gradient convolutions */
 int hla_vgg_pack_weights_T(const hla_vgg_params* params, void* packed_T, int dtype, hla_stream_t stream);
-size_t hla_vgg_bwd_workspace_bytes(int B, int H, int W, int dtype);
+size_t hla_vgg_bwd_workspace_bytes(int B, int H, int W, int level, int dtype);
 
 /* x, params        as in the forward call
  * fwd_workspace    the workspace of the forward call made with HLA_VGG_SAVE_FOR_BACKWARD | HLA_VGG_DEFER_NORM
@@ -116,8 +117,8 @@ size_t hla_vgg_bwd_workspace_bytes(int B, int H, int W, int dtype);
  *                  hla_s2g_lm_solve_bwd produces with using_weight=1, models_kitti.py:994-996); both arrays or
  *                  single entries may be NULL: then the heads get no gradient, as in the reference's default run. */
 int hla_vgg_backward(const float* x, const hla_vgg_params* params, const void* packed_weights_T,
-                     const void* fwd_workspace, const float* const feat[3], const double* inv_norm,
-                     const float* const d_feat[3], const float* const conf[3], const float* const d_conf[3],
+                     const void* fwd_workspace, const float* const feat[4], const double* inv_norm,
+                     const float* const d_feat[4], const float* const conf[4], const float* const d_conf[4],
                      const hla_vgg_grads* grads, void* workspace, size_t workspace_bytes, int B, int H, int W, int level,
                      int dtype, hla_stream_t stream);
 

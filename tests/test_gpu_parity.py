@@ -361,9 +361,73 @@ def test_e2e_kitti_level4_vs_golden():
     trace = _exec_order(net.last_trace, 0).cpu().numpy().astype(np.float64)
     assert trace.shape == g['trace64'].shape == (B, 20, 3)
     _pose_gate(trace, g['trace64'], g['trace32'], 'kitti level 4')
-    with pytest.raises(NotImplementedError):
-        net.train()(torch.zeros(1, 3, 64, 64, device=_dev()), torch.zeros(1, 3, 64, 256, device=_dev()),
-                    torch.zeros(1, 1), torch.zeros(1, 1), torch.zeros(1, 1), mode='train')
+
+
+def test_vgg_backward_level4_vs_oracle_autograd():
+    """VGGUnet(level=4) backward: gradients arriving at x24 (16 real channels of the padded map) and conf3 flow through the
+    zero-padded conv_dec3 layers, the full-resolution skip connection into conv2 (unpool + skip merge) and into x21."""
+    from oracle import ref_cpu as O
+    from highlyaccurate_amd.VGG import VGGUnet, vgg_forward_nhwc, vgg_backward_nhwc
+    d = _dev()
+    rs = np.random.RandomState(41)
+    sd = O.synth_vgg_state(rs, bias_scale=0.05)
+    x = T(rs.random_sample((2, 3, 32, 64)).astype(np.float32))
+    onet = O.VGGUnet(4)
+    onet.load_state_dict(sd)
+    onet = onet.double()
+    feats64, confs64 = onet(x.double())
+    ups = [T(rs.standard_normal(tuple(f.shape))) for f in feats64]
+    cups = [T(rs.standard_normal(tuple(c.shape))) * 30.0 for c in confs64]
+    loss = sum((u * f).sum() for u, f in zip(ups, feats64)) + sum((u * c).sum() for u, c in zip(cups, confs64))
+    loss.backward()
+    ref = {k: p.grad for k, p in onet.named_parameters()}
+    net = VGGUnet(4, precision='fp32')
+    net.load_state_dict(sd)
+    net = net.to(d)
+    feats, confs, inv, ctx = vgg_forward_nhwc(net, x.to(d), want_conf=True, defer_norm=True, save_for_backward=True)
+    dfe = [u.permute(0, 2, 3, 1).contiguous().float().to(d) for u in ups]
+    dfe[3] = torch.cat([dfe[3], torch.randn(2, 32, 64, 48, device=d)], -1).contiguous()     # the padded channels' gradient is ignored
+    grads = vgg_backward_nhwc(net, ctx, dfe, confs, [u[:, 0].contiguous().float().to(d) for u in cups])
+    assert set(grads) == set(k for k, v in ref.items() if v is not None)
+    for k, g in grads.items():
+        r = ref[k].numpy()
+        assert tuple(g.shape) == r.shape, k
+        e = np.abs(g.cpu().double().numpy() - r).max() / max(np.abs(r).max(), 1e-30)
+        print(f'vgg bwd level4 {k:24s} rel err max {e:.2e} (max |ref| {np.abs(r).max():.2e})')
+        assert e < 2e-4, (k, e)
+
+
+def test_level4_train_step_vs_oracle_autograd_small():
+    """LM_S2GP with args.level = 4, mode='train' under autograd on a reduced shape: loss and every parameter gradient."""
+    from oracle import ref_cpu as O
+    from highlyaccurate_amd.models_kitti import LM_S2GP
+    d = _dev()
+    args = O.default_args(level=4, N_iters=2, using_weight=1)
+    B, grd_hw, sat_a = 2, (64, 256), 128
+    sd = O.synth_model_state(4, bias_scale=0.02)
+    sat, grd, gu, gv, gh = O.synth_images(9, B, grd_hw=grd_hw, sat_a=sat_a)
+    on = O.LM_S2GP(args, grd_hw=grd_hw)
+    on.load_state_dict(sd)
+    on = on.double()
+    torch.manual_seed(0)
+    ro = on(sat.double(), grd.double(), gu.double(), gv.double(), gh.double(), mode='train')
+    ro[0].backward()
+    ref = {k: p.grad for k, p in on.named_parameters()}
+    net = LM_S2GP(args)
+    net.load_state_dict(sd)
+    net = net.to(d).train()
+    torch.manual_seed(0)
+    r = net(sat.to(d), grd.to(d), gu.to(d), gv.to(d), gh.to(d), mode='train')
+    assert abs(float(r[0].detach()) - float(ro[0])) < 1e-4 * abs(float(ro[0])) and len(r[13]) == 4
+    r[0].backward()
+    for k, p in net.named_parameters():
+        assert (p.grad is None) == (ref[k] is None), k
+        if p.grad is None:
+            continue
+        rr = ref[k].numpy()
+        e = np.abs(p.grad.cpu().double().numpy() - rr).max() / max(np.abs(rr).max(), 1e-30)
+        print(f'level4 train grad {k:36s} rel err {e:.2e} (max |ref| {np.abs(rr).max():.2e})')
+        assert e < 5e-3, (k, e)
 
 
 def test_e2e_hires_config5_vs_golden():
