@@ -23,8 +23,8 @@ class LM_G2SP(nn.Module):
         self.N_iters = args.N_iters
         self.using_weight = args.using_weight
         self.loss_method = args.loss_method
-        if args.level != 3:
-            raise NotImplementedError('only args.level == 3 (x15, x18, x21) is built so far')
+        if args.level not in (3, 4):
+            raise NotImplementedError('args.level must be 3 (x15, x18, x21) or 4 (+ x24)')
         if getattr(args, 'proj', 'geo') != 'geo':
             raise NotImplementedError("only proj='geo' is built (proj='nn' needs VGGUnet_G2S, VGG.py:206-350)")
         precision = getattr(args, 'precision', 'fp32')
@@ -126,7 +126,7 @@ class LM_G2SP(nn.Module):
             names = [n for n, _ in self.named_parameters()]
             params = [p for _, p in self.named_parameters()]
             out = _G2sFn.apply(self, names, sat_map, grd_img_left, left_camera_k, want_conf, init_pose, *params)
-            trace, grd_confs = out[0], (list(out[1:]) if want_conf else [None] * 3)
+            trace, grd_confs = out[0], (list(out[1:]) if want_conf else [None] * self.level)
         else:
             sat_feats, _, sat_inv = vgg_forward_nhwc(self.SatFeatureNet, sat_map, want_conf=False, defer_norm=True)
             grd_feats, grd_confs, grd_inv = vgg_forward_nhwc(self.GrdFeatureNet, grd_img_left, want_conf=want_conf, defer_norm=True)

@@ -1008,12 +1008,13 @@ def test_g2s_lm_backward_small_vs_oracle_autograd(kw):
         assert e < 1e-5
 
 
-def test_g2s_train_step_vs_oracle_autograd_small():
+@pytest.mark.parametrize('level', [3, 4])
+def test_g2s_train_step_vs_oracle_autograd_small(level):
     """LM_G2SP mode='train' under autograd on a reduced shape: loss and parameter gradients vs the fp64 oracle."""
     from oracle import ref_cpu as O
     from highlyaccurate_amd.models_kitti import LM_G2SP
     d = _dev()
-    args = O.default_args(N_iters=2, using_weight=1, train_damping=1)
+    args = O.default_args(level=level, N_iters=2, using_weight=1, train_damping=1)
     B, grd_hw, sat_a = 2, (64, 256), 128
     sd = O.synth_model_state(4, bias_scale=0.02)
     sd['damping'] = torch.tensor([[0.1, 0.2, 0.15]])
