@@ -787,12 +787,13 @@ def test_reference_call_pattern_harness_runs():
     assert len(log) == 2 and all(np.isfinite(log))
 
 
-def test_ford_train_step_vs_oracle_autograd_small():
+@pytest.mark.parametrize('level', [3, 4])
+def test_ford_train_step_vs_oracle_autograd_small(level):
     """Ford model, mode='train' under autograd on a reduced shape: loss and a few gradients vs the fp64 oracle."""
     from oracle import ref_cpu as O
     from highlyaccurate_amd.models_ford import LM_S2GP_Ford
     d = _dev()
-    args = O.default_args(N_iters=2)
+    args = O.default_args(N_iters=2, level=level)
     B, grd_hw, sat_a = 2, (64, 256), 128
     sd = O.synth_model_state(4, bias_scale=0.02)
     sat, grd, gu, gv, gh = O.synth_images(9, B, grd_hw=grd_hw, sat_a=sat_a)
