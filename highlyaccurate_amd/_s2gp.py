@@ -80,8 +80,10 @@ class S2GPBase(nn.Module):
             raise NotImplementedError("only proj='geo' is in scope")
         if getattr(args, 'Optimizer', 'LM') != 'LM':
             raise NotImplementedError("only Optimizer='LM' is in scope (SURVEY section 2)")
-        if getattr(args, 'use_gt_depth', 0) or getattr(args, 'estimate_depth', 0):
-            raise NotImplementedError('use_gt_depth / estimate_depth are out of scope')
+        if getattr(args, 'estimate_depth', 0):
+            raise NotImplementedError('estimate_depth (Ford height heads, VGG.py:85-118) is out of scope')
+        # args.use_gt_depth only takes effect when a gt_depth tensor is passed to forward (models_kitti.py:741); neither
+        # driver ever passes one (train_kitti.py:357,49), so the flag is accepted and forward() rejects an actual depth map
         precision = getattr(args, 'precision', 'fp32')
         self.SatFeatureNet = VGGUnet(self.level, precision=precision)
         self.GrdFeatureNet = VGGUnet(self.level, precision=precision)

@@ -20,6 +20,8 @@ class LM_S2GP(S2GPBase):
         mode='test'  -> (shift_lat[B], shift_lon[B], theta[B])   (models_kitti.py:1316)
         mode='train' -> the reference's 14-tuple                 (models_kitti.py:1312-1314)
         ``init_pose`` [B,3] (shift_u, shift_v, heading) is an extension; the reference always starts at 0."""
+        if gt_depth is not None and getattr(self.args, 'use_gt_depth', 0):
+            raise NotImplementedError('projection with a ground-truth depth map (models_kitti.py:741-747) is out of scope')
         want_conf = bool(self.using_weight) or mode == 'train'
         trace, grd_confs = self.localise(sat_map, grd_img_left, want_conf, None, level_first, init_pose,
                                           return_confs=(mode == 'train'))
