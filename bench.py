@@ -63,8 +63,8 @@ def cpu_baseline(max_seconds=30.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=10)
-    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--steps', type=int, default=50)
+    ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--batch', type=int, default=32, help='pairs per GPU')
     ap.add_argument('--precision', default='bf16', choices=['bf16', 'fp16', 'fp32'])
     ap.add_argument('--n-iters', type=int, default=None, help='LM iterations (default 5; 10 for --model ford = BASELINE configs[3])')
