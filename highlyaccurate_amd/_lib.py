@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get('HLA_LIB') or os.path.join(HERE, 'libhla.so')   # HLA_
 
 HLA_F32, HLA_BF16, HLA_F16 = 0, 1, 2
 HLA_VGG_WANT_CONF, HLA_VGG_DEFER_NORM, HLA_VGG_SAVE_FOR_BACKWARD = 1, 2, 4
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 
 class HlaError(RuntimeError):
@@ -37,7 +37,8 @@ class S2GConfig(C.Structure):
     _fields_ = [('ford', C.c_int), ('n_levels', C.c_int), ('n_iters', C.c_int), ('level_first', C.c_int),
                 ('using_weight', C.c_int), ('use_hessian', C.c_int), ('dof', C.c_int),
                 ('shift_range_lat', C.c_double), ('shift_range_lon', C.c_double), ('rotation_range', C.c_double),
-                ('damping', C.c_double * 3), ('keep', C.c_void_p), ('keep_stride', C.c_size_t)]
+                ('damping', C.c_double * 3), ('keep', C.c_void_p), ('keep_stride', C.c_size_t),
+                ('optimizer', C.c_int), ('beta1', C.c_double), ('beta2', C.c_double)]
 
 
 class VggGrads(C.Structure):

@@ -78,8 +78,8 @@ class S2GPBase(nn.Module):
             raise NotImplementedError('args.level must be 3 (x15, x18, x21) or 4 (+ x24)')
         if getattr(args, 'proj', 'geo') != 'geo':
             raise NotImplementedError("only proj='geo' is in scope")
-        if getattr(args, 'Optimizer', 'LM') != 'LM':
-            raise NotImplementedError("only Optimizer='LM' is in scope (SURVEY section 2)")
+        if getattr(args, 'Optimizer', 'LM') not in ('LM', 'SGD', 'ADAM'):
+            raise NotImplementedError("Optimizer must be 'LM', 'SGD' or 'ADAM' ('NN' needs the NNrefine network: out of scope)")
         if getattr(args, 'estimate_depth', 0):
             raise NotImplementedError('estimate_depth (Ford height heads, VGG.py:85-118) is out of scope')
         # args.use_gt_depth only takes effect when a gt_depth tensor is passed to forward (models_kitti.py:741); neither
@@ -128,6 +128,8 @@ class S2GPBase(nn.Module):
             cfg.dof = 3
         cfg.shift_range_lat, cfg.shift_range_lon = float(a.shift_range_lat), float(a.shift_range_lon)
         cfg.rotation_range = float(a.rotation_range)
+        cfg.optimizer = {'LM': 0, 'SGD': 1, 'ADAM': 2}[getattr(a, 'Optimizer', 'LM')]
+        cfg.beta1, cfg.beta2 = float(getattr(a, 'beta1', 0.9)), float(getattr(a, 'beta2', 0.999))
         if getattr(a, 'train_damping', 0):
             lam = (10.0 ** (-6 + torch.sigmoid(self.damping.detach().double()) * 11.0)).reshape(-1).tolist()
         else:
@@ -206,7 +208,7 @@ class S2GPBase(nn.Module):
         cfg, lv, R_FL, T_FL = self._lm_structs(sat_feats, grd_feats, grd_confs, grd_hw, extra, level_first,
                                                sat_inv_norm, grd_inv_norm)
         steps = L * self.N_iters
-        reinit = self.ford or cfg.dof == 3
+        reinit = (self.ford or cfg.dof == 3) and cfg.optimizer == 0
         rand_uv = self._draw_reinit(steps, B, dev) if reinit else None
         self.last_keep = self._draw_dropout(lv, level_first, dev)
         if self.last_keep is not None:
@@ -267,6 +269,8 @@ class S2GPBase(nn.Module):
             raise ValueError(f'expected sat_map [B,3,A,A] and grd_img [B,3,H,W] with one B, got {tuple(sat_map.shape)} '
                              f'and {tuple(grd_img.shape)}')
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            if getattr(self.args, 'Optimizer', 'LM') != 'LM':
+                raise NotImplementedError("Optimizer='SGD'/'ADAM' (the reference's ablation updaters) are forward-only here")
             names = [n for n, _ in self.named_parameters()]
             params = [p for _, p in self.named_parameters()]
             out = _LocaliseFn.apply(self, names, sat_map, grd_img, want_conf, extra, level_first, init_pose, *params)
@@ -288,7 +292,9 @@ class S2GPBase(nn.Module):
         else:
             sat_feats, _, sat_inv = vgg_forward_nhwc(self.SatFeatureNet, sat_map, want_conf=False, defer_norm=True)
             grd_in = grd_img
+            # (only LM_update renormalises the ground features; SGD / ADAM see the whole-map L2_norm scale, so they need every row)
             skip = dead_ground_rows(grd_img.shape[-2]) if (not return_confs and self.level == 3
+                                                           and getattr(self.args, 'Optimizer', 'LM') == 'LM'
                                                            and os.environ.get('HLA_GRD_CROP', '1') != '0') else 0
             if skip:
                 grd_in = grd_img[:, :, skip:, :].contiguous()

@@ -317,6 +317,7 @@ extern "C" int hla_s2g_lm_solve_bwd(const hla_s2g_config* cfg, const hla_s2g_lev
                                     const double* normal_eq, const float* d_trace, double* d_damping, void* workspace,
                                     size_t workspace_bytes, int B, hla_stream_t stream) {
   HLA_REQUIRE(gr && trace && normal_eq && d_trace && d_damping && workspace, "hla_s2g_lm_solve_bwd: null argument");
+  HLA_REQUIRE(cfg && cfg->optimizer == 0, "hla_s2g_lm_solve_bwd: only the LM update has a backward");
   const int rc = hla_s2g_validate("hla_s2g_lm_solve_bwd", cfg, lv, R_FL, T_FL, B);
   if (rc) return rc;
   for (int l = 0; l < cfg->n_levels; ++l)

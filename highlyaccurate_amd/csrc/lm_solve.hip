@@ -120,6 +120,9 @@ struct SolveArgs {
   const float* R_FL;     // [B,3,3]
   const float* T_FL;     // [B,3]
   int B, reinit;
+  int optimizer, t;      // 0 LM; 1 SGD; 2 ADAM (t = step index in execution order)
+  double beta1, beta2;
+  double* adam;          // [B,6] first / second moment of the three pose components (ADAM only)
   LmSolveCfg cfg;
   LmGeom next;           // geometry of the level the NEXT step runs on
 };
@@ -151,7 +154,21 @@ __global__ __launch_bounds__(64) void lm_solve(SolveArgs a) {
         a.normal_eq[(size_t)b * 16 + 14] = 0.0; a.normal_eq[(size_t)b * 16 + 15] = 0.0;
       }
       double H[3][3], g[3], Mi[3][3], d[3], ns, ng;
-      lm_solve_step(a.cfg, s, H, g, Mi, d, ns, ng);
+      if (a.optimizer == 0) {
+        lm_solve_step(a.cfg, s, H, g, Mi, d, ns, ng);
+      } else {                       // ablation optimisers on the raw residual: delta_pose = sum 2 r J (models_kitti.py:1075-1076)
+        for (int p = 0; p < 3; ++p) d[p] = 2.0 * (s[8 + p] - s[11 + p]);
+        if (a.optimizer == 2) {      // ADAM_update, 1110-1116
+          double* mv = a.adam + (size_t)b * 6;
+          for (int p = 0; p < 3; ++p) {
+            const double m = a.beta1 * mv[p] + (1.0 - a.beta1) * d[p];
+            const double v = a.beta2 * mv[3 + p] + (1.0 - a.beta2) * d[p] * d[p];
+            mv[p] = m; mv[3 + p] = v;
+            d[p] = (m / (1.0 - pow(a.beta1, a.t + 1))) / (sqrt(v / (1.0 - pow(a.beta2, a.t + 1))) + 1e-8);
+          }
+        }
+        for (int p = 0; p < 3; ++p) d[p] *= 0.01;
+      }
       su = (float)((double)su - d[0]);
       sv = (float)((double)sv - d[1]);
       th = (float)((double)th - d[2]);
@@ -183,6 +200,7 @@ static size_t ws_layout(const hla_s2g_config* cfg, const hla_s2g_level* lv, int 
   *off_coef = o; o += hla_align_up((size_t)B * COEF_N * sizeof(double), 256);
   *off_pose = o; o += hla_align_up((size_t)B * 3 * sizeof(float), 256);
   *off_part = o; o += hla_align_up((size_t)B * max_nt * PART_N * sizeof(double), 256);
+  o += hla_align_up((size_t)B * 6 * sizeof(double), 256);      // ADAM moments (last region)
   return o;
 }
 
@@ -226,7 +244,9 @@ extern "C" int hla_s2g_lm_solve(const hla_s2g_config* cfg, const hla_s2g_level* 
   HLA_REQUIRE(trace && workspace, "hla_s2g_lm_solve: null argument");
   const int rc = hla_s2g_validate("hla_s2g_lm_solve", cfg, lv, R_FL, T_FL, B);
   if (rc) return rc;
-  const bool reinit = cfg->ford || cfg->dof == 3;
+  HLA_REQUIRE(cfg->optimizer >= 0 && cfg->optimizer <= 2, "hla_s2g_lm_solve: optimizer must be 0 (LM), 1 (SGD) or 2 (ADAM)");
+  HLA_REQUIRE(cfg->optimizer == 0 || !cfg->level_first, "hla_s2g_lm_solve: SGD / ADAM exist for the iteration-first loop only");
+  const bool reinit = (cfg->ford || cfg->dof == 3) && cfg->optimizer == 0;     // SGD_update / ADAM_update never re-initialise
   HLA_REQUIRE(!reinit || rand_uv, "hla_s2g_lm_solve: rand_uv required");
   size_t oc, op, opart;
   const size_t need = ws_layout(cfg, lv, B, &oc, &op, &opart);
@@ -253,7 +273,10 @@ extern "C" int hla_s2g_lm_solve(const hla_s2g_config* cfg, const hla_s2g_level* 
     return g;
   };
 
+  double* adam = (double*)(ws + need - hla_align_up((size_t)B * 6 * sizeof(double), 256));
+  if (cfg->optimizer == 2) HLA_CHECK_HIP(hipMemsetAsync(adam, 0, (size_t)B * 6 * sizeof(double), st));
   SolveArgs sa{};
+  sa.optimizer = cfg->optimizer; sa.beta1 = cfg->beta1; sa.beta2 = cfg->beta2; sa.adam = adam;
   sa.pose = pose; sa.B = B; sa.reinit = reinit ? 1 : 0; sa.R_FL = R_FL; sa.T_FL = T_FL;
   sa.cfg.dof = cfg->dof; sa.cfg.use_hessian = cfg->use_hessian;
   for (int i = 0; i < 3; ++i) sa.cfg.lam[i] = cfg->damping[i];
@@ -276,10 +299,11 @@ extern "C" int hla_s2g_lm_solve(const hla_s2g_config* cfg, const hla_s2g_level* 
     const int nblk = aa.xcd_affine ? 8 * ((B + 7) / 8) * aa.nt : B * aa.nt;
     hla_prof_begin(v.C == 256 ? K_LM256 : v.C == 128 ? K_LM128 : v.C == 64 ? K_LM64 : K_LM16, 0,
                    (double)B * ((double)v.A * v.A + (double)aa.npix) * v.C * 4.0, st);
-    if (cfg->using_weight) launch_accum<true>(v.C, dim3(nblk), st, aa);
+    if (cfg->using_weight && cfg->optimizer == 0) launch_accum<true>(v.C, dim3(nblk), st, aa);   // SGD / ADAM ignore the confidence
     else launch_accum<false>(v.C, dim3(nblk), st, aa);
     hla_prof_end(st);
 
+    sa.t = k;
     sa.part = part; sa.nt = aa.nt; sa.sat_inv = v.sat_inv_norm; sa.grd_inv = v.grd_inv_norm;
     sa.trace_out = trace + ((size_t)it * L + l) * 3; sa.trace_stride = N * L * 3;
     sa.rand_uv = reinit ? rand_uv + (size_t)k * 2 * B : nullptr;

@@ -185,6 +185,10 @@ typedef struct hla_s2g_config {
   const unsigned char* keep;  /* args.dropout (models_kitti.py:968-974): [steps][keep_stride] bytes in execution order, 1 = the
                                  pixel (index within the rows row0..h-1 of that step's level) takes part; NULL = no dropout */
   size_t keep_stride;
+  int optimizer;          /* 0: LM_update; 1: SGD_update (models_kitti.py:1056-1084: pose -= 0.01 * 2 J'(s - g), raw features,
+                             no weights, no re-initialisation); 2: ADAM_update (1086-1125, beta1/beta2 below).  1 and 2 are
+                             the reference's ablation optimisers: forward only */
+  double beta1, beta2;
 } hla_s2g_config;
 
 size_t hla_s2g_workspace_bytes(const hla_s2g_config* cfg, const hla_s2g_level* levels, int B);

@@ -192,7 +192,8 @@ def gen_kat(mk, mf, jac, VGG):
     print('kat_small.npz written,', len(out), 'arrays')
 
 
-def run_e2e(mod, cls, args, seed, B, dtype, extra=None, level_first=0, bias_scale=0.0, grd_hw=(256, 1024), sat_a=512):
+def run_e2e(mod, cls, args, seed, B, dtype, extra=None, level_first=0, bias_scale=0.0, grd_hw=(256, 1024), sat_a=512,
+            hook='LM_update'):
     net = ref_model(mod, cls, args, seed, dtype, bias_scale)
     if tuple(grd_hw) != (256, 1024):
         # the reference hard-codes its ground-plane tables for a 256x1024 input (models_kitti.py:622); rebuild them with
@@ -208,13 +209,13 @@ def run_e2e(mod, cls, args, seed, B, dtype, extra=None, level_first=0, bias_scal
     # monkey-patch loss_func-free access: call train mode with gt to get nothing extra, so
     # we wrap LM_update to log.
     log = []
-    orig = net.LM_update
+    orig = getattr(net, hook)
 
     def wrap(*a, **k):
         r = orig(*a, **k)
-        log.append(torch.stack([x.detach()[:, 0] for x in r], -1))  # [B,3] = (u, v, theta)
+        log.append(torch.stack([x.detach()[:, 0] for x in r[:3]], -1))  # [B,3] = (u, v, theta)
         return r
-    net.LM_update = wrap
+    setattr(net, hook, wrap)
     with torch.no_grad():
         sf, _ = net.SatFeatureNet(sat)
         gf, _ = net.GrdFeatureNet(grd)
@@ -261,6 +262,18 @@ def gen_e2e(mk, seeds, B=2):
         out[f'trace64_{tag}'], out[f'trace32_{tag}'] = t64, t32
         print(f'kitti {tag}: gap {np.abs(t32 - t64).max():.2e}', flush=True)
     np.savez_compressed(os.path.join(GOLD, 'e2e_kitti.npz'), **out)
+
+
+def gen_optim(mk, seed=1, B=1):
+    """The reference's ablation updaters Optimizer='SGD' / 'ADAM' (models_kitti.py:1056-1125), 15 steps each."""
+    out = {'seed': np.array(seed), 'B': np.array(B)}
+    for opt in ('SGD', 'ADAM'):
+        args = O.default_args(Optimizer=opt)
+        for dtype, tag in ((torch.float32, '32'), (torch.float64, '64')):
+            t, f, _, _ = run_e2e(mk, 'LM_S2GP', args, seed, B, dtype, hook=opt + '_update')
+            out[f'trace{tag}_{opt}'] = t
+        print(f"{opt}: gap {np.abs(out[f'trace32_{opt}'] - out[f'trace64_{opt}']).max():.2e} last {out[f'trace64_{opt}'][0, -1].tolist()}", flush=True)
+    np.savez_compressed(os.path.join(GOLD, 'e2e_kitti_optim.npz'), **out)
 
 
 def gen_level4(mk, seed=1, B=1):
@@ -436,6 +449,8 @@ if __name__ == '__main__':
         gen_train(mk, (seeds or [1])[0])
     if a.only in ('all', 'g2s'):
         gen_g2s(mk, seeds or [1, 2])
+    if a.only in ('all', 'optim'):
+        gen_optim(mk, (seeds or [1])[0])
     if a.only in ('all', 'level4'):
         gen_level4(mk, (seeds or [1])[0])
     if a.only in ('all', 'hires'):

@@ -453,13 +453,28 @@ class _S2GPBase(nn.Module):
         gc = grd_conf * mask[:, None]
         if self.args.proj == 'geo':
             f, g, gc, jac = f[:, :, h // 2:], g[:, :, h // 2:], gc[:, :, h // 2:], jac[:, :, :, h // 2:]
-        return lm_update(self.args, self.damping, su, sv, th, f, g, gc, jac, self.using_weight, ford=self.ford)
+        opt = getattr(self.args, 'Optimizer', 'LM')
+        if opt == 'LM':
+            return lm_update(self.args, self.damping, su, sv, th, f, g, gc, jac, self.using_weight, ford=self.ford)
+        # the reference's ablation updaters (models_kitti.py:1056-1125): gradient of sum r^2 on the raw maps, step 0.01
+        B = f.shape[0]
+        delta = (2 * (f - g)[None] * jac).reshape(3, B, -1).sum(-1).transpose(0, 1)          # [B,3]
+        if opt == 'ADAM':
+            b1, b2, t = self.args.beta1, self.args.beta2, self._adam_t
+            if t == 0:
+                self._adam_m = self._adam_v = 0
+            self._adam_m = b1 * self._adam_m + (1 - b1) * delta
+            self._adam_v = b2 * self._adam_v + (1 - b2) * delta * delta
+            delta = (self._adam_m / (1 - b1 ** (t + 1))) / ((self._adam_v / (1 - b2 ** (t + 1))) ** 0.5 + 1e-8)
+            self._adam_t = t + 1
+        return su - 0.01 * delta[:, 0:1], sv - 0.01 * delta[:, 1:2], th - 0.01 * delta[:, 2:3]
 
     def solve(self, sat_feats, sat_confs, grd_feats, grd_confs, extra=None, level_first=0):
         """The 15/30-step loop (models_kitti.py:1176-1283 iter-first; 1352-1459 level-first).
         Returns (us, vs, thetas) each [B, N_iters, Level] (iter-first stacking)."""
         B = sat_feats[0].shape[0]
         dt = sat_feats[0].dtype
+        self._adam_t = 0
         su = torch.zeros(B, 1, dtype=dt)
         sv = torch.zeros(B, 1, dtype=dt)
         th = torch.zeros(B, 1, dtype=dt)

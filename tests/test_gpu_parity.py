@@ -353,6 +353,24 @@ def test_reduced_precision_pose_deviation_reported(precision):
     assert np.isfinite(trace).all() and err.max() < (0.2 if precision == 'bf16' else 0.05)
 
 
+@pytest.mark.parametrize('opt', ['SGD', 'ADAM'])
+def test_e2e_ablation_optimisers_vs_golden(opt):
+    """Optimizer='SGD' / 'ADAM', the reference's ablation updaters (forward only): 15-step trace vs the reference."""
+    g = load_golden('e2e_kitti_optim.npz')
+    seed, B = int(g['seed']), int(g['B'])
+    net, _ = _run_kitti(seed, B, Optimizer=opt)
+    trace = _exec_order(net.last_trace, 0).cpu().numpy().astype(np.float64)
+    if opt == 'SGD':
+        _pose_gate(trace, g[f'trace64_{opt}'], g[f'trace32_{opt}'], f'kitti {opt}')
+    else:
+        # ADAM's normalised steps amplify rounding ~10x per step (tests/test_oracle_golden.py): gate the first steps tightly
+        # and the whole trace against the reference's own fp32-vs-fp64 gap (6.7e-4)
+        err = np.abs(trace - g['trace64_ADAM'])
+        gap = np.abs(g['trace32_ADAM'] - g['trace64_ADAM']).max()
+        print(f'kitti ADAM: max err per step {np.array2string(err.max((0, 2)), precision=1)} (reference fp32-fp64 gap {gap:.2e})')
+        assert err[:, :3].max() < 1e-5 and err.max() < 0.5 * gap
+
+
 def test_e2e_kitti_level4_vs_golden():
     """args.level = 4 (inference): 4 levels x 5 iterations = 20 LM steps, the last level on the full-resolution x24 map."""
     g = load_golden('e2e_kitti_level4.npz')
@@ -897,7 +915,7 @@ def test_bad_arguments_raise():
     with pytest.raises(NotImplementedError):
         VGGUnet(5)
     with pytest.raises(NotImplementedError):
-        LM_S2GP(O.default_args(Optimizer='SGD'))
+        LM_S2GP(O.default_args(Optimizer='NN'))
     m = LM_S2GP(O.default_args(N_iters=1)).to(d)
     with pytest.raises(Exception):                       # sat / grd batch mismatch
         with torch.no_grad():
