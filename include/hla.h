@@ -9,7 +9,7 @@
  *   - plain pointers + sizes only; all pointers are DEVICE pointers unless marked [host]
  *   - the caller allocates every buffer (PyTorch's caching allocator in practice);
  *     the library never allocates or frees device memory and keeps no global state
- *     except a thread-local last-error string
+ *     except a thread-local last-error string and the opt-in timing log (hla_prof_*)
  *   - all work is enqueued on the given hipStream_t (passed as void*); no implicit
  *     synchronisation, no host<->device copies except the small [host] structs
  *     passed by value
@@ -43,7 +43,7 @@ typedef enum hla_dtype {
 } hla_dtype;
 
 const char* hla_last_error(void);
-int hla_abi_version(void);
+int hla_abi_version(void);   /* 7 (bumped whenever a struct or signature in this file changes; _lib.py checks it) */
 
 /* ------------------------------------------------------------------------- *
  * VGGUnet.forward  (VGG.py:121-203; L2_norm VGG.py:511-514)
