@@ -388,8 +388,9 @@ def gen_ford(mf, seeds, B=1):
         print(f'ford seed {seed}: gap {np.abs(t32 - t64).max():.2e} final {f64.tolist()}', flush=True)
     # level-first ordering (models_ford.py:868-1026) and confidence weighting, first seed
     seed = seeds[0]
-    for tag, kw, lf in (('levelfirst', {}, 1), ('weight', dict(using_weight=1), 0)):
-        a = O.default_args(N_iters=10, **kw)
+    for tag, kw, lf in (('levelfirst', {}, 1), ('weight', dict(using_weight=1), 0), ('dropout', dict(dropout=1), 0),
+                        ('level4', dict(level=4, N_iters=5), 0)):
+        a = O.default_args(**{'N_iters': 10, **kw})
         t64, _, _, _ = run_e2e(mf, 'LM_S2GP_Ford', a, seed, B, torch.float64, extra=ford_extra(B), level_first=lf)
         t32, _, _, _ = run_e2e(mf, 'LM_S2GP_Ford', a, seed, B, torch.float32, extra=ford_extra(B), level_first=lf)
         out[f'trace64_{tag}'], out[f'trace32_{tag}'] = t64, t32

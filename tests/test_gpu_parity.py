@@ -321,7 +321,8 @@ def test_e2e_ford_full_shape_vs_golden():
         np.testing.assert_array_equal(torch.stack(res, -1).cpu().numpy(), trace[:, -1].astype(np.float32))
 
 
-@pytest.mark.parametrize('tag,kw,lf', [('levelfirst', {}, 1), ('weight', dict(using_weight=1), 0)])
+@pytest.mark.parametrize('tag,kw,lf', [('levelfirst', {}, 1), ('weight', dict(using_weight=1), 0), ('dropout', dict(dropout=1), 0),
+                                       ('level4', dict(level=4, N_iters=5), 0)])
 def test_e2e_ford_variants_vs_golden(tag, kw, lf):
     """Ford level-first ordering (models_ford.py:868-1026) and confidence weighting, 30 steps, full shape."""
     from oracle import ref_cpu as O
@@ -329,13 +330,14 @@ def test_e2e_ford_variants_vs_golden(tag, kw, lf):
     g = load_golden('e2e_ford.npz')
     seed, B = int(g['seeds'][0]), int(g['B'])
     d = _dev()
-    net = LM_S2GP_Ford(O.default_args(N_iters=10, **kw))
+    net = LM_S2GP_Ford(O.default_args(**{'N_iters': 10, **kw}))
     net.load_state_dict(O.synth_model_state(seed))
     net = net.to(d)
     sat, grd, *_ = O.synth_images(seed + 100, B)
     R_FL = torch.tensor([[[0., 0., 1.], [1., 0., 0.], [0., 1., 0.]]]).repeat(B, 1, 1)
     T_FL = torch.tensor([[1.7, 0.3, -1.2]]).repeat(B, 1)
     torch.manual_seed(seed)
+    np.random.seed(seed)
     with torch.no_grad():
         net(sat.to(d), grd.to(d), 112.64, R_FL.to(d), T_FL.to(d), mode='test', level_first=lf)
     trace = _exec_order(net.last_trace, lf).cpu().numpy().astype(np.float64)
