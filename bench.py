@@ -83,13 +83,21 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
     assert torch.cuda.is_available(), 'bench.py needs an MI355X'
+    # HLA_BENCH_REHEARSE=1: run the N>1 control flow on a box with fewer GPUs than ranks (ranks share devices, the
+    # collectives go over gloo instead of RCCL).  For checking the multi-rank logic only; the numbers mean nothing.
+    rehearse = bool(os.environ.get('HLA_BENCH_REHEARSE'))
+    if rehearse:
+        local %= torch.cuda.device_count()
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+        if rehearse:
+            dist.init_process_group('gloo', rank=rank, world_size=world)
+        else:
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
 
     from types import SimpleNamespace
     from highlyaccurate_amd import _lib
