@@ -201,8 +201,10 @@ def main():
               dist.barrier()
           torch.cuda.synchronize()
           t1 = time.perf_counter()
+          ar0 = net.grad_sync.bytes_reduced if dist else 0
           for _ in range(a.train_steps):
               lossv = tstep()
+          ar_bytes = ((net.grad_sync.bytes_reduced - ar0) // a.train_steps) if dist else 0
           torch.cuda.synchronize()
           if dist:
               dist.barrier()
@@ -227,7 +229,7 @@ def main():
           train = {'value': round(B * world * a.train_steps / tdt, 3), 'unit': 'pairs/s', 'steps': a.train_steps,
                    'ms_per_step': round(tdt / a.train_steps * 1e3, 3), 'loss_finite': bool(torch.isfinite(lossv)),
                    'what': "forward(mode='train') + HIP backward (LM loop + both VGGs) + gradient all-reduce + Adam",
-                   'allreduce_bytes_per_step': (net.grad_sync.bytes_reduced // (a.train_steps + 2)) if dist else 0}
+                   'allreduce_bytes_per_step': ar_bytes}
           if trecs:
               tagg = {}
               for name, ms, fl, by in trecs:
