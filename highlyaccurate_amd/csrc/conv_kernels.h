@@ -432,13 +432,27 @@ __global__ __launch_bounds__(256, (NT == 1 && !PF_UPFRONT) ? 3 : 2) void conv3x3
         v = *(const uint4*)(src + e0);
         if (a.unpool_idx) {          // keep only the elements whose forward argmax is this (y&1, x&1) position
           const unsigned pos = ((y & 1) << 1) | (x & 1);
-          T e[EPL];
-          unsigned char id[EPL];
-          __builtin_memcpy(e, &v, 16);
-          __builtin_memcpy(id, a.unpool_idx + e0, EPL);
+          if constexpr (sizeof(T) == 2) {
+            // 8 argmax bytes -> eight 16-bit keep masks with packed 16-bit math: (id ^ pos) - 1 is negative only for a match
+            typedef short s16x2 __attribute__((ext_vector_type(2)));
+            const uint2 id = *(const uint2*)(a.unpool_idx + e0);
+            const unsigned m0 = id.x ^ (pos * 0x01010101u), m1 = id.y ^ (pos * 0x01010101u);
+            auto keep = [](unsigned m, unsigned sel) {
+              s16x2 w = __builtin_bit_cast(s16x2, __builtin_amdgcn_perm(0u, m, sel));   // two id bytes, zero-extended
+              w = (w - (short)1) >> 15;
+              return __builtin_bit_cast(unsigned, w);
+            };
+            v.x &= keep(m0, 0x0c010c00u); v.y &= keep(m0, 0x0c030c02u);
+            v.z &= keep(m1, 0x0c010c00u); v.w &= keep(m1, 0x0c030c02u);
+          } else {
+            T e[EPL];
+            unsigned char id[EPL];
+            __builtin_memcpy(e, &v, 16);
+            __builtin_memcpy(id, a.unpool_idx + e0, EPL);
 #pragma unroll
-          for (int k = 0; k < EPL; ++k) if (id[k] != pos) e[k] = (T)0.f;
-          __builtin_memcpy(&v, e, 16);
+            for (int k = 0; k < EPL; ++k) if (id[k] != pos) e[k] = (T)0.f;
+            __builtin_memcpy(&v, e, 16);
+          }
         }
       }
       st[i] = v;
