@@ -214,7 +214,8 @@ class S2GPBase(nn.Module):
         if self.last_keep is not None:
             cfg.keep, cfg.keep_stride = self.last_keep.data_ptr(), self.last_keep.shape[1]
         trace = torch.empty(B, self.N_iters, L, 3, device=dev, dtype=torch.float32)
-        want_neq = self.keep_normal_eq if keep_normal_eq is None else keep_normal_eq
+        strict = bool(getattr(self.args, 'strict_errors', 0)) or os.environ.get('HLA_STRICT_ERRORS', '0') == '1'
+        want_neq = strict or (self.keep_normal_eq if keep_normal_eq is None else keep_normal_eq)
         neq = torch.empty(steps, B, 16, device=dev, dtype=torch.float64) if want_neq else None
         nbytes = lib.hla_s2g_workspace_bytes(C.byref(cfg), lv, B)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
@@ -222,6 +223,18 @@ class S2GPBase(nn.Module):
         rc = lib.hla_s2g_lm_solve(C.byref(cfg), lv, _lib.ptr(R_FL), _lib.ptr(T_FL), _lib.ptr(p0), _lib.ptr(rand_uv),
                                   _lib.ptr(trace), _lib.ptr(neq), _lib.ptr(ws), nbytes, B, _lib.stream_ptr())
         _lib.check(rc, 'hla_s2g_lm_solve')
+        # Error behaviour of the reference, which costs a host sync and is therefore only reproduced (a) under the ablation
+        # flags that can make H + damping*D exactly singular (use_hessian / zero damping) and (b) when strict error checking
+        # is asked for (HLA_STRICT_ERRORS=1 or args.strict_errors).  With the default flags the forward has no host sync;
+        # a step whose pixels all fall outside the satellite map then leaves the pose unchanged (J = 0, r = -g).
+        risky = cfg.optimizer == 0 and (cfg.use_hessian or min(cfg.damping[i] for i in range(3)) <= 0.0)
+        if strict and bool((neq[:, :, 0].sum(1) == 0).any()):
+            # jacobian.py:172 `assert mask.sum() > 0`: no pixel of the whole batch samples inside the map in some step
+            raise AssertionError('grid_sample: no ground pixel of the batch projects inside the satellite map (jacobian.py:172)')
+        if (risky or strict) and not bool(torch.isfinite(trace).all()):
+            # torch.inverse on a singular matrix (models_kitti.py:1012, models_ford.py:446)
+            raise RuntimeError('linalg.inv: the damped normal matrix of an LM step is singular '
+                               '(use_hessian / zero damping with no Jacobian support in one pose component)')
         # a detached alias: under autograd `trace` becomes the Function's output (grad_fn -> ctx), and ctx/model must not hold it
         # or every step's ctx (8.5 GB of saved workspaces at B = 32) lives in a reference cycle until the cyclic GC runs
         self.last_trace, self.last_normal_eq = trace.detach(), neq

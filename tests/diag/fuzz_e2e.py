@@ -1,0 +1,107 @@
+"""Randomised end-to-end comparison of the HIP path (fp32 mode) with the fp64 oracle: random batch sizes, image
+sizes (multiples of 8, mostly not of the conv / LM tiles), model family, level, flags and iteration counts.
+Forward poses and, every other case, the training-step loss + parameter gradients.
+
+    python tests/diag/fuzz_e2e.py [n_cases] [first_seed]
+
+A diagnostic, not part of the pytest suite (the oracle side takes a few seconds per case).  Prints one line per case
+and exits non-zero when a case exceeds its bound.
+"""
+import sys, os
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from oracle import ref_cpu as O
+from highlyaccurate_amd.models_kitti import LM_S2GP
+from highlyaccurate_amd.models_ford import LM_S2GP_Ford
+
+d = torch.device('cuda:0')
+R_FL0 = torch.tensor([[[0., 0., 1.], [1., 0., 0.], [0., 1., 0.]]])
+T_FL0 = torch.tensor([[1.7, 0.3, -1.2]])
+
+
+def one_case(seed):
+    rs = np.random.RandomState(seed)
+    ford = bool(rs.randint(2))
+    B = int(rs.randint(1, 5))
+    gh, gw = int(rs.randint(4, 13)) * 8, int(rs.randint(8, 37)) * 8
+    sa = int(rs.randint(8, 21)) * 8
+    kw = dict(N_iters=int(rs.randint(1, 4)), level=int(rs.choice([3, 3, 4])), using_weight=int(rs.randint(2)),
+              use_hessian=int(rs.randint(2)), train_damping=int(rs.randint(2)))
+    if not ford and rs.randint(4) == 0:
+        kw['rotation_range'] = 0.0          # 2-DoF (models_kitti.py:954-957)
+    if rs.randint(3) == 0:
+        kw['damping'] = float(rs.choice([0.01, 0.5, 1.0]))
+    lf = int(rs.randint(2))
+    train = seed % 2 == 1
+    args = O.default_args(**kw)
+    sd = O.synth_model_state(seed, bias_scale=0.02, rotation_range=10.0 if ford else args.rotation_range)
+    if kw['train_damping']:
+        sd['damping'] = torch.from_numpy(rs.uniform(-1, 1, tuple(sd['damping'].shape))).float()
+    sat, grd, gu, gv, gt = O.synth_images(seed + 1000, B, grd_hw=(gh, gw), sat_a=sa)
+    extra_o = (0.22 * sa, R_FL0.repeat(B, 1, 1).double(), T_FL0.repeat(B, 1).double()) if ford else ()
+    extra_g = (0.22 * sa, R_FL0.repeat(B, 1, 1).to(d), T_FL0.repeat(B, 1).to(d)) if ford else ()
+    onet = (O.LM_S2GP_Ford if ford else O.LM_S2GP)(args, grd_hw=(gh, gw))
+    onet.load_state_dict(sd)
+    onet = onet.double()
+    net = (LM_S2GP_Ford if ford else LM_S2GP)(args)
+    net.load_state_dict(sd)
+    net = net.to(d)
+    desc = f"seed {seed:3d} {'ford ' if ford else 'kitti'} B{B} grd {gh}x{gw} sat {sa} lf{lf} {kw}"
+    try:        # does the reference raise (singular normal matrix)?  then so must the HIP path
+        torch.manual_seed(seed)
+        with torch.no_grad():
+            onet(sat.double(), grd.double(), *extra_o, mode='test', level_first=lf)
+    except torch.linalg.LinAlgError:
+        try:
+            with torch.no_grad():
+                net(sat.to(d), grd.to(d), *extra_g, mode='test', level_first=lf)
+        except RuntimeError as e:
+            print(f'ok   raise {desc}: both raise ({str(e)[:40]}...)', flush=True)
+            return True
+        print(f'FAIL raise {desc}: the oracle raised, the HIP path did not', flush=True)
+        return False
+    if not train:
+        torch.manual_seed(seed)
+        with torch.no_grad():
+            ref = torch.stack(onet(sat.double(), grd.double(), *extra_o, mode='test', level_first=lf), -1).numpy()
+        torch.manual_seed(seed)
+        with torch.no_grad():
+            res = torch.stack(net(sat.to(d), grd.to(d), *extra_g, mode='test', level_first=lf), -1).cpu().numpy()
+        err = float(np.abs(res - ref).max())
+        ok = np.isfinite(res).all() and err < 5e-4
+        print(f"{'ok  ' if ok else 'FAIL'} fwd   {desc}: pose err {err:.2e} (range {np.abs(ref).max():.2e})", flush=True)
+        return ok
+    gts_o = [g.double() if not ford else g.double().reshape(-1) for g in (gu, gv, gt)]
+    gts_g = [g.to(d) if not ford else g.double().reshape(-1).to(d) for g in (gu, gv, gt)]
+    torch.manual_seed(seed)
+    ro = onet(sat.double(), grd.double(), *extra_o, *gts_o, mode='train', level_first=lf)
+    ro[0].backward()
+    torch.manual_seed(seed)
+    r = net(sat.to(d), grd.to(d), *extra_g, *gts_g, mode='train', level_first=lf)
+    r[0].backward()
+    lerr = abs(float(r[0].detach()) - float(ro[0].detach())) / max(abs(float(ro[0].detach())), 1e-9)
+    worst, wname, nchk = 1.0, '', 0
+    for (n, p), (_, po) in zip(net.named_parameters(), onet.named_parameters()):
+        if po.grad is None:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, n
+            continue
+        a, b = p.grad.detach().double().cpu().flatten(), po.grad.flatten()
+        if float(b.norm()) < 1e-12:
+            continue
+        cos = float((a @ b) / (a.norm() * b.norm() + 1e-300)) if a.numel() > 1 else 1.0 - abs(float(a - b)) / abs(float(b))
+        nchk += 1
+        if cos < worst:
+            worst, wname = cos, n
+    ok = lerr < 1e-3 and worst > 0.995
+    print(f"{'ok  ' if ok else 'FAIL'} train {desc}: loss rel err {lerr:.1e}, {nchk} grads, worst cosine {worst:.6f} ({wname})", flush=True)
+    return ok
+
+
+if __name__ == '__main__':
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 24
+    s0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    bad = [s for s in range(s0, s0 + n) if not one_case(s)]
+    print('failed seeds:', bad)
+    sys.exit(1 if bad else 0)

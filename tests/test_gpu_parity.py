@@ -902,6 +902,47 @@ def test_e2e_ragged_shapes_vs_oracle(B, grd_hw, sat_a):
     assert np.isfinite(res).all() and err < 2e-4
 
 
+def test_error_behaviour_matches_the_reference(monkeypatch):
+    """(1) use_hessian=1 with a pose component that has no Jacobian support: H + damping*diag(H) is singular and the
+    reference raises from torch.inverse (models_ford.py:446); the HIP path must raise too, not return a NaN pose.
+    (2) No pixel of the batch projecting inside the satellite map: the reference asserts (jacobian.py:172); the HIP path
+    reproduces that under HLA_STRICT_ERRORS=1 (it costs a host sync) and otherwise leaves the pose unchanged."""
+    from oracle import ref_cpu as O
+    from highlyaccurate_amd.models_ford import LM_S2GP_Ford
+    d = _dev()
+    R_FL = torch.tensor([[[0., 0., 1.], [1., 0., 0.], [0., 1., 0.]]])
+    T_FL = torch.tensor([[1.7, 0.3, -1.2]])
+    # (1) a naturally singular case found by tests/diag/fuzz_e2e.py (seed 59)
+    args = O.default_args(N_iters=2, using_weight=1, use_hessian=1)
+    grd_hw, sat_a = (88, 152), 104
+    sd = O.synth_model_state(59, bias_scale=0.02)
+    sat, grd, *_ = O.synth_images(1059, 1, grd_hw=grd_hw, sat_a=sat_a)
+    on = O.LM_S2GP_Ford(args, grd_hw=grd_hw)
+    on.load_state_dict(sd)
+    with pytest.raises(RuntimeError, match='singular'), torch.no_grad():      # torch.linalg.LinAlgError is a RuntimeError
+        on.double()(sat.double(), grd.double(), 0.22 * sat_a, R_FL.double(), T_FL.double(), mode='test')
+    net = LM_S2GP_Ford(args)
+    net.load_state_dict(sd)
+    net = net.to(d)
+    with pytest.raises(RuntimeError, match='singular'), torch.no_grad():
+        net(sat.to(d), grd.to(d), 0.22 * sat_a, R_FL.to(d), T_FL.to(d), mode='test')
+    # (2) a 1 mm satellite footprint: every projected point falls outside the map
+    args = O.default_args(N_iters=1)
+    on = O.LM_S2GP_Ford(args, grd_hw=grd_hw)
+    on.load_state_dict(sd)
+    with pytest.raises(AssertionError), torch.no_grad():
+        on.double()(sat.double(), grd.double(), 1e-3, R_FL.double(), T_FL.double(), mode='test')
+    net = LM_S2GP_Ford(args)
+    net.load_state_dict(sd)
+    net = net.to(d)
+    with torch.no_grad():
+        out = net(sat.to(d), grd.to(d), 1e-3, R_FL.to(d), T_FL.to(d), mode='test')
+    assert all(float(o.abs().max()) == 0.0 for o in out)          # J = 0: the pose stays at its initial value
+    monkeypatch.setenv('HLA_STRICT_ERRORS', '1')
+    with pytest.raises(AssertionError, match='jacobian.py:172'), torch.no_grad():
+        net(sat.to(d), grd.to(d), 1e-3, R_FL.to(d), T_FL.to(d), mode='test')
+
+
 def test_bad_arguments_raise():
     """Error behaviour at the boundary: every misuse is a Python exception carrying hla_last_error(), never a crash."""
     from oracle import ref_cpu as O
