@@ -83,6 +83,9 @@ class LM_G2SP(nn.Module):
         rc = lib.hla_g2s_lm_solve(C.byref(cfg), lv, _lib.ptr(K), int(ori_hw[0]), int(ori_hw[1]), _lib.ptr(p0), _lib.ptr(trace),
                                   _lib.ptr(neq), _lib.ptr(ws), nbytes, B, _lib.stream_ptr())
         _lib.check(rc, 'hla_g2s_lm_solve')
+        if (cfg.use_hessian or min(cfg.damping[i] for i in range(3)) <= 0.0) and not bool(torch.isfinite(trace).all()):
+            # torch.inverse on a singular H + damping*D (models_kitti.py:372); only these ablation flags can produce one
+            raise RuntimeError('linalg.inv: the damped normal matrix of an LM step is singular (use_hessian / zero damping)')
         # a detached alias: under autograd `trace` becomes the Function's output (grad_fn -> ctx), and ctx/model must not hold it
         # or every step's ctx (8.5 GB of saved workspaces at B = 32) lives in a reference cycle until the cyclic GC runs
         self.last_trace, self.last_normal_eq = trace.detach(), neq
