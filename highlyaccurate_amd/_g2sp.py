@@ -119,7 +119,7 @@ class LM_G2SP(nn.Module):
     def forward(self, sat_map, grd_img_left, left_camera_k, gt_shift_u=None, gt_shift_v=None, gt_heading=None,
                 mode='train', file_name=None, gt_depth=None, init_pose=None):
         """mode='test' -> (shift_lat[B], shift_lon[B], theta[B]) (models_kitti.py:498-499);
-        mode='train' -> the 14-tuple (486-496) -- values only: no backward for this direction yet."""
+        mode='train' -> the 14-tuple (486-496); under autograd its loss back-propagates through the HIP backward (_G2sFn)."""
         if sat_map.dim() != 4 or grd_img_left.dim() != 4 or sat_map.shape[0] != grd_img_left.shape[0] \
                 or sat_map.shape[2] != sat_map.shape[3]:
             raise ValueError(f'expected sat_map [B,3,A,A] and grd_img [B,3,H,W], got {tuple(sat_map.shape)} and '

@@ -13,7 +13,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from oracle import ref_cpu as O
-from highlyaccurate_amd.models_kitti import LM_S2GP
+from highlyaccurate_amd.models_kitti import LM_G2SP, LM_S2GP
 from highlyaccurate_amd.models_ford import LM_S2GP_Ford
 
 d = torch.device('cuda:0')
@@ -23,13 +23,14 @@ T_FL0 = torch.tensor([[1.7, 0.3, -1.2]])
 
 def one_case(seed):
     rs = np.random.RandomState(seed)
-    ford = bool(rs.randint(2))
+    fam = int(rs.randint(2)) if seed < 1000 else int(rs.randint(3))     # seeds >= 1000 add LM_G2SP (keeps the old seeds' cases)
+    ford, g2s = fam == 1, fam == 2
     B = int(rs.randint(1, 5))
     gh, gw = int(rs.randint(4, 13)) * 8, int(rs.randint(8, 37)) * 8
     sa = int(rs.randint(8, 21)) * 8
     kw = dict(N_iters=int(rs.randint(1, 4)), level=int(rs.choice([3, 3, 4])), using_weight=int(rs.randint(2)),
               use_hessian=int(rs.randint(2)), train_damping=int(rs.randint(2)))
-    if not ford and rs.randint(4) == 0:
+    if fam == 0 and rs.randint(4) == 0:
         kw['rotation_range'] = 0.0          # 2-DoF (models_kitti.py:954-957)
     if rs.randint(3) == 0:
         kw['damping'] = float(rs.choice([0.01, 0.5, 1.0]))
@@ -42,21 +43,27 @@ def one_case(seed):
     sat, grd, gu, gv, gt = O.synth_images(seed + 1000, B, grd_hw=(gh, gw), sat_a=sa)
     extra_o = (0.22 * sa, R_FL0.repeat(B, 1, 1).double(), T_FL0.repeat(B, 1).double()) if ford else ()
     extra_g = (0.22 * sa, R_FL0.repeat(B, 1, 1).to(d), T_FL0.repeat(B, 1).to(d)) if ford else ()
-    onet = (O.LM_S2GP_Ford if ford else O.LM_S2GP)(args, grd_hw=(gh, gw))
+    if g2s:
+        K = (torch.tensor([O.KITTI_K]) * torch.tensor([[gw / 1024.0], [gh / 256.0], [1.0]])).float().repeat(B, 1, 1)
+        extra_o, extra_g, lf = (K,), (K.to(d),), 0
+        onet = O.LM_G2SP(args)
+    else:
+        onet = (O.LM_S2GP_Ford if ford else O.LM_S2GP)(args, grd_hw=(gh, gw))
     onet.load_state_dict(sd)
     onet = onet.double()
-    net = (LM_S2GP_Ford if ford else LM_S2GP)(args)
+    net = LM_G2SP(args) if g2s else (LM_S2GP_Ford if ford else LM_S2GP)(args)
     net.load_state_dict(sd)
     net = net.to(d)
-    desc = f"seed {seed:3d} {'ford ' if ford else 'kitti'} B{B} grd {gh}x{gw} sat {sa} lf{lf} {kw}"
+    lfkw = {} if g2s else {'level_first': lf}
+    desc = f"seed {seed:3d} {('kitti', 'ford ', 'g2sp ')[fam]} B{B} grd {gh}x{gw} sat {sa} lf{lf} {kw}"
     try:        # does the reference raise (singular normal matrix)?  then so must the HIP path
         torch.manual_seed(seed)
         with torch.no_grad():
-            onet(sat.double(), grd.double(), *extra_o, mode='test', level_first=lf)
+            onet(sat.double(), grd.double(), *extra_o, mode='test', **lfkw)
     except torch.linalg.LinAlgError:
         try:
             with torch.no_grad():
-                net(sat.to(d), grd.to(d), *extra_g, mode='test', level_first=lf)
+                net(sat.to(d), grd.to(d), *extra_g, mode='test', **lfkw)
         except RuntimeError as e:
             print(f'ok   raise {desc}: both raise ({str(e)[:40]}...)', flush=True)
             return True
@@ -65,10 +72,10 @@ def one_case(seed):
     if not train:
         torch.manual_seed(seed)
         with torch.no_grad():
-            ref = torch.stack(onet(sat.double(), grd.double(), *extra_o, mode='test', level_first=lf), -1).numpy()
+            ref = torch.stack(onet(sat.double(), grd.double(), *extra_o, mode='test', **lfkw), -1).numpy()
         torch.manual_seed(seed)
         with torch.no_grad():
-            res = torch.stack(net(sat.to(d), grd.to(d), *extra_g, mode='test', level_first=lf), -1).cpu().numpy()
+            res = torch.stack(net(sat.to(d), grd.to(d), *extra_g, mode='test', **lfkw), -1).cpu().numpy()
         err = float(np.abs(res - ref).max())
         ok = np.isfinite(res).all() and err < 5e-4
         print(f"{'ok  ' if ok else 'FAIL'} fwd   {desc}: pose err {err:.2e} (range {np.abs(ref).max():.2e})", flush=True)
@@ -76,10 +83,10 @@ def one_case(seed):
     gts_o = [g.double() if not ford else g.double().reshape(-1) for g in (gu, gv, gt)]
     gts_g = [g.to(d) if not ford else g.double().reshape(-1).to(d) for g in (gu, gv, gt)]
     torch.manual_seed(seed)
-    ro = onet(sat.double(), grd.double(), *extra_o, *gts_o, mode='train', level_first=lf)
+    ro = onet(sat.double(), grd.double(), *extra_o, *gts_o, mode='train', **lfkw)
     ro[0].backward()
     torch.manual_seed(seed)
-    r = net(sat.to(d), grd.to(d), *extra_g, *gts_g, mode='train', level_first=lf)
+    r = net(sat.to(d), grd.to(d), *extra_g, *gts_g, mode='train', **lfkw)
     r[0].backward()
     lerr = abs(float(r[0].detach()) - float(ro[0].detach())) / max(abs(float(ro[0].detach())), 1e-9)
     worst, wname, nchk = 1.0, '', 0
