@@ -116,7 +116,9 @@ class S2GPBase(nn.Module):
         cfg = _lib.S2GConfig()
         cfg.ford = 1 if self.ford else 0
         cfg.n_levels, cfg.n_iters, cfg.level_first = n_levels, self.N_iters, 1 if level_first else 0
-        cfg.using_weight = 1 if self.using_weight else 0
+        cfg.optimizer = {'LM': 0, 'SGD': 1, 'ADAM': 2}[getattr(a, 'Optimizer', 'LM')]
+        # SGD_update / ADAM_update (models_kitti.py:1056-1116) read neither the confidence maps nor args.dropout
+        cfg.using_weight = 1 if (self.using_weight and cfg.optimizer == 0) else 0
         cfg.use_hessian = 1 if getattr(a, 'use_hessian', 0) else 0
         if self.ford:
             cfg.dof = 3
@@ -128,7 +130,6 @@ class S2GPBase(nn.Module):
             cfg.dof = 3
         cfg.shift_range_lat, cfg.shift_range_lon = float(a.shift_range_lat), float(a.shift_range_lon)
         cfg.rotation_range = float(a.rotation_range)
-        cfg.optimizer = {'LM': 0, 'SGD': 1, 'ADAM': 2}[getattr(a, 'Optimizer', 'LM')]
         cfg.beta1, cfg.beta2 = float(getattr(a, 'beta1', 0.9)), float(getattr(a, 'beta2', 0.999))
         if getattr(a, 'train_damping', 0):
             lam = (10.0 ** (-6 + torch.sigmoid(self.damping.detach().double()) * 11.0)).reshape(-1).tolist()
@@ -155,7 +156,7 @@ class S2GPBase(nn.Module):
         """args.dropout > 0 (models_kitti.py:968-974, models_ford.py:406-412): every LM step keeps a random half of the
         pixels, ``np.random.permutation(H*W)[:H*W//2]`` from numpy's GLOBAL generator, one draw per step in execution
         order.  Returns a uint8 [steps, stride] keep mask on the device (or None)."""
-        if not getattr(self.args, 'dropout', 0):
+        if not getattr(self.args, 'dropout', 0) or getattr(self.args, 'Optimizer', 'LM') != 'LM':
             return None
         L, N = len(lv), self.N_iters
         order = [l for l in range(L) for _ in range(N)] if level_first else [l for _ in range(N) for l in range(L)]
@@ -282,8 +283,6 @@ class S2GPBase(nn.Module):
             raise ValueError(f'expected sat_map [B,3,A,A] and grd_img [B,3,H,W] with one B, got {tuple(sat_map.shape)} '
                              f'and {tuple(grd_img.shape)}')
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            if getattr(self.args, 'Optimizer', 'LM') != 'LM':
-                raise NotImplementedError("Optimizer='SGD'/'ADAM' (the reference's ablation updaters) are forward-only here")
             names = [n for n, _ in self.named_parameters()]
             params = [p for _, p in self.named_parameters()]
             out = _LocaliseFn.apply(self, names, sat_map, grd_img, want_conf, extra, level_first, init_pose, *params)

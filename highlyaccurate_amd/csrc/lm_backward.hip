@@ -205,6 +205,12 @@ struct BwdSolveArgs {
   double* d_lambda;           // [3] accumulated over samples and steps
   const float* R_FL; const float* T_FL;
   int B, reinit, first;       // first: this is the last forward step (nothing to close, gid is not read)
+  // the ablation updaters (models_kitti.py:1056-1116): 1 SGD, 2 ADAM.  ADAM re-runs its moment recurrence from the saved
+  // sums of steps 0..t (neq_all) and carries the moment adjoints backwards in adam_adj [B,6]
+  int optimizer, t;
+  double beta1, beta2;
+  const double* neq_all;
+  double* adam_adj;
   LmSolveCfg cfg; LmGeom geom;
 };
 
@@ -238,6 +244,37 @@ __global__ __launch_bounds__(64) void lm_bwd_solve(BwdSolveArgs a) {
   if (a.pose_in) { const float* pi = a.pose_in + (size_t)b * a.pose_in_stride; pin[0] = pi[0]; pin[1] = pi[1]; pin[2] = pi[2]; }
 
   const double* s = a.normal_eq + (size_t)b * 16;
+  if (a.optimizer != 0) {
+    // pose_out = pose_in - 0.01 * f(g),  g = 2 (J^T s - J^T g_grd) on the whole-map-normalised features; no re-initialisation
+    double gg[3];                    // adjoint of the raw gradient g
+    for (int p = 0; p < 3; ++p) a.gid[(size_t)b * 3 + p] = gout[p];
+    if (a.optimizer == 1) {
+      for (int p = 0; p < 3; ++p) gg[p] = -0.01 * gout[p];
+    } else {
+      double* am = a.adam_adj + (size_t)b * 6;
+      const double c1 = 1.0 - pow(a.beta1, a.t + 1), c2 = 1.0 - pow(a.beta2, a.t + 1);
+      for (int p = 0; p < 3; ++p) {
+        double m = 0.0, v = 0.0, g_t = 0.0;
+        for (int j = 0; j <= a.t; ++j) {           // moments after step t
+          const double* sj = a.neq_all + ((size_t)j * a.B + b) * 16;
+          g_t = 2.0 * (sj[8 + p] - sj[11 + p]);
+          m = a.beta1 * m + (1.0 - a.beta1) * g_t;
+          v = a.beta2 * v + (1.0 - a.beta2) * g_t * g_t;
+        }
+        const double mh = m / c1, vh = v / c2, rt = sqrt(vh), den = rt + 1e-8;
+        const double gd = -0.01 * gout[p];         // adjoint of delta_final
+        const double g_m = am[p] + gd / (c1 * den);
+        const double g_v = am[3 + p] + (rt > 0.0 ? -gd * mh / (den * den) * 0.5 / (rt * c2) : 0.0);
+        gg[p] = (1.0 - a.beta1) * g_m + 2.0 * (1.0 - a.beta2) * g_t * g_v;
+        am[p] = a.beta1 * g_m; am[3 + p] = a.beta2 * g_v;
+      }
+    }
+    double* ad = a.adj + (size_t)b * 16;
+    for (int k = 0; k < 16; ++k) ad[k] = 0.0;
+    for (int p = 0; p < 3; ++p) { ad[8 + p] = 2.0 * gg[p]; ad[11 + p] = -2.0 * gg[p]; }
+    lm_coefficients(a.geom, pin[0], pin[1], pin[2], R, T, a.coef + (size_t)b * COEF_N);
+    return;
+  }
   double H[3][3], g[3], Mi[3][3], d[3], ns, ng;
   lm_solve_step(a.cfg, s, H, g, Mi, d, ns, ng);
   // which components survived the re-initialisation rule (models_kitti.py:1032-1033)?
@@ -293,7 +330,7 @@ static size_t bwd_layout(const hla_s2g_config* cfg, const hla_s2g_level* lv, int
   off[1] = o; o += hla_align_up((size_t)B * 16 * sizeof(double), 256);              // adj
   off[2] = o; o += hla_align_up((size_t)B * 3 * sizeof(double), 256);               // gid
   off[3] = o; o += hla_align_up((size_t)B * max_nt * PART_N * sizeof(double), 256); // part
-  off[4] = o;
+  off[4] = o; o += hla_align_up((size_t)B * 6 * sizeof(double), 256);               // ADAM moment adjoints
   return o;
 }
 
@@ -317,7 +354,7 @@ extern "C" int hla_s2g_lm_solve_bwd(const hla_s2g_config* cfg, const hla_s2g_lev
                                     const double* normal_eq, const float* d_trace, double* d_damping, void* workspace,
                                     size_t workspace_bytes, int B, hla_stream_t stream) {
   HLA_REQUIRE(gr && trace && normal_eq && d_trace && d_damping && workspace, "hla_s2g_lm_solve_bwd: null argument");
-  HLA_REQUIRE(cfg && cfg->optimizer == 0, "hla_s2g_lm_solve_bwd: only the LM update has a backward");
+  HLA_REQUIRE(cfg && cfg->optimizer >= 0 && cfg->optimizer <= 2, "hla_s2g_lm_solve_bwd: optimizer must be 0 (LM), 1 (SGD) or 2 (ADAM)");
   const int rc = hla_s2g_validate("hla_s2g_lm_solve_bwd", cfg, lv, R_FL, T_FL, B);
   if (rc) return rc;
   for (int l = 0; l < cfg->n_levels; ++l)
@@ -335,8 +372,10 @@ extern "C" int hla_s2g_lm_solve_bwd(const hla_s2g_config* cfg, const hla_s2g_lev
   double* gid = (double*)(ws + off[2]);
   double* part = (double*)(ws + off[3]);
   HLA_CHECK_HIP(hipMemsetAsync(d_damping, 0, 3 * sizeof(double), st));
+  double* adam_adj = (double*)(ws + off[4]);
+  if (cfg->optimizer == 2) HLA_CHECK_HIP(hipMemsetAsync(adam_adj, 0, (size_t)B * 6 * sizeof(double), st));
 
-  const bool reinit = cfg->ford || cfg->dof == 3;
+  const bool reinit = (cfg->ford || cfg->dof == 3) && cfg->optimizer == 0;
   const int L = cfg->n_levels, N = cfg->n_iters, steps = L * N, tstride = N * L * 3;
   auto step_level = [&](int k) { return cfg->level_first ? k / N : k % L; };
   auto step_iter = [&](int k) { return cfg->level_first ? k % N : k / L; };
@@ -363,6 +402,8 @@ extern "C" int hla_s2g_lm_solve_bwd(const hla_s2g_config* cfg, const hla_s2g_lev
     sa.R_FL = R_FL; sa.T_FL = T_FL; sa.B = B; sa.reinit = reinit ? 1 : 0;
     sa.cfg.dof = cfg->dof; sa.cfg.use_hessian = cfg->use_hessian;
     for (int i = 0; i < 3; ++i) sa.cfg.lam[i] = cfg->damping[i];
+    sa.optimizer = cfg->optimizer; sa.t = k; sa.beta1 = cfg->beta1; sa.beta2 = cfg->beta2;
+    sa.neq_all = normal_eq; sa.adam_adj = adam_adj;
     sa.geom = geom(l);
     hla_prof_begin(K_LMSOLVE, 0, 0, st);
     hipLaunchKernelGGL(lm_bwd_solve, dim3(B), dim3(64), 0, st, sa);

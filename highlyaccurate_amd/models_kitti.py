@@ -7,7 +7,7 @@ from __future__ import annotations
 
 import torch
 
-from ._g2sp import LM_G2SP  # noqa: F401  (models_kitti.py:22-499; forward only so far)
+from ._g2sp import LM_G2SP  # noqa: F401  (models_kitti.py:22-499)
 from ._s2gp import S2GPBase, loss_func  # noqa: F401  (loss_func re-exported like the reference module)
 
 
