@@ -187,7 +187,8 @@ typedef struct hla_s2g_config {
   size_t keep_stride;
   int optimizer;          /* 0: LM_update; 1: SGD_update (models_kitti.py:1056-1084: pose -= 0.01 * 2 J'(s - g), raw features,
                              no weights, no re-initialisation); 2: ADAM_update (1086-1125, beta1/beta2 below).  1 and 2 are
-                             the reference's ablation optimisers: forward only */
+                             the reference's ablation optimisers; iteration-first loop only (as in the reference), they
+                             ignore grd_conf and keep; hla_s2g_lm_solve_bwd differentiates all three */
   double beta1, beta2;
 } hla_s2g_config;
 
