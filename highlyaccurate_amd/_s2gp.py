@@ -80,6 +80,10 @@ class S2GPBase(nn.Module):
             raise NotImplementedError("only proj='geo' is in scope")
         if getattr(args, 'Optimizer', 'LM') not in ('LM', 'SGD', 'ADAM'):
             raise NotImplementedError("Optimizer must be 'LM', 'SGD' or 'ADAM' ('NN' needs the NNrefine network: out of scope)")
+        if self.ford and getattr(args, 'Optimizer', 'LM') != 'LM':
+            # models_ford.py has no ADAM_update; its SGD_update (609-634, a sign-of-residual step of 0.001) indexes the [B,3]
+            # update with three subscripts (631-633) and raises IndexError as shipped; 'GN' (534-598) is one more ablation
+            raise NotImplementedError("LM_S2GP_Ford: only Optimizer='LM' (the reference's Ford SGD_update raises as shipped)")
         if getattr(args, 'estimate_depth', 0):
             raise NotImplementedError('estimate_depth (Ford height heads, VGG.py:85-118) is out of scope')
         # args.use_gt_depth only takes effect when a gt_depth tensor is passed to forward (models_kitti.py:741); neither
