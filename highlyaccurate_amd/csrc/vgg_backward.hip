@@ -296,15 +296,26 @@ __global__ __launch_bounds__(256) void wgrad0_kernel(Wgrad0Args a) {
   }
 }
 
-// out[i] (=) sum_k part[k][i]  (fixed order: deterministic)
+// out[i] = sum_k part[k][i]  (fixed order: deterministic).  Generic 2-D gather: element i = (row, col) with col < out_inner,
+// input row pitch in_inner (conv0: 32 -> 27).  16 columns x 16 k-lanes per block: the bias / conv0 / conf-head reductions
+// have few columns and up to 2048 partial rows, so the parallelism has to come from k (a single thread walking all of
+// K costs one load latency per row: 0.5 ms for K = 512).  Launch with (n + 15) / 16 blocks.
 static __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ part, float* __restrict__ out,
                                                               size_t n, int K, int in_stride_inner, int out_inner, int in_inner) {
-  // generic 2-D gather: element i = (row, col) with col < out_inner; input row pitch in_inner (conv0: 32 -> 27)
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
-    const size_t row = i / out_inner, col = i % out_inner;
-    const size_t src = row * in_inner + col;
-    float s = 0.f;
-    for (int k = 0; k < K; ++k) s += part[(size_t)k * in_stride_inner + src];
+  __shared__ float sh[16][17];
+  const int col = threadIdx.x & 15, kl = threadIdx.x >> 4;
+  const size_t i = (size_t)blockIdx.x * 16 + col;
+  float s = 0.f;
+  if (i < n) {
+    const size_t src = (i / out_inner) * in_inner + i % out_inner;
+#pragma unroll 8
+    for (int k = kl; k < K; k += 16) s += part[(size_t)k * in_stride_inner + src];
+  }
+  sh[kl][col] = s;
+  __syncthreads();
+  if (kl == 0 && i < n) {
+#pragma unroll
+    for (int k = 1; k < 16; ++k) s += sh[k][col];
     out[i] = s;
   }
 }
@@ -586,7 +597,7 @@ int vgg_backward_t(const float* x, const hla_vgg_params* prm, const char* packed
       hipLaunchKernelGGL((conf_bwd_kernel<T>), dim3(grid), dim3(256), 4 * 9 * Cs[l] * sizeof(float), st, acts[l],
                          prm->w[13 + l], (const float*)dz, (T*)l2out[l], (float*)(bw + bp.part), B, hs[l], wsz[l], Cs[l]);
       const size_t n = (size_t)9 * Cs[l];
-      hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const float*)(bw + bp.part),
+      hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((n + 15) / 16)), dim3(256), 0, st, (const float*)(bw + bp.part),
                          gr->dw[13 + l], n, grid, (int)n, 1, 1);
       hla_prof_end(st);
     }
@@ -623,7 +634,7 @@ int vgg_backward_t(const float* x, const hla_vgg_params* prm, const char* packed
                        (float4*)gr->dw[l], n / 4, a.KS);
     hla_prof_end(st);
     if (a.bpart)
-      hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(256), 0, st, a.bpart, gr->db[l], (size_t)a.Cout, a.KS, a.Cout, 1, 1);
+      hipLaunchKernelGGL(reduce_partials_kernel, dim3((a.Cout + 15) / 16), dim3(256), 0, st, a.bpart, gr->db[l], (size_t)a.Cout, a.KS, a.Cout, 1, 1);
   };
   const unsigned char* idx3 = (const unsigned char*)(fw + fp.idx3);
   const unsigned char* idx8 = (const unsigned char*)(fw + fp.idx8);
@@ -686,8 +697,8 @@ int vgg_backward_t(const float* x, const hla_vgg_params* prm, const char* packed
     hla_prof_begin(K_WGRAD, 2.0 * 27 * 64 * P, P * (12 + 64 * sizeof(T)), st);
     hipLaunchKernelGGL((wgrad0_kernel<T>), dim3(a.KS), dim3(256), lds, st, a);
     hla_prof_end(st);
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3(7), dim3(256), 0, st, a.part, gr->dw[0], (size_t)64 * 27, a.KS * 2, 64 * 32, 27, 32);
-    if (gr->db[0]) hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(256), 0, st, a.bpart, gr->db[0], (size_t)64, a.KS * 2, 64, 1, 1);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((64 * 27 + 15) / 16), dim3(256), 0, st, a.part, gr->dw[0], (size_t)64 * 27, a.KS * 2, 64 * 32, 27, 32);
+    if (gr->db[0]) hipLaunchKernelGGL(reduce_partials_kernel, dim3(4), dim3(256), 0, st, a.bpart, gr->db[0], (size_t)64, a.KS * 2, 64, 1, 1);
   }
   HLA_CHECK_HIP(hipGetLastError());
   return HLA_OK;
