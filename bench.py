@@ -49,7 +49,8 @@ def cpu_baseline(max_seconds=30.0):
         t0 = time.time()
         net(sat, grd, mode='test')                      # warm-up (also bounds the sample)
         warm = time.time() - t0
-        reps = max(1, min(3, int(max_seconds / max(warm, 1e-3)) - 1))
+        # about 10-15 s of CPU work (1.1-1.4 s per pair on this host), never more than max_seconds
+        reps = max(1, min(int(12.0 / max(warm, 1e-3)) + 1, int(max_seconds / max(warm, 1e-3)) - 1, 12))
         for _ in range(reps):
             t0 = time.time()
             net(sat, grd, mode='test')
