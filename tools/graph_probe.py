@@ -6,7 +6,7 @@ from types import SimpleNamespace
 from highlyaccurate_amd.models_kitti import LM_S2GP
 
 d = torch.device('cuda:0')
-B = 32
+B = int(os.environ.get("GRAPH_B", "32"))
 args = SimpleNamespace(level=3, N_iters=5, using_weight=0, loss_method=0, proj='geo', Optimizer='LM', rotation_range=10.0,
                        shift_range_lat=20.0, shift_range_lon=20.0, damping=0.1, train_damping=0, dropout=0, use_hessian=0,
                        use_gt_depth=0, visualize=0, coe_shift_lat=100.0, coe_shift_lon=100.0, coe_heading=100.0, coe_L1=100.0,
