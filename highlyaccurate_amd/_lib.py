@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get('HLA_LIB') or os.path.join(HERE, 'libhla.so')   # HLA_
 
 HLA_F32, HLA_BF16, HLA_F16 = 0, 1, 2
 HLA_VGG_WANT_CONF, HLA_VGG_DEFER_NORM, HLA_VGG_SAVE_FOR_BACKWARD = 1, 2, 4
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 
 class HlaError(RuntimeError):

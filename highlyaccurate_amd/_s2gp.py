@@ -78,12 +78,13 @@ class S2GPBase(nn.Module):
             raise NotImplementedError('args.level must be 3 (x15, x18, x21) or 4 (+ x24)')
         if getattr(args, 'proj', 'geo') != 'geo':
             raise NotImplementedError("only proj='geo' is in scope")
-        if getattr(args, 'Optimizer', 'LM') not in ('LM', 'SGD', 'ADAM'):
-            raise NotImplementedError("Optimizer must be 'LM', 'SGD' or 'ADAM' ('NN' needs the NNrefine network: out of scope)")
-        if self.ford and getattr(args, 'Optimizer', 'LM') != 'LM':
-            # models_ford.py has no ADAM_update; its SGD_update (609-634, a sign-of-residual step of 0.001) indexes the [B,3]
-            # update with three subscripts (631-633) and raises IndexError as shipped; 'GN' (534-598) is one more ablation
-            raise NotImplementedError("LM_S2GP_Ford: only Optimizer='LM' (the reference's Ford SGD_update raises as shipped)")
+        opt = getattr(args, 'Optimizer', 'LM')
+        # KITTI (models_kitti.py:1176-1283): LM, SGD, ADAM, NN.  Ford (models_ford.py:751-788): LM, GN, NN and an SGD_update
+        # (609-634, a sign-of-residual step of 0.001) that indexes its [B,3] update with three subscripts and raises as shipped.
+        allowed = ('LM', 'GN') if self.ford else ('LM', 'SGD', 'ADAM')
+        if opt not in allowed:
+            raise NotImplementedError(f"{type(self).__name__}: Optimizer must be one of {allowed} ('NN' needs the NNrefine "
+                                      f"network: out of scope; the reference's Ford SGD_update raises as shipped)")
         if getattr(args, 'estimate_depth', 0):
             raise NotImplementedError('estimate_depth (Ford height heads, VGG.py:85-118) is out of scope')
         # args.use_gt_depth only takes effect when a gt_depth tensor is passed to forward (models_kitti.py:741); neither
@@ -120,9 +121,10 @@ class S2GPBase(nn.Module):
         cfg = _lib.S2GConfig()
         cfg.ford = 1 if self.ford else 0
         cfg.n_levels, cfg.n_iters, cfg.level_first = n_levels, self.N_iters, 1 if level_first else 0
-        cfg.optimizer = {'LM': 0, 'SGD': 1, 'ADAM': 2}[getattr(a, 'Optimizer', 'LM')]
-        # SGD_update / ADAM_update (models_kitti.py:1056-1116) read neither the confidence maps nor args.dropout
-        cfg.using_weight = 1 if (self.using_weight and cfg.optimizer == 0) else 0
+        cfg.optimizer = {'LM': 0, 'SGD': 1, 'ADAM': 2, 'GN': 3}[getattr(a, 'Optimizer', 'LM')]
+        # SGD_update / ADAM_update (models_kitti.py:1056-1116) read neither the confidence maps nor args.dropout;
+        # GN_update (models_ford.py:534-598) reads the confidence maps but not args.dropout
+        cfg.using_weight = 1 if (self.using_weight and cfg.optimizer in (0, 3)) else 0
         cfg.use_hessian = 1 if getattr(a, 'use_hessian', 0) else 0
         if self.ford:
             cfg.dof = 3
@@ -213,7 +215,7 @@ class S2GPBase(nn.Module):
         cfg, lv, R_FL, T_FL = self._lm_structs(sat_feats, grd_feats, grd_confs, grd_hw, extra, level_first,
                                                sat_inv_norm, grd_inv_norm)
         steps = L * self.N_iters
-        reinit = (self.ford or cfg.dof == 3) and cfg.optimizer == 0
+        reinit = (self.ford or cfg.dof == 3) and cfg.optimizer in (0, 3)
         rand_uv = self._draw_reinit(steps, B, dev) if reinit else None
         self.last_keep = self._draw_dropout(lv, level_first, dev)
         if self.last_keep is not None:
@@ -232,7 +234,7 @@ class S2GPBase(nn.Module):
         # flags that can make H + damping*D exactly singular (use_hessian / zero damping) and (b) when strict error checking
         # is asked for (HLA_STRICT_ERRORS=1 or args.strict_errors).  With the default flags the forward has no host sync;
         # a step whose pixels all fall outside the satellite map then leaves the pose unchanged (J = 0, r = -g).
-        risky = cfg.optimizer == 0 and (cfg.use_hessian or min(cfg.damping[i] for i in range(3)) <= 0.0)
+        risky = cfg.optimizer == 3 or (cfg.optimizer == 0 and (cfg.use_hessian or min(cfg.damping[i] for i in range(3)) <= 0.0))
         if strict and bool((neq[:, :, 0].sum(1) == 0).any()):
             # jacobian.py:172 `assert mask.sum() > 0`: no pixel of the whole batch samples inside the map in some step
             raise AssertionError('grid_sample: no ground pixel of the batch projects inside the satellite map (jacobian.py:172)')

@@ -244,7 +244,7 @@ __global__ __launch_bounds__(64) void lm_bwd_solve(BwdSolveArgs a) {
   if (a.pose_in) { const float* pi = a.pose_in + (size_t)b * a.pose_in_stride; pin[0] = pi[0]; pin[1] = pi[1]; pin[2] = pi[2]; }
 
   const double* s = a.normal_eq + (size_t)b * 16;
-  if (a.optimizer != 0) {
+  if (a.optimizer == 1 || a.optimizer == 2) {
     // pose_out = pose_in - 0.01 * f(g),  g = 2 (J^T s - J^T g_grd) on the whole-map-normalised features; no re-initialisation
     double gg[3];                    // adjoint of the raw gradient g
     for (int p = 0; p < 3; ++p) a.gid[(size_t)b * 3 + p] = gout[p];
@@ -294,7 +294,7 @@ __global__ __launch_bounds__(64) void lm_bwd_solve(BwdSolveArgs a) {
   for (int i = 0; i < nl; ++i) {
     const int p = a.cfg.dof == 1 ? 2 : i;
     const double gM = gH[p][p];
-    atomicAdd(a.d_lambda + i, gM * (a.cfg.use_hessian ? H[p][p] : 1.0));
+    if (!a.cfg.gn) atomicAdd(a.d_lambda + i, gM * (a.cfg.use_hessian ? H[p][p] : 1.0));     // GN_update has no damping
     if (a.cfg.use_hessian) gH[p][p] += a.cfg.lam[i] * gM;
   }
   const double is2 = 1.0 / (ns * ns), isg = 1.0 / (ns * ng);
@@ -309,7 +309,7 @@ __global__ __launch_bounds__(64) void lm_bwd_solve(BwdSolveArgs a) {
   const double g_ng = -g_isg / (ns * ng * ng);
   double* ad = a.adj + (size_t)b * 16;
   ad[0] = sqrt(s[0]) > 1e-6 ? g_ns / (2.0 * ns) : 0.0;
-  ad[1] = sqrt(s[1]) > 1e-6 ? g_ng / (2.0 * ng) : 0.0;
+  ad[1] = (!a.cfg.gn && sqrt(s[1]) > 1e-6) ? g_ng / (2.0 * ng) : 0.0;      // GN: ng is the constant 1
   ad[2] = 2.0 * is2 * gH[0][0]; ad[3] = is2 * (gH[0][1] + gH[1][0]); ad[4] = is2 * (gH[0][2] + gH[2][0]);
   ad[5] = 2.0 * is2 * gH[1][1]; ad[6] = is2 * (gH[1][2] + gH[2][1]); ad[7] = 2.0 * is2 * gH[2][2];
   for (int p = 0; p < 3; ++p) { ad[8 + p] = is2 * y[p]; ad[11 + p] = -isg * y[p]; }
@@ -354,7 +354,7 @@ extern "C" int hla_s2g_lm_solve_bwd(const hla_s2g_config* cfg, const hla_s2g_lev
                                     const double* normal_eq, const float* d_trace, double* d_damping, void* workspace,
                                     size_t workspace_bytes, int B, hla_stream_t stream) {
   HLA_REQUIRE(gr && trace && normal_eq && d_trace && d_damping && workspace, "hla_s2g_lm_solve_bwd: null argument");
-  HLA_REQUIRE(cfg && cfg->optimizer >= 0 && cfg->optimizer <= 2, "hla_s2g_lm_solve_bwd: optimizer must be 0 (LM), 1 (SGD) or 2 (ADAM)");
+  HLA_REQUIRE(cfg && cfg->optimizer >= 0 && cfg->optimizer <= 3, "hla_s2g_lm_solve_bwd: optimizer must be 0 (LM), 1 (SGD), 2 (ADAM) or 3 (GN)");
   const int rc = hla_s2g_validate("hla_s2g_lm_solve_bwd", cfg, lv, R_FL, T_FL, B);
   if (rc) return rc;
   for (int l = 0; l < cfg->n_levels; ++l)
@@ -375,7 +375,8 @@ extern "C" int hla_s2g_lm_solve_bwd(const hla_s2g_config* cfg, const hla_s2g_lev
   double* adam_adj = (double*)(ws + off[4]);
   if (cfg->optimizer == 2) HLA_CHECK_HIP(hipMemsetAsync(adam_adj, 0, (size_t)B * 6 * sizeof(double), st));
 
-  const bool reinit = (cfg->ford || cfg->dof == 3) && cfg->optimizer == 0;
+  const bool newton = cfg->optimizer == 0 || cfg->optimizer == 3;
+  const bool reinit = (cfg->ford || cfg->dof == 3) && newton;
   const int L = cfg->n_levels, N = cfg->n_iters, steps = L * N, tstride = N * L * 3;
   auto step_level = [&](int k) { return cfg->level_first ? k / N : k % L; };
   auto step_iter = [&](int k) { return cfg->level_first ? k % N : k / L; };
@@ -400,8 +401,9 @@ extern "C" int hla_s2g_lm_solve_bwd(const hla_s2g_config* cfg, const hla_s2g_lev
     sa.pose_out = trace + slot(k); sa.d_trace = d_trace + slot(k); sa.trace_stride = tstride;
     sa.gid = gid; sa.adj = adj; sa.coef = coef; sa.d_lambda = d_damping;
     sa.R_FL = R_FL; sa.T_FL = T_FL; sa.B = B; sa.reinit = reinit ? 1 : 0;
-    sa.cfg.dof = cfg->dof; sa.cfg.use_hessian = cfg->use_hessian;
-    for (int i = 0; i < 3; ++i) sa.cfg.lam[i] = cfg->damping[i];
+    sa.cfg.gn = cfg->optimizer == 3 ? 1 : 0;
+    sa.cfg.dof = cfg->dof; sa.cfg.use_hessian = sa.cfg.gn ? 0 : cfg->use_hessian;
+    for (int i = 0; i < 3; ++i) sa.cfg.lam[i] = sa.cfg.gn ? 0.0 : cfg->damping[i];
     sa.optimizer = cfg->optimizer; sa.t = k; sa.beta1 = cfg->beta1; sa.beta2 = cfg->beta2;
     sa.neq_all = normal_eq; sa.adam_adj = adam_adj;
     sa.geom = geom(l);
@@ -420,7 +422,7 @@ extern "C" int hla_s2g_lm_solve_bwd(const hla_s2g_config* cfg, const hla_s2g_lev
     aa.xcd_affine = (B >= 8) ? 1 : 0;
     const int nblk = aa.xcd_affine ? 8 * ((B + 7) / 8) * aa.nt : B * aa.nt;
     hla_prof_begin(K_LMBWD, 0, (double)B * (5.0 * (double)v.A * v.A + 3.0 * (double)aa.npix) * v.C * 4.0, st);
-    if (cfg->using_weight) launch_bwd_accum<true>(v.C, dim3(nblk), st, aa);
+    if (cfg->using_weight && newton) launch_bwd_accum<true>(v.C, dim3(nblk), st, aa);
     else launch_bwd_accum<false>(v.C, dim3(nblk), st, aa);
     hla_prof_end(st);
     nt_prev = aa.nt;

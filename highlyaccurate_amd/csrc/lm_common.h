@@ -141,7 +141,7 @@ __device__ static inline void lm_inv3(const double M[3][3], double I[3][3]) {
   I[2][0] = c02 * id; I[2][1] = (M[0][1] * M[2][0] - M[0][0] * M[2][1]) * id; I[2][2] = (M[0][0] * M[1][1] - M[0][1] * M[1][0]) * id;
 }
 
-struct LmSolveCfg { int dof, use_hessian; double lam[3]; };
+struct LmSolveCfg { int dof, use_hessian; double lam[3]; int gn; };   // gn: GN_update (models_ford.py:534-598)
 
 // The damped normal-equation solve of one step from the 14 (already de-normalised) sums.
 // Fills H (normalised), g, M^-1 restricted to the active DoFs (others zero) and d = M^-1 g.
@@ -149,6 +149,7 @@ __device__ static inline void lm_solve_step(const LmSolveCfg& S, const double* s
                                             double Mi[3][3], double d[3], double& ns, double& ng) {
   // models_kitti.py:976-984: both norms clamped at 1e-6; J is divided by ||s|| as well
   ns = fmax(sqrt(s[0]), 1e-6); ng = fmax(sqrt(s[1]), 1e-6);
+  if (S.gn) ng = 1.0;            // GN_update keeps the whole-map L2_norm of the ground features (the host zeroes lam)
   const double is2 = 1.0 / (ns * ns), isg = 1.0 / (ns * ng);
   H[0][0] = s[2] * is2; H[0][1] = H[1][0] = s[3] * is2; H[0][2] = H[2][0] = s[4] * is2;
   H[1][1] = s[5] * is2; H[1][2] = H[2][1] = s[6] * is2; H[2][2] = s[7] * is2;

@@ -120,7 +120,7 @@ struct SolveArgs {
   const float* R_FL;     // [B,3,3]
   const float* T_FL;     // [B,3]
   int B, reinit;
-  int optimizer, t;      // 0 LM; 1 SGD; 2 ADAM (t = step index in execution order)
+  int optimizer, t;      // 0 LM; 1 SGD; 2 ADAM (t = step index in execution order); 3 GN (cfg.gn)
   double beta1, beta2;
   double* adam;          // [B,6] first / second moment of the three pose components (ADAM only)
   LmSolveCfg cfg;
@@ -154,7 +154,7 @@ __global__ __launch_bounds__(64) void lm_solve(SolveArgs a) {
         a.normal_eq[(size_t)b * 16 + 14] = 0.0; a.normal_eq[(size_t)b * 16 + 15] = 0.0;
       }
       double H[3][3], g[3], Mi[3][3], d[3], ns, ng;
-      if (a.optimizer == 0) {
+      if (a.optimizer == 0 || a.optimizer == 3) {
         lm_solve_step(a.cfg, s, H, g, Mi, d, ns, ng);
       } else {                       // ablation optimisers on the raw residual: delta_pose = sum 2 r J (models_kitti.py:1075-1076)
         for (int p = 0; p < 3; ++p) d[p] = 2.0 * (s[8 + p] - s[11 + p]);
@@ -244,9 +244,11 @@ extern "C" int hla_s2g_lm_solve(const hla_s2g_config* cfg, const hla_s2g_level* 
   HLA_REQUIRE(trace && workspace, "hla_s2g_lm_solve: null argument");
   const int rc = hla_s2g_validate("hla_s2g_lm_solve", cfg, lv, R_FL, T_FL, B);
   if (rc) return rc;
-  HLA_REQUIRE(cfg->optimizer >= 0 && cfg->optimizer <= 2, "hla_s2g_lm_solve: optimizer must be 0 (LM), 1 (SGD) or 2 (ADAM)");
-  HLA_REQUIRE(cfg->optimizer == 0 || !cfg->level_first, "hla_s2g_lm_solve: SGD / ADAM exist for the iteration-first loop only");
-  const bool reinit = (cfg->ford || cfg->dof == 3) && cfg->optimizer == 0;     // SGD_update / ADAM_update never re-initialise
+  HLA_REQUIRE(cfg->optimizer >= 0 && cfg->optimizer <= 3, "hla_s2g_lm_solve: optimizer must be 0 (LM), 1 (SGD), 2 (ADAM) or 3 (GN)");
+  HLA_REQUIRE(cfg->optimizer == 0 || !cfg->level_first, "hla_s2g_lm_solve: SGD / ADAM / GN exist for the iteration-first loop only");
+  HLA_REQUIRE(cfg->optimizer != 3 || cfg->ford, "hla_s2g_lm_solve: GN_update exists in the Ford model only");
+  const bool newton = cfg->optimizer == 0 || cfg->optimizer == 3;
+  const bool reinit = (cfg->ford || cfg->dof == 3) && newton;     // SGD_update / ADAM_update never re-initialise
   HLA_REQUIRE(!reinit || rand_uv, "hla_s2g_lm_solve: rand_uv required");
   size_t oc, op, opart;
   const size_t need = ws_layout(cfg, lv, B, &oc, &op, &opart);
@@ -278,8 +280,9 @@ extern "C" int hla_s2g_lm_solve(const hla_s2g_config* cfg, const hla_s2g_level* 
   SolveArgs sa{};
   sa.optimizer = cfg->optimizer; sa.beta1 = cfg->beta1; sa.beta2 = cfg->beta2; sa.adam = adam;
   sa.pose = pose; sa.B = B; sa.reinit = reinit ? 1 : 0; sa.R_FL = R_FL; sa.T_FL = T_FL;
-  sa.cfg.dof = cfg->dof; sa.cfg.use_hessian = cfg->use_hessian;
-  for (int i = 0; i < 3; ++i) sa.cfg.lam[i] = cfg->damping[i];
+  sa.cfg.gn = cfg->optimizer == 3 ? 1 : 0;
+  sa.cfg.dof = cfg->dof; sa.cfg.use_hessian = sa.cfg.gn ? 0 : cfg->use_hessian;
+  for (int i = 0; i < 3; ++i) sa.cfg.lam[i] = sa.cfg.gn ? 0.0 : cfg->damping[i];     // GN_update: delta = -H^-1 J^T W r
   sa.coef = coef;
 
   // init launch: coefficients of step 0
@@ -299,7 +302,7 @@ extern "C" int hla_s2g_lm_solve(const hla_s2g_config* cfg, const hla_s2g_level* 
     const int nblk = aa.xcd_affine ? 8 * ((B + 7) / 8) * aa.nt : B * aa.nt;
     hla_prof_begin(v.C == 256 ? K_LM256 : v.C == 128 ? K_LM128 : v.C == 64 ? K_LM64 : K_LM16, 0,
                    (double)B * ((double)v.A * v.A + (double)aa.npix) * v.C * 4.0, st);
-    if (cfg->using_weight && cfg->optimizer == 0) launch_accum<true>(v.C, dim3(nblk), st, aa);   // SGD / ADAM ignore the confidence
+    if (cfg->using_weight && newton) launch_accum<true>(v.C, dim3(nblk), st, aa);   // SGD / ADAM ignore the confidence
     else launch_accum<false>(v.C, dim3(nblk), st, aa);
     hla_prof_end(st);
 

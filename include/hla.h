@@ -43,7 +43,7 @@ typedef enum hla_dtype {
 } hla_dtype;
 
 const char* hla_last_error(void);
-int hla_abi_version(void);   /* 7 (bumped whenever a struct or signature in this file changes; _lib.py checks it) */
+int hla_abi_version(void);   /* 8 (bumped whenever a struct or signature in this file changes; _lib.py checks it) */
 
 /* ------------------------------------------------------------------------- *
  * VGGUnet.forward  (VGG.py:121-203; L2_norm VGG.py:511-514)
@@ -187,8 +187,10 @@ typedef struct hla_s2g_config {
   size_t keep_stride;
   int optimizer;          /* 0: LM_update; 1: SGD_update (models_kitti.py:1056-1084: pose -= 0.01 * 2 J'(s - g), raw features,
                              no weights, no re-initialisation); 2: ADAM_update (1086-1125, beta1/beta2 below).  1 and 2 are
-                             the reference's ablation optimisers; iteration-first loop only (as in the reference), they
-                             ignore grd_conf and keep; hla_s2g_lm_solve_bwd differentiates all three */
+                             the reference's ablation optimisers; they ignore grd_conf and keep.  3: GN_update (Ford only,
+                             models_ford.py:534-598: LM_update without damping and without renormalising the ground map;
+                             reads grd_conf, ignores keep).  1-3 exist in the iteration-first loop only, as in the
+                             reference; hla_s2g_lm_solve_bwd differentiates all four */
   double beta1, beta2;
 } hla_s2g_config;
 

@@ -398,6 +398,19 @@ def gen_ford(mf, seeds, B=1):
     np.savez_compressed(os.path.join(GOLD, 'e2e_ford.npz'), **out)
 
 
+def gen_ford_gn(mf, seed, B=1):
+    """Optimizer='GN' (GN_update, models_ford.py:534-598, dispatched at 775-781): undamped Gauss-Newton without
+    renormalising the ground map.  Traces with and without confidence weighting, fp32 and fp64."""
+    out = {'seed': np.array(seed), 'B': np.array(B)}
+    for tag, kw in (('plain', {}), ('weight', dict(using_weight=1))):
+        a = O.default_args(N_iters=5, Optimizer='GN', **kw)
+        t64, _, _, _ = run_e2e(mf, 'LM_S2GP_Ford', a, seed, B, torch.float64, extra=ford_extra(B), hook='GN_update')
+        t32, _, _, _ = run_e2e(mf, 'LM_S2GP_Ford', a, seed, B, torch.float32, extra=ford_extra(B), hook='GN_update')
+        out[f'trace64_{tag}'], out[f'trace32_{tag}'] = t64, t32
+        print(f'ford GN {tag}: gap {np.abs(t32 - t64).max():.2e} final {t64[:, -1].tolist()}', flush=True)
+    np.savez_compressed(os.path.join(GOLD, 'e2e_ford_gn.npz'), **out)
+
+
 GRAD_KEYS = ['SatFeatureNet.conv0.weight', 'SatFeatureNet.conv14.weight', 'SatFeatureNet.conv_dec2.3.weight',
              'GrdFeatureNet.conv0.weight', 'GrdFeatureNet.conv14.weight', 'GrdFeatureNet.conv_dec1.1.weight',
              'GrdFeatureNet.conv2.bias']
@@ -446,6 +459,8 @@ if __name__ == '__main__':
         gen_e2e(mk, seeds or [1, 2, 3])
     if a.only in ('all', 'ford'):
         gen_ford(mf, (seeds or [1])[:2])
+    if a.only in ('all', 'fordgn'):
+        gen_ford_gn(mf, (seeds or [1])[0])
     if a.only in ('all', 'train'):
         gen_train(mk, (seeds or [1])[0])
     if a.only in ('all', 'g2s'):

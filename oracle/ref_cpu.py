@@ -315,7 +315,7 @@ def ford_pose_to_uv(args, xyz_grd, R_FL, T_FL, shift_u, shift_v, theta, side_m, 
 # one damped Gauss-Newton / LM step (models_kitti.py:939-1041, models_ford.py:380-466)
 # ----------------------------------------------------------------------------
 def lm_update(args, damping_param, shift_u, shift_v, theta, sat_feat_proj, grd_feat, grd_conf, dfeat_dpose,
-              using_weight, ford=False, rand_uv=None):
+              using_weight, ford=False, rand_uv=None, gauss_newton=False):
     """All map tensors are already restricted to the rows that take part
     (bottom half for proj=='geo').  ``rand_uv`` optionally supplies the (rand_u, rand_v)
     pair instead of drawing from the global torch CPU generator."""
@@ -331,7 +331,7 @@ def lm_update(args, damping_param, shift_u, shift_v, theta, sat_feat_proj, grd_f
     else:
         lam = args.damping * torch.ones(1, 3 if ford else N, dtype=torch.float32)
     lam = lam.to(dt)
-    if args.dropout > 0:
+    if args.dropout > 0 and not gauss_newton:
         inds = np.random.permutation(np.arange(H * W))[: H * W // 2]
         J = dfeat_dpose.reshape(N, B, C, -1)[:, :, :, inds].reshape(N, B, -1)
         s = sat_feat_proj.reshape(B, C, -1)[:, :, inds].reshape(B, -1)
@@ -342,11 +342,18 @@ def lm_update(args, damping_param, shift_u, shift_v, theta, sat_feat_proj, grd_f
         s = sat_feat_proj.reshape(B, -1)
         g = grd_feat.reshape(B, -1)
         gc = grd_conf.reshape(B, -1)
-    ns = s.norm(dim=-1).clamp_min(1e-6)
-    s = s / ns[:, None]
-    J = J / ns[None, :, None]
-    ng = g.norm(dim=-1).clamp_min(1e-6)
-    g = g / ng[:, None]
+    if gauss_newton:
+        # GN_update (models_ford.py:534-598): torch.norm without a clamp, the ground map is NOT renormalised, no damping,
+        # no dropout (args.dropout is not read there)
+        ns = s.norm(dim=-1)
+        s = s / ns[:, None]
+        J = J / ns[None, :, None]
+    else:
+        ns = s.norm(dim=-1).clamp_min(1e-6)
+        s = s / ns[:, None]
+        J = J / ns[None, :, None]
+        ng = g.norm(dim=-1).clamp_min(1e-6)
+        g = g / ng[:, None]
     r = s - g
     Jb = J.permute(1, 2, 0)                                   # [B,D,N]
     if using_weight:
@@ -359,7 +366,10 @@ def lm_update(args, damping_param, shift_u, shift_v, theta, sat_feat_proj, grd_f
         D = torch.diag_embed(torch.diagonal(Hm, dim1=1, dim2=2))
     else:
         D = torch.eye(N, dtype=dt).expand(B, N, N)
-    delta = -torch.inverse(Hm + lam * D) @ JtW @ r.reshape(B, -1, 1)
+    if gauss_newton:
+        delta = -torch.inverse(Hm) @ JtW @ r.reshape(B, -1, 1)
+    else:
+        delta = -torch.inverse(Hm + lam * D) @ JtW @ r.reshape(B, -1, 1)
     if (not ford) and args.rotation_range == 0:
         return shift_u + delta[:, 0:1, 0], shift_v + delta[:, 1:2, 0], theta
     if (not ford) and args.shift_range_lat == 0 and args.shift_range_lon == 0:
@@ -456,6 +466,9 @@ class _S2GPBase(nn.Module):
         opt = getattr(self.args, 'Optimizer', 'LM')
         if opt == 'LM':
             return lm_update(self.args, self.damping, su, sv, th, f, g, gc, jac, self.using_weight, ford=self.ford)
+        if opt == 'GN':                 # Ford only (models_ford.py:775-781)
+            assert self.ford
+            return lm_update(self.args, self.damping, su, sv, th, f, g, gc, jac, self.using_weight, ford=True, gauss_newton=True)
         # the reference's ablation updaters (models_kitti.py:1056-1125): gradient of sum r^2 on the raw maps, step 0.01
         B = f.shape[0]
         delta = (2 * (f - g)[None] * jac).reshape(3, B, -1).sum(-1).transpose(0, 1)          # [B,3]

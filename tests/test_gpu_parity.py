@@ -682,6 +682,66 @@ def test_lm_backward_small_vs_oracle_autograd(kw):
         assert e < 1e-5
 
 
+def test_e2e_ford_gauss_newton_vs_golden():
+    """Optimizer='GN' (GN_update, models_ford.py:534-598: LM_update without damping and without renormalising the ground
+    map; dispatched in the iteration-first loop, 775-781) against the REAL reference's traces."""
+    from oracle import ref_cpu as O
+    from highlyaccurate_amd.models_ford import LM_S2GP_Ford
+    d = _dev()
+    g = load_golden('e2e_ford_gn.npz')
+    seed, B = int(g['seed']), int(g['B'])
+    sat, grd, *_ = O.synth_images(seed + 100, B)
+    R_FL = torch.tensor([[[0., 0., 1.], [1., 0., 0.], [0., 1., 0.]]]).repeat(B, 1, 1)
+    T_FL = torch.tensor([[1.7, 0.3, -1.2]]).repeat(B, 1)
+    for tag, kw in (('plain', {}), ('weight', dict(using_weight=1))):
+        net = LM_S2GP_Ford(O.default_args(N_iters=5, Optimizer='GN', **kw))
+        net.load_state_dict(O.synth_model_state(seed))
+        net = net.to(d)
+        torch.manual_seed(seed)
+        with torch.no_grad():
+            net(sat.to(d), grd.to(d), 112.64, R_FL.to(d), T_FL.to(d), mode='test')
+        trace = _exec_order(net.last_trace, 0).cpu().numpy().astype(np.float64)
+        _pose_gate(trace, g[f'trace64_{tag}'], g[f'trace32_{tag}'], f'ford GN {tag}')
+
+
+def test_ford_gauss_newton_train_step_vs_oracle_autograd_small():
+    """Optimizer='GN' under autograd (using_weight=1): loss and parameter gradients against the fp64 oracle."""
+    from oracle import ref_cpu as O
+    from highlyaccurate_amd.models_ford import LM_S2GP_Ford
+    d = _dev()
+    args = O.default_args(N_iters=2, Optimizer='GN', using_weight=1)
+    B, grd_hw, sat_a = 2, (64, 256), 128
+    sd = O.synth_model_state(4, bias_scale=0.02)
+    sat, grd, gu, gv, gh = O.synth_images(9, B, grd_hw=grd_hw, sat_a=sat_a)
+    R_FL = torch.tensor([[[0., 0., 1.], [1., 0., 0.], [0., 1., 0.]]]).repeat(B, 1, 1)
+    T_FL = torch.tensor([[1.7, 0.3, -1.2]]).repeat(B, 1)
+    gts = [gu[:, 0].double(), gv[:, 0].double(), gh[:, 0].double()]
+    on = O.LM_S2GP_Ford(args, grd_hw=grd_hw)
+    on.load_state_dict(sd)
+    on = on.double()
+    torch.manual_seed(0)
+    ro = on(sat.double(), grd.double(), 28.16, R_FL.double(), T_FL.double(), *gts, mode='train')
+    ro[0].backward()
+    net = LM_S2GP_Ford(args)
+    net.load_state_dict(sd)
+    net = net.to(d).train()
+    torch.manual_seed(0)
+    r = net(sat.to(d), grd.to(d), 28.16, R_FL.to(d), T_FL.to(d), *[x.to(d) for x in gts], mode='train')
+    r[0].backward()
+    lerr = abs(float(r[0].detach()) - float(ro[0].detach())) / abs(float(ro[0].detach()))
+    ref = dict(on.named_parameters())
+    worst = 1.0
+    for k, p in net.named_parameters():
+        if ref[k].grad is None or float(ref[k].grad.norm()) == 0.0:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, k
+            continue
+        a, b = p.grad.double().cpu().flatten(), ref[k].grad.flatten()
+        worst = min(worst, float(a @ b / (a.norm() * b.norm())) if a.numel() > 1 else 1.0 - abs(float(a - b)) / abs(float(b)))
+        assert abs(float(a.norm() / b.norm()) - 1) < 2e-2, (k, float(a.norm()), float(b.norm()))
+    print(f'ford GN train step: loss rel err {lerr:.2e}, worst gradient cosine {worst:.6f}')
+    assert lerr < 1e-4 and worst > 0.999
+
+
 @pytest.mark.parametrize('opt,lf', [('SGD', 0), ('ADAM', 0)])   # the reference has them in the iteration-first loop only
 def test_ablation_optimisers_backward_vs_oracle_autograd(opt, lf):
     """Optimizer='SGD' / 'ADAM' (models_kitti.py:1056-1116) under autograd: hla_s2g_lm_solve_bwd's branch for the

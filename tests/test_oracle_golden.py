@@ -164,6 +164,23 @@ def test_oracle_e2e_ford_matches_reference_golden():
     assert err < 1e-7      # fp64 both sides; only the summation order differs
 
 
+def test_oracle_ford_gauss_newton_matches_reference_golden():
+    """Optimizer='GN' (GN_update, models_ford.py:534-598), with and without confidence weighting."""
+    g = load_golden('e2e_ford_gn.npz')
+    seed, B = int(g['seed']), int(g['B'])
+    R_FL = torch.tensor([[[0., 0., 1.], [1., 0., 0.], [0., 1., 0.]]], dtype=torch.float64).repeat(B, 1, 1)
+    T_FL = torch.tensor([[1.7, 0.3, -1.2]], dtype=torch.float64).repeat(B, 1)
+    for tag, kw in (('plain', {}), ('weight', dict(using_weight=1))):
+        net = O.build('ford', O.default_args(N_iters=5, Optimizer='GN', **kw), seed, torch.float64)
+        sat, grd, *_ = O.synth_images(seed + 100, B)
+        torch.manual_seed(seed)
+        with torch.no_grad():
+            net(sat.double(), grd.double(), 112.64, R_FL, T_FL, mode='test')
+        err = np.abs(_oracle_trace(net) - g[f'trace64_{tag}']).max()
+        print(f'oracle vs reference, ford GN {tag} fp64: max pose err', err)
+        assert err < 1e-6      # undamped: rounding differences are amplified a little more than under LM
+
+
 def test_oracle_train_step_matches_reference_autograd_golden():
     """mode='train' (using_weight=1, train_damping=1): the 14-tuple's values and gradient samples of 11 parameters
     (incl. the confidence heads and `damping`) against the REAL reference's autograd, fp64, full KITTI shape."""
