@@ -6,12 +6,13 @@ inside one ``torch.autograd.Function`` whose backward is ``hla_g2s_lm_solve_bwd`
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import torch
 from torch import nn
 
 from . import _lib, utils
-from ._s2gp import loss_func
+from ._s2gp import loss_func, raise_like_reference
 from .VGG import VGGUnet, vgg_backward_nhwc, vgg_forward_nhwc
 
 
@@ -75,7 +76,8 @@ class LM_G2SP(nn.Module):
         B, L = sat_feats[0].shape[0], len(sat_feats)
         cfg, lv, K = self._structs(sat_feats, grd_feats, grd_confs, camera_k, sat_inv_norm, grd_inv_norm)
         trace = torch.empty(B, self.N_iters, L, 3, device=dev, dtype=torch.float32)
-        want_neq = self.keep_normal_eq if keep_normal_eq is None else keep_normal_eq
+        strict = bool(getattr(self.args, 'strict_errors', 0)) or os.environ.get('HLA_STRICT_ERRORS', '0') == '1'
+        want_neq = strict or (self.keep_normal_eq if keep_normal_eq is None else keep_normal_eq)
         neq = torch.empty(L * self.N_iters, B, 16, device=dev, dtype=torch.float64) if want_neq else None
         nbytes = lib.hla_g2s_workspace_bytes(C.byref(cfg), lv, B)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
@@ -83,9 +85,11 @@ class LM_G2SP(nn.Module):
         rc = lib.hla_g2s_lm_solve(C.byref(cfg), lv, _lib.ptr(K), int(ori_hw[0]), int(ori_hw[1]), _lib.ptr(p0), _lib.ptr(trace),
                                   _lib.ptr(neq), _lib.ptr(ws), nbytes, B, _lib.stream_ptr())
         _lib.check(rc, 'hla_g2s_lm_solve')
-        if (cfg.use_hessian or min(cfg.damping[i] for i in range(3)) <= 0.0) and not bool(torch.isfinite(trace).all()):
-            # torch.inverse on a singular H + damping*D (models_kitti.py:372); only these ablation flags can produce one
-            raise RuntimeError('linalg.inv: the damped normal matrix of an LM step is singular (use_hessian / zero damping)')
+        # the reference's run-time errors (see _s2gp.raise_like_reference).  This direction has no norms among its sums: a
+        # sample with no satellite pixel projecting into the ground image has H = 0 exactly
+        risky = cfg.use_hessian or min(cfg.damping[i] for i in range(3)) <= 0.0
+        if risky or strict:
+            raise_like_reference(trace, neq[:, :, 2:8].abs().sum(-1) if strict else None, 0)
         # a detached alias: under autograd `trace` becomes the Function's output (grad_fn -> ctx), and ctx/model must not hold it
         # or every step's ctx (8.5 GB of saved workspaces at B = 32) lives in a reference cycle until the cyclic GC runs
         self.last_trace, self.last_normal_eq = trace.detach(), neq

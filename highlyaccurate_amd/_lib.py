@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get('HLA_LIB') or os.path.join(HERE, 'libhla.so')   # HLA_
 
 HLA_F32, HLA_BF16, HLA_F16 = 0, 1, 2
 HLA_VGG_WANT_CONF, HLA_VGG_DEFER_NORM, HLA_VGG_SAVE_FOR_BACKWARD = 1, 2, 4
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 
 class HlaError(RuntimeError):
@@ -38,7 +38,7 @@ class S2GConfig(C.Structure):
                 ('using_weight', C.c_int), ('use_hessian', C.c_int), ('dof', C.c_int),
                 ('shift_range_lat', C.c_double), ('shift_range_lon', C.c_double), ('rotation_range', C.c_double),
                 ('damping', C.c_double * 3), ('keep', C.c_void_p), ('keep_stride', C.c_size_t),
-                ('optimizer', C.c_int), ('beta1', C.c_double), ('beta2', C.c_double)]
+                ('optimizer', C.c_int), ('beta1', C.c_double), ('beta2', C.c_double), ('count_in_view', C.c_int)]
 
 
 class VggGrads(C.Structure):

@@ -222,7 +222,8 @@ class S2GPBase(nn.Module):
             cfg.keep, cfg.keep_stride = self.last_keep.data_ptr(), self.last_keep.shape[1]
         trace = torch.empty(B, self.N_iters, L, 3, device=dev, dtype=torch.float32)
         strict = bool(getattr(self.args, 'strict_errors', 0)) or os.environ.get('HLA_STRICT_ERRORS', '0') == '1'
-        want_neq = strict or (self.keep_normal_eq if keep_normal_eq is None else keep_normal_eq)
+        want_neq = strict or cfg.optimizer == 3 or (self.keep_normal_eq if keep_normal_eq is None else keep_normal_eq)
+        cfg.count_in_view = 1 if strict else 0
         neq = torch.empty(steps, B, 16, device=dev, dtype=torch.float64) if want_neq else None
         nbytes = lib.hla_s2g_workspace_bytes(C.byref(cfg), lv, B)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
@@ -235,13 +236,9 @@ class S2GPBase(nn.Module):
         # is asked for (HLA_STRICT_ERRORS=1 or args.strict_errors).  With the default flags the forward has no host sync;
         # a step whose pixels all fall outside the satellite map then leaves the pose unchanged (J = 0, r = -g).
         risky = cfg.optimizer == 3 or (cfg.optimizer == 0 and (cfg.use_hessian or min(cfg.damping[i] for i in range(3)) <= 0.0))
-        if strict and bool((neq[:, :, 0].sum(1) == 0).any()):
-            # jacobian.py:172 `assert mask.sum() > 0`: no pixel of the whole batch samples inside the map in some step
-            raise AssertionError('grid_sample: no ground pixel of the batch projects inside the satellite map (jacobian.py:172)')
-        if (risky or strict) and not bool(torch.isfinite(trace).all()):
-            # torch.inverse on a singular matrix (models_kitti.py:1012, models_ford.py:446)
-            raise RuntimeError('linalg.inv: the damped normal matrix of an LM step is singular '
-                               '(use_hessian / zero damping with no Jacobian support in one pose component)')
+        if risky or strict:
+            raise_like_reference(trace, neq[:, :, 14] if strict else None, level_first,
+                                 gn_norm2=neq[:, :, 0] if cfg.optimizer == 3 else None)
         # a detached alias: under autograd `trace` becomes the Function's output (grad_fn -> ctx), and ctx/model must not hold it
         # or every step's ctx (8.5 GB of saved workspaces at B = 32) lives in a reference cycle until the cyclic GC runs
         self.last_trace, self.last_normal_eq = trace.detach(), neq
@@ -320,6 +317,38 @@ class S2GPBase(nn.Module):
         trace = self.lm_solve(sat_feats, grd_feats, grd_confs, grd_img.shape[-2:], extra, level_first, init_pose,
                               sat_inv, grd_inv)
         return trace, grd_confs
+
+
+def raise_like_reference(trace, in_view, level_first, gn_norm2=None):
+    """The reference's two run-time errors, in the order it would hit them.  trace [B,N,L,3]; in_view [steps,B] (or None):
+    per sample, the number of pixels sampled inside the map in that step (any quantity that is zero iff there is none).
+    * jacobian.py:172 `assert mask.sum() > 0` fires in step k when NO pixel of the whole batch is in view (checked before
+      that step's solve);
+    * torch.inverse (models_kitti.py:372,1012, models_ford.py:446,578) raises in step k when any sample's matrix is exactly
+      singular -- here that step's pose comes out non-finite.
+    Steps after the first failure are garbage (the reference never ran them), so only the first one counts.
+    gn_norm2 [steps,B] (GN_update only): ||s||^2.  GN_update divides by the UNclamped norm (models_ford.py:551-553), so a
+    sample with no pixel in the compared rows gets a NaN matrix, which torch.inverse accepts: its pose is NaN from then on
+    without an error of its own (the next step's assertion fires if the rest of the batch is out of view as well)."""
+    B, N, L, _ = trace.shape
+    steps = N * L
+    tr = (trace.permute(0, 2, 1, 3) if level_first else trace).reshape(B, steps, 3)
+    bad = ~torch.isfinite(tr).all(-1)                                # [B,steps]
+    if gn_norm2 is not None:
+        first = torch.where(bad.any(1), bad.float().argmax(1), torch.full((B,), steps - 1, device=bad.device))
+        poisoned = bad.any(1) & (gn_norm2.t().gather(1, first[:, None])[:, 0] == 0)
+        bad = bad & ~poisoned[:, None]
+    bad = bad.any(0)                                                 # [steps]
+    k_s = int(torch.nonzero(bad)[0]) if bool(bad.any()) else steps
+    k_a = steps
+    if in_view is not None:
+        empty = in_view.sum(1) == 0
+        k_a = int(torch.nonzero(empty)[0]) if bool(empty.any()) else steps
+    if k_a < steps and k_a <= k_s:
+        raise AssertionError(f'grid_sample: no pixel of the batch is sampled inside the map in LM step {k_a} (jacobian.py:172)')
+    if k_s < steps:
+        raise RuntimeError(f'linalg.inv: the normal matrix of LM step {k_s} is singular '
+                           '(use_hessian / zero damping / Gauss-Newton with no Jacobian support in one pose component)')
 
 
 def dead_ground_rows(H: int) -> int:

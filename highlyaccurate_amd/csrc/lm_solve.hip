@@ -106,6 +106,24 @@ __global__ __launch_bounds__(256) void lm_accum(AccumArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// hla_s2g_config.count_in_view: the quantity jacobian.py:172 asserts on -- how many pixels of the WHOLE level map (all rows,
+// whatever their z > 0 mask) have satellite coordinates inside the map.  Geometry only; one thread per pixel.
+__global__ __launch_bounds__(256) void lm_inview_kernel(const double* __restrict__ coef, const float* __restrict__ xyz, int A,
+                                                        int npix, int* __restrict__ count) {
+  const int b = blockIdx.y, p = blockIdx.x * 256 + threadIdx.x;
+  const double* cf = coef + (size_t)b * COEF_N;
+  int in = 0;
+  if (p < npix) {
+    const double X = xyz[(size_t)p * 3], Y = xyz[(size_t)p * 3 + 1], Z = xyz[(size_t)p * 3 + 2];
+    const double u = cf[0] * X + cf[1] * Y + cf[2] * Z + cf[3];
+    const double v = cf[4] * X + cf[5] * Y + cf[6] * Z + cf[7];
+    const double lim = (double)(A - 1);
+    in = ((u >= 0.0) && (u <= lim) && (v >= 0.0) && (v <= lim)) ? 1 : 0;
+  }
+  const unsigned long long m = __ballot(in);
+  if ((threadIdx.x & 63) == 0 && m) atomicAdd(count + b, __popcll(m));
+}
+
 struct SolveArgs {
   const double* part;    // [B,nt,PART_N] of the step being closed, or null (init launch)
   const double* sat_inv; // [B] or null: feature maps are stored un-normalised, sums are rescaled here
@@ -123,6 +141,7 @@ struct SolveArgs {
   int optimizer, t;      // 0 LM; 1 SGD; 2 ADAM (t = step index in execution order); 3 GN (cfg.gn)
   double beta1, beta2;
   double* adam;          // [B,6] first / second moment of the three pose components (ADAM only)
+  const int* in_view;    // [B] pixels in view in this step (count_in_view), or null
   LmSolveCfg cfg;
   LmGeom next;           // geometry of the level the NEXT step runs on
 };
@@ -151,7 +170,8 @@ __global__ __launch_bounds__(64) void lm_solve(SolveArgs a) {
       for (int k = 11; k < 14; ++k) s[k] *= as * ag;
       if (a.normal_eq) {
         for (int k = 0; k < 14; ++k) a.normal_eq[(size_t)b * 16 + k] = s[k];
-        a.normal_eq[(size_t)b * 16 + 14] = 0.0; a.normal_eq[(size_t)b * 16 + 15] = 0.0;
+        a.normal_eq[(size_t)b * 16 + 14] = a.in_view ? (double)a.in_view[b] : 0.0;
+        a.normal_eq[(size_t)b * 16 + 15] = 0.0;
       }
       double H[3][3], g[3], Mi[3][3], d[3], ns, ng;
       if (a.optimizer == 0 || a.optimizer == 3) {
@@ -200,6 +220,7 @@ static size_t ws_layout(const hla_s2g_config* cfg, const hla_s2g_level* lv, int 
   *off_coef = o; o += hla_align_up((size_t)B * COEF_N * sizeof(double), 256);
   *off_pose = o; o += hla_align_up((size_t)B * 3 * sizeof(float), 256);
   *off_part = o; o += hla_align_up((size_t)B * max_nt * PART_N * sizeof(double), 256);
+  o += hla_align_up((size_t)B * cfg->n_levels * cfg->n_iters * sizeof(int), 256);   // in-view counts (count_in_view)
   o += hla_align_up((size_t)B * 6 * sizeof(double), 256);      // ADAM moments (last region)
   return o;
 }
@@ -276,6 +297,9 @@ extern "C" int hla_s2g_lm_solve(const hla_s2g_config* cfg, const hla_s2g_level* 
   };
 
   double* adam = (double*)(ws + need - hla_align_up((size_t)B * 6 * sizeof(double), 256));
+  int* in_view = (int*)((char*)adam - hla_align_up((size_t)B * steps * sizeof(int), 256));
+  const bool count = cfg->count_in_view && normal_eq;
+  if (count) HLA_CHECK_HIP(hipMemsetAsync(in_view, 0, (size_t)B * steps * sizeof(int), st));
   if (cfg->optimizer == 2) HLA_CHECK_HIP(hipMemsetAsync(adam, 0, (size_t)B * 6 * sizeof(double), st));
   SolveArgs sa{};
   sa.optimizer = cfg->optimizer; sa.beta1 = cfg->beta1; sa.beta2 = cfg->beta2; sa.adam = adam;
@@ -292,6 +316,9 @@ extern "C" int hla_s2g_lm_solve(const hla_s2g_config* cfg, const hla_s2g_level* 
   for (int k = 0; k < steps; ++k) {
     const int l = step_level(k), it = step_iter(k);
     const hla_s2g_level& v = lv[l];
+    if (count)
+      hipLaunchKernelGGL(lm_inview_kernel, dim3((v.h * v.w + 255) / 256, B), dim3(256), 0, st, coef, v.xyz, v.A, v.h * v.w,
+                         in_view + (size_t)k * B);
     AccumArgs aa{};
     aa.sat = v.sat_feat; aa.grd = v.grd_feat; aa.conf = v.grd_conf; aa.xyz = v.xyz; aa.coef = coef; aa.part = part;
     aa.A = v.A; aa.h = v.h; aa.w = v.w; aa.row0 = v.row0; aa.npix = (v.h - v.row0) * v.w;
@@ -311,6 +338,7 @@ extern "C" int hla_s2g_lm_solve(const hla_s2g_config* cfg, const hla_s2g_level* 
     sa.trace_out = trace + ((size_t)it * L + l) * 3; sa.trace_stride = N * L * 3;
     sa.rand_uv = reinit ? rand_uv + (size_t)k * 2 * B : nullptr;
     sa.normal_eq = normal_eq ? normal_eq + (size_t)k * B * 16 : nullptr;
+    sa.in_view = count ? in_view + (size_t)k * B : nullptr;
     if (k + 1 < steps) { sa.coef = coef; sa.next = geom(step_level(k + 1)); }
     else sa.coef = nullptr;
     hla_prof_begin(K_LMSOLVE, 0, (double)B * aa.nt * PART_N * 8.0, st);

@@ -43,7 +43,7 @@ typedef enum hla_dtype {
 } hla_dtype;
 
 const char* hla_last_error(void);
-int hla_abi_version(void);   /* 8 (bumped whenever a struct or signature in this file changes; _lib.py checks it) */
+int hla_abi_version(void);   /* 9 (bumped whenever a struct or signature in this file changes; _lib.py checks it) */
 
 /* ------------------------------------------------------------------------- *
  * VGGUnet.forward  (VGG.py:121-203; L2_norm VGG.py:511-514)
@@ -192,6 +192,9 @@ typedef struct hla_s2g_config {
                              reads grd_conf, ignores keep).  1-3 exist in the iteration-first loop only, as in the
                              reference; hla_s2g_lm_solve_bwd differentiates all four */
   double beta1, beta2;
+  int count_in_view;      /* != 0 (and normal_eq given): slot 14 of normal_eq = the number of pixels of the WHOLE level map whose
+                             satellite coordinates fall inside the map in that step -- what `assert mask.sum() > 0`
+                             (jacobian.py:172) tests, summed over the batch.  One small extra launch per step. */
 } hla_s2g_config;
 
 size_t hla_s2g_workspace_bytes(const hla_s2g_config* cfg, const hla_s2g_level* levels, int B);
@@ -201,7 +204,7 @@ size_t hla_s2g_workspace_bytes(const hla_s2g_config* cfg, const hla_s2g_level* l
  * rand_uv  [n_steps,2,B] fp32: the (rand_u, rand_v) re-initialisation draws of every step
  *          (models_kitti.py:1028-1033), drawn by the caller from torch's CPU generator
  * trace    [B,n_iters,n_levels,3] fp32 out: (shift_u, shift_v, theta) after every step
- * normal_eq[n_steps,B,16] fp64 out or NULL: ||s||^2, ||g||^2, H(6), J^T s (3), J^T g (3), pad(2) */
+ * normal_eq[n_steps,B,16] fp64 out or NULL: ||s||^2, ||g||^2, H(6), J^T s (3), J^T g (3), pixels in view (count_in_view), pad */
 int hla_s2g_lm_solve(const hla_s2g_config* cfg, const hla_s2g_level* levels, const float* R_FL,
                      const float* T_FL, const float* pose0, const float* rand_uv, float* trace,
                      double* normal_eq, void* workspace, size_t workspace_bytes, int B, hla_stream_t stream);

@@ -35,6 +35,9 @@ def one_case(seed):
     if rs.randint(3) == 0:
         kw['damping'] = float(rs.choice([0.01, 0.5, 1.0]))
     lf = int(rs.randint(2))
+    if seed >= 2000 and rs.randint(3) == 0 and not g2s:      # seeds >= 2000 add the ablation updaters (iteration-first loop only)
+        kw['Optimizer'] = 'GN' if ford else 'SGD'
+        lf = 0
     train = seed % 2 == 1
     args = O.default_args(**kw)
     sd = O.synth_model_state(seed, bias_scale=0.02, rotation_range=10.0 if ford else args.rotation_range)
@@ -60,14 +63,20 @@ def one_case(seed):
         torch.manual_seed(seed)
         with torch.no_grad():
             onet(sat.double(), grd.double(), *extra_o, mode='test', **lfkw)
-    except torch.linalg.LinAlgError:
+    except (torch.linalg.LinAlgError, AssertionError) as oe:
+        # LinAlgError: singular normal matrix (torch.inverse); AssertionError: no pixel of the batch in view (jacobian.py:172),
+        # which the HIP path reproduces in strict mode only (it costs a host sync)
+        os.environ['HLA_STRICT_ERRORS'] = '1'
         try:
             with torch.no_grad():
                 net(sat.to(d), grd.to(d), *extra_g, mode='test', **lfkw)
-        except RuntimeError as e:
-            print(f'ok   raise {desc}: both raise ({str(e)[:40]}...)', flush=True)
-            return True
-        print(f'FAIL raise {desc}: the oracle raised, the HIP path did not', flush=True)
+        except (RuntimeError, AssertionError) as e:
+            same = isinstance(oe, AssertionError) == isinstance(e, AssertionError)
+            print(f"{'ok  ' if same else 'FAIL'} raise ({type(oe).__name__} / {type(e).__name__}) {desc}", flush=True)
+            return same
+        finally:
+            os.environ.pop('HLA_STRICT_ERRORS', None)
+        print(f'FAIL raise {desc}: the oracle raised {type(oe).__name__}, the HIP path did not', flush=True)
         return False
     if not train:
         torch.manual_seed(seed)
