@@ -256,7 +256,8 @@ def main():
                        'pairs_per_gpu': B, 'global_batch': B * world, 'parallelism': f'batch-sharded x{world}, no collective',
                        'dead_work_skipped': 'dec3/conf3 (VGG.py:153-155,163: computed and dropped by the reference at level 3); '
                                             f'ground-image rows 0..{dead_ground_rows(grd.shape[-2]) - 1} (cannot reach the bottom-half '
-                                            'rows the LM loop reads; computed rows are bit-identical, DESIGN.md 3.5)'},
+                                            'rows the LM loop reads) and, layer by layer, the feature rows those rows do not '
+                                            'depend on; computed rows are bit-identical, DESIGN.md 3.5)'},
         }
         # whole-forward conv rate on the FLOPs that were actually executed (the reference's as-written count is 316.3
         # GFLOP/pair, 272.4 without dec3/conf3)

@@ -74,11 +74,13 @@ def _packed_weights(module: 'VGGUnet', prm, versions, dt: int, device):
 
 
 def vgg_forward_nhwc(module: 'VGGUnet', x: torch.Tensor, want_conf: bool = True, defer_norm: bool = False,
-                     save_for_backward: bool = False):
+                     save_for_backward: bool = False, first_row8: int = 0):
     """Run the three-level extractor.  Returns (feats, confs, inv_norm): lists of NHWC fp32 tensors
     [B,h,w,C] and [B,h,w] (or None), and inv_norm [3,B] fp64 = 1/max(||map||, 1e-12).
     With ``defer_norm`` the maps are left un-normalised (the LM loop folds inv_norm into its sums);
-    otherwise they are L2-normalised per sample like the reference's (VGG.py:172-175)."""
+    otherwise they are L2-normalised per sample like the reference's (VGG.py:172-175).
+    ``first_row8`` = f > 0 promises that only rows f / 2f / 4f.. of the three maps will be read (include/hla.h): the layers
+    skip the rows nothing depends on, the rows above stay unwritten and inv_norm covers the computed rows only."""
     _lib.require_gpu(x, 'VGGUnet input')
     if x.dim() != 4 or x.shape[1] != 3:
         raise ValueError(f'expected [B,3,H,W], got {tuple(x.shape)}')
@@ -105,7 +107,7 @@ def vgg_forward_nhwc(module: 'VGGUnet', x: torch.Tensor, want_conf: bool = True,
             raise ValueError('save_for_backward needs defer_norm=True (the backward works on the raw maps)')
         flags |= _lib.HLA_VGG_SAVE_FOR_BACKWARD
     rc = lib.hla_vgg_forward(_lib.ptr(x), C.byref(prm), _lib.ptr(packed), fp, cp, _lib.ptr(inv_norm), _lib.ptr(ws), nbytes,
-                             B, H, W, L, dt, flags, _lib.stream_ptr())
+                             B, H, W, L, dt, flags, int(first_row8), _lib.stream_ptr())
     _lib.check(rc, 'hla_vgg_forward')
     # ws is only used by work already enqueued on this stream; the caching allocator keeps the block
     # stream-ordered, so dropping the Python reference here is safe.

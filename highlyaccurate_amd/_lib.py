@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get('HLA_LIB') or os.path.join(HERE, 'libhla.so')   # HLA_
 
 HLA_F32, HLA_BF16, HLA_F16 = 0, 1, 2
 HLA_VGG_WANT_CONF, HLA_VGG_DEFER_NORM, HLA_VGG_SAVE_FOR_BACKWARD = 1, 2, 4
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 
 class HlaError(RuntimeError):
@@ -72,7 +72,7 @@ def load() -> C.CDLL:
     lib.hla_vgg_workspace_bytes.argtypes = [i, i, i, i, i]
     lib.hla_vgg_forward.restype = i
     lib.hla_vgg_forward.argtypes = [vp, C.POINTER(VggParams), vp, C.POINTER(vp), C.POINTER(vp), vp, vp, sz,
-                                    i, i, i, i, i, i, vp]
+                                    i, i, i, i, i, i, i, vp]
     lib.hla_vgg_packed_weight_bytes.restype = sz
     lib.hla_vgg_packed_weight_bytes.argtypes = [i]
     lib.hla_vgg_pack_weights.restype = i

@@ -95,6 +95,8 @@ struct ConvArgs {
   int B, H, W, Cout;
   int relu_act;
   int tiles_x, tiles_y;
+  int row_begin;      // first output row this launch computes (even for POOL); rows above it are left untouched.  The halo row
+                      // row_begin-1 of the sources is read as it lies in memory (the caller guarantees it was written)
   // --- training / backward extras (all optional) ---
   const unsigned char* unpool_idx;  // src1 is a max-pooled map's gradient at half resolution [B,H/2,W/2,C1] and this is
                                     // the forward argmax (0..3): the loader routes it to full resolution (virtual unpool)
@@ -409,7 +411,7 @@ __global__ __launch_bounds__(256, (NT == 1 && !PF_UPFRONT) ? 3 : 2) void conv3x3
   const int tx = bid % a.tiles_x; bid /= a.tiles_x;
   const int ty = bid % a.tiles_y;
   const int b = bid / a.tiles_y;
-  const int y0 = ty * TH, x0 = tx * 32;
+  const int y0 = a.row_begin + ty * TH, x0 = tx * 32;
   const int nstage = (a.C1 + a.C2) / KC;
   const int part = t & 3, pbase = t >> 2;   // 256 % 4 == 0: a thread always moves the same 16-B part of a pixel
 
@@ -538,6 +540,7 @@ struct Conv02Args {
   unsigned char* idx_out;  // training: pool argmax [B,H/2,W/2,64], or null
   void* a2_out;        // level 4: NHWC T [B,H,W,64] = relu(conv2) before the pool (the skip input of conv_dec3), or null
   int B, H, W, tiles_x, tiles_y;
+  int row_begin;       // first conv2 output row (full resolution, even) this launch computes; see ConvArgs::row_begin
 };
 
 template <typename T> constexpr int conv02_lds_bytes() {
@@ -558,7 +561,7 @@ __global__ __launch_bounds__(256, 2) void conv02_kernel(Conv02Args a0) {
   const int tx = bid % a0.tiles_x; bid /= a0.tiles_x;
   const int ty = bid % a0.tiles_y;
   const int b = bid / a0.tiles_y;
-  const int y0 = ty * TH, x0 = tx * 32;
+  const int y0 = a0.row_begin + ty * TH, x0 = tx * 32;
   const int x = lane & 31, g = lane >> 5;
 
   // start the first conv2 weight loads before anything else (they do not depend on the input)
@@ -776,7 +779,7 @@ static __global__ __launch_bounds__(256) void scale_kernel(float* __restrict__ x
 template <typename T>
 static void launch_conv(hipStream_t st, ConvArgs a, bool pool) {
   a.tiles_x = (a.W + 31) / 32;
-  a.tiles_y = (a.H + 7) / 8;
+  a.tiles_y = (a.H - a.row_begin + 7) / 8;
 #if CONV_VARIANT == 51 || CONV_VARIANT == 52    // experiment: every layer on the 64-channel block (3 blocks per CU)
   const bool big = false;
   const dim3 grid(a.tiles_x * a.tiles_y * a.B, a.Cout / 64);
@@ -784,7 +787,7 @@ static void launch_conv(hipStream_t st, ConvArgs a, bool pool) {
   const bool big = a.Cout >= 128;
   const dim3 grid(a.tiles_x * a.tiles_y * a.B, big ? a.Cout / 128 : 1);
 #endif
-  const size_t es = sizeof(T), P = (size_t)a.B * a.H * a.W, Po = pool ? P / 4 : P;
+  const size_t es = sizeof(T), P = (size_t)a.B * (a.H - a.row_begin) * a.W, Po = pool ? P / 4 : P;
   const double flops = 2.0 * 9.0 * (a.C1 + a.C2) * a.Cout * (double)P;
   const double bytes = (double)P * ((a.up1 ? a.C1 / 4.0 : a.C1) + a.C2) * es + (double)Po * a.Cout * ((a.out_act ? es : 0) + (a.out_raw ? 4 : 0));
 #if CONV_VARIANT == 40 || CONV_VARIANT == 104

@@ -18,7 +18,7 @@ void vgg_pack_all(const hla_vgg_params* prm, char* packed, int dtype, hipStream_
 template <typename T>
 int vgg_forward_t(const float* x, const hla_vgg_params* prm, const char* packed, int dtype, float* const feat[4],
                          float* const conf[4], double* inv_norm, char* ws, const VggPlan& pl, int B, int H, int W,
-                         int flags, hipStream_t st) {
+                         int flags, int first_row8, hipStream_t st) {
   const bool level4 = pl.x2r != 0;
   const int NL = level4 ? 4 : 3;
   auto W_ = [&](int l) { return (const uint4*)(packed + packed_offset(l, dtype)); };
@@ -29,8 +29,11 @@ int vgg_forward_t(const float* x, const hla_vgg_params* prm, const char* packed,
     a.x = x; a.w0 = W_(0); a.b0 = prm->b[0]; a.w2 = W_(1); a.b2 = prm->b[1]; a.out_act = w + pl.x3;
     if (flags & HLA_VGG_SAVE_FOR_BACKWARD) { a.a0_out = w + pl.a0; a.idx_out = (unsigned char*)(w + pl.idx3); }
     if (level4) a.a2_out = w + pl.x2r;
-    a.B = B; a.H = H; a.W = W; a.tiles_x = (W + 31) / 32; a.tiles_y = (H + 7) / 8;
-    const double P = (double)B * H * W;
+    // (first_row8, see below: x3 is needed from row 4f-16 on = conv2 row 8f-32)
+    const int f0 = (level4 || (flags & HLA_VGG_SAVE_FOR_BACKWARD) || ((flags & HLA_VGG_WANT_CONF) && conf)) ? 0 : first_row8;
+    a.row_begin = f0 ? 8 * f0 - 32 : 0;
+    a.B = B; a.H = H; a.W = W; a.tiles_x = (W + 31) / 32; a.tiles_y = (H - a.row_begin + 7) / 8;
+    const double P = (double)B * (H - a.row_begin) * W;
     constexpr int lds_bytes = conv02_lds_bytes<T>();
     static bool attr_set = false;
     if (!attr_set) {
@@ -42,35 +45,50 @@ int vgg_forward_t(const float* x, const hla_vgg_params* prm, const char* packed,
     hla_prof_end(st);
   }
   const bool train = flags & HLA_VGG_SAVE_FOR_BACKWARD;
+  int np_used[4] = {pl.np[0], pl.np[1], pl.np[2], pl.np[3]};
   auto conv = [&](int l, const void* s1, int C1, int H_, int W_h, void* act, int relu, bool pool, const void* s2 = nullptr,
-                  int C2 = 0, int up1 = 0, float* raw = nullptr, double* ss = nullptr, unsigned char* idx = nullptr) {
+                  int C2 = 0, int up1 = 0, float* raw = nullptr, double* ss = nullptr, unsigned char* idx = nullptr,
+                  int row_begin = 0, int norm_level = -1) {
     ConvArgs a{};
     a.idx_out = train ? idx : nullptr;
     a.src1 = s1; a.src2 = s2; a.C1 = C1; a.C2 = C2; a.up1 = up1; a.wpk = W_(l);
     a.bias = kLayers[l].has_bias ? prm->b[l] : nullptr;
     a.out_act = act; a.out_raw = raw; a.sumsq = ss; a.B = B; a.H = H_; a.W = W_h; a.Cout = kLayers[l].cout;
     a.relu_act = relu;
+    a.row_begin = row_begin < 0 ? 0 : row_begin;
     launch_conv<T>(st, a, pool);
+    if (norm_level >= 0)      // sum-of-squares partials actually written by this launch: one per (tile, 128-cout block)
+      np_used[norm_level] = ((W_h + 31) / 32) * ((H_ - a.row_begin + 7) / 8) * (a.Cout >= 128 ? a.Cout / 128 : 1);
   };
+  // first_row8 = f > 0: the caller reads the returned maps only from rows f (x15), 2f (x18), 4f (x21) on, so every layer only
+  // has to produce the rows those depend on -- a 3x3 conv needs one more input row, a 2x upsample halves, a 2x2 pool doubles:
+  //   x21 <- dec2.3 [4f..] <- dec2.1 [4f-1..] <- {up(x18) [2f-1..], x3 [4f-2..]};  x18 <- dec1.3 [2f-1..] <- dec1.1 [2f-2..] <-
+  //   {up(x15) [f-2..], x8 [2f-3..]};  x15 [f-2..] <- pool(conv14 [2f-4..]) <- conv12 [2f-5..] <- conv10 [2f-6..] <- x8 [2f-7..]
+  //   <- pool(conv7 [4f-14..]) <- conv5 [4f-15..] <- x3 [4f-16..]  (<- image row 8f-34: `dead_ground_rows`).
+  // Each launch starts exactly at its first needed row, so the one halo row above it is the first row its producer wrote.
+  const int f = (level4 || train || ((flags & HLA_VGG_WANT_CONF) && conf)) ? 0 : first_row8;
+  const int r_c5 = f ? 4 * f - 15 : 0, r_c7 = f ? 4 * f - 14 : 0, r_c10 = f ? 2 * f - 6 : 0, r_c12 = f ? 2 * f - 5 : 0,
+            r_c14 = f ? 2 * f - 4 : 0, r_d11 = f ? 2 * f - 2 : 0, r_d13 = f ? 2 * f - 1 : 0, r_d21 = f ? 4 * f - 1 : 0,
+            r_d23 = f ? 4 * f : 0;
   // encoder (VGG.py:129-141).  ReLU commutes with max-pool, so pooled maps are stored post-ReLU.
-  conv(2, w + pl.x3, 64, H / 2, W / 2, w + pl.a5, 1, false);                          // conv5
+  conv(2, w + pl.x3, 64, H / 2, W / 2, w + pl.a5, 1, false, nullptr, 0, 0, nullptr, nullptr, nullptr, r_c5);      // conv5
   conv(3, w + pl.a5, 128, H / 2, W / 2, w + pl.x8, 1, true, nullptr, 0, 0, nullptr, nullptr,
-       (unsigned char*)(w + pl.idx8));                                                // conv7 + pool -> relu(x8)
-  conv(4, w + pl.x8, 128, H / 4, W / 4, w + pl.a10, 1, false);                        // conv10
-  conv(5, w + pl.a10, 256, H / 4, W / 4, w + pl.a12, 1, false);                       // conv12
+       (unsigned char*)(w + pl.idx8), r_c7);                                          // conv7 + pool -> relu(x8)
+  conv(4, w + pl.x8, 128, H / 4, W / 4, w + pl.a10, 1, false, nullptr, 0, 0, nullptr, nullptr, nullptr, r_c10);   // conv10
+  conv(5, w + pl.a10, 256, H / 4, W / 4, w + pl.a12, 1, false, nullptr, 0, 0, nullptr, nullptr, nullptr, r_c12);  // conv12
   conv(6, w + pl.a12, 256, H / 4, W / 4, w + pl.x15r, 1, true, nullptr, 0, 0, feat[0],
-       (double*)(w + pl.ss[0]), (unsigned char*)(w + pl.idx15));                      // conv14 + pool -> x15
+       (double*)(w + pl.ss[0]), (unsigned char*)(w + pl.idx15), r_c14, 0);            // conv14 + pool -> x15
   // decoder (VGG.py:144-151): conv(relu(cat(up(a), skip))) with both inputs stored post-ReLU
-  conv(7, w + pl.x15r, 256, H / 4, W / 4, w + pl.d1a, 1, false, w + pl.x8, 128, 1);   // dec1.1
+  conv(7, w + pl.x15r, 256, H / 4, W / 4, w + pl.d1a, 1, false, w + pl.x8, 128, 1, nullptr, nullptr, nullptr, r_d11);   // dec1.1
   conv(8, w + pl.d1a, 128, H / 4, W / 4, w + pl.x18r, 1, false, nullptr, 0, 0, feat[1],
-       (double*)(w + pl.ss[1]));                                                      // dec1.3 -> x18
-  conv(9, w + pl.x18r, 128, H / 2, W / 2, w + pl.d2a, 1, false, w + pl.x3, 64, 1);    // dec2.1
+       (double*)(w + pl.ss[1]), nullptr, r_d13, 1);                                   // dec1.3 -> x18
+  conv(9, w + pl.x18r, 128, H / 2, W / 2, w + pl.d2a, 1, false, w + pl.x3, 64, 1, nullptr, nullptr, nullptr, r_d21);    // dec2.1
   conv(10, w + pl.d2a, 64, H / 2, W / 2, w + pl.x21r, 1, false, nullptr, 0, 0, feat[2],
-       (double*)(w + pl.ss[2]));                                                      // dec2.3 -> x21
+       (double*)(w + pl.ss[2]), nullptr, r_d23, 2);                                   // dec2.3 -> x21
   if (level4) {      // VGG.py:153-155: conv_dec3 on cat(up(x21), x2), zero-padded to 64 channels (vgg_layers.h)
     conv(11, w + pl.x21r, 64, H, W, w + pl.d3a, 1, false, w + pl.x2r, 64, 1);          // dec3.1
     conv(12, w + pl.d3a, 64, H, W, w + pl.x24r, 1, false, nullptr, 0, 0, feat[3],
-         (double*)(w + pl.ss[3]));                                                     // dec3.3 -> x24 (16 real channels)
+         (double*)(w + pl.ss[3]), nullptr, 0, 3);                                      // dec3.3 -> x24 (16 real channels)
   }
   // confidence heads on the ReLU'd maps
   if ((flags & HLA_VGG_WANT_CONF) && conf) {
@@ -95,7 +113,7 @@ int vgg_forward_t(const float* x, const hla_vgg_params* prm, const char* packed,
     double* inv = inv_norm ? inv_norm : (double*)(w + pl.inv);
     for (int l = 0; l < NL; ++l) {
       hla_prof_begin(K_L2NORM, 0, (double)B * pl.np[l] * 8, st);
-      hipLaunchKernelGGL(inv_norm_kernel, dim3(B), dim3(256), 0, st, (const double*)(w + pl.ss[l]), pl.np[l], inv + (size_t)l * B);
+      hipLaunchKernelGGL(inv_norm_kernel, dim3(B), dim3(256), 0, st, (const double*)(w + pl.ss[l]), np_used[l], inv + (size_t)l * B);
       hla_prof_end(st);
       if (flags & HLA_VGG_DEFER_NORM) continue;
       int bps = (int)(per[l] / 4 / 256 / 4);
@@ -113,11 +131,11 @@ int vgg_forward_t(const float* x, const hla_vgg_params* prm, const char* packed,
 template void vgg_pack_all<TuT>(const hla_vgg_params* prm, char* packed, int dtype, hipStream_t st);
 template int vgg_forward_t<TuT>(const float* x, const hla_vgg_params* prm, const char* packed, int dtype, float* const feat[4],
                               float* const conf[4], double* inv_norm, char* ws, const VggPlan& pl, int B, int H, int W,
-                              int flags, hipStream_t st);
+                              int flags, int first_row8, hipStream_t st);
 #else
 #define HLA_EXTERN_T(T) \
   extern template void vgg_pack_all<T>(const hla_vgg_params* prm, char* packed, int dtype, hipStream_t st); \
-  extern template int vgg_forward_t<T>(const float* x, const hla_vgg_params* prm, const char* packed, int dtype, float* const feat[4],                               float* const conf[4], double* inv_norm, char* ws, const VggPlan& pl, int B, int H, int W,                               int flags, hipStream_t st);
+  extern template int vgg_forward_t<T>(const float* x, const hla_vgg_params* prm, const char* packed, int dtype, float* const feat[4],                               float* const conf[4], double* inv_norm, char* ws, const VggPlan& pl, int B, int H, int W,                               int flags, int first_row8, hipStream_t st);
 HLA_EXTERN_T(float) HLA_EXTERN_T(bf16) HLA_EXTERN_T(f16)
 
 extern "C" size_t hla_vgg_packed_weight_bytes(int dtype) { return packed_offset(kAllLayers, dtype); }
@@ -141,7 +159,7 @@ extern "C" size_t hla_vgg_workspace_bytes(int B, int H, int W, int level, int dt
 extern "C" int hla_vgg_forward(const float* x, const hla_vgg_params* params, const void* packed_weights,
                                float* const feat[4], float* const conf[4], double* inv_norm, void* workspace,
                                size_t workspace_bytes, int B, int H, int W, int level, int dtype, int flags,
-                               hla_stream_t stream) {
+                               int first_row8, hla_stream_t stream) {
   HLA_REQUIRE(x && params && packed_weights && feat && workspace, "hla_vgg_forward: null argument");
   HLA_REQUIRE(hla_dtype_ok(dtype), "hla_vgg_forward: dtype must be HLA_F32, HLA_BF16 or HLA_F16 (got %d)", dtype);
   HLA_REQUIRE(B > 0 && H >= 8 && W >= 8 && H % 8 == 0 && W % 8 == 0, "hla_vgg_forward: H and W must be multiples of 8");
@@ -151,6 +169,7 @@ extern "C" int hla_vgg_forward(const float* x, const hla_vgg_params* params, con
               "hla_vgg_forward: level 4 needs feat[3] ([B,H,W,64], 16 real channels) and the zero-padded conv_dec3 weights in w[11], w[12]");
   HLA_REQUIRE(level == 3 || !(flags & HLA_VGG_WANT_CONF) || !conf || !conf[3] || params->w[16], "hla_vgg_forward: conf[3] needs w[16]");
   HLA_REQUIRE(!(flags & HLA_VGG_DEFER_NORM) || inv_norm, "hla_vgg_forward: HLA_VGG_DEFER_NORM needs inv_norm");
+  HLA_REQUIRE(first_row8 == 0 || (first_row8 >= 4 && first_row8 < H / 8), "hla_vgg_forward: first_row8 must be 0 or in [4, H/8)");
   VggPlan pl;
   vgg_plan(B, H, W, dtype, (flags & HLA_VGG_SAVE_FOR_BACKWARD) != 0, &pl, level == 4);
   if (workspace_bytes < pl.total) {
@@ -159,11 +178,11 @@ extern "C" int hla_vgg_forward(const float* x, const hla_vgg_params* params, con
   }
   if (dtype == HLA_BF16)
     return vgg_forward_t<bf16>(x, params, (const char*)packed_weights, dtype, feat, conf, inv_norm, (char*)workspace, pl,
-                               B, H, W, flags, (hipStream_t)stream);
+                               B, H, W, flags, first_row8, (hipStream_t)stream);
   if (dtype == HLA_F16)
     return vgg_forward_t<f16>(x, params, (const char*)packed_weights, dtype, feat, conf, inv_norm, (char*)workspace, pl,
-                              B, H, W, flags, (hipStream_t)stream);
+                              B, H, W, flags, first_row8, (hipStream_t)stream);
   return vgg_forward_t<float>(x, params, (const char*)packed_weights, dtype, feat, conf, inv_norm, (char*)workspace, pl,
-                              B, H, W, flags, (hipStream_t)stream);
+                              B, H, W, flags, first_row8, (hipStream_t)stream);
 }
 #endif

@@ -43,7 +43,7 @@ typedef enum hla_dtype {
 } hla_dtype;
 
 const char* hla_last_error(void);
-int hla_abi_version(void);   /* 9 (bumped whenever a struct or signature in this file changes; _lib.py checks it) */
+int hla_abi_version(void);   /* 10 (bumped whenever a struct or signature in this file changes; _lib.py checks it) */
 
 /* ------------------------------------------------------------------------- *
  * VGGUnet.forward  (VGG.py:121-203; L2_norm VGG.py:511-514)
@@ -86,11 +86,15 @@ size_t hla_vgg_workspace_bytes(int B, int H, int W, int level, int dtype);
  * level    the reference's VGGUnet(level); 4 additionally computes x24 / conf3: feat[3] is [B,H,W,64] with the
  *          16 real channels first and zeros behind them, and params->w[11], w[12], w[16] must point at conv_dec3.1 /
  *          conv_dec3.3 / conf3.1 weights ZERO-PADDED to [64,128,3,3], [64,64,3,3], [1,64,3,3]; inv_norm is [4,B].
- *          3 -> maps 0..2 (the dead dec3/conf3 work of VGG.py:153-155,163
- *          is skipped).  Level 4 (x24) is not built yet.                                              */
+ *          3 -> maps 0..2 (the dead dec3/conf3 work of VGG.py:153-155,163 is skipped).
+ * first_row8  0, or f in [4, H/8): a promise that the caller reads feat[0] / feat[1] / feat[2] only from rows f / 2f / 4f
+ *          on (the LM loop reads rows h_l/2.. only, models_kitti.py:1194-1199).  Every layer then computes just the rows
+ *          those depend on; rows above are left unwritten, and inv_norm covers the computed rows only (usable only where
+ *          the per-sample scale cancels, as in LM_update).  Ignored (treated as 0) at level 4, with
+ *          HLA_VGG_SAVE_FOR_BACKWARD, and when confidence maps are requested.                                    */
 int hla_vgg_forward(const float* x, const hla_vgg_params* params, const void* packed_weights, float* const feat[4],
                     float* const conf[4], double* inv_norm, void* workspace, size_t workspace_bytes, int B, int H,
-                    int W, int level, int dtype, int flags, hla_stream_t stream);
+                    int W, int level, int dtype, int flags, int first_row8, hla_stream_t stream);
 
 /* ------------------------------------------------------------------------- *
  * Backward of VGGUnet (autograd through VGG.py:121-203 in the reference).

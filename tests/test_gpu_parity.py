@@ -1005,6 +1005,14 @@ def test_dead_ground_rows_elimination_is_exact(monkeypatch):
             assert crop[l].shape[1] == h - skip
             assert torch.equal(full[l][:, h // 2:], crop[l][:, h // 2 - skip:]), (precision, l)
             assert torch.equal(cfull[l][:, h // 2:], ccrop[l][:, h // 2 - skip:]), (precision, l)
+        # per-layer trimming (first_row8 = f: only rows f / 2f / 4f.. of the three maps are promised to be read): those rows
+        # are still bit-identical, whatever lies above them
+        f8 = 16 - 11
+        trim, _, _ = vgg_forward_nhwc(net, x[:, :, 88:].contiguous(), want_conf=False, defer_norm=True, first_row8=f8)
+        for l in range(3):
+            r = f8 << l
+            assert torch.equal(trim[l][:, r:], crop[l][:, r:]), (precision, l)
+            assert r == full[l].shape[1] // 2 - (88 >> (3 - l))
     g = load_golden('e2e_kitti.npz')
     seed, B = int(g['seeds'][0]), int(g['B'])
     for kw in (dict(), dict(using_weight=1)):
@@ -1106,7 +1114,7 @@ def test_bad_arguments_raise():
         with torch.no_grad():
             m(torch.zeros(2, 3, 128, 128, device=d), torch.zeros(1, 3, 64, 256, device=d), mode='test')
     lib = _lib.load()
-    assert lib.hla_vgg_forward(None, None, None, None, None, None, None, 0, 1, 8, 8, 3, 0, 0, None) != 0
+    assert lib.hla_vgg_forward(None, None, None, None, None, None, None, 0, 1, 8, 8, 3, 0, 0, 0, None) != 0
     assert b'null' in lib.hla_last_error()
 
 
