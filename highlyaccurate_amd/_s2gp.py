@@ -316,7 +316,7 @@ class S2GPBase(nn.Module):
                 grd_in = grd_img[:, :, skip:, :].contiguous()
                 # ... and inside the extractor every layer only computes the rows the LM loop's rows depend on
                 f8 = (grd_img.shape[-2] // 8) // 2 - skip // 8
-                f8 = f8 if (f8 >= 4 and not want_conf and os.environ.get('HLA_GRD_TRIM', '1') != '0') else 0
+                f8 = f8 if (f8 >= 4 and os.environ.get('HLA_GRD_TRIM', '1') != '0') else 0
             grd_feats, grd_confs, grd_inv = vgg_forward_nhwc(self.GrdFeatureNet, grd_in, want_conf=want_conf, defer_norm=True,
                                                              first_row8=f8)
         trace = self.lm_solve(sat_feats, grd_feats, grd_confs, grd_img.shape[-2:], extra, level_first, init_pose,

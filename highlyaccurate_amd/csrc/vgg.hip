@@ -30,7 +30,7 @@ int vgg_forward_t(const float* x, const hla_vgg_params* prm, const char* packed,
     if (flags & HLA_VGG_SAVE_FOR_BACKWARD) { a.a0_out = w + pl.a0; a.idx_out = (unsigned char*)(w + pl.idx3); }
     if (level4) a.a2_out = w + pl.x2r;
     // (first_row8, see below: x3 is needed from row 4f-16 on = conv2 row 8f-32)
-    const int f0 = (level4 || (flags & HLA_VGG_SAVE_FOR_BACKWARD) || ((flags & HLA_VGG_WANT_CONF) && conf)) ? 0 : first_row8;
+    const int f0 = (level4 || (flags & HLA_VGG_SAVE_FOR_BACKWARD)) ? 0 : first_row8;
     a.row_begin = f0 ? 8 * f0 - 32 : 0;
     a.B = B; a.H = H; a.W = W; a.tiles_x = (W + 31) / 32; a.tiles_y = (H - a.row_begin + 7) / 8;
     const double P = (double)B * (H - a.row_begin) * W;
@@ -66,10 +66,13 @@ int vgg_forward_t(const float* x, const hla_vgg_params* prm, const char* packed,
   //   {up(x15) [f-2..], x8 [2f-3..]};  x15 [f-2..] <- pool(conv14 [2f-4..]) <- conv12 [2f-5..] <- conv10 [2f-6..] <- x8 [2f-7..]
   //   <- pool(conv7 [4f-14..]) <- conv5 [4f-15..] <- x3 [4f-16..]  (<- image row 8f-34: `dead_ground_rows`).
   // Each launch starts exactly at its first needed row, so the one halo row above it is the first row its producer wrote.
-  const int f = (level4 || train || ((flags & HLA_VGG_WANT_CONF) && conf)) ? 0 : first_row8;
+  // The 3x3 confidence heads read one row above the first confidence row that is used, so with them the decoder starts one
+  // row earlier (the encoder's needs do not change: x15 [f-2..] and x8 [2f-4..] are covered).
+  const int f = (level4 || train) ? 0 : first_row8;
+  const int wc = ((flags & HLA_VGG_WANT_CONF) && conf) ? 1 : 0;
   const int r_c5 = f ? 4 * f - 15 : 0, r_c7 = f ? 4 * f - 14 : 0, r_c10 = f ? 2 * f - 6 : 0, r_c12 = f ? 2 * f - 5 : 0,
-            r_c14 = f ? 2 * f - 4 : 0, r_d11 = f ? 2 * f - 2 : 0, r_d13 = f ? 2 * f - 1 : 0, r_d21 = f ? 4 * f - 1 : 0,
-            r_d23 = f ? 4 * f : 0;
+            r_c14 = f ? 2 * f - 4 : 0, r_d11 = f ? 2 * f - 2 - wc : 0, r_d13 = f ? 2 * f - 1 - wc : 0,
+            r_d21 = f ? 4 * f - 1 - wc : 0, r_d23 = f ? 4 * f - wc : 0;
   // encoder (VGG.py:129-141).  ReLU commutes with max-pool, so pooled maps are stored post-ReLU.
   conv(2, w + pl.x3, 64, H / 2, W / 2, w + pl.a5, 1, false, nullptr, 0, 0, nullptr, nullptr, nullptr, r_c5);      // conv5
   conv(3, w + pl.a5, 128, H / 2, W / 2, w + pl.x8, 1, true, nullptr, 0, 0, nullptr, nullptr,

@@ -90,8 +90,8 @@ size_t hla_vgg_workspace_bytes(int B, int H, int W, int level, int dtype);
  * first_row8  0, or f in [4, H/8): a promise that the caller reads feat[0] / feat[1] / feat[2] only from rows f / 2f / 4f
  *          on (the LM loop reads rows h_l/2.. only, models_kitti.py:1194-1199).  Every layer then computes just the rows
  *          those depend on; rows above are left unwritten, and inv_norm covers the computed rows only (usable only where
- *          the per-sample scale cancels, as in LM_update).  Ignored (treated as 0) at level 4, with
- *          HLA_VGG_SAVE_FOR_BACKWARD, and when confidence maps are requested.                                    */
+ *          the per-sample scale cancels, as in LM_update).  conf[l], if requested, is likewise only valid from rows
+ *          f / 2f / 4f on.  Ignored (treated as 0) at level 4 and with HLA_VGG_SAVE_FOR_BACKWARD.                */
 int hla_vgg_forward(const float* x, const hla_vgg_params* params, const void* packed_weights, float* const feat[4],
                     float* const conf[4], double* inv_norm, void* workspace, size_t workspace_bytes, int B, int H,
                     int W, int level, int dtype, int flags, int first_row8, hla_stream_t stream);

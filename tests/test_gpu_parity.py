@@ -1008,11 +1008,13 @@ def test_dead_ground_rows_elimination_is_exact(monkeypatch):
         # per-layer trimming (first_row8 = f: only rows f / 2f / 4f.. of the three maps are promised to be read): those rows
         # are still bit-identical, whatever lies above them
         f8 = 16 - 11
-        trim, _, _ = vgg_forward_nhwc(net, x[:, :, 88:].contiguous(), want_conf=False, defer_norm=True, first_row8=f8)
-        for l in range(3):
-            r = f8 << l
-            assert torch.equal(trim[l][:, r:], crop[l][:, r:]), (precision, l)
-            assert r == full[l].shape[1] // 2 - (88 >> (3 - l))
+        for wc in (False, True):
+            trim, ctrim, _ = vgg_forward_nhwc(net, x[:, :, 88:].contiguous(), want_conf=wc, defer_norm=True, first_row8=f8)
+            for l in range(3):
+                r = f8 << l
+                assert torch.equal(trim[l][:, r:], crop[l][:, r:]), (precision, l, wc)
+                assert not wc or torch.equal(ctrim[l][:, r:], ccrop[l][:, r:]), (precision, l)
+                assert r == full[l].shape[1] // 2 - (88 >> (3 - l))
     g = load_golden('e2e_kitti.npz')
     seed, B = int(g['seeds'][0]), int(g['B'])
     for kw in (dict(), dict(using_weight=1)):
