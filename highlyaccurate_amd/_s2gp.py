@@ -308,15 +308,14 @@ class S2GPBase(nn.Module):
             sat_feats, _, sat_inv = vgg_forward_nhwc(self.SatFeatureNet, sat_map, want_conf=False, defer_norm=True)
             grd_in = grd_img
             # (only LM_update renormalises the ground features; SGD / ADAM see the whole-map L2_norm scale, so they need every row)
-            skip = dead_ground_rows(grd_img.shape[-2]) if (not return_confs and self.level == 3
-                                                           and getattr(self.args, 'Optimizer', 'LM') == 'LM'
-                                                           and os.environ.get('HLA_GRD_CROP', '1') != '0') else 0
-            f8 = 0
+            dead_ok = (not return_confs and self.level == 3 and getattr(self.args, 'Optimizer', 'LM') == 'LM'
+                       and os.environ.get('HLA_GRD_CROP', '1') != '0')
+            skip = dead_ground_rows(grd_img.shape[-2]) if dead_ok else 0
             if skip:
                 grd_in = grd_img[:, :, skip:, :].contiguous()
-                # ... and inside the extractor every layer only computes the rows the LM loop's rows depend on
-                f8 = (grd_img.shape[-2] // 8) // 2 - skip // 8
-                f8 = f8 if (f8 >= 4 and os.environ.get('HLA_GRD_TRIM', '1') != '0') else 0
+            # ... and inside the extractor every layer only computes the rows the LM loop's rows depend on
+            f8 = ((grd_img.shape[-2] // 8) // 2 - skip // 8) if dead_ok else 0
+            f8 = f8 if (f8 >= 4 and os.environ.get('HLA_GRD_TRIM', '1') != '0') else 0
             grd_feats, grd_confs, grd_inv = vgg_forward_nhwc(self.GrdFeatureNet, grd_in, want_conf=want_conf, defer_norm=True,
                                                              first_row8=f8)
         trace = self.lm_solve(sat_feats, grd_feats, grd_confs, grd_img.shape[-2:], extra, level_first, init_pose,
