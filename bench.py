@@ -231,6 +231,32 @@ def main():
                    'ms_per_step': round(tdt / a.train_steps * 1e3, 3), 'loss_finite': bool(torch.isfinite(lossv)),
                    'what': "forward(mode='train') + HIP backward (LM loop + both VGGs) + gradient all-reduce + Adam",
                    'allreduce_bytes_per_step': ar_bytes}
+          if a.model != 'g2sp':
+              # secondary number: the same step with args.train_ground_crop=1 (an extension: the ground branch trains on the
+              # image rows that can reach the loss; loss and gradients equal to rounding, the RETURNED confidence maps are
+              # only computed from the crop on -- DESIGN.md 3.5).  Not the default, so it is not `train.value`.
+              net.args.train_ground_crop = 1
+              for _ in range(2):
+                  tstep()
+              torch.cuda.synchronize()
+              if dist:
+                  dist.barrier()
+              torch.cuda.synchronize()
+              t1 = time.perf_counter()
+              for _ in range(a.train_steps):
+                  tstep()
+              torch.cuda.synchronize()
+              if dist:
+                  dist.barrier()
+              torch.cuda.synchronize()
+              cdt = time.perf_counter() - t1
+              net.args.train_ground_crop = 0
+              if dist:
+                  tt = torch.tensor([cdt], device=dev, dtype=torch.float64)
+                  dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                  cdt = float(tt.item())
+              train['with_train_ground_crop'] = {'value': round(B * world * a.train_steps / cdt, 3), 'unit': 'pairs/s',
+                                                 'ms_per_step': round(cdt / a.train_steps * 1e3, 3)}
           if trecs:
               tagg = {}
               for name, ms, fl, by in trecs:

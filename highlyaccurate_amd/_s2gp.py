@@ -373,17 +373,29 @@ class _LocaliseFn(torch.autograd.Function):
     def forward(ctx, model, names, sat_map, grd_img, want_conf, extra, level_first, init_pose, *params):
         sat_feats, _, sat_inv, cs = vgg_forward_nhwc(model.SatFeatureNet, sat_map, want_conf=False, defer_norm=True,
                                                      save_for_backward=True)
-        grd_feats, grd_confs, grd_inv, cg = vgg_forward_nhwc(model.GrdFeatureNet, grd_img, want_conf=want_conf,
+        # args.train_ground_crop (an extension, default 0): train on the image rows that can reach the loss only.  The loss
+        # sees the ground branch through rows h_l/2.. of its maps, so the gradient of every other row is exactly zero and the
+        # rows above `dead_ground_rows` influence neither the loss nor any gradient (the L2_norm scale cancels in
+        # LM_update, forward and backward).  What changes is the 14th element of the train-mode tuple: the returned confidence
+        # maps are then only computed from the crop on (valid from row h_l/2, zero above the crop).
+        skip = 0
+        if getattr(model.args, 'train_ground_crop', 0) and model.level == 3 and getattr(model.args, 'Optimizer', 'LM') == 'LM':
+            skip = dead_ground_rows(grd_img.shape[-2])
+        grd_in = grd_img[:, :, skip:, :].contiguous() if skip else grd_img
+        grd_feats, grd_confs, grd_inv, cg = vgg_forward_nhwc(model.GrdFeatureNet, grd_in, want_conf=want_conf,
                                                              defer_norm=True, save_for_backward=True)
         trace = model.lm_solve(sat_feats, grd_feats, grd_confs, grd_img.shape[-2:], extra, level_first, init_pose,
                                sat_inv, grd_inv, keep_normal_eq=True)
         ctx.model, ctx.names, ctx.extra, ctx.level_first, ctx.init_pose = model, names, extra, level_first, init_pose
         ctx.state = (sat_feats, grd_feats, grd_confs, tuple(grd_img.shape[-2:]), trace.detach(), model.last_normal_eq, sat_inv, grd_inv, cs, cg,
                      model.last_keep)
-        outs = (trace,) + (tuple(grd_confs) if want_conf else ())
+        out_confs = ()
         if want_conf:
-            ctx.mark_non_differentiable(*grd_confs)     # loss_method 0 does not read them; their LM-weight role is in backward()
-        return outs
+            out_confs = tuple(grd_confs)
+            if skip:                                    # full-size maps for the caller, zero above the crop
+                out_confs = tuple(torch.nn.functional.pad(c, (0, 0, skip >> (3 - l), 0)) for l, c in enumerate(grd_confs))
+            ctx.mark_non_differentiable(*out_confs)     # loss_method 0 does not read them; their LM-weight role is in backward()
+        return (trace,) + out_confs
 
     @staticmethod
     def backward(ctx, d_trace, *unused):

@@ -1027,6 +1027,45 @@ def test_dead_ground_rows_elimination_is_exact(monkeypatch):
         assert dev < 2e-6
 
 
+@pytest.mark.parametrize('kw', [dict(), dict(using_weight=1, train_damping=1)])
+def test_training_ground_crop_is_exact(kw):
+    """args.train_ground_crop=1 (an extension): forward(train) + backward on the ground-image rows that can reach the loss.
+    Loss and every parameter gradient must equal the full-image run up to the rounding of the (cancelling) L2_norm scale;
+    the returned confidence maps keep their shape and agree from row h_l/2 on."""
+    from oracle import ref_cpu as O
+    from highlyaccurate_amd.models_kitti import LM_S2GP
+    d = _dev()
+    seed, B = 1, 2
+    sat, grd, gu, gv, gh = O.synth_images(seed + 100, B)
+    res = {}
+    for crop in (0, 1):
+        args = O.default_args(train_ground_crop=crop, **kw)
+        net = LM_S2GP(args)
+        sd = O.synth_model_state(seed, bias_scale=0.02)
+        if kw.get('train_damping'):
+            sd['damping'] = torch.tensor([[0.1, -0.2, 0.15]])
+        net.load_state_dict(sd)
+        net = net.to(d).train()
+        torch.manual_seed(0)
+        r = net(sat.to(d), grd.to(d), gu.to(d), gv.to(d), gh.to(d), mode='train')
+        r[0].backward()
+        res[crop] = (float(r[0].detach()), {k: p.grad.double().cpu() for k, p in net.named_parameters() if p.grad is not None},
+                     [c.detach().cpu() for c in r[13]])
+    (l0, g0, c0), (l1, g1, c1) = res[0], res[1]
+    assert abs(l0 - l1) < 1e-6 * abs(l0)
+    assert set(g0) == set(g1)
+    worst = 0.0
+    for k in g0:
+        e = float((g0[k] - g1[k]).norm() / max(float(g0[k].norm()), 1e-30))
+        worst = max(worst, e)
+    print(f'train_ground_crop {kw}: loss {l0:.6f} / {l1:.6f}, worst gradient rel-l2 deviation {worst:.2e}')
+    assert worst < 2e-5
+    for l in range(3):
+        assert c0[l].shape == c1[l].shape
+        h = c0[l].shape[-2]
+        assert torch.equal(c0[l][..., h // 2:, :], c1[l][..., h // 2:, :])
+
+
 @pytest.mark.parametrize('B,grd_hw,sat_a', [(3, (72, 264), 136), (1, (64, 256), 128), (5, (88, 200), 104)])
 def test_e2e_ragged_shapes_vs_oracle(B, grd_hw, sat_a):
     """Sizes that are multiples of 8 but not of the 8x32 conv tile / the LM pixel tile, odd batch sizes, B = 1:
