@@ -404,10 +404,14 @@ class _LocaliseFn(torch.autograd.Function):
         d_sat, d_grd, d_conf, d_lam = model.lm_backward(sat_feats, grd_feats, grd_confs, grd_hw, trace, neq, d_trace, ctx.extra,
                                                    ctx.level_first, ctx.init_pose, sat_inv, grd_inv, keep)
         sync = getattr(model, 'grad_sync', None)        # optional: overlap the sat-branch all-reduce with the grd backward
-        g_sat = vgg_backward_nhwc(model.SatFeatureNet, cs, d_sat)
+        # LM_update renormalises both projected maps (models_kitti.py:982-990), so the loss does not depend on the per-sample
+        # scale of either extractor's output: d_feat is orthogonal to feat and the L2_norm backward needs no (x . dy) pass
+        inv = getattr(model.args, 'Optimizer', 'LM') == 'LM' and os.environ.get('HLA_L2BWD_FULL', '0') != '1'
+        g_sat = vgg_backward_nhwc(model.SatFeatureNet, cs, d_sat, scale_invariant=inv)
         h1 = sync.start({'SatFeatureNet.' + k: v for k, v in g_sat.items()}) if sync else None
         use_w = model.using_weight and all(c is not None for c in d_conf)
-        g_grd = vgg_backward_nhwc(model.GrdFeatureNet, cg, d_grd, grd_confs if use_w else None, d_conf if use_w else None)
+        g_grd = vgg_backward_nhwc(model.GrdFeatureNet, cg, d_grd, grd_confs if use_w else None, d_conf if use_w else None,
+                                  scale_invariant=inv)
         h2 = sync.start({'GrdFeatureNet.' + k: v for k, v in g_grd.items()}) if sync else None
         if sync:
             sync.finish(h1)

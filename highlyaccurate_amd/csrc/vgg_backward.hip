@@ -367,21 +367,27 @@ static __global__ __launch_bounds__(256) void l2bwd_dot_kernel(const float* __re
   if (threadIdx.x == 0) part[(size_t)b * nblk + k] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
 }
 
-template <typename T>
+template <typename T, bool ORTHO>
 __global__ __launch_bounds__(256) void l2bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                           const double* __restrict__ part, const double* __restrict__ inv,
                                                           T* __restrict__ out, size_t per_sample, int nblk) {
   const int b = blockIdx.x / nblk, k = blockIdx.x % nblk;
   double dot = 0.0;
-  for (int i = 0; i < nblk; ++i) dot += part[(size_t)b * nblk + i];
+  if (!ORTHO)
+    for (int i = 0; i < nblk; ++i) dot += part[(size_t)b * nblk + i];
   const double al = inv[b];
   const float c1 = (float)al, c3 = (float)(al * al * al * dot);
   const float4* px = (const float4*)(x + (size_t)b * per_sample);
   const float4* pd = (const float4*)(dy + (size_t)b * per_sample);
   T* po = out + (size_t)b * per_sample;
   for (size_t i = (size_t)k * 256 + threadIdx.x; i < per_sample / 4; i += (size_t)nblk * 256) {
-    const float4 u = px[i], v = pd[i];
-    store4(po + i * 4, c1 * v.x - c3 * u.x, c1 * v.y - c3 * u.y, c1 * v.z - c3 * u.z, c1 * v.w - c3 * u.w);
+    const float4 v = pd[i];
+    if (ORTHO) {       // HLA_VGG_BWD_SCALE_INVARIANT: x . dy = 0 analytically, dx = dy / ||x||; x is not read
+      store4(po + i * 4, c1 * v.x, c1 * v.y, c1 * v.z, c1 * v.w);
+    } else {
+      const float4 u = px[i];
+      store4(po + i * 4, c1 * v.x - c3 * u.x, c1 * v.y - c3 * u.y, c1 * v.z - c3 * u.z, c1 * v.w - c3 * u.w);
+    }
   }
 }
 
@@ -550,7 +556,7 @@ void vgg_pack_all_T(const hla_vgg_params* prm, char* packed, int dtype, hipStrea
 template <typename T>
 int vgg_backward_t(const float* x, const hla_vgg_params* prm, const char* packedT, int dtype, const char* fw,
                           const float* const feat[4], const double* inv_norm, const float* const d_feat[4],
-                          const float* const conf[4], const float* const d_conf[4], const hla_vgg_grads* gr, char* bw, const BwdPlan& bp, int B, int H, int W, hipStream_t st) {
+                          const float* const conf[4], const float* const d_conf[4], const hla_vgg_grads* gr, char* bw, const BwdPlan& bp, int B, int H, int W, int flags, hipStream_t st) {
   const bool level4 = bp.g_x24 != 0;
   const int NL = level4 ? 4 : 3;
   VggPlan fp;
@@ -573,10 +579,16 @@ int vgg_backward_t(const float* x, const hla_vgg_params* prm, const char* packed
     int nblk = (int)(per[l] / 4 / 256 / 8);
     nblk = nblk < 1 ? 1 : (nblk > 64 ? 64 : nblk);
     double* part = (double*)(bw + bp.dot);
-    hla_prof_begin(K_ELEMWISE, 0, (double)B * per[l] * 8, st);
-    hipLaunchKernelGGL(l2bwd_dot_kernel, dim3(B * nblk), dim3(256), 0, st, feat[l], d_feat[l], part, per[l], nblk);
-    hipLaunchKernelGGL((l2bwd_apply_kernel<T>), dim3(B * nblk), dim3(256), 0, st, feat[l], d_feat[l], part,
-                       inv_norm + (size_t)l * B, (T*)l2out[l], per[l], nblk);
+    if (flags & HLA_VGG_BWD_SCALE_INVARIANT) {
+      hla_prof_begin(K_ELEMWISE, 0, (double)B * per[l] * (4 + sizeof(T)), st);
+      hipLaunchKernelGGL((l2bwd_apply_kernel<T, true>), dim3(B * nblk), dim3(256), 0, st, feat[l], d_feat[l], part,
+                         inv_norm + (size_t)l * B, (T*)l2out[l], per[l], nblk);
+    } else {
+      hla_prof_begin(K_ELEMWISE, 0, (double)B * per[l] * (16 + sizeof(T)), st);
+      hipLaunchKernelGGL(l2bwd_dot_kernel, dim3(B * nblk), dim3(256), 0, st, feat[l], d_feat[l], part, per[l], nblk);
+      hipLaunchKernelGGL((l2bwd_apply_kernel<T, false>), dim3(B * nblk), dim3(256), 0, st, feat[l], d_feat[l], part,
+                         inv_norm + (size_t)l * B, (T*)l2out[l], per[l], nblk);
+    }
     hla_prof_end(st);
   }
 
@@ -706,11 +718,11 @@ int vgg_backward_t(const float* x, const hla_vgg_params* prm, const char* packed
 
 #if HLA_TU_DTYPE >= 0
 template void vgg_pack_all_T<TuT>(const hla_vgg_params* prm, char* packed, int dtype, hipStream_t st);
-template int vgg_backward_t<TuT>(const float* x, const hla_vgg_params* prm, const char* packedT, int dtype, const char* fw, const float* const feat[3], const double* inv_norm, const float* const d_feat[3], const float* const conf[3], const float* const d_conf[3], const hla_vgg_grads* gr, char* bw, const BwdPlan& bp, int B, int H, int W, hipStream_t st);
+template int vgg_backward_t<TuT>(const float* x, const hla_vgg_params* prm, const char* packedT, int dtype, const char* fw, const float* const feat[3], const double* inv_norm, const float* const d_feat[3], const float* const conf[3], const float* const d_conf[3], const hla_vgg_grads* gr, char* bw, const BwdPlan& bp, int B, int H, int W, int flags, hipStream_t st);
 #else
 #define HLA_EXTERN_T(T) \
   extern template void vgg_pack_all_T<T>(const hla_vgg_params* prm, char* packed, int dtype, hipStream_t st); \
-  extern template int vgg_backward_t<T>(const float* x, const hla_vgg_params* prm, const char* packedT, int dtype, const char* fw, const float* const feat[3], const double* inv_norm, const float* const d_feat[3], const float* const conf[3], const float* const d_conf[3], const hla_vgg_grads* gr, char* bw, const BwdPlan& bp, int B, int H, int W, hipStream_t st);
+  extern template int vgg_backward_t<T>(const float* x, const hla_vgg_params* prm, const char* packedT, int dtype, const char* fw, const float* const feat[3], const double* inv_norm, const float* const d_feat[3], const float* const conf[3], const float* const d_conf[3], const hla_vgg_grads* gr, char* bw, const BwdPlan& bp, int B, int H, int W, int flags, hipStream_t st);
 HLA_EXTERN_T(float) HLA_EXTERN_T(bf16) HLA_EXTERN_T(f16)
 
 extern "C" size_t hla_vgg_bwd_workspace_bytes(int B, int H, int W, int level, int dtype) {
@@ -735,7 +747,7 @@ extern "C" int hla_vgg_backward(const float* x, const hla_vgg_params* params, co
                                 const void* fwd_workspace, const float* const feat[4], const double* inv_norm,
                                 const float* const d_feat[4], const float* const conf[4], const float* const d_conf[4],
                                 const hla_vgg_grads* grads, void* workspace, size_t workspace_bytes, int B, int H, int W,
-                                int level, int dtype, hla_stream_t stream) {
+                                int level, int dtype, int flags, hla_stream_t stream) {
   HLA_REQUIRE(x && params && packed_weights_T && fwd_workspace && feat && inv_norm && d_feat && grads && workspace,
               "hla_vgg_backward: null argument");
   HLA_REQUIRE(hla_dtype_ok(dtype), "hla_vgg_backward: bad dtype %d", dtype);
@@ -758,11 +770,11 @@ extern "C" int hla_vgg_backward(const float* x, const hla_vgg_params* params, co
   }
   if (dtype == HLA_BF16)
     return vgg_backward_t<bf16>(x, params, (const char*)packed_weights_T, dtype, (const char*)fwd_workspace, feat, inv_norm,
-                                d_feat, conf, d_conf, grads, (char*)workspace, bp, B, H, W, (hipStream_t)stream);
+                                d_feat, conf, d_conf, grads, (char*)workspace, bp, B, H, W, flags, (hipStream_t)stream);
   if (dtype == HLA_F16)
     return vgg_backward_t<f16>(x, params, (const char*)packed_weights_T, dtype, (const char*)fwd_workspace, feat, inv_norm,
-                               d_feat, conf, d_conf, grads, (char*)workspace, bp, B, H, W, (hipStream_t)stream);
+                               d_feat, conf, d_conf, grads, (char*)workspace, bp, B, H, W, flags, (hipStream_t)stream);
   return vgg_backward_t<float>(x, params, (const char*)packed_weights_T, dtype, (const char*)fwd_workspace, feat, inv_norm,
-                               d_feat, conf, d_conf, grads, (char*)workspace, bp, B, H, W, (hipStream_t)stream);
+                               d_feat, conf, d_conf, grads, (char*)workspace, bp, B, H, W, flags, (hipStream_t)stream);
 }
 #endif
