@@ -116,7 +116,8 @@ def vgg_forward_nhwc(module: 'VGGUnet', x: torch.Tensor, want_conf: bool = True,
     return feats, confs, inv_norm
 
 
-def vgg_backward_nhwc(module: 'VGGUnet', ctx: dict, d_feats, confs=None, d_confs=None, scale_invariant: bool = False):
+def vgg_backward_nhwc(module: 'VGGUnet', ctx: dict, d_feats, confs=None, d_confs=None, scale_invariant: bool = False,
+                      first_row8: int = 0):
     """Backward of ``vgg_forward_nhwc(..., defer_norm=True, save_for_backward=True)``.
     d_feats[l]: NHWC fp32 gradient w.r.t. the L2-normalised map l.  Returns {parameter name: gradient} for the
     22 tensors that receive one at level 3 (conv0..conv14 weights+biases, conv_dec1/2 weights), plus the conf head weights
@@ -170,7 +171,7 @@ def vgg_backward_nhwc(module: 'VGGUnet', ctx: dict, d_feats, confs=None, d_confs
     ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
     rc = lib.hla_vgg_backward(_lib.ptr(x), C.byref(prm), _lib.ptr(cache['buf']), _lib.ptr(ctx['ws']), fp, _lib.ptr(ctx['inv_norm']),
                               dp, cp, dcp, C.byref(gs), _lib.ptr(ws), nbytes, B, H, W, L, dt,
-                              _lib.HLA_VGG_BWD_SCALE_INVARIANT if scale_invariant else 0, _lib.stream_ptr())
+                              _lib.HLA_VGG_BWD_SCALE_INVARIANT if scale_invariant else 0, int(first_row8), _lib.stream_ptr())
     _lib.check(rc, 'hla_vgg_backward')
     for name, g in padded.items():
         co, ci = sd[name].shape[:2]

@@ -16,7 +16,7 @@ LIB_PATH = os.environ.get('HLA_LIB') or os.path.join(HERE, 'libhla.so')   # HLA_
 HLA_F32, HLA_BF16, HLA_F16 = 0, 1, 2
 HLA_VGG_WANT_CONF, HLA_VGG_DEFER_NORM, HLA_VGG_SAVE_FOR_BACKWARD = 1, 2, 4
 HLA_VGG_BWD_SCALE_INVARIANT = 1
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 
 class HlaError(RuntimeError):
@@ -86,7 +86,7 @@ def load() -> C.CDLL:
     lib.hla_vgg_bwd_workspace_bytes.argtypes = [i, i, i, i, i]
     lib.hla_vgg_backward.restype = i
     lib.hla_vgg_backward.argtypes = [vp, C.POINTER(VggParams), vp, vp, C.POINTER(vp), vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(VggGrads),
-                                     vp, sz, i, i, i, i, i, i, vp]
+                                     vp, sz, i, i, i, i, i, i, i, vp]
     lib.hla_resize_bilinear.restype = i
     lib.hla_resize_bilinear.argtypes = [vp, vp, vp, i, vp, vp, i, vp, vp, i, i, i, i, i, vp]
     lib.hla_sat_tile.restype = i

@@ -410,8 +410,11 @@ class _LocaliseFn(torch.autograd.Function):
         g_sat = vgg_backward_nhwc(model.SatFeatureNet, cs, d_sat, scale_invariant=inv)
         h1 = sync.start({'SatFeatureNet.' + k: v for k, v in g_sat.items()}) if sync else None
         use_w = model.using_weight and all(c is not None for c in d_conf)
+        # the ground maps' gradient lives in rows h_l/2.. (all the LM loop reads): the backward skips the rows above its support
+        f8 = (grd_hw[0] // 8) // 2 - (grd_hw[0] - grd_feats[2].shape[1] * 2) // 8
+        f8 = f8 if (inv and f8 >= 4 and model.level == 3 and os.environ.get('HLA_BWD_TRIM', '1') != '0') else 0
         g_grd = vgg_backward_nhwc(model.GrdFeatureNet, cg, d_grd, grd_confs if use_w else None, d_conf if use_w else None,
-                                  scale_invariant=inv)
+                                  scale_invariant=inv, first_row8=f8)
         h2 = sync.start({'GrdFeatureNet.' + k: v for k, v in g_grd.items()}) if sync else None
         if sync:
             sync.finish(h1)

@@ -12,4 +12,4 @@ void hla_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* hla_last_error(void) { return g_err; }
-extern "C" int hla_abi_version(void) { return 11; }
+extern "C" int hla_abi_version(void) { return 12; }

@@ -97,6 +97,9 @@ struct ConvArgs {
   int tiles_x, tiles_y;
   int row_begin;      // first output row this launch computes (even for POOL); rows above it are left untouched.  The halo row
                       // row_begin-1 of the sources is read as it lies in memory (the caller guarantees it was written)
+  int src_row_lo;     // source rows above this one (in THIS launch's full-resolution row coordinates) read as zero: the
+                      // backward's gradient maps are exactly zero -- and unwritten -- above their first row
+  int add_row_lo;     // likewise for add_src, in output row coordinates
   // --- training / backward extras (all optional) ---
   const unsigned char* unpool_idx;  // src1 is a max-pooled map's gradient at half resolution [B,H/2,W/2,C1] and this is
                                     // the forward argmax (0..3): the loader routes it to full resolution (virtual unpool)
@@ -241,7 +244,7 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[MT][NT], const ConvA
       const size_t o = pix0 * a.Cout + cb;
       if (row_ok) RowStager<T, NT>::flush(stage, (T*)a.out_act + o, NPX, nvalid, a.Cout, lane,
                                           a.mask_act ? (const T*)a.mask_act + o : nullptr,
-                                          a.add_src ? (const T*)a.add_src + o : nullptr);
+                                          (a.add_src && yo >= a.add_row_lo) ? (const T*)a.add_src + o : nullptr);
     }
     if (POOL && a.idx_out) {            // training only: recompute which of the 4 window positions won (2*row+col)
 #pragma unroll
@@ -429,7 +432,7 @@ __global__ __launch_bounds__(256, (NT == 1 && !PF_UPFRONT) ? 3 : 2) void conv3x3
       const int hy = pix / HWID, hx = pix - hy * HWID;
       const int y = y0 - 1 + hy, x = x0 - 1 + hx;
       uint4 v = make_uint4(0, 0, 0, 0);
-      if (pix < HPIX && y >= 0 && y < a.H && x >= 0 && x < a.W) {
+      if (pix < HPIX && y >= a.src_row_lo && y < a.H && x >= 0 && x < a.W) {
         const size_t e0 = (((size_t)b * Hs + (y >> sh)) * Ws + (x >> sh)) * Cs + coff;
         v = *(const uint4*)(src + e0);
         if (a.unpool_idx) {          // keep only the elements whose forward argmax is this (y&1, x&1) position

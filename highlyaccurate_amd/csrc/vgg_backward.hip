@@ -56,6 +56,7 @@ struct WgradArgs {
   float* part;                         // [KS][Cout][Cin][9] partial sums
   float* bpart;                        // [KS][Cout] partial bias gradients, or null
   int C1, C2, up1, B, H, W, Cout, Cin, tiles_x, tiles_y, ntile, KS;
+  int row_begin;                       // first pixel row that carries gradient (even with g_unpool); rows above are skipped
 };
 
 constexpr int WG_TH = 4;                                  // pixel tile: 4 rows x 32 px
@@ -98,7 +99,7 @@ __global__ __launch_bounds__(256, CONV_VARIANT == 73 ? 1 : 2) void wgrad_kernel(
   auto tile_origin = [&](int tile, int& b, int& y0, int& x0) {
     int q = tile;
     x0 = (q % a.tiles_x) * 32; q /= a.tiles_x;
-    y0 = (q % a.tiles_y) * WG_TH;
+    y0 = a.row_begin + (q % a.tiles_y) * WG_TH;
     b = q / a.tiles_y;
   };
   auto load_x = [&](int tile, int lo, int hi) {
@@ -230,6 +231,7 @@ struct Wgrad0Args {
   float* part;           // [KS][2 row-halves][64][32]
   float* bpart;          // [KS][2][64]
   int B, H, W, tiles_x, tiles_y, ntile, KS;
+  int row_begin;         // first pixel row that carries gradient
 };
 
 template <typename T>
@@ -252,7 +254,7 @@ __global__ __launch_bounds__(256) void wgrad0_kernel(Wgrad0Args a) {
     const int tx = q % a.tiles_x; q /= a.tiles_x;
     const int ty = q % a.tiles_y;
     const int b = q / a.tiles_y;
-    const int y0 = ty * WG_TH, x0 = tx * 32;
+    const int y0 = a.row_begin + ty * WG_TH, x0 = tx * 32;
     __syncthreads();
     for (int e = t; e < 3 * (WG_TH + 2) * IW; e += 256) {
       const int c = e / ((WG_TH + 2) * IW), r = e % ((WG_TH + 2) * IW), iy = r / IW, ix = r % IW;
@@ -556,7 +558,7 @@ void vgg_pack_all_T(const hla_vgg_params* prm, char* packed, int dtype, hipStrea
 template <typename T>
 int vgg_backward_t(const float* x, const hla_vgg_params* prm, const char* packedT, int dtype, const char* fw,
                           const float* const feat[4], const double* inv_norm, const float* const d_feat[4],
-                          const float* const conf[4], const float* const d_conf[4], const hla_vgg_grads* gr, char* bw, const BwdPlan& bp, int B, int H, int W, int flags, hipStream_t st) {
+                          const float* const conf[4], const float* const d_conf[4], const hla_vgg_grads* gr, char* bw, const BwdPlan& bp, int B, int H, int W, int flags, int first_row8, hipStream_t st) {
   const bool level4 = bp.g_x24 != 0;
   const int NL = level4 ? 4 : 3;
   VggPlan fp;
@@ -618,25 +620,27 @@ int vgg_backward_t(const float* x, const hla_vgg_params* prm, const char* packed
   // ---- helpers
   // data gradient of layer l restricted to its input channels [c0, c0+n): a forward conv on the transposed weights
   auto dgrad = [&](int l, int c0, int n, const void* gsrc, const unsigned char* unpool, int Hout, int Wout, void* out,
-                   const void* mask, const void* add, bool pool_sum) {
+                   const void* mask, const void* add, bool pool_sum, int row_begin = 0, int src_lo = 0, int add_lo = 0) {
     ConvArgs a{};
     a.src1 = gsrc; a.C1 = kLayers[l].cout; a.unpool_idx = unpool;
     const int nstage = kLayers[l].cout / KC;
     a.wpk = (const uint4*)(packedT + packed_offset(l, dtype)) + (size_t)(c0 / 32) * nstage * 18 * 64;
     a.out_act = out; a.mask_act = mask; a.add_src = add; a.pool_sum = pool_sum ? 1 : 0;
     a.B = B; a.H = Hout; a.W = Wout; a.Cout = n; a.relu_act = 0;
+    a.row_begin = row_begin > 0 ? row_begin : 0; a.src_row_lo = src_lo > 0 ? src_lo : 0; a.add_row_lo = add_lo > 0 ? add_lo : 0;
     launch_conv<T>(st, a, pool_sum);
   };
   auto wgrad = [&](int l, const void* x1, int C1, const void* x2, int C2, int up1, const void* g, const unsigned char* unpool,
-                   int Hout, int Wout) {
+                   int Hout, int Wout, int row_begin = 0) {
     WgradArgs a{};
     a.x1 = x1; a.x2 = x2; a.C1 = C1; a.C2 = C2; a.up1 = up1; a.g = g; a.g_unpool = unpool;
     a.B = B; a.H = Hout; a.W = Wout; a.Cout = kLayers[l].cout; a.Cin = kLayers[l].cin;
-    a.tiles_x = (Wout + 31) / 32; a.tiles_y = (Hout + WG_TH - 1) / WG_TH; a.ntile = B * a.tiles_x * a.tiles_y;
+    a.row_begin = row_begin > 0 ? row_begin : 0;
+    a.tiles_x = (Wout + 31) / 32; a.tiles_y = (Hout - a.row_begin + WG_TH - 1) / WG_TH; a.ntile = B * a.tiles_x * a.tiles_y;
     a.KS = wgrad_ksplit(a.Cout, a.Cin, a.ntile);
     a.part = (float*)(bw + bp.part);
     a.bpart = (kLayers[l].has_bias && gr->db[l]) ? (float*)(bw + bp.bpart) : nullptr;
-    const double P = (double)B * Hout * Wout;
+    const double P = (double)B * (Hout - a.row_begin) * Wout;
     hla_prof_begin(K_WGRAD, 2.0 * 9 * a.Cin * a.Cout * P, P * (a.Cin + a.Cout) * sizeof(T), st);
     hipLaunchKernelGGL((wgrad_kernel<T>), dim3(a.KS, a.Cin / 64, a.Cout / 64), dim3(256), wg_lds_bytes<T>(), st, a);
     hla_prof_end(st);
@@ -661,30 +665,57 @@ int vgg_backward_t(const float* x, const hla_vgg_params* prm, const char* packed
     dgrad(11, 64, 64, G(bp.g_d3a), nullptr, H, W, G(bp.g_x2p), F(fp.x2r), nullptr, false);         // x2 skip branch
     wgrad(11, F(fp.x21r), 64, F(fp.x2r), 64, 1, G(bp.g_d3a), nullptr, H, W);
   }
+  // Row ranges.  first_row8 = f > 0 is the caller's promise that d_feat[0..2] are zero above rows f / 2f / 4f (the LM loop
+  // only ever reads rows h_l/2.. of the ground maps, so that is where its gradient lives).  The gradient of every activation
+  // is then exactly zero above a first row that follows from the layer graph -- a 3x3 conv widens the support by one row, a 2x
+  // upsample / 2x2 pool halves / doubles it -- and every launch below starts at that row (ConvArgs::row_begin, even where a
+  // pool is involved), reading its sources as zero above THEIR first row (src_row_lo / add_row_lo: those rows are never
+  // written).  With confidence heads (d_conf) the support of the three raw-map gradients starts one row higher.
+  // n_* : first row of a gradient map in its own resolution; all zero (= no trimming) when f == 0.
+  const int f = (level4 || !(flags & HLA_VGG_BWD_SCALE_INVARIANT)) ? 0 : first_row8;   // (the two-pass L2 backward leaves
+                                                                                       //  rounding noise above the support)
+  const int wc = (conf && d_conf) ? 1 : 0;
+  auto ev = [](int v) { return v < 0 ? 0 : (v & ~1); };
+  auto nn = [](int v) { return v < 0 ? 0 : v; };
+  const int n_x21 = f ? 4 * f - wc : 0;                 // H/2
+  const int n_d2a = nn(n_x21 - 1);                      // H/2
+  const int rb_up18 = ev(n_d2a - 1);                    // H/2 rows of the pool_sum launch that produces g_x18
+  const int n_x18 = rb_up18 / 2;                        // H/4   (<= 2f - wc: covers x18's own L2 / conf gradient)
+  const int n_x3p = nn(n_d2a - 1);                      // H/2
+  const int n_d1a = nn(n_x18 - 1);                      // H/4
+  const int rb_up15 = ev(n_d1a - 1);
+  const int n_x15 = rb_up15 / 2;                        // H/8
+  const int n_x8p = nn(n_d1a - 1);                      // H/4
+  const int n_a12 = nn(2 * n_x15 - 1);                  // H/4
+  const int n_a10 = nn(n_a12 - 1);
+  const int n_x8 = nn(n_a10 - 1);                       // H/4
+  const int n_a5 = nn(2 * n_x8 - 1);                    // H/2
+  const int n_x3 = nn(n_a5 - 1);                        // H/2
+  const int n_a0 = nn(2 * n_x3 - 1);                    // H
   // ---- decoder 2 (VGG.py:148-151)
-  dgrad(10, 0, 64, G(bp.g_x21), nullptr, H2, W2, G(bp.g_d2a), F(fp.d2a), nullptr, false);
-  wgrad(10, F(fp.d2a), 64, nullptr, 0, 0, G(bp.g_x21), nullptr, H2, W2);
-  dgrad(9, 0, 128, G(bp.g_d2a), nullptr, H2, W2, G(bp.g_x18), F(fp.x18r), G(bp.l2_18), true);     // up(x18) branch
-  dgrad(9, 128, 64, G(bp.g_d2a), nullptr, H2, W2, G(bp.g_x3p), F(fp.x3), nullptr, false);          // x3 skip branch
-  wgrad(9, F(fp.x18r), 128, F(fp.x3), 64, 1, G(bp.g_d2a), nullptr, H2, W2);
+  dgrad(10, 0, 64, G(bp.g_x21), nullptr, H2, W2, G(bp.g_d2a), F(fp.d2a), nullptr, false, n_d2a, 0, 0);
+  wgrad(10, F(fp.d2a), 64, nullptr, 0, 0, G(bp.g_x21), nullptr, H2, W2, n_x21);
+  dgrad(9, 0, 128, G(bp.g_d2a), nullptr, H2, W2, G(bp.g_x18), F(fp.x18r), G(bp.l2_18), true, rb_up18, n_d2a, 0);   // up(x18) branch
+  dgrad(9, 128, 64, G(bp.g_d2a), nullptr, H2, W2, G(bp.g_x3p), F(fp.x3), nullptr, false, n_x3p, n_d2a, 0);          // x3 skip branch
+  wgrad(9, F(fp.x18r), 128, F(fp.x3), 64, 1, G(bp.g_d2a), nullptr, H2, W2, n_d2a);
   // ---- decoder 1 (VGG.py:144-146)
-  dgrad(8, 0, 128, G(bp.g_x18), nullptr, H4, W4, G(bp.g_d1a), F(fp.d1a), nullptr, false);
-  wgrad(8, F(fp.d1a), 128, nullptr, 0, 0, G(bp.g_x18), nullptr, H4, W4);
-  dgrad(7, 0, 256, G(bp.g_d1a), nullptr, H4, W4, G(bp.g_x15), F(fp.x15r), G(bp.l2_15), true);     // up(x15) branch
-  dgrad(7, 256, 128, G(bp.g_d1a), nullptr, H4, W4, G(bp.g_x8p), F(fp.x8), nullptr, false);        // x8 skip branch
-  wgrad(7, F(fp.x15r), 256, F(fp.x8), 128, 1, G(bp.g_d1a), nullptr, H4, W4);
+  dgrad(8, 0, 128, G(bp.g_x18), nullptr, H4, W4, G(bp.g_d1a), F(fp.d1a), nullptr, false, n_d1a, n_x18, 0);
+  wgrad(8, F(fp.d1a), 128, nullptr, 0, 0, G(bp.g_x18), nullptr, H4, W4, n_x18);
+  dgrad(7, 0, 256, G(bp.g_d1a), nullptr, H4, W4, G(bp.g_x15), F(fp.x15r), G(bp.l2_15), true, rb_up15, n_d1a, 0);   // up(x15) branch
+  dgrad(7, 256, 128, G(bp.g_d1a), nullptr, H4, W4, G(bp.g_x8p), F(fp.x8), nullptr, false, n_x8p, n_d1a, 0);        // x8 skip branch
+  wgrad(7, F(fp.x15r), 256, F(fp.x8), 128, 1, G(bp.g_d1a), nullptr, H4, W4, n_d1a);
   // ---- encoder block 2 (VGG.py:136-141); conv14 is followed by the pool (no ReLU in between)
-  dgrad(6, 0, 256, G(bp.g_x15), idx15, H4, W4, G(bp.g_a12), F(fp.a12), nullptr, false);
-  wgrad(6, F(fp.a12), 256, nullptr, 0, 0, G(bp.g_x15), idx15, H4, W4);
-  dgrad(5, 0, 256, G(bp.g_a12), nullptr, H4, W4, G(bp.g_a10), F(fp.a10), nullptr, false);
-  wgrad(5, F(fp.a10), 256, nullptr, 0, 0, G(bp.g_a12), nullptr, H4, W4);
-  dgrad(4, 0, 128, G(bp.g_a10), nullptr, H4, W4, G(bp.g_x8), F(fp.x8), G(bp.g_x8p), false);
-  wgrad(4, F(fp.x8), 128, nullptr, 0, 0, G(bp.g_a10), nullptr, H4, W4);
+  dgrad(6, 0, 256, G(bp.g_x15), idx15, H4, W4, G(bp.g_a12), F(fp.a12), nullptr, false, n_a12, 2 * n_x15, 0);
+  wgrad(6, F(fp.a12), 256, nullptr, 0, 0, G(bp.g_x15), idx15, H4, W4, 2 * n_x15);
+  dgrad(5, 0, 256, G(bp.g_a12), nullptr, H4, W4, G(bp.g_a10), F(fp.a10), nullptr, false, n_a10, n_a12, 0);
+  wgrad(5, F(fp.a10), 256, nullptr, 0, 0, G(bp.g_a12), nullptr, H4, W4, n_a12);
+  dgrad(4, 0, 128, G(bp.g_a10), nullptr, H4, W4, G(bp.g_x8), F(fp.x8), G(bp.g_x8p), false, n_x8, n_a10, n_x8p);
+  wgrad(4, F(fp.x8), 128, nullptr, 0, 0, G(bp.g_a10), nullptr, H4, W4, n_a10);
   // ---- encoder block 1
-  dgrad(3, 0, 128, G(bp.g_x8), idx8, H2, W2, G(bp.g_a5), F(fp.a5), nullptr, false);
-  wgrad(3, F(fp.a5), 128, nullptr, 0, 0, G(bp.g_x8), idx8, H2, W2);
-  dgrad(2, 0, 64, G(bp.g_a5), nullptr, H2, W2, G(bp.g_x3), F(fp.x3), G(bp.g_x3p), false);
-  wgrad(2, F(fp.x3), 64, nullptr, 0, 0, G(bp.g_a5), nullptr, H2, W2);
+  dgrad(3, 0, 128, G(bp.g_x8), idx8, H2, W2, G(bp.g_a5), F(fp.a5), nullptr, false, n_a5, 2 * n_x8, 0);
+  wgrad(3, F(fp.a5), 128, nullptr, 0, 0, G(bp.g_x8), idx8, H2, W2, 2 * n_x8);
+  dgrad(2, 0, 64, G(bp.g_a5), nullptr, H2, W2, G(bp.g_x3), F(fp.x3), G(bp.g_x3p), false, n_x3, n_a5, n_x3p);
+  wgrad(2, F(fp.x3), 64, nullptr, 0, 0, G(bp.g_a5), nullptr, H2, W2, n_a5);
   // ---- encoder block 0
   if (level4) {      // the conv2 output also fed conv_dec3: materialise unpool(g_x3) + skip gradient once
     const size_t n = (size_t)B * H * W * (64 * sizeof(T) / 16);
@@ -695,17 +726,18 @@ int vgg_backward_t(const float* x, const hla_vgg_params* prm, const char* packed
     dgrad(1, 0, 64, G(bp.g_c2), nullptr, H, W, G(bp.g_a0), F(fp.a0), nullptr, false);
     wgrad(1, F(fp.a0), 64, nullptr, 0, 0, G(bp.g_c2), nullptr, H, W);
   } else {
-    dgrad(1, 0, 64, G(bp.g_x3), idx3, H, W, G(bp.g_a0), F(fp.a0), nullptr, false);
-    wgrad(1, F(fp.a0), 64, nullptr, 0, 0, G(bp.g_x3), idx3, H, W);
+    dgrad(1, 0, 64, G(bp.g_x3), idx3, H, W, G(bp.g_a0), F(fp.a0), nullptr, false, n_a0, 2 * n_x3, 0);
+    wgrad(1, F(fp.a0), 64, nullptr, 0, 0, G(bp.g_x3), idx3, H, W, 2 * n_x3);
   }
   {
     Wgrad0Args a{};
     a.x = x; a.g = G(bp.g_a0); a.B = B; a.H = H; a.W = W;
-    a.tiles_x = (W + 31) / 32; a.tiles_y = (H + WG_TH - 1) / WG_TH; a.ntile = B * a.tiles_x * a.tiles_y;
+    a.row_begin = level4 ? 0 : n_a0;
+    a.tiles_x = (W + 31) / 32; a.tiles_y = (H - a.row_begin + WG_TH - 1) / WG_TH; a.ntile = B * a.tiles_x * a.tiles_y;
     a.KS = a.ntile < 1024 ? a.ntile : 1024;
     a.part = (float*)(bw + bp.part); a.bpart = (float*)(bw + bp.bpart);
     const int lds = WG_TH * 32 * wg_stride<T>() + 3 * (WG_TH + 2) * 48 * 4;
-    const double P = (double)B * H * W;
+    const double P = (double)B * (H - a.row_begin) * W;
     hla_prof_begin(K_WGRAD, 2.0 * 27 * 64 * P, P * (12 + 64 * sizeof(T)), st);
     hipLaunchKernelGGL((wgrad0_kernel<T>), dim3(a.KS), dim3(256), lds, st, a);
     hla_prof_end(st);
@@ -718,11 +750,11 @@ int vgg_backward_t(const float* x, const hla_vgg_params* prm, const char* packed
 
 #if HLA_TU_DTYPE >= 0
 template void vgg_pack_all_T<TuT>(const hla_vgg_params* prm, char* packed, int dtype, hipStream_t st);
-template int vgg_backward_t<TuT>(const float* x, const hla_vgg_params* prm, const char* packedT, int dtype, const char* fw, const float* const feat[3], const double* inv_norm, const float* const d_feat[3], const float* const conf[3], const float* const d_conf[3], const hla_vgg_grads* gr, char* bw, const BwdPlan& bp, int B, int H, int W, int flags, hipStream_t st);
+template int vgg_backward_t<TuT>(const float* x, const hla_vgg_params* prm, const char* packedT, int dtype, const char* fw, const float* const feat[3], const double* inv_norm, const float* const d_feat[3], const float* const conf[3], const float* const d_conf[3], const hla_vgg_grads* gr, char* bw, const BwdPlan& bp, int B, int H, int W, int flags, int first_row8, hipStream_t st);
 #else
 #define HLA_EXTERN_T(T) \
   extern template void vgg_pack_all_T<T>(const hla_vgg_params* prm, char* packed, int dtype, hipStream_t st); \
-  extern template int vgg_backward_t<T>(const float* x, const hla_vgg_params* prm, const char* packedT, int dtype, const char* fw, const float* const feat[3], const double* inv_norm, const float* const d_feat[3], const float* const conf[3], const float* const d_conf[3], const hla_vgg_grads* gr, char* bw, const BwdPlan& bp, int B, int H, int W, int flags, hipStream_t st);
+  extern template int vgg_backward_t<T>(const float* x, const hla_vgg_params* prm, const char* packedT, int dtype, const char* fw, const float* const feat[3], const double* inv_norm, const float* const d_feat[3], const float* const conf[3], const float* const d_conf[3], const hla_vgg_grads* gr, char* bw, const BwdPlan& bp, int B, int H, int W, int flags, int first_row8, hipStream_t st);
 HLA_EXTERN_T(float) HLA_EXTERN_T(bf16) HLA_EXTERN_T(f16)
 
 extern "C" size_t hla_vgg_bwd_workspace_bytes(int B, int H, int W, int level, int dtype) {
@@ -747,11 +779,12 @@ extern "C" int hla_vgg_backward(const float* x, const hla_vgg_params* params, co
                                 const void* fwd_workspace, const float* const feat[4], const double* inv_norm,
                                 const float* const d_feat[4], const float* const conf[4], const float* const d_conf[4],
                                 const hla_vgg_grads* grads, void* workspace, size_t workspace_bytes, int B, int H, int W,
-                                int level, int dtype, int flags, hla_stream_t stream) {
+                                int level, int dtype, int flags, int first_row8, hla_stream_t stream) {
   HLA_REQUIRE(x && params && packed_weights_T && fwd_workspace && feat && inv_norm && d_feat && grads && workspace,
               "hla_vgg_backward: null argument");
   HLA_REQUIRE(hla_dtype_ok(dtype), "hla_vgg_backward: bad dtype %d", dtype);
   HLA_REQUIRE(level == 3 || level == 4, "hla_vgg_backward: level must be 3 or 4");
+  HLA_REQUIRE(first_row8 == 0 || (first_row8 >= 4 && first_row8 < H / 8), "hla_vgg_backward: first_row8 must be 0 or in [4, H/8)");
   const int NLc = level == 4 ? 4 : 3;
   HLA_REQUIRE(B > 0 && H % 8 == 0 && W % 8 == 0, "hla_vgg_backward: H and W must be multiples of 8");
   for (int l = 0; l < kPackedLayers; ++l) HLA_REQUIRE(grads->dw[l], "hla_vgg_backward: dw[%d] missing", l);
@@ -770,11 +803,11 @@ extern "C" int hla_vgg_backward(const float* x, const hla_vgg_params* params, co
   }
   if (dtype == HLA_BF16)
     return vgg_backward_t<bf16>(x, params, (const char*)packed_weights_T, dtype, (const char*)fwd_workspace, feat, inv_norm,
-                                d_feat, conf, d_conf, grads, (char*)workspace, bp, B, H, W, flags, (hipStream_t)stream);
+                                d_feat, conf, d_conf, grads, (char*)workspace, bp, B, H, W, flags, first_row8, (hipStream_t)stream);
   if (dtype == HLA_F16)
     return vgg_backward_t<f16>(x, params, (const char*)packed_weights_T, dtype, (const char*)fwd_workspace, feat, inv_norm,
-                               d_feat, conf, d_conf, grads, (char*)workspace, bp, B, H, W, flags, (hipStream_t)stream);
+                               d_feat, conf, d_conf, grads, (char*)workspace, bp, B, H, W, flags, first_row8, (hipStream_t)stream);
   return vgg_backward_t<float>(x, params, (const char*)packed_weights_T, dtype, (const char*)fwd_workspace, feat, inv_norm,
-                               d_feat, conf, d_conf, grads, (char*)workspace, bp, B, H, W, flags, (hipStream_t)stream);
+                               d_feat, conf, d_conf, grads, (char*)workspace, bp, B, H, W, flags, first_row8, (hipStream_t)stream);
 }
 #endif

@@ -43,7 +43,7 @@ typedef enum hla_dtype {
 } hla_dtype;
 
 const char* hla_last_error(void);
-int hla_abi_version(void);   /* 11 (bumped whenever a struct or signature in this file changes; _lib.py checks it) */
+int hla_abi_version(void);   /* 12 (bumped whenever a struct or signature in this file changes; _lib.py checks it) */
 
 /* ------------------------------------------------------------------------- *
  * VGGUnet.forward  (VGG.py:121-203; L2_norm VGG.py:511-514)
@@ -123,13 +123,18 @@ size_t hla_vgg_bwd_workspace_bytes(int B, int H, int W, int level, int dtype);
  * flags            HLA_VGG_BWD_SCALE_INVARIANT: the consumer of the normalised maps does not depend on their per-sample
  *                  scale (LM_update renormalises both maps, models_kitti.py:982-990), so d_feat[l] is orthogonal to feat[l]
  *                  and the L2_norm Jacobian  dx = a*dy - a^3 (x.dy) x  (a = 1/||x||) reduces to a*dy: the (x.dy) pass and the
- *                  re-read of feat are skipped.  (In the reference that dot product is fp32 rounding noise, ~1e-7 |x||dy|.) */
+ *                  re-read of feat are skipped.  (In the reference that dot product is fp32 rounding noise, ~1e-7 |x||dy|.)
+ * first_row8       0, or f in [4, H/8): a promise that d_feat[0] / d_feat[1] / d_feat[2] (and d_conf) are zero above rows
+ *                  f / 2f / 4f -- the LM loop only reads rows h_l/2.. of the ground maps, so that is where its gradient
+ *                  lives.  Every activation's gradient is then exactly zero above a first row that follows from the layer
+ *                  graph, and the data- and weight-gradient launches skip those rows.  Needs HLA_VGG_BWD_SCALE_INVARIANT;
+ *                  ignored (0) otherwise and at level 4. */
 #define HLA_VGG_BWD_SCALE_INVARIANT 1
 int hla_vgg_backward(const float* x, const hla_vgg_params* params, const void* packed_weights_T,
                      const void* fwd_workspace, const float* const feat[4], const double* inv_norm,
                      const float* const d_feat[4], const float* const conf[4], const float* const d_conf[4],
                      const hla_vgg_grads* grads, void* workspace, size_t workspace_bytes, int B, int H, int W, int level,
-                     int dtype, int flags, hla_stream_t stream);
+                     int dtype, int flags, int first_row8, hla_stream_t stream);
 
 /* ------------------------------------------------------------------------- *
  * Dataset-side satellite tile: KITTI_dataset.py:128-157, Ford_dataset.py:185-209

@@ -1027,6 +1027,39 @@ def test_dead_ground_rows_elimination_is_exact(monkeypatch):
         assert dev < 2e-6
 
 
+@pytest.mark.parametrize('kw', [dict(), dict(using_weight=1, train_damping=1), dict(train_ground_crop=1)])
+def test_backward_row_trimming_is_exact(kw, monkeypatch):
+    """The ground branch's gradient lives in rows h_l/2.. of its three maps; hla_vgg_backward(first_row8) skips, layer by
+    layer, the rows above the support of every activation gradient (exact zeros).  Gradients must equal the untrimmed
+    backward up to the summation order of the weight-gradient partials."""
+    from oracle import ref_cpu as O
+    from highlyaccurate_amd.models_kitti import LM_S2GP
+    d = _dev()
+    seed, B = 2, 2
+    sat, grd, gu, gv, gh = O.synth_images(seed + 100, B)
+    res = {}
+    for trim in ('0', '1'):
+        monkeypatch.setenv('HLA_BWD_TRIM', trim)
+        net = LM_S2GP(O.default_args(**kw))
+        sd = O.synth_model_state(seed, bias_scale=0.02)
+        if kw.get('train_damping'):
+            sd['damping'] = torch.tensor([[0.1, -0.2, 0.15]])
+        net.load_state_dict(sd)
+        net = net.to(d).train()
+        torch.manual_seed(0)
+        r = net(sat.to(d), grd.to(d), gu.to(d), gv.to(d), gh.to(d), mode='train')
+        r[0].backward()
+        res[trim] = {k: p.grad.double().cpu() for k, p in net.named_parameters() if p.grad is not None}
+    assert set(res['0']) == set(res['1'])
+    worst, wk = 0.0, ''
+    for k in res['0']:
+        e = float((res['0'][k] - res['1'][k]).norm() / max(float(res['0'][k].norm()), 1e-30))
+        if e > worst:
+            worst, wk = e, k
+    print(f'backward row trimming {kw}: worst gradient rel-l2 deviation {worst:.2e} ({wk})')
+    assert worst < 2e-5
+
+
 @pytest.mark.parametrize('kw', [dict(), dict(using_weight=1, train_damping=1)])
 def test_training_ground_crop_is_exact(kw):
     """args.train_ground_crop=1 (an extension): forward(train) + backward on the ground-image rows that can reach the loss.
