@@ -73,6 +73,7 @@ def _packed_weights(module: 'VGGUnet', prm, versions, dt: int, device):
     return cache['buf']
 
 
+@_lib.on_device(lambda module, x, *a, **k: x)
 def vgg_forward_nhwc(module: 'VGGUnet', x: torch.Tensor, want_conf: bool = True, defer_norm: bool = False,
                      save_for_backward: bool = False, first_row8: int = 0):
     """Run the three-level extractor.  Returns (feats, confs, inv_norm): lists of NHWC fp32 tensors
@@ -87,6 +88,7 @@ def vgg_forward_nhwc(module: 'VGGUnet', x: torch.Tensor, want_conf: bool = True,
     lib = _lib.load()
     x = x.contiguous().float()
     B, _, H, W = x.shape
+    _lib.same_device(('input', x), ('parameters', module.conv0.weight))
     dt = _dtype_code(module.precision)
     prm, keep, versions = _param_table(module)
     packed = _packed_weights(module, prm, versions, dt, x.device)
@@ -116,6 +118,7 @@ def vgg_forward_nhwc(module: 'VGGUnet', x: torch.Tensor, want_conf: bool = True,
     return feats, confs, inv_norm
 
 
+@_lib.on_device(lambda module, ctx, *a, **k: ctx['x'])
 def vgg_backward_nhwc(module: 'VGGUnet', ctx: dict, d_feats, confs=None, d_confs=None, scale_invariant: bool = False,
                       first_row8: int = 0):
     """Backward of ``vgg_forward_nhwc(..., defer_norm=True, save_for_backward=True)``.

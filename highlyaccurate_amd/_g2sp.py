@@ -68,6 +68,7 @@ class LM_G2SP(nn.Module):
             raise ValueError(f'left_camera_k must be [B,3,3], got {tuple(K.shape)}')
         return cfg, lv, K
 
+    @_lib.on_device(lambda self, sat_feats, *a, **k: sat_feats[0])
     def lm_solve(self, sat_feats, grd_feats, grd_confs, camera_k, ori_hw, init_pose=None, sat_inv_norm=None,
                  grd_inv_norm=None, keep_normal_eq=None):
         """NHWC fp32 feature lists (raw + [L,B] fp64 inverse norms, or already normalised) -> trace [B,N_iters,L,3]."""
@@ -95,6 +96,7 @@ class LM_G2SP(nn.Module):
         self.last_trace, self.last_normal_eq = trace.detach(), neq
         return trace
 
+    @_lib.on_device(lambda self, sat_feats, *a, **k: sat_feats[0])
     def lm_backward(self, sat_feats, grd_feats, grd_confs, camera_k, ori_hw, trace, normal_eq, d_trace, init_pose=None,
                     sat_inv_norm=None, grd_inv_norm=None):
         """d(loss)/d(trace) -> (d_sat[l], d_grd[l], d_conf[l] or None, d_lambda[3]); gradients w.r.t. the normalised maps."""
@@ -120,6 +122,7 @@ class LM_G2SP(nn.Module):
         _lib.check(rc, 'hla_g2s_lm_solve_bwd')
         return d_sat, d_grd, d_conf, d_lambda
 
+    @_lib.on_device(lambda self, sat_map, *a, **k: sat_map)
     def forward(self, sat_map, grd_img_left, left_camera_k, gt_shift_u=None, gt_shift_v=None, gt_heading=None,
                 mode='train', file_name=None, gt_depth=None, init_pose=None):
         """mode='test' -> (shift_lat[B], shift_lon[B], theta[B]) (models_kitti.py:498-499);

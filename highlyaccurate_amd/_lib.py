@@ -16,7 +16,7 @@ LIB_PATH = os.environ.get('HLA_LIB') or os.path.join(HERE, 'libhla.so')   # HLA_
 HLA_F32, HLA_BF16, HLA_F16 = 0, 1, 2
 HLA_VGG_WANT_CONF, HLA_VGG_DEFER_NORM, HLA_VGG_SAVE_FOR_BACKWARD = 1, 2, 4
 HLA_VGG_BWD_SCALE_INVARIANT = 1
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 
 class HlaError(RuntimeError):
@@ -57,18 +57,44 @@ class ProfRecord(C.Structure):
 _lib = None
 
 
+def _check_binary(lib: C.CDLL, path: str) -> None:
+    """Refuse a library that does not match this binding: ABI version, then the size of every struct that crosses the
+    boundary (ctypes structs are positional, so a mismatch would corrupt memory silently)."""
+    lib.hla_abi_version.restype = C.c_int
+    have = lib.hla_abi_version()
+    if have != ABI_VERSION:
+        raise HlaError(f'{path}: ABI version {have}, this binding needs {ABI_VERSION}; rebuild it '
+                       f'(python -m highlyaccurate_amd.build --force)')
+    try:
+        fn = lib.hla_sizeof_struct
+    except AttributeError:
+        raise HlaError(f'{path}: no hla_sizeof_struct export; rebuild it') from None
+    fn.restype, fn.argtypes = C.c_size_t, [C.c_int]
+    for sid, cls in enumerate((VggParams, VggGrads, S2GLevel, S2GConfig, S2GLevelGrad, ProfRecord)):
+        if fn(sid) != C.sizeof(cls):
+            raise HlaError(f'{path}: sizeof({cls.__name__}) is {fn(sid)} in the library and {C.sizeof(cls)} in the binding')
+
+
 def load() -> C.CDLL:
-    """Load libhla.so; build it with hipcc first if it is missing and a compiler is present."""
+    """Load libhla.so.  The binary must have been built from the sources next to it (content hash baked in at build
+    time): a missing or stale one is rebuilt with hipcc when a compiler is present and refused otherwise.  Then the ABI
+    version and struct sizes are compared with this binding's."""
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
-        from . import build as _b
-        _b.build()
+    from . import build as _b
+    if _b.lib_hash(LIB_PATH) != _b.source_hash():
+        if os.environ.get('HLA_LIB'):
+            raise HlaError(f'{LIB_PATH} (HLA_LIB) was not built from the sources in {_b.CSRC}; rebuild the variant')
+        if not _b.have_compiler():
+            what = 'is missing' if not os.path.exists(LIB_PATH) else 'is stale (built from different sources)'
+            raise HlaError(f'{LIB_PATH} {what} and there is no hipcc to rebuild it; highlyaccurate_amd has no fallback path')
+        _b.build(force=True)
     lib = C.CDLL(LIB_PATH)
+    _check_binary(lib, LIB_PATH)
     vp, i, sz = C.c_void_p, C.c_int, C.c_size_t
     lib.hla_last_error.restype = C.c_char_p
-    lib.hla_abi_version.restype = i
+    lib.hla_source_hash.restype = C.c_char_p
     lib.hla_vgg_workspace_bytes.restype = sz
     lib.hla_vgg_workspace_bytes.argtypes = [i, i, i, i, i]
     lib.hla_vgg_forward.restype = i
@@ -141,7 +167,36 @@ def check(rc: int, what: str) -> None:
 
 
 def stream_ptr() -> C.c_void_p:
+    """The CURRENT device's current stream.  The C side launches on whatever device is current, so every Python entry point
+    that reaches it is wrapped in ``on_device`` (below), which makes the tensors' device current first."""
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def on_device(pick):
+    """Decorator: run ``fn`` with the device of ``pick(*args, **kwargs)`` (a tensor) current, so that ``stream_ptr()``, the
+    workspaces allocated inside and the kernels all belong to the device the data lives on -- a model moved to 'cuda:1'
+    without ``torch.cuda.set_device(1)`` would otherwise launch on device 0's stream against device-1 pointers."""
+    import functools
+
+    def deco(fn):
+        @functools.wraps(fn)
+        def wrapper(*a, **k):
+            t = pick(*a, **k)
+            if t is None or not t.is_cuda:
+                return fn(*a, **k)            # fn raises its own "no CPU path" error
+            if torch.cuda.current_device() == t.device.index:
+                return fn(*a, **k)
+            with torch.cuda.device(t.device):
+                return fn(*a, **k)
+        return wrapper
+    return deco
+
+
+def same_device(*named) -> None:
+    """named: (name, tensor-or-None) pairs; all tensors must live on one HIP device."""
+    devs = {(n, str(t.device)) for n, t in named if t is not None}
+    if len({d for _, d in devs}) > 1:
+        raise ValueError('all inputs and the model must be on one device, got ' + ', '.join(f'{n}: {d}' for n, d in sorted(devs)))
 
 
 def require_gpu(t: torch.Tensor, name: str) -> None:

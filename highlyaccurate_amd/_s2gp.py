@@ -205,6 +205,7 @@ class S2GPBase(nn.Module):
         T_FL = extra['T_FL'].to(dev).float().contiguous() if self.ford else None
         return cfg, lv, R_FL, T_FL
 
+    @_lib.on_device(lambda self, sat_feats, *a, **k: sat_feats[0])
     def lm_solve(self, sat_feats, grd_feats, grd_confs, grd_hw, extra=None, level_first=0, init_pose=None,
                  sat_inv_norm=None, grd_inv_norm=None, keep_normal_eq=None):
         """sat_feats/grd_feats: NHWC fp32 lists (L2-normalised, or raw together with their [L,B] fp64
@@ -244,6 +245,7 @@ class S2GPBase(nn.Module):
         self.last_trace, self.last_normal_eq = trace.detach(), neq
         return trace
 
+    @_lib.on_device(lambda self, sat_feats, *a, **k: sat_feats[0])
     def lm_backward(self, sat_feats, grd_feats, grd_confs, grd_hw, trace, normal_eq, d_trace, extra=None, level_first=0,
                     init_pose=None, sat_inv_norm=None, grd_inv_norm=None, keep=None):
         """Backward of ``lm_solve``: d(loss)/d(trace) [B,N,L,3] -> (d_sat[l], d_grd[l], d_conf[l] or None, d_lambda[3]).
@@ -275,6 +277,7 @@ class S2GPBase(nn.Module):
         _lib.check(rc, 'hla_s2g_lm_solve_bwd')
         return d_sat, d_grd, d_conf, d_lambda
 
+    @_lib.on_device(lambda self, sat_map, *a, **k: sat_map)
     def localise(self, sat_map, grd_img, want_conf, extra, level_first, init_pose, return_confs=True):
         """Both feature pyramids (normalisation deferred into the LM sums) + the whole LM loop.
         return_confs=False (mode='test'): the caller does not need full-size confidence maps, so the ground extractor
@@ -285,6 +288,7 @@ class S2GPBase(nn.Module):
                 or grd_img.shape[1] != 3 or sat_map.shape[2] != sat_map.shape[3]:
             raise ValueError(f'expected sat_map [B,3,A,A] and grd_img [B,3,H,W] with one B, got {tuple(sat_map.shape)} '
                              f'and {tuple(grd_img.shape)}')
+        _lib.same_device(('sat_map', sat_map), ('grd_img', grd_img), ('parameters', self.damping))
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
             names = [n for n, _ in self.named_parameters()]
             params = [p for _, p in self.named_parameters()]

@@ -15,12 +15,41 @@ SOURCES = [('capi.hip', -1), ('prof.hip', -1), ('lm_solve.hip', -1), ('lm_backwa
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=fast', '-munsafe-fp-atomics', '-Wno-unused-result']
 
 
-def _stale() -> bool:
-    if not os.path.exists(LIB):
-        return True
-    t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, '..', 'include', 'hla.h')]
-    return any(os.path.getmtime(d) > t for d in deps)
+HASH_MARK = b'HLA_SOURCE_HASH='
+
+
+def source_hash() -> str:
+    """sha256 over everything the library is built from (csrc/*, include/hla.h, the compiler flags).  The build bakes it
+    into the binary (``hla_source_hash()``), so a stale libhla.so is detected by CONTENT: file times do not survive the
+    copy to the GPU box, and *.so is git-ignored but shipped prebuilt."""
+    import hashlib
+    h = hashlib.sha256(' '.join(FLAGS).encode())
+    deps = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(('.hip', '.h')))
+    for d in deps + [os.path.join(HERE, '..', 'include', 'hla.h')]:
+        h.update(os.path.basename(d).encode() + b'\0')
+        h.update(open(d, 'rb').read())
+    return h.hexdigest()
+
+
+def lib_hash(path: str = None):
+    """The source hash baked into a built library, read from the file (no dlopen), or None."""
+    path = path or LIB
+    try:
+        blob = open(path, 'rb').read()
+    except OSError:
+        return None
+    k = blob.find(HASH_MARK)
+    if k < 0:
+        return None
+    return blob[k + len(HASH_MARK):k + len(HASH_MARK) + 64].decode('ascii', 'replace')
+
+
+def have_compiler() -> bool:
+    return os.path.exists(os.environ.get('HIPCC', '/opt/rocm/bin/hipcc'))
+
+
+def _stale(path: str = None) -> bool:
+    return lib_hash(path or LIB) != source_hash()
 
 
 def _resource_table(text: str) -> None:
@@ -61,12 +90,15 @@ def build(force: bool = False, verbose: bool = False, variant: int = 0) -> str:
     if not force and not _stale():
         return LIB
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+    srchash = source_hash()
     objs = []
     procs = []
     os.makedirs(os.path.join(HERE, 'build'), exist_ok=True)
     for s, tu in SOURCES:
         o = os.path.join(HERE, 'build', s.replace('.hip', f'.v{variant}.t{tu + 1}.o'))
         cmd = [hipcc, *FLAGS, f'-DCONV_VARIANT={variant}', f'-DHLA_TU_DTYPE={tu}', '-c', os.path.join(CSRC, s), '-o', o]
+        if s == 'capi.hip':
+            cmd.insert(-4, f'-DHLA_SOURCE_HASH_HEX="{srchash}"')
         if verbose:
             cmd.insert(1, '-Rpass-analysis=kernel-resource-usage')
             print(' '.join(cmd), flush=True)
@@ -80,8 +112,11 @@ def build(force: bool = False, verbose: bool = False, variant: int = 0) -> str:
             _resource_table(out)
         if p.returncode:
             raise RuntimeError(f'hipcc failed on {s}')
-    cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', *objs, '-o', LIB]
+    # link to a temporary name and rename: a concurrent loader never sees a half-written library
+    tmp = LIB + f'.tmp{os.getpid()}'
+    cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', *objs, '-o', tmp]
     subprocess.run(cmd, check=True)
+    os.replace(tmp, LIB)
     return LIB
 
 

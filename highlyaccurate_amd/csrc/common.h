@@ -1,6 +1,7 @@
 // Shared helpers for libhla (gfx950 only).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <stdarg.h>
 #include <stdio.h>
 #include "../../include/hla.h"
@@ -31,6 +32,21 @@ static inline bool hla_dtype_ok(int dtype) { return dtype == HLA_F32 || dtype ==
       return HLA_ERR_ARG;           \
     }                               \
   } while (0)
+
+// hipFuncSetAttribute applies to the CURRENT device: remember per (call site, device) that it was done.  Thread-safe; two
+// threads racing on a first call both set the attribute (idempotent) before either marks it done.
+struct HlaPerDeviceOnce {
+  std::atomic<unsigned long long> mask{0};
+  template <typename F> hipError_t run(F&& f) {
+    int d = 0;
+    (void)hipGetDevice(&d);
+    const unsigned long long bit = 1ull << (d & 63);
+    if (mask.load(std::memory_order_acquire) & bit) return hipSuccess;
+    const hipError_t e = f();
+    if (e == hipSuccess) mask.fetch_or(bit, std::memory_order_release);
+    return e;
+  }
+};
 
 static inline size_t hla_align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 

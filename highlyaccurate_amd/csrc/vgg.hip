@@ -35,11 +35,10 @@ int vgg_forward_t(const float* x, const hla_vgg_params* prm, const char* packed,
     a.B = B; a.H = H; a.W = W; a.tiles_x = (W + 31) / 32; a.tiles_y = (H - a.row_begin + 7) / 8;
     const double P = (double)B * (H - a.row_begin) * W;
     constexpr int lds_bytes = conv02_lds_bytes<T>();
-    static bool attr_set = false;
-    if (!attr_set) {
-      HLA_CHECK_HIP(hipFuncSetAttribute((const void*)conv02_kernel<T, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
-      attr_set = true;
-    }
+    static HlaPerDeviceOnce attr_once;
+    HLA_CHECK_HIP(attr_once.run([] {
+      return hipFuncSetAttribute((const void*)conv02_kernel<T, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+    }));
     hla_prof_begin(K_CONV02, 2.0 * 9 * (3 + 64) * 64 * P, P * (3 * 4 + 16 * sizeof(T)), st);
     hipLaunchKernelGGL((conv02_kernel<T, 2, true>), dim3(a.tiles_x * a.tiles_y * B), dim3(256), lds_bytes, st, a);
     hla_prof_end(st);

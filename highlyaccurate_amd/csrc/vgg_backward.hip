@@ -564,11 +564,10 @@ int vgg_backward_t(const float* x, const hla_vgg_params* prm, const char* packed
   VggPlan fp;
   vgg_plan(B, H, W, dtype, true, &fp, level4);
   constexpr int KC = SB / (int)sizeof(T);
-  static bool attr_set = false;
-  if (!attr_set) {
-    HLA_CHECK_HIP(hipFuncSetAttribute((const void*)wgrad_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, wg_lds_bytes<T>()));
-    attr_set = true;
-  }
+  static HlaPerDeviceOnce attr_once;
+  HLA_CHECK_HIP(attr_once.run([] {
+    return hipFuncSetAttribute((const void*)wgrad_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, wg_lds_bytes<T>());
+  }));
   auto F = [&](size_t off) { return (const void*)(fw + off); };
   auto G = [&](size_t off) { return (void*)(bw + off); };
 

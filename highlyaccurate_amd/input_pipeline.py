@@ -37,6 +37,7 @@ def _bilinear(tx, ty):
     return [1.0, 1.0, 0.0, float(tx), 0.0, 1.0, float(ty), 0.0]
 
 
+@_lib.on_device(lambda sat_u8, *a, **k: sat_u8)
 def _run(sat_u8: torch.Tensor, stages: np.ndarray, crop: int) -> torch.Tensor:
     lib = _lib.load()
     _lib.require_gpu(sat_u8, 'sat_u8')
@@ -108,6 +109,7 @@ def _resample_tables(insize: int, outsize: int, device):
 _table_cache = {}
 
 
+@_lib.on_device(lambda grd_u8, *a, **k: grd_u8)
 def grd_resize(grd_u8: torch.Tensor, out_h: int = 256, out_w: int = 1024) -> torch.Tensor:
     """grd_u8 [B,H,W,3] uint8 on the GPU (e.g. the 375x1242 KITTI frames) -> [B,3,out_h,out_w] fp32 in [0,1]:
     ``transforms.Resize([out_h, out_w])`` + ``ToTensor`` (KITTI_dataset.py:300-311), bit-identical to Pillow."""

@@ -8,6 +8,7 @@ import torch
 from . import _lib
 
 
+@_lib.on_device(lambda image, *a, **k: image)
 def grid_sample(image: torch.Tensor, optical: torch.Tensor, jac: torch.Tensor | None = None):
     """image [N,C,IH,IW]; optical [N,H,W,2] pixel coordinates (x, y); jac [M,N,H,W,2] or None.
     Returns (out [N,C,H,W], jac_out [M,N,C,H,W] or None).  Out-of-bounds samples (and samples exactly on

@@ -9,7 +9,10 @@
  *   - plain pointers + sizes only; all pointers are DEVICE pointers unless marked [host]
  *   - the caller allocates every buffer (PyTorch's caching allocator in practice);
  *     the library never allocates or frees device memory and keeps no global state
- *     except a thread-local last-error string and the opt-in timing log (hla_prof_*)
+ *     except a thread-local last-error string, the opt-in timing log (hla_prof_*) and
+ *     per-device "kernel attribute already set" bits (dynamic-LDS opt-in of two kernels)
+ *   - kernels are launched on the CURRENT device: the caller makes the device that owns the
+ *     buffers and the stream current before the call (highlyaccurate_amd/_lib.py on_device)
  *   - all work is enqueued on the given hipStream_t (passed as void*); no implicit
  *     synchronisation, no host<->device copies except the small [host] structs
  *     passed by value
@@ -43,7 +46,20 @@ typedef enum hla_dtype {
 } hla_dtype;
 
 const char* hla_last_error(void);
-int hla_abi_version(void);   /* 12 (bumped whenever a struct or signature in this file changes; _lib.py checks it) */
+
+/* Bumped whenever a struct or signature in this file changes.  A binding must refuse a library whose
+ * hla_abi_version() differs from the HLA_ABI_VERSION it was written against, and should compare hla_sizeof_struct()
+ * with its own struct sizes (ctypes structs are positional: a mismatch corrupts silently).  highlyaccurate_amd/_lib.py
+ * does both at load time, and rebuilds or refuses a binary whose hla_source_hash() is not the hash of the sources
+ * next to it (the library is git-ignored but shipped prebuilt). */
+#define HLA_ABI_VERSION 13
+int hla_abi_version(void);
+const char* hla_source_hash(void); /* sha256 (hex) of the csrc sources, this header and the compiler flags at build time */
+typedef enum hla_struct_id {
+  HLA_STRUCT_VGG_PARAMS = 0, HLA_STRUCT_VGG_GRADS = 1, HLA_STRUCT_S2G_LEVEL = 2, HLA_STRUCT_S2G_CONFIG = 3,
+  HLA_STRUCT_S2G_LEVEL_GRAD = 4, HLA_STRUCT_PROF_RECORD = 5
+} hla_struct_id;
+size_t hla_sizeof_struct(int id);  /* sizeof of the struct with that hla_struct_id, 0 for an unknown id */
 
 /* ------------------------------------------------------------------------- *
  * VGGUnet.forward  (VGG.py:121-203; L2_norm VGG.py:511-514)

@@ -41,7 +41,7 @@ def test_ctypes_layer_binds_every_declared_symbol_and_rejects_cpu_tensors():
     lib = _lib.load()
     for n in _declared():
         fn = getattr(lib, n)
-        if n not in ('hla_last_error', 'hla_abi_version', 'hla_prof_kernel_name'):
+        if n not in ('hla_last_error', 'hla_abi_version', 'hla_source_hash', 'hla_prof_kernel_name'):
             assert fn.argtypes is not None, f'{n}: argtypes not declared in _lib.py'
     from highlyaccurate_amd.VGG import VGGUnet
     with pytest.raises(_lib.HlaError):                # the product path has no CPU fallback
@@ -68,3 +68,59 @@ def test_header_is_plain_c_and_links_from_a_c_program(tmp_path):
     subprocess.run([gcc, '-std=c99', '-Wall', '-I', os.path.join(ROOT, 'include'), str(src), '-L', lib_dir, '-l:libhla.so',
                     f'-Wl,-rpath,{lib_dir}', '-o', str(exe)], check=True)
     assert subprocess.run([str(exe)]).returncode == 0
+
+
+def _fresh_loader(monkeypatch):
+    from highlyaccurate_amd import _lib
+    monkeypatch.setattr(_lib, '_lib', None)           # force load() to run its checks again (restored afterwards)
+    return _lib
+
+
+def test_stale_binary_is_refused_or_rebuilt(monkeypatch, tmp_path):
+    """*.so is git-ignored but shipped prebuilt, so a binary built from OTHER sources must never be called: load() compares
+    the content hash baked into the library with the hash of the sources next to it."""
+    import shutil
+    from highlyaccurate_amd import build as B
+    good = B.build()
+    assert B.lib_hash(good) == B.source_hash() and not B._stale()
+    # a library whose baked-in hash differs from the sources (here: flip one hex digit inside a copy of the file)
+    stale = tmp_path / 'libhla.so'
+    blob = bytearray(open(good, 'rb').read())
+    k = blob.find(B.HASH_MARK) + len(B.HASH_MARK)
+    blob[k] = ord('0') if blob[k] != ord('0') else ord('1')
+    stale.write_bytes(bytes(blob))
+    assert B.lib_hash(str(stale)) != B.source_hash() and B._stale(str(stale))
+    _lib = _fresh_loader(monkeypatch)
+    monkeypatch.setattr(_lib, 'LIB_PATH', str(stale))
+    monkeypatch.setattr(B, 'have_compiler', lambda: False)
+    with pytest.raises(_lib.HlaError, match='stale'):
+        _lib.load()
+    # with a compiler present the loader rebuilds instead of calling the stale binary
+    called = []
+    monkeypatch.setattr(B, 'have_compiler', lambda: True)
+    monkeypatch.setattr(B, 'build', lambda force=False, **kw: called.append(force) or shutil.copy(good, str(stale)))
+    _lib.load()
+    assert called == [True]
+    # a missing library without a compiler: loud, no fallback
+    _lib = _fresh_loader(monkeypatch)
+    monkeypatch.setattr(_lib, 'LIB_PATH', str(tmp_path / 'nothing.so'))
+    monkeypatch.setattr(B, 'have_compiler', lambda: False)
+    with pytest.raises(_lib.HlaError, match='missing'):
+        _lib.load()
+
+
+def test_abi_version_and_struct_sizes_are_enforced_at_load(monkeypatch):
+    import ctypes as C
+    _lib = _fresh_loader(monkeypatch)
+    monkeypatch.setattr(_lib, 'ABI_VERSION', _lib.ABI_VERSION + 1)
+    with pytest.raises(_lib.HlaError, match='ABI version'):
+        _lib.load()
+    _lib = _fresh_loader(monkeypatch)
+    monkeypatch.undo()
+    _lib = _fresh_loader(monkeypatch)
+
+    class Wider(C.Structure):                          # a binding written against an older/newer struct layout
+        _fields_ = list(_lib.S2GConfig._fields_) + [('extra', C.c_double)]
+    monkeypatch.setattr(_lib, 'S2GConfig', Wider)
+    with pytest.raises(_lib.HlaError, match='sizeof'):
+        _lib.load()
