@@ -27,7 +27,8 @@ if ROOT not in sys.path:
 import torch  # noqa: E402
 
 # dense peaks, /opt/skills/guides/MI355X_MICROARCH.md "Chip-level parameters"
-PEAK_TFLOPS = {'bf16': 2500.0, 'fp16': 2500.0, 'fp32': 157.3}
+# fp16x3: every algorithmic FLOP costs three fp16 MFMA FLOPs, so the ceiling on ALGORITHMIC FLOPs is a third of the fp16 peak
+PEAK_TFLOPS = {'bf16': 2500.0, 'fp16': 2500.0, 'fp32': 157.3, 'fp16x3': 2500.0 / 3}
 PEAK_HBM_GBS = 8000.0
 # conv FLOPs per pair, forward, live outputs at level 3: 272.4 GFLOP
 GFLOP_PER_PAIR_LIVE = 272.4
@@ -67,7 +68,7 @@ def main():
     ap.add_argument('--steps', type=int, default=50)
     ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--batch', type=int, default=32, help='pairs per GPU')
-    ap.add_argument('--precision', default='bf16', choices=['bf16', 'fp16', 'fp32'])
+    ap.add_argument('--precision', default='bf16', choices=['bf16', 'fp16', 'fp32', 'fp16x3'])
     ap.add_argument('--n-iters', type=int, default=None, help='LM iterations (default 5; 10 for --model ford = BASELINE configs[3])')
     ap.add_argument('--grd-hw', type=int, nargs=2, default=[256, 1024], help='ground image size (BASELINE configs[4]: 512 2048)')
     ap.add_argument('--sat-a', type=int, default=512, help='satellite image side (BASELINE configs[4]: 1024)')

@@ -13,7 +13,7 @@ import torch
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('HLA_LIB') or os.path.join(HERE, 'libhla.so')   # HLA_LIB: experiment builds
 
-HLA_F32, HLA_BF16, HLA_F16 = 0, 1, 2
+HLA_F32, HLA_BF16, HLA_F16, HLA_F16X3 = 0, 1, 2, 3
 HLA_VGG_WANT_CONF, HLA_VGG_DEFER_NORM, HLA_VGG_SAVE_FOR_BACKWARD = 1, 2, 4
 HLA_VGG_BWD_SCALE_INVARIANT = 1
 ABI_VERSION = 13

@@ -23,7 +23,7 @@ void hla_prof_end(hipStream_t st);
     }                                                                                    \
   } while (0)
 
-static inline bool hla_dtype_ok(int dtype) { return dtype == HLA_F32 || dtype == HLA_BF16 || dtype == HLA_F16; }
+static inline bool hla_dtype_ok(int dtype) { return dtype == HLA_F32 || dtype == HLA_BF16 || dtype == HLA_F16 || dtype == HLA_F16X3; }
 
 #define HLA_REQUIRE(cond, ...)      \
   do {                              \

@@ -2,7 +2,12 @@
 #pragma once
 // VGG16-U-Net feature extractor on gfx950 matrix cores: VGG.py:13-203, L2_norm VGG.py:511-514.
 //
-// Layout: activations NHWC; T = bf16 (throughput mode, fp32 accumulate) or float (exact-fp32 MFMA, parity mode).
+// Layout: activations NHWC; T = bf16 / f16 (throughput modes, fp32 accumulate), float (exact-fp32 MFMA) or split32
+//   ("fp16x3", the matched-accuracy throughput mode): activations and weights stay fp32 in HBM, and every operand is fed
+//   to the matrix cores as hi + lo = fp16(s x) + fp16(s x - hi) with a power-of-two scale s per tensor and sample, so that
+//   a product costs three v_mfma_f32_32x32x16_f16 (hi hi + hi lo + lo hi, fp32 accumulate) instead of sixteen
+//   v_mfma_f32_32x32x2_f32 passes: fp32-class results (hi + lo carries 23 significand bits, the dropped lo lo term is
+//   2^-24 relative) at 1/3 of the fp16 MFMA rate instead of 1/16.
 //
 // conv3x3_kernel -- implicit GEMM computed as D^T = W * X^T, so a lane owns one output pixel and four
 //   consecutive output channels per accumulator quad:
@@ -24,6 +29,42 @@ typedef _Float16 f16;
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
 using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
+using f16x4 = __attribute__((ext_vector_type(4))) _Float16;
+
+// storage type of the split-fp16 mode: an fp32 in memory, (hi, lo) fp16 pairs in LDS and in the packed weights
+struct split32 {
+  float v;
+  split32() = default;
+  __host__ __device__ explicit split32(float f) : v(f) {}
+  __host__ __device__ explicit operator float() const { return v; }
+};
+// CEPL = elements of one 16-B MFMA operand fragment (what the matrix core consumes); 16 / sizeof(T) = elements of one 16-B
+// piece of an activation map in memory.  They differ only in split mode.
+template <typename T> struct Prec { static constexpr bool SPLIT = false; static constexpr int CEPL = 16 / (int)sizeof(T); };
+template <> struct Prec<split32> { static constexpr bool SPLIT = true; static constexpr int CEPL = 8; };
+
+// Power-of-two scale that maps a tensor whose largest magnitude has the fp32 bit pattern `amax_bits` into [2^14, 2^15]: hi
+// never overflows fp16 (65504) and lo = s x - hi stays a NORMAL fp16 for every |x| > 2^-17 max|x| (smaller values keep an
+// absolute error of 2^-25 / s, i.e. 2^-39 of the maximum).  Scaling by a power of two is exact, so the choice of s never
+// changes a result as long as nothing leaves the normal range.  The exponent is clamped to [-60, 60] so that the product of
+// an activation scale and a weight scale, and its reciprocal, stay finite.
+__device__ __host__ __forceinline__ float split_scale(unsigned amax_bits) {
+  int E = (int)(amax_bits >> 23) & 0xff;
+  E = E < 81 ? 81 : (E > 201 ? 201 : E);
+  const unsigned bits = (unsigned)(127 + 141 - E) << 23;      // 2^(14 - (E - 127))
+  float f;
+  __builtin_memcpy(&f, &bits, 4);
+  return f;
+}
+// four fp32 values -> four (hi, lo) fp16 pairs of s x
+__device__ __forceinline__ void split4(float x0, float x1, float x2, float x3, float s, uint2& hi, uint2& lo) {
+  x0 *= s; x1 *= s; x2 *= s; x3 *= s;
+  const f16 h0 = (f16)x0, h1 = (f16)x1, h2 = (f16)x2, h3 = (f16)x3;     // round to nearest even
+  const f16x4 h = {h0, h1, h2, h3};
+  const f16x4 l = {(f16)(x0 - (float)h0), (f16)(x1 - (float)h1), (f16)(x2 - (float)h2), (f16)(x3 - (float)h3)};
+  hi = __builtin_bit_cast(uint2, h);
+  lo = __builtin_bit_cast(uint2, l);
+}
 
 // Every dtype's kernels are compiled in their own translation unit (build.py passes -DHLA_TU_DTYPE=0|1|2); the
 // dispatcher TU (-1, the default) only declares them.
@@ -36,6 +77,8 @@ typedef float TuT;
 typedef bf16 TuT;
 #elif HLA_TU_DTYPE == 2
 typedef f16 TuT;
+#elif HLA_TU_DTYPE == 3
+typedef split32 TuT;     // forward only (the backward of a split-mode forward runs on the fp32 kernels: same storage)
 #endif
 
 template <typename T> __device__ __forceinline__ void mma16(f32x16& acc, const uint4& w, const uint4& p);
@@ -43,6 +86,9 @@ template <> __device__ __forceinline__ void mma16<bf16>(f32x16& acc, const uint4
   acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w), __builtin_bit_cast(bf16x8, p), acc, 0, 0, 0);
 }
 template <> __device__ __forceinline__ void mma16<f16>(f32x16& acc, const uint4& w, const uint4& p) {
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, w), __builtin_bit_cast(f16x8, p), acc, 0, 0, 0);
+}
+template <> __device__ __forceinline__ void mma16<split32>(f32x16& acc, const uint4& w, const uint4& p) {
   acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, w), __builtin_bit_cast(f16x8, p), acc, 0, 0, 0);
 }
 template <> __device__ __forceinline__ void mma16<float>(f32x16& acc, const uint4& w, const uint4& p) {
@@ -64,12 +110,21 @@ __device__ __forceinline__ void store4(f16* p, float a, float b, float c, float 
 __device__ __forceinline__ void store4(float* p, float a, float b, float c, float d) {
   *(float4*)p = make_float4(a, b, c, d);
 }
+__device__ __forceinline__ void store4(split32* p, float a, float b, float c, float d) {
+  *(float4*)p = make_float4(a, b, c, d);
+}
 __device__ __forceinline__ void store4(unsigned char* p, float a, float b, float c, float d) {
   *(unsigned*)p = (unsigned)a | ((unsigned)b << 8) | ((unsigned)c << 16) | ((unsigned)d << 24);
 }
 __device__ __forceinline__ float to_f32(bf16 v) { return (float)v; }
 __device__ __forceinline__ float to_f32(f16 v) { return (float)v; }
 __device__ __forceinline__ float to_f32(float v) { return v; }
+__device__ __forceinline__ float to_f32(split32 v) { return v.v; }
+__device__ __forceinline__ float wave_max_f32(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
 
 // Workgroups are dealt round-robin to the 8 XCDs (each with its own L2).  Remap the linear id so that every XCD works on
 // a CONTIGUOUS run of tiles: vertically adjacent tiles, which share two halo rows, then hit the same L2.  Bijective for
@@ -108,6 +163,11 @@ struct ConvArgs {
   unsigned char* idx_out;           // POOL (max): argmax position 2*row+col of every pooled element (forward, training)
   int pool_sum;                     // POOL epilogue sums the 2x2 block instead of max (backward of nearest upsample)
   unsigned long long* dbg;          // CONV_VARIANT 40 only: per-wave cycle accounting
+  // --- split-fp16 mode (T = split32) ---
+  const unsigned* amax1;            // [B] fp32 bit pattern of max |src1| per sample (written by the producer's epilogue)
+  const unsigned* amax2;            // likewise for src2, or null; the two sources share one scale
+  unsigned* amax_out;               // [B] atomicMax target for max |out_act| per sample (zeroed before the forward), or null
+  const float* wscale;              // the power-of-two scale baked into wpk (device scalar written by the packer)
 };
 
 constexpr int HWID = 34;   // halo tile width in pixels
@@ -173,9 +233,10 @@ template <typename E, int NT> struct RowStager {
   }
 };
 
+// dsc (split mode): accumulators hold (s_x s_w) * result; 1 otherwise.  red: 8 floats of LDS.
 template <typename T, int MT, int NT, bool POOL>
 __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[MT][NT], const ConvArgs& a, int b, int yrow0, int x0,
-                                              int cb, float* red, char* stage) {
+                                              int cb, float* red, char* stage, float dsc = 1.f) {
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, x = lane & 31, g = lane >> 5;
   const int Ho = POOL ? a.H >> 1 : a.H, Wo = POOL ? a.W >> 1 : a.W;
   constexpr int NPX = POOL ? 16 : 32;
@@ -187,7 +248,7 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[MT][NT], const ConvA
       bias[j][q] = a.bias ? *(const float4*)(a.bias + cb + j * 32 + q * 8 + g * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
   const int xo0 = POOL ? x0 >> 1 : x0;
   const int nvalid = min(NPX, Wo - xo0);              // pixels of this row segment inside the image
-  float ss = 0.f;
+  float ss = 0.f, mx = 0.f;
 #pragma unroll
   for (int i = 0; i < MT; i += (POOL ? 2 : 1)) {
     const int y = yrow0 + i;
@@ -213,6 +274,7 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[MT][NT], const ConvA
               t = fmaxf(t, __shfl_xor(t, 1, 64));
             }
           }
+          if (Prec<T>::SPLIT) t *= dsc;           // exact: a power of two (and > 0, so it commutes with the pooling)
           v[j][q][e] = t;
         }
         v[j][q][0] += bias[j][q].x; v[j][q][1] += bias[j][q].y; v[j][q][2] += bias[j][q].z; v[j][q][3] += bias[j][q].w;
@@ -238,6 +300,7 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[MT][NT], const ConvA
           for (int q = 0; q < 4; ++q) {
             float w0 = v[j][q][0], w1 = v[j][q][1], w2 = v[j][q][2], w3 = v[j][q][3];
             if (a.relu_act) { w0 = fmaxf(w0, 0.f); w1 = fmaxf(w1, 0.f); w2 = fmaxf(w2, 0.f); w3 = fmaxf(w3, 0.f); }
+            if (Prec<T>::SPLIT && lane_ok) mx = fmaxf(fmaxf(mx, fmaxf(fabsf(w0), fabsf(w1))), fmaxf(fabsf(w2), fabsf(w3)));
             RowStager<T, NT>::put(stage, px, j * 32 + q * 8 + g * 4, w0, w1, w2, w3);
           }
       }
@@ -265,14 +328,20 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[MT][NT], const ConvA
       if (row_ok) RowStager<unsigned char, NT>::flush(stage, a.idx_out + pix0 * a.Cout + cb, NPX, nvalid, a.Cout, lane);
     }
   }
-  if (a.sumsq) {
+  const bool want_max = Prec<T>::SPLIT && a.amax_out;          // kernel-uniform
+  if (a.sumsq || want_max) {
     ss = wave_sum_f32(ss);
-    if (lane == 0) red[wv] = ss;
+    if (want_max) mx = wave_max_f32(mx);
+    if (lane == 0) { red[wv] = ss; red[4 + wv] = mx; }
     __syncthreads();
     if (threadIdx.x == 0) {
-      const int np = a.tiles_x * a.tiles_y * gridDim.y;
-      const int tile = (xcd_contiguous(blockIdx.x, gridDim.x) % (a.tiles_x * a.tiles_y)) * gridDim.y + blockIdx.y;
-      a.sumsq[(size_t)b * np + tile] = ((double)red[0] + (double)red[1]) + ((double)red[2] + (double)red[3]);
+      if (a.sumsq) {
+        const int np = a.tiles_x * a.tiles_y * gridDim.y;
+        const int tile = (xcd_contiguous(blockIdx.x, gridDim.x) % (a.tiles_x * a.tiles_y)) * gridDim.y + blockIdx.y;
+        a.sumsq[(size_t)b * np + tile] = ((double)red[0] + (double)red[1]) + ((double)red[2] + (double)red[3]);
+      }
+      if (want_max)      // non-negative floats order like their bit patterns
+        atomicMax(a.amax_out + b, __float_as_uint(fmaxf(fmaxf(red[4], red[5]), fmaxf(red[6], red[7]))));
     }
   }
 }
@@ -370,12 +439,22 @@ __device__ __forceinline__ void stage_mma(f32x16 (&acc)[MT][NT], const char* cur
           else pf[kg][i] = ring.wb[0][kg][0];
         }
       __builtin_amdgcn_sched_barrier(0);
+      if constexpr (Prec<T>::SPLIT) {
+        // fragment 0 = hi, fragment 1 = lo of both operands: hi hi + lo_w hi + hi lo_x (lo lo is 2^-24 relative: dropped)
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+          for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) mma16<T>(acc[i][j], ring.wb[tap % RS][c == 1][j], pf[c == 2][i]);
+      } else {
 #pragma unroll
       for (int kg = 0; kg < 2; ++kg)
 #pragma unroll
         for (int i = 0; i < MT; ++i)
 #pragma unroll
           for (int j = 0; j < NT; ++j) mma16<T>(acc[i][j], ring.wb[tap % RS][kg][j], pf[kg][i]);
+      }
     } else {
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -386,10 +465,20 @@ __device__ __forceinline__ void stage_mma(f32x16 (&acc)[MT][NT], const char* cur
           if (!ABL_NO_LDS) pf[i] = *(const uint4*)(ap + i * HWID * PSTR + kg * 32);
           else pf[i] = ring.wb[0][kg][0];
         }
+        if constexpr (Prec<T>::SPLIT) {
+          // kg 0: the hi pixel fragments against the hi and the lo weights; kg 1: the lo pixel fragments against the hi weights
+#pragma unroll
+          for (int c = 0; c < (kg == 0 ? 2 : 1); ++c)
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+              for (int j = 0; j < NT; ++j) mma16<T>(acc[i][j], ring.wb[tap % RS][c][j], pf[i]);
+        } else {
 #pragma unroll
         for (int i = 0; i < MT; ++i)
 #pragma unroll
           for (int j = 0; j < NT; ++j) mma16<T>(acc[i][j], ring.wb[tap % RS][kg][j], pf[i]);
+        }
       }
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -404,7 +493,7 @@ __global__ __launch_bounds__(256, (NT == 1 && !PF_UPFRONT) ? 3 : 2) void conv3x3
   constexpr int TH = WM * MT, HPIX = (TH + 2) * HWID, BUF = HPIX * PSTR;
   constexpr int NPIECE = (HPIX * 4 + 255) / 256;               // 16-B pieces per thread per stage
   __shared__ __attribute__((aligned(16))) char lds[2 * BUF];
-  __shared__ float red[4];
+  __shared__ float red[8];
 
 #if CONV_VARIANT == 40
   const unsigned long long t_begin = __builtin_readcyclecounter();
@@ -417,6 +506,13 @@ __global__ __launch_bounds__(256, (NT == 1 && !PF_UPFRONT) ? 3 : 2) void conv3x3
   const int y0 = a.row_begin + ty * TH, x0 = tx * 32;
   const int nstage = (a.C1 + a.C2) / KC;
   const int part = t & 3, pbase = t >> 2;   // 256 % 4 == 0: a thread always moves the same 16-B part of a pixel
+  float sx = 1.f, dsc = 1.f;                // split mode: activation scale of this sample, 1 / (activation scale * weight scale)
+  if constexpr (Prec<T>::SPLIT) {
+    unsigned m = a.amax1[b];
+    if (a.amax2) m = max(m, a.amax2[b]);
+    sx = split_scale(m);
+    dsc = 1.f / (sx * *a.wscale);
+  }
 
   auto load_stage = [&](int sg, uint4 (&st)[NPIECE]) {
     const int c0 = sg * KC;
@@ -467,7 +563,14 @@ __global__ __launch_bounds__(256, (NT == 1 && !PF_UPFRONT) ? 3 : 2) void conv3x3
 #pragma unroll
     for (int i = 0; i < NPIECE; ++i) {
       const int pix = pbase + 64 * i;
-      if (pix < HPIX) *(uint4*)(buf + pix * PSTR + part * 16) = st[i];
+      if constexpr (Prec<T>::SPLIT) {
+        // a stage = 16 channels: [pixel][hi: 16 x fp16 | lo: 16 x fp16]; lane half g of the MFMA reads channels 8g..8g+7
+        uint2 hi, lo;
+        split4(__uint_as_float(st[i].x), __uint_as_float(st[i].y), __uint_as_float(st[i].z), __uint_as_float(st[i].w), sx, hi, lo);
+        if (pix < HPIX) { *(uint2*)(buf + pix * PSTR + part * 8) = hi; *(uint2*)(buf + pix * PSTR + 32 + part * 8) = lo; }
+      } else {
+        if (pix < HPIX) *(uint4*)(buf + pix * PSTR + part * 16) = st[i];
+      }
     }
   };
 
@@ -515,7 +618,7 @@ __global__ __launch_bounds__(256, (NT == 1 && !PF_UPFRONT) ? 3 : 2) void conv3x3
   }
   // the loop's last barrier guarantees nobody still reads the halo buffers: reuse them as 4 wave-private stagers
   static_assert(2 * BUF / 4 >= 32 * (NT * 32 * 4 + 16) && (2 * BUF / 4) % 16 == 0, "stager does not fit");
-  conv_epilogue<T, MT, NT, POOL>(acc, a, b, y0 + wm * MT, x0, ntg0 * 32, red, lds + wv * (2 * BUF / 4));
+  conv_epilogue<T, MT, NT, POOL>(acc, a, b, y0 + wm * MT, x0, ntg0 * 32, red, lds + wv * (2 * BUF / 4), dsc);
 #if CONV_VARIANT == 40
   TICK(4)
   if (a.dbg && lane == 0) {
@@ -544,6 +647,10 @@ struct Conv02Args {
   void* a2_out;        // level 4: NHWC T [B,H,W,64] = relu(conv2) before the pool (the skip input of conv_dec3), or null
   int B, H, W, tiles_x, tiles_y;
   int row_begin;       // first conv2 output row (full resolution, even) this launch computes; see ConvArgs::row_begin
+  // --- split-fp16 mode ---
+  const float* wtail;      // the packer's tail: [l] = power-of-two scale of layer l's packed weights, [16] = max_cout sum_k |w0|
+  unsigned* amax_out;      // [B] atomicMax target: max of out_act per sample
+  unsigned* amax_a2_out;   // likewise for a2_out (level 4), or null
 };
 
 template <typename T> constexpr int conv02_lds_bytes() {
@@ -552,12 +659,13 @@ template <typename T> constexpr int conv02_lds_bytes() {
 
 template <typename T, int WD, bool PF_UPFRONT>
 __global__ __launch_bounds__(256, 2) void conv02_kernel(Conv02Args a0) {
-  constexpr int EPL = 16 / sizeof(T), KC = SB / sizeof(T), NSG = 64 / KC, NFRAG = 32 / (2 * EPL);
+  constexpr bool SPLIT = Prec<T>::SPLIT;
+  constexpr int EPL = Prec<T>::CEPL, KC = SB / sizeof(T), NSG = 64 / KC, NFRAG = 32 / (2 * EPL), NH = SPLIT ? 2 : 1;
   constexpr int MT = 4, NT = 1, WN = 2, TH = 8, HPIX = (TH + 2) * HWID, BUF = HPIX * PSTR, IW = 36, IH = 12;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* lds = smem;                                  // NSG halo buffers (all of conv0's 64 channels)
   float* in = (float*)(smem + NSG * BUF);            // [3][12][36] input patch
-  __shared__ float red[4];
+  __shared__ float red[8];
 
   const int t = threadIdx.x, lane = t & 63, wv = t >> 6, wm = wv / WN, wn = wv % WN;
   int bid = blockIdx.x;                    // (the XCD-contiguous order measured 2-3 % slower for this kernel)
@@ -573,18 +681,26 @@ __global__ __launch_bounds__(256, 2) void conv02_kernel(Conv02Args a0) {
   ring.prime();
 
   // phase A: input patch (2-pixel border) -> LDS
+  float amx = 0.f;
   for (int e = t; e < 3 * IH * IW; e += 256) {
     const int c = e / (IH * IW), r = e % (IH * IW), iy = r / IW, ix = r % IW;
     const int y = y0 - 2 + iy, xx = x0 - 2 + ix;
     float v = 0.f;
     if (y >= 0 && y < a0.H && xx >= 0 && xx < a0.W) v = a0.x[(((size_t)b * 3 + c) * a0.H + y) * a0.W + xx];
     in[e] = v;
+    if (SPLIT) amx = fmaxf(amx, fabsf(v));
   }
-  uint4 wf0[2][NFRAG];
+  uint4 wf0[2][NFRAG][NH];          // split mode: [..][0] = hi, [..][1] = lo
 #pragma unroll
   for (int j = 0; j < 2; ++j)
 #pragma unroll
-    for (int f = 0; f < NFRAG; ++f) wf0[j][f] = a0.w0[(j * NFRAG + f) * 64 + lane];
+    for (int f = 0; f < NFRAG; ++f)
+#pragma unroll
+      for (int h = 0; h < NH; ++h) wf0[j][f][h] = a0.w0[((j * NFRAG + f) * NH + h) * 64 + lane];
+  if (SPLIT) {
+    amx = wave_max_f32(amx);
+    if (lane == 0) red[4 + wv] = amx;
+  }
   __syncthreads();
 
   // phase B: conv0 on the 10x34 halo pixels, 32 pixels per MFMA tile, straight into the conv2 halo buffers
@@ -593,6 +709,24 @@ __global__ __launch_bounds__(256, 2) void conv02_kernel(Conv02Args a0) {
   for (int j = 0; j < 2; ++j)
 #pragma unroll
     for (int q = 0; q < 4; ++q) bias0[j][q] = *(const float4*)(a0.b0 + j * 32 + q * 8 + g * 4);
+  // split mode: every scale is local to this block (a power-of-two scale never changes a result).  Input patch: from its own
+  // maximum.  relu(conv0): from the bound  max_co sum_k |w0[co][k]| * max |x| + max |b0|  (it is split into hi / lo while it is
+  // produced, before its true maximum could be known; the bound is a few binades loose, the window is 17 binades wide).
+  float s_in = 1.f, s_a0 = 1.f, d0 = 1.f, dsc2 = 1.f;
+  if constexpr (SPLIT) {
+    const float m = fmaxf(fmaxf(red[4], red[5]), fmaxf(red[6], red[7]));
+    float bm = 0.f;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        bm = fmaxf(fmaxf(bm, fmaxf(fabsf(bias0[j][q].x), fabsf(bias0[j][q].y))), fmaxf(fabsf(bias0[j][q].z), fabsf(bias0[j][q].w)));
+    bm = wave_max_f32(bm);
+    s_in = split_scale(__float_as_uint(m));
+    s_a0 = split_scale(__float_as_uint(a0.wtail[16] * m + bm));
+    d0 = 1.f / (s_in * a0.wtail[0]);
+    dsc2 = 1.f / (s_a0 * a0.wtail[1]);
+  }
   for (int m = wv; m * 32 < (CONV_VARIANT == 95 ? 0 : HPIX); m += 4) {   // (ablation 95: no conv0 phase)
     const int p = m * 32 + x, pc = p < HPIX ? p : HPIX - 1;
     const int hy = pc / HWID, hx = pc - hy * HWID;
@@ -604,7 +738,7 @@ __global__ __launch_bounds__(256, 2) void conv02_kernel(Conv02Args a0) {
       for (int r = 0; r < 16; ++r) c0[j][r] = 0.f;
 #pragma unroll
     for (int f = 0; f < NFRAG; ++f) {
-      T e[EPL];
+      float ev[EPL];
 #pragma unroll
       for (int jj = 0; jj < EPL; ++jj) {
         // this lane's k is klo (lanes 0-31) or khi (lanes 32-63): select the OFFSET, then read once
@@ -614,11 +748,27 @@ __global__ __launch_bounds__(256, 2) void conv02_kernel(Conv02Args a0) {
         float v = ib[g ? oh : ol];
         if (kh >= 27 && g) v = 0.f;                          // padded k (27..31) only occurs in the upper half
         if (kl >= 27 && !g) v = 0.f;
-        e[jj] = (T)v;
+        ev[jj] = v;
       }
-      const uint4 pf = __builtin_bit_cast(uint4, e);
+      if constexpr (SPLIT) {
+        uint2 h0, l0, h1, l1;
+        split4(ev[0], ev[1], ev[2], ev[3], s_in, h0, l0);
+        split4(ev[4], ev[5], ev[6], ev[7], s_in, h1, l1);
+        const uint4 phi = make_uint4(h0.x, h0.y, h1.x, h1.y), plo = make_uint4(l0.x, l0.y, l1.x, l1.y);
 #pragma unroll
-      for (int j = 0; j < 2; ++j) mma16<T>(c0[j], wf0[j][f], pf);
+        for (int j = 0; j < 2; ++j) {
+          mma16<T>(c0[j], wf0[j][f][0], phi);
+          mma16<T>(c0[j], wf0[j][f][NH - 1], phi);
+          mma16<T>(c0[j], wf0[j][f][0], plo);
+        }
+      } else {
+        T e[EPL];
+#pragma unroll
+        for (int jj = 0; jj < EPL; ++jj) e[jj] = (T)ev[jj];
+        const uint4 pf = __builtin_bit_cast(uint4, e);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) mma16<T>(c0[j], wf0[j][f][0], pf);
+      }
     }
     // conv2 zero-pads conv0's OUTPUT map: halo pixels outside the image are 0, not conv0 of padded input
     const int yy = y0 - 1 + hy, xx = x0 - 1 + hx;
@@ -630,10 +780,18 @@ __global__ __launch_bounds__(256, 2) void conv02_kernel(Conv02Args a0) {
         for (int q = 0; q < 4; ++q) {
           const int co = j * 32 + q * 8 + g * 4;
           const float4 bb = bias0[j][q];
-          float v0 = fmaxf(c0[j][q * 4 + 0] + bb.x, 0.f), v1 = fmaxf(c0[j][q * 4 + 1] + bb.y, 0.f);
-          float v2 = fmaxf(c0[j][q * 4 + 2] + bb.z, 0.f), v3 = fmaxf(c0[j][q * 4 + 3] + bb.w, 0.f);
+          float v0 = fmaxf(c0[j][q * 4 + 0] * d0 + bb.x, 0.f), v1 = fmaxf(c0[j][q * 4 + 1] * d0 + bb.y, 0.f);
+          float v2 = fmaxf(c0[j][q * 4 + 2] * d0 + bb.z, 0.f), v3 = fmaxf(c0[j][q * 4 + 3] * d0 + bb.w, 0.f);
           if (!inside) v0 = v1 = v2 = v3 = 0.f;
-          store4((T*)(lds + (co / KC) * BUF + p * PSTR) + (co % KC), v0, v1, v2, v3);
+          if constexpr (SPLIT) {
+            uint2 hi, lo;
+            split4(v0, v1, v2, v3, s_a0, hi, lo);
+            char* px = lds + (co / KC) * BUF + p * PSTR + (co % KC) * 2;
+            *(uint2*)px = hi;
+            *(uint2*)(px + 32) = lo;
+          } else {
+            store4((T*)(lds + (co / KC) * BUF + p * PSTR) + (co % KC), v0, v1, v2, v3);
+          }
         }
     }
   }
@@ -644,9 +802,19 @@ __global__ __launch_bounds__(256, 2) void conv02_kernel(Conv02Args a0) {
     for (int e = t; e < TH * 32 * PPP; e += 256) {
       const int pxl = e / PPP, piece = e % PPP, sgi = piece / 4, part = piece % 4;
       const int r = pxl / 32, c = pxl % 32, yy = y0 + r, xx = x0 + c;
-      if (yy < a0.H && xx < a0.W)
-        *(uint4*)((char*)a0.a0_out + (((size_t)b * a0.H + yy) * a0.W + xx) * 64 * sizeof(T) + piece * 16) =
-            *(const uint4*)(lds + sgi * BUF + ((r + 1) * HWID + c + 1) * PSTR + part * 16);
+      if (yy < a0.H && xx < a0.W) {
+        char* dst = (char*)a0.a0_out + (((size_t)b * a0.H + yy) * a0.W + xx) * 64 * sizeof(T) + piece * 16;
+        const char* px = lds + sgi * BUF + ((r + 1) * HWID + c + 1) * PSTR;
+        if constexpr (SPLIT) {      // what conv2 actually consumes: (hi + lo) / s, 23 of relu(conv0)'s 24 significand bits
+          const f16x4 h = __builtin_bit_cast(f16x4, *(const uint2*)(px + part * 8));
+          const f16x4 l = __builtin_bit_cast(f16x4, *(const uint2*)(px + 32 + part * 8));
+          const float is = 1.f / s_a0;
+          *(float4*)dst = make_float4(((float)h[0] + (float)l[0]) * is, ((float)h[1] + (float)l[1]) * is,
+                                      ((float)h[2] + (float)l[2]) * is, ((float)h[3] + (float)l[3]) * is);
+        } else {
+          *(uint4*)dst = *(const uint4*)(px + part * 16);
+        }
+      }
     }
   }
 
@@ -664,14 +832,15 @@ __global__ __launch_bounds__(256, 2) void conv02_kernel(Conv02Args a0) {
 
   ConvArgs a{};
   a.bias = a0.b2; a.out_act = a0.out_act; a.B = a0.B; a.H = a0.H; a.W = a0.W; a.Cout = 64; a.relu_act = 1;
-  a.tiles_x = a0.tiles_x; a.tiles_y = a0.tiles_y; a.idx_out = a0.idx_out;
+  a.tiles_x = a0.tiles_x; a.tiles_y = a0.tiles_y; a.idx_out = a0.idx_out; a.amax_out = a0.amax_out;
   __syncthreads();   // all waves are done with the halo buffers; reuse them as wave-private stagers
   if (a0.a2_out) {   // the epilogue only reads the accumulators: run it twice, un-pooled first
     ConvArgs f = a;
-    f.out_act = a0.a2_out; f.idx_out = nullptr;
-    conv_epilogue<T, MT, NT, false>(acc, f, b, y0 + wm * MT, x0, wn * 32, red, lds + wv * (NSG * BUF / 4));
+    f.out_act = a0.a2_out; f.idx_out = nullptr; f.amax_out = a0.amax_a2_out;
+    conv_epilogue<T, MT, NT, false>(acc, f, b, y0 + wm * MT, x0, wn * 32, red, lds + wv * (NSG * BUF / 4), dsc2);
+    if (SPLIT) __syncthreads();     // `red` is reused by the second epilogue's maximum
   }
-  conv_epilogue<T, MT, NT, true>(acc, a, b, y0 + wm * MT, x0, wn * 32, red, lds + wv * (NSG * BUF / 4));
+  conv_epilogue<T, MT, NT, true>(acc, a, b, y0 + wm * MT, x0, wn * 32, red, lds + wv * (NSG * BUF / 4), dsc2);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -707,6 +876,55 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, T* __restrict__
     }
     out[e] = (T)v;
   }
+}
+
+// Split-fp16 packing: the same fragment order with the two k-groups of a stage replaced by (hi, lo) of ONE 16-channel
+// k-group, elements fp16 of s_w * w:
+//   generic: idx = ((((nt*nstage + sg)*9 + tap)*2 + hl)*64 + lane)*8 + j,  cout = nt*32 + (lane&31), cin = sg*16 + (lane>>5)*8 + j
+//   conv0:   idx = (((nt*2 + f)*2 + hl)*64 + lane)*8 + j,                   k = f*16 + (lane>>5)*8 + j  (k = cin*9+tap, <27)
+// wmax_bits = fp32 bit pattern of max |w| (absmax_kernel); thread 0 of block 0 publishes the scale for the conv kernels.
+static __global__ void pack_weights_split_kernel(const float* __restrict__ w, f16* __restrict__ out, int Cout, int Cin, int first,
+                                          const unsigned* __restrict__ wmax_bits, float* __restrict__ scale_out) {
+  const float sw = split_scale(*wmax_bits);
+  if (blockIdx.x == 0 && threadIdx.x == 0) *scale_out = sw;
+  const size_t total = first == 1 ? (size_t)(Cout / 32) * 2 * 2 * 64 * 8 : (size_t)Cout * Cin * 9 * 2;
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+    size_t r = e;
+    const int j = r % 8; r /= 8;
+    const int lane = r % 64; r /= 64;
+    const int hl = r % 2; r /= 2;
+    float v = 0.f;
+    if (first == 1) {
+      const int f = r % 2; r /= 2;
+      const int nt = (int)r;
+      const int k = f * 16 + (lane >> 5) * 8 + j, cout = nt * 32 + (lane & 31);
+      if (k < 27) v = w[(size_t)cout * 27 + k];
+    } else {
+      const int tap = r % 9; r /= 9;
+      const int nsg = Cin / 16;
+      const int sg = r % nsg; r /= nsg;
+      const int nt = (int)r;
+      const int cout = nt * 32 + (lane & 31), cin = sg * 16 + (lane >> 5) * 8 + j;
+      v = w[((size_t)cout * Cin + cin) * 9 + tap];
+    }
+    v *= sw;
+    const f16 h = (f16)v;
+    out[e] = hl ? (f16)(v - (float)h) : h;
+  }
+}
+// max |w| (as fp32 bits) and, for conv0, max over output channels of sum_k |w[co][k]| (row = 27): both atomicMax'ed into
+// zero-initialised words
+static __global__ void absmax_kernel(const float* __restrict__ w, size_t n, int row, unsigned* __restrict__ amax, unsigned* __restrict__ l1max) {
+  float m = 0.f;
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) m = fmaxf(m, fabsf(w[e]));
+  m = wave_max_f32(m);
+  if ((threadIdx.x & 63) == 0) atomicMax(amax, __float_as_uint(m));
+  if (l1max && blockIdx.x == 0)
+    for (size_t r0 = threadIdx.x; r0 * row < n; r0 += blockDim.x) {
+      float s = 0.f;
+      for (int k = 0; k < row; ++k) s += fabsf(w[r0 * row + k]);
+      atomicMax(l1max, __float_as_uint(s));
+    }
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -1,16 +1,32 @@
 // VGG16-U-Net forward: host orchestration (kernels live in conv_kernels.h).  VGG.py:13-203, 511-514.
 #include "conv_kernels.h"
 #include "vgg_layers.h"
+#include <type_traits>
 
 template <typename T>
 void vgg_pack_all(const hla_vgg_params* prm, char* packed, int dtype, hipStream_t st) {
+  // split mode: the tail behind the last layer holds float[16] per-layer weight scales, float[16..31] (slot 16 = conv0's
+  // L1 bound) and 32 scratch words for the two reductions
+  float* tail = (float*)(packed + packed_offset(kAllLayers, dtype));
+  unsigned* scratch = (unsigned*)tail + 32;
+  if (Prec<T>::SPLIT) (void)hipMemsetAsync(tail, 0, kPackTailBytes, st);
   for (int l = 0; l < kAllLayers; ++l) {
     if (l >= kPackedLayers && !prm->w[l]) continue;        // conv_dec3.* only when the caller supplies its padded weights
     const size_t n = l == 0 ? (size_t)2 * 32 * 32 : (size_t)kLayers[l].cin * kLayers[l].cout * 9;
     const int grid = (int)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024);
     hla_prof_begin(K_PACK, 0, (double)n * (4 + sizeof(T)), st);
-    hipLaunchKernelGGL((pack_weights_kernel<T>), dim3(grid), dim3(256), 0, st, prm->w[l],
-                       (T*)(packed + packed_offset(l, dtype)), kLayers[l].cout, kLayers[l].cin, l == 0 ? 1 : 0);
+    if constexpr (Prec<T>::SPLIT) {
+      const size_t nw = (size_t)kLayers[l].cin * kLayers[l].cout * 9;
+      const int g1 = (int)((nw + 255) / 256 < 256 ? (nw + 255) / 256 : 256);
+      hipLaunchKernelGGL(absmax_kernel, dim3(g1), dim3(256), 0, st, prm->w[l], nw, 27, scratch + l,
+                         l == 0 ? (unsigned*)tail + 16 : (unsigned*)nullptr);
+      hipLaunchKernelGGL(pack_weights_split_kernel, dim3(grid), dim3(256), 0, st, prm->w[l],
+                         (f16*)(packed + packed_offset(l, dtype)), kLayers[l].cout, kLayers[l].cin, l == 0 ? 1 : 0,
+                         (const unsigned*)(scratch + l), tail + l);
+    } else {
+      hipLaunchKernelGGL((pack_weights_kernel<T>), dim3(grid), dim3(256), 0, st, prm->w[l],
+                         (T*)(packed + packed_offset(l, dtype)), kLayers[l].cout, kLayers[l].cin, l == 0 ? 1 : 0);
+    }
     hla_prof_end(st);
   }
 }
@@ -23,12 +39,18 @@ int vgg_forward_t(const float* x, const hla_vgg_params* prm, const char* packed,
   const int NL = level4 ? 4 : 3;
   auto W_ = [&](int l) { return (const uint4*)(packed + packed_offset(l, dtype)); };
   char* w = ws;
+  constexpr bool SPLIT = Prec<T>::SPLIT;
+  const float* wtail = (const float*)(packed + packed_offset(kAllLayers, dtype));       // split mode: weight scales
+  unsigned* amax = (unsigned*)(w + pl.amax);                                           // split mode: [slot][B]
+  auto AM = [&](int slot) { return (SPLIT && slot >= 0) ? amax + (size_t)slot * B : (unsigned*)nullptr; };
+  if (SPLIT) HLA_CHECK_HIP(hipMemsetAsync(amax, 0, (size_t)kAmaxSlots * B * sizeof(unsigned), st));
   // conv0 + conv2 + pool fused (VGG.py:123-128): relu(x3)
   {
     Conv02Args a{};
     a.x = x; a.w0 = W_(0); a.b0 = prm->b[0]; a.w2 = W_(1); a.b2 = prm->b[1]; a.out_act = w + pl.x3;
     if (flags & HLA_VGG_SAVE_FOR_BACKWARD) { a.a0_out = w + pl.a0; a.idx_out = (unsigned char*)(w + pl.idx3); }
     if (level4) a.a2_out = w + pl.x2r;
+    a.wtail = wtail; a.amax_out = AM(AM_X3); a.amax_a2_out = level4 ? AM(AM_X2) : nullptr;
     // (first_row8, see below: x3 is needed from row 4f-16 on = conv2 row 8f-32)
     const int f0 = (level4 || (flags & HLA_VGG_SAVE_FOR_BACKWARD)) ? 0 : first_row8;
     a.row_begin = f0 ? 8 * f0 - 32 : 0;
@@ -55,6 +77,12 @@ int vgg_forward_t(const float* x, const hla_vgg_params* prm, const char* packed,
     a.out_act = act; a.out_raw = raw; a.sumsq = ss; a.B = B; a.H = H_; a.W = W_h; a.Cout = kLayers[l].cout;
     a.relu_act = relu;
     a.row_begin = row_begin < 0 ? 0 : row_begin;
+    if (SPLIT) {      // which per-sample maxima the layer reads (its one or two sources) and writes (its activation output)
+      static const signed char kAm[13][3] = {{-1, -1, -1}, {-1, -1, -1}, {AM_X3, -1, AM_A5}, {AM_A5, -1, AM_X8}, {AM_X8, -1, AM_A10},
+                                             {AM_A10, -1, AM_A12}, {AM_A12, -1, AM_X15}, {AM_X15, AM_X8, AM_D1A}, {AM_D1A, -1, AM_X18},
+                                             {AM_X18, AM_X3, AM_D2A}, {AM_D2A, -1, AM_X21}, {AM_X21, AM_X2, AM_D3A}, {AM_D3A, -1, AM_X24}};
+      a.amax1 = AM(kAm[l][0]); a.amax2 = AM(kAm[l][1]); a.amax_out = AM(kAm[l][2]); a.wscale = wtail + l;
+    }
     launch_conv<T>(st, a, pool);
     if (norm_level >= 0)      // sum-of-squares partials actually written by this launch: one per (tile, 128-cout block)
       np_used[norm_level] = ((W_h + 31) / 32) * ((H_ - a.row_begin + 7) / 8) * (a.Cout >= 128 ? a.Cout / 128 : 1);
@@ -94,16 +122,17 @@ int vgg_forward_t(const float* x, const hla_vgg_params* prm, const char* packed,
   }
   // confidence heads on the ReLU'd maps
   if ((flags & HLA_VGG_WANT_CONF) && conf) {
-    const T* acts[4] = {(const T*)(w + pl.x15r), (const T*)(w + pl.x18r), (const T*)(w + pl.x21r), (const T*)(w + pl.x24r)};
+    using CT = std::conditional_t<SPLIT, float, T>;      // split mode stores fp32 activations: the heads run in plain fp32
+    const CT* acts[4] = {(const CT*)(w + pl.x15r), (const CT*)(w + pl.x18r), (const CT*)(w + pl.x21r), (const CT*)(w + pl.x24r)};
     const int Cs[4] = {256, 128, 64, 64}, hs[4] = {H / 8, H / 4, H / 2, H}, wsz[4] = {W / 8, W / 4, W / 2, W};
     for (int l = 0; l < NL; ++l) {
       if (!conf[l]) continue;
-      constexpr int EPL = 16 / sizeof(T);
+      constexpr int EPL = 16 / sizeof(CT);
       const int ppb = 256 / (Cs[l] / EPL);
       const size_t npix = (size_t)B * hs[l] * wsz[l];
       const int grid = (int)((npix + ppb - 1) / ppb < 4096 ? (npix + ppb - 1) / ppb : 4096);
-      hla_prof_begin(K_CONF, 2.0 * 9 * Cs[l] * (double)npix, (double)npix * (Cs[l] * sizeof(T) + 4), st);
-      hipLaunchKernelGGL((conf_kernel<T>), dim3(grid), dim3(256), 9 * Cs[l] * sizeof(float), st, acts[l],
+      hla_prof_begin(K_CONF, 2.0 * 9 * Cs[l] * (double)npix, (double)npix * (Cs[l] * sizeof(CT) + 4), st);
+      hipLaunchKernelGGL((conf_kernel<CT>), dim3(grid), dim3(256), 9 * Cs[l] * sizeof(float), st, acts[l],
                          prm->w[13 + l], conf[l], B, hs[l], wsz[l], Cs[l]);
       hla_prof_end(st);
     }
@@ -138,15 +167,18 @@ template int vgg_forward_t<TuT>(const float* x, const hla_vgg_params* prm, const
 #define HLA_EXTERN_T(T) \
   extern template void vgg_pack_all<T>(const hla_vgg_params* prm, char* packed, int dtype, hipStream_t st); \
   extern template int vgg_forward_t<T>(const float* x, const hla_vgg_params* prm, const char* packed, int dtype, float* const feat[4],                               float* const conf[4], double* inv_norm, char* ws, const VggPlan& pl, int B, int H, int W,                               int flags, int first_row8, hipStream_t st);
-HLA_EXTERN_T(float) HLA_EXTERN_T(bf16) HLA_EXTERN_T(f16)
+HLA_EXTERN_T(float) HLA_EXTERN_T(bf16) HLA_EXTERN_T(f16) HLA_EXTERN_T(split32)
 
-extern "C" size_t hla_vgg_packed_weight_bytes(int dtype) { return packed_offset(kAllLayers, dtype); }
+extern "C" size_t hla_vgg_packed_weight_bytes(int dtype) {
+  return packed_offset(kAllLayers, dtype) + (dtype == HLA_F16X3 ? kPackTailBytes : 0);
+}
 
 extern "C" int hla_vgg_pack_weights(const hla_vgg_params* params, void* packed, int dtype, hla_stream_t stream) {
   HLA_REQUIRE(params && packed, "hla_vgg_pack_weights: null argument");
   HLA_REQUIRE(hla_dtype_ok(dtype), "hla_vgg_pack_weights: bad dtype %d", dtype);
   if (dtype == HLA_BF16) vgg_pack_all<bf16>(params, (char*)packed, dtype, (hipStream_t)stream);
   else if (dtype == HLA_F16) vgg_pack_all<f16>(params, (char*)packed, dtype, (hipStream_t)stream);
+  else if (dtype == HLA_F16X3) vgg_pack_all<split32>(params, (char*)packed, dtype, (hipStream_t)stream);
   else vgg_pack_all<float>(params, (char*)packed, dtype, (hipStream_t)stream);
   HLA_CHECK_HIP(hipGetLastError());
   return HLA_OK;
@@ -163,7 +195,7 @@ extern "C" int hla_vgg_forward(const float* x, const hla_vgg_params* params, con
                                size_t workspace_bytes, int B, int H, int W, int level, int dtype, int flags,
                                int first_row8, hla_stream_t stream) {
   HLA_REQUIRE(x && params && packed_weights && feat && workspace, "hla_vgg_forward: null argument");
-  HLA_REQUIRE(hla_dtype_ok(dtype), "hla_vgg_forward: dtype must be HLA_F32, HLA_BF16 or HLA_F16 (got %d)", dtype);
+  HLA_REQUIRE(hla_dtype_ok(dtype), "hla_vgg_forward: dtype must be HLA_F32, HLA_BF16, HLA_F16 or HLA_F16X3 (got %d)", dtype);
   HLA_REQUIRE(B > 0 && H >= 8 && W >= 8 && H % 8 == 0 && W % 8 == 0, "hla_vgg_forward: H and W must be multiples of 8");
   HLA_REQUIRE(level == 3 || level == 4, "hla_vgg_forward: level must be 3 (x15,x18,x21) or 4 (+x24), got %d", level);
   HLA_REQUIRE(feat[0] && feat[1] && feat[2], "hla_vgg_forward: feat[0..2] are required");
@@ -184,6 +216,9 @@ extern "C" int hla_vgg_forward(const float* x, const hla_vgg_params* params, con
   if (dtype == HLA_F16)
     return vgg_forward_t<f16>(x, params, (const char*)packed_weights, dtype, feat, conf, inv_norm, (char*)workspace, pl,
                               B, H, W, flags, first_row8, (hipStream_t)stream);
+  if (dtype == HLA_F16X3)
+    return vgg_forward_t<split32>(x, params, (const char*)packed_weights, dtype, feat, conf, inv_norm, (char*)workspace, pl,
+                                  B, H, W, flags, first_row8, (hipStream_t)stream);
   return vgg_forward_t<float>(x, params, (const char*)packed_weights, dtype, feat, conf, inv_norm, (char*)workspace, pl,
                               B, H, W, flags, first_row8, (hipStream_t)stream);
 }

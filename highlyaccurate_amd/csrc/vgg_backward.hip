@@ -510,7 +510,7 @@ static int wgrad_ksplit(int Cout, int Cin, int ntile) {
 }
 
 static void bwd_plan(int B, int H, int W, int dtype, BwdPlan* p, bool level4 = false) {
-  const size_t es = dtype == HLA_F32 ? 4 : 2;
+  const size_t es = hla_elem_bytes(dtype);
   size_t o = 0;
   auto take = [&](size_t bytes) { size_t r = o; o += hla_align_up(bytes, 256); return r; };
   const size_t P = (size_t)B * H * W;
@@ -762,11 +762,16 @@ extern "C" size_t hla_vgg_bwd_workspace_bytes(int B, int H, int W, int level, in
   return p.total;
 }
 
-extern "C" size_t hla_vgg_packed_weight_T_bytes(int dtype) { return packed_offset(kAllLayers, dtype); }
+// HLA_F16X3 has no backward kernels of its own: its forward stores fp32 activations in the HLA_F32 layout, so the backward of
+// a split-mode forward IS the HLA_F32 backward (exact-fp32 MFMA) on those activations.
+static inline int bwd_dtype(int dtype) { return dtype == HLA_F16X3 ? HLA_F32 : dtype; }
+
+extern "C" size_t hla_vgg_packed_weight_T_bytes(int dtype) { return packed_offset(kAllLayers, bwd_dtype(dtype)); }
 
 extern "C" int hla_vgg_pack_weights_T(const hla_vgg_params* params, void* packed, int dtype, hla_stream_t stream) {
   HLA_REQUIRE(params && packed, "hla_vgg_pack_weights_T: null argument");
   HLA_REQUIRE(hla_dtype_ok(dtype), "hla_vgg_pack_weights_T: bad dtype %d", dtype);
+  dtype = bwd_dtype(dtype);
   if (dtype == HLA_BF16) vgg_pack_all_T<bf16>(params, (char*)packed, dtype, (hipStream_t)stream);
   else if (dtype == HLA_F16) vgg_pack_all_T<f16>(params, (char*)packed, dtype, (hipStream_t)stream);
   else vgg_pack_all_T<float>(params, (char*)packed, dtype, (hipStream_t)stream);
@@ -782,6 +787,7 @@ extern "C" int hla_vgg_backward(const float* x, const hla_vgg_params* params, co
   HLA_REQUIRE(x && params && packed_weights_T && fwd_workspace && feat && inv_norm && d_feat && grads && workspace,
               "hla_vgg_backward: null argument");
   HLA_REQUIRE(hla_dtype_ok(dtype), "hla_vgg_backward: bad dtype %d", dtype);
+  dtype = bwd_dtype(dtype);
   HLA_REQUIRE(level == 3 || level == 4, "hla_vgg_backward: level must be 3 or 4");
   HLA_REQUIRE(first_row8 == 0 || (first_row8 >= 4 && first_row8 < H / 8), "hla_vgg_backward: first_row8 must be 0 or in [4, H/8)");
   const int NLc = level == 4 ? 4 : 3;

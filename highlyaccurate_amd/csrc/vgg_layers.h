@@ -13,8 +13,12 @@ static const LayerDef kLayers[13] = {
 constexpr int kPackedLayers = 11;   // conv0..dec2.3: what level 3 and the backward pass use
 constexpr int kAllLayers = 13;      // + conv_dec3.1/3 (level 4, forward only)
 
+// bytes per stored activation element / per packed weight (split mode: fp32 activations, (hi, lo) fp16 weight pairs)
+static inline size_t hla_elem_bytes(int dtype) { return (dtype == HLA_F32 || dtype == HLA_F16X3) ? 4 : 2; }
+constexpr size_t kPackTailBytes = 256;   // HLA_F16X3: float[16] weight scales, float[16] = conv0 L1 bound, 32 scratch words
+
 static inline size_t packed_bytes(int l, int dtype) {
-  const size_t es = dtype == HLA_F32 ? 4 : 2;
+  const size_t es = hla_elem_bytes(dtype);
   if (l == 0) return (size_t)2 * 32 * 32 * es;   // 2 ntiles x 32 (padded K) x 32 couts
   return (size_t)kLayers[l].cin * kLayers[l].cout * 9 * es + 4096;   // + two taps of fragments: prefetch overrun
 }
@@ -25,17 +29,21 @@ static inline size_t packed_offset(int l, int dtype) {
 }
 
 // Forward workspace: every activation a later layer (or the backward pass) reads.  All maps NHWC, T elements.
+// split mode: one per-sample maximum per activation map that a convolution reads
+enum { AM_X3 = 0, AM_A5, AM_X8, AM_A10, AM_A12, AM_X15, AM_D1A, AM_X18, AM_D2A, AM_X21, AM_X2, AM_D3A, AM_X24, kAmaxSlots = 16 };
+
 struct VggPlan {
   size_t x3, a5, x8, a10, a12, x15r, d1a, x18r, d2a, x21r;   // post-ReLU activations
   size_t x2r, d3a, x24r;                                     // level 4 only: relu(conv2) at full resolution, dec3 maps
   size_t ss[4], inv;                                         // sum-of-squares partials, 1/norm
   size_t a0, idx3, idx8, idx15;                              // training only: conv0 output, pool argmax (u8)
+  size_t amax;                                               // split mode: [kAmaxSlots][B] per-sample max |activation| (fp32 bits)
   int np[4];
   size_t total;
 };
 
 static inline void vgg_plan(int B, int H, int W, int dtype, bool train, VggPlan* p, bool level4 = false) {
-  const size_t es = dtype == HLA_F32 ? 4 : 2;
+  const size_t es = hla_elem_bytes(dtype);
   size_t o = 0;
   auto take = [&](size_t bytes) { size_t r = o; o += hla_align_up(bytes, 256); return r; };
   const size_t P = (size_t)B * H * W;
@@ -57,6 +65,7 @@ static inline void vgg_plan(int B, int H, int W, int dtype, bool train, VggPlan*
   p->np[3] = tiles(H, W) * 1;           // dec3.3: Cout 16 (padded to 64)
   for (int i = 0; i < 4; ++i) p->ss[i] = take((size_t)B * p->np[i] * sizeof(double));
   p->inv = take((size_t)4 * B * sizeof(double));
+  p->amax = take((size_t)kAmaxSlots * B * sizeof(unsigned));
   p->x2r = p->d3a = p->x24r = 0;
   if (level4) {
     p->x2r = take(P * 64 * es);

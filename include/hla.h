@@ -41,8 +41,14 @@ typedef enum hla_status {
 typedef enum hla_dtype {
   HLA_F32 = 0,  /* exact-fp32 MFMA (v_mfma_f32_32x32x2_f32): the parity mode      */
   HLA_BF16 = 1, /* bf16 MFMA (v_mfma_f32_32x32x16_bf16), fp32 accumulate: perf mode */
-  HLA_F16 = 2   /* fp16 MFMA (v_mfma_f32_32x32x16_f16), fp32 accumulate: same speed, 3 more mantissa bits,
+  HLA_F16 = 2,  /* fp16 MFMA (v_mfma_f32_32x32x16_f16), fp32 accumulate: same speed, 3 more mantissa bits,
                    narrower range -- fine for inference on [0,1] images, not recommended for the backward pass */
+  HLA_F16X3 = 3 /* split-fp16: fp32 activations and weights in memory; every operand enters the matrix cores as
+                   hi + lo = fp16(s x) + fp16(s x - hi) (power-of-two scale s per tensor and sample), one product =
+                   three fp16 MFMAs (hi hi + hi lo + lo hi), fp32 accumulate.  fp32-class results (meets the fp32
+                   parity gates) at 1/3 of the fp16 MFMA rate instead of the 1/16 of HLA_F32: the matched-accuracy
+                   throughput mode.  Workspaces and packed weights have the HLA_F32 sizes; hla_vgg_backward with this
+                   dtype runs the HLA_F32 kernels on the activations the split forward saved. */
 } hla_dtype;
 
 const char* hla_last_error(void);

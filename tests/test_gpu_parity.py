@@ -58,7 +58,7 @@ def _rel(a, b):
     return np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)
 
 
-@pytest.mark.parametrize('precision,tol', [('fp32', 1e-5), ('bf16', 3e-2), ('fp16', 4e-3)])
+@pytest.mark.parametrize('precision,tol', [('fp32', 1e-5), ('fp16x3', 1e-5), ('bf16', 3e-2), ('fp16', 4e-3)])
 def test_vgg_small_vs_golden(kat, precision, tol):
     """VGGUnet on [2,3,32,64] with non-zero biases against the reference's fp64 maps."""
     from oracle import ref_cpu as O
@@ -81,7 +81,7 @@ def test_vgg_small_vs_golden(kat, precision, tol):
         assert ec < max(tol, 2e-6), (precision, l, ec)
 
 
-@pytest.mark.parametrize('precision,tol', [('fp32', 1e-5), ('bf16', 3e-2)])
+@pytest.mark.parametrize('precision,tol', [('fp32', 1e-5), ('fp16x3', 1e-5), ('bf16', 3e-2)])
 def test_vgg_level4_vs_golden(kat, precision, tol):
     """VGGUnet(level=4): the fourth map x24 (conv_dec3 on cat(up(x21), x2), 16 channels at full resolution) and conf3
     against the reference's fp64 maps; the first three maps must be bit-identical to the level-3 run."""
@@ -213,6 +213,10 @@ def test_lm_solve_ford_small_vs_oracle():
     assert err < 2e-5 * max(1.0, np.abs(ref).max())
 
 
+# reduced-precision pose deviation limits (shift, yaw; normalised units) = 3x the deviation measured on MI355X on golden seed 0
+REDUCED_LIMITS = {'bf16': (2.2e-3, 1.1e-2), 'fp16': (1.2e-3, 2.0e-3)}
+
+
 def _pose_gate(got, g64, g32, what):
     """|hip - ref64| <= max(tol, 2*|ref32 - ref64|), componentwise; last axis = (u, v, theta)."""
     tol = np.array([TOL_SHIFT, TOL_SHIFT, TOL_YAW])
@@ -246,22 +250,25 @@ def _exec_order(trace, level_first):
     return t.reshape(B, N * L, 3)
 
 
-def test_e2e_kitti_full_shape_vs_golden():
-    """Full KITTI shapes, B=2, fp32 mode: pose trace of all 15 steps + feature samples vs the reference."""
+@pytest.mark.parametrize('precision', ['fp32', 'fp16x3'])
+def test_e2e_kitti_full_shape_vs_golden(precision):
+    """Full KITTI shapes, B=2: pose trace of all 15 steps + feature samples vs the reference.  Both fp32-class modes
+    (exact-fp32 MFMA and split fp16) must pass the SAME gate."""
     g = load_golden('e2e_kitti.npz')
     B = int(g['B'])
     from make_idx import sample_idx
     for seed in g['seeds']:
         seed = int(seed)
-        net, res = _run_kitti(seed, B)
+        net, res = _run_kitti(seed, B, precision=precision)
         trace = _exec_order(net.last_trace, 0).cpu().numpy().astype(np.float64)
-        _pose_gate(trace, g[f'trace64_{seed}'], g[f'trace32_{seed}'], f'kitti seed {seed}')
+        _pose_gate(trace, g[f'trace64_{seed}'], g[f'trace32_{seed}'], f'kitti {precision} seed {seed}')
         final = torch.stack(res, -1).cpu().numpy()
         np.testing.assert_allclose(final, g[f'final64_{seed}'], atol=2e-3)   # ordering check (lat, lon, theta)
         np.testing.assert_array_equal(final[:, [1, 0, 2]], trace[:, -1].astype(np.float32))
 
 
-def test_e2e_kitti_features_vs_golden():
+@pytest.mark.parametrize('precision', ['fp32', 'fp16x3'])
+def test_e2e_kitti_features_vs_golden(precision):
     from oracle import ref_cpu as O
     from highlyaccurate_amd.models_kitti import LM_S2GP
     from make_idx import sample_idx
@@ -269,7 +276,7 @@ def test_e2e_kitti_features_vs_golden():
     B = int(g['B'])
     seed = int(g['seeds'][0])
     d = _dev()
-    net = LM_S2GP(O.default_args())
+    net = LM_S2GP(O.default_args(precision=precision))
     net.load_state_dict(O.synth_model_state(seed))
     net = net.to(d)
     sat, grd, *_ = O.synth_images(seed + 100, B)
@@ -282,7 +289,7 @@ def test_e2e_kitti_features_vs_golden():
             got = np.concatenate([f.sum(1, keepdim=True).numpy(), (f * f).sum(1, keepdim=True).numpy(), f[:, idx].numpy()], 1)
             scale = np.abs(ref[:, 2:]).max()
             e = np.abs(got[:, 2:] - ref[:, 2:]).max() / scale
-            print(f'{name} level {l}: sampled rel err {e:.2e}, sumsq {got[:, 1]}, sum err {np.abs(got[:, 0] - ref[:, 0]).max():.2e}')
+            print(f'{precision} {name} level {l}: sampled rel err {e:.2e}, sumsq {got[:, 1]}, sum err {np.abs(got[:, 0] - ref[:, 0]).max():.2e}')
             assert e < 1e-5
             np.testing.assert_allclose(got[:, 1], 1.0, atol=1e-6)
 
@@ -298,7 +305,8 @@ def test_e2e_kitti_variants_vs_golden(tag, kw, lf):
     _pose_gate(trace, g[f'trace64_{tag}'], g[f'trace32_{tag}'], f'kitti {tag}')
 
 
-def test_e2e_ford_full_shape_vs_golden():
+@pytest.mark.parametrize('precision', ['fp32', 'fp16x3'])
+def test_e2e_ford_full_shape_vs_golden(precision):
     from oracle import ref_cpu as O
     from highlyaccurate_amd.models_ford import LM_S2GP_Ford
     g = load_golden('e2e_ford.npz')
@@ -306,7 +314,7 @@ def test_e2e_ford_full_shape_vs_golden():
     d = _dev()
     for seed in g['seeds']:
         seed = int(seed)
-        args = O.default_args(N_iters=10)
+        args = O.default_args(N_iters=10, precision=precision)
         net = LM_S2GP_Ford(args)
         net.load_state_dict(O.synth_model_state(seed))
         net = net.to(d)
@@ -317,7 +325,7 @@ def test_e2e_ford_full_shape_vs_golden():
         with torch.no_grad():
             res = net(sat.to(d), grd.to(d), 112.64, R_FL.to(d), T_FL.to(d), mode='test')
         trace = _exec_order(net.last_trace, 0).cpu().numpy().astype(np.float64)
-        _pose_gate(trace, g[f'trace64_{seed}'], g[f'trace32_{seed}'], f'ford seed {seed}')
+        _pose_gate(trace, g[f'trace64_{seed}'], g[f'trace32_{seed}'], f'ford {precision} seed {seed}')
         np.testing.assert_array_equal(torch.stack(res, -1).cpu().numpy(), trace[:, -1].astype(np.float32))
 
 
@@ -352,7 +360,10 @@ def test_reduced_precision_pose_deviation_reported(precision):
     trace = _exec_order(net.last_trace, 0).cpu().numpy().astype(np.float64)
     err = np.abs(trace - g[f'trace64_{seed}'])
     print(f'{precision} mode pose deviation vs fp64 reference: shift {err[..., :2].max():.3e} yaw {err[..., 2].max():.3e} (normalised)')
-    assert np.isfinite(trace).all() and err.max() < (0.2 if precision == 'bf16' else 0.05)
+    # bounds = 3x what this seed measures on MI355X (bf16: 7.2e-4 shift / 3.7e-3 yaw; fp16: 3.9e-4 / 6.7e-4): a regression of
+    # the reduced-precision paths by more than that fails, not only one by two orders of magnitude
+    lim_s, lim_y = REDUCED_LIMITS[precision]
+    assert np.isfinite(trace).all() and err[..., :2].max() < lim_s and err[..., 2].max() < lim_y, (err[..., :2].max(), err[..., 2].max())
 
 
 @pytest.mark.parametrize('opt', ['SGD', 'ADAM'])
@@ -612,6 +623,90 @@ def test_full_bench_config_runs_and_is_consistent():
         t5 = net.last_trace.clone()
     assert torch.isfinite(t).all()
     assert torch.equal(t[5:6], t5)
+
+
+@pytest.mark.parametrize('precision', ['fp32', 'fp16x3', 'bf16'])
+def test_bench_batch_per_sample_vs_oracle(precision):
+    """BASELINE configs[1] batch size (B = 32, what bench.py times): four samples of the batch are compared ONE BY ONE with
+    the oracle run on that sample alone (fp64, and fp32 for the reference's own rounding gap).  The two fp32-class modes
+    pass the parity gate; bf16 stays within its measured-deviation limits."""
+    from oracle import ref_cpu as O
+    from highlyaccurate_amd.models_kitti import LM_S2GP
+    d = _dev()
+    seed = 2
+    args = O.default_args(precision=precision)
+    net = LM_S2GP(args)
+    sd = O.synth_model_state(seed)
+    net.load_state_dict(sd)
+    net = net.to(d)
+    sat, grd, *_ = O.synth_images(seed + 300, 32)
+    torch.manual_seed(seed)
+    with torch.no_grad():
+        net(sat.to(d), grd.to(d), mode='test')
+    trace = net.last_trace.cpu().numpy().astype(np.float64)              # [32,5,3,(u,v,theta)]
+    assert np.isfinite(trace).all()
+    o32 = O.LM_S2GP(O.default_args())
+    o32.load_state_dict(sd)
+    o64 = O.LM_S2GP(O.default_args())
+    o64.load_state_dict(sd)
+    o64 = o64.double()
+    for k in (0, 7, 19, 31):
+        with torch.no_grad():
+            torch.manual_seed(seed)
+            o64(sat[k:k + 1].double(), grd[k:k + 1].double(), mode='test')
+            torch.manual_seed(seed)
+            o32(sat[k:k + 1], grd[k:k + 1], mode='test')
+        t64 = torch.stack([o64.trace[1], o64.trace[0], o64.trace[2]], -1)[0].numpy()     # (lon, lat, theta) = (u, v, theta)
+        t32 = torch.stack([o32.trace[1], o32.trace[0], o32.trace[2]], -1)[0].double().numpy()
+        if precision in ('fp32', 'fp16x3'):
+            _pose_gate(trace[k], t64, t32, f'B=32 {precision} sample {k}')
+        else:
+            err = np.abs(trace[k] - t64)
+            print(f'B=32 {precision} sample {k}: shift {err[..., :2].max():.3e} yaw {err[..., 2].max():.3e}')
+            lim_s, lim_y = REDUCED_LIMITS[precision]
+            assert err[..., :2].max() < 2 * lim_s and err[..., 2].max() < 2 * lim_y      # other seed than the limits' own: 2x slack
+
+
+def test_split_fp16_scaling_is_robust_and_sample_local():
+    """fp16x3 feeds the matrix cores (hi, lo) fp16 pairs of s*x with a power-of-two scale s per tensor and SAMPLE.
+    (1) Dynamic range: weights scaled by 2^-9 / 2^+7 layer by layer and inputs far from [0,1] (x 3e-4 and x 5e3 in one
+        batch) must still give fp32-class maps -- a fixed or batch-wide scale would push small samples into the fp16
+        subnormals or overflow the large one.
+    (2) The scale is per sample: a sample's result is bitwise independent of its batch mates.
+    (3) An all-zero image gives finite maps (the bias path) and does not disturb its batch mates."""
+    from oracle import ref_cpu as O
+    from highlyaccurate_amd.VGG import VGGUnet
+    d = _dev()
+    rs = np.random.RandomState(33)
+    sd = O.synth_vgg_state(rs, bias_scale=0.05)
+    names = ['conv0', 'conv2', 'conv5', 'conv7', 'conv10', 'conv12', 'conv14', 'conv_dec1.1', 'conv_dec1.3', 'conv_dec2.1', 'conv_dec2.3']
+    for i, n in enumerate(names):                     # alternate tiny / large layers; biases scaled with the running gain
+        sd[n + '.weight'] = sd[n + '.weight'] * (2.0 ** -9 if i % 2 == 0 else 2.0 ** 7)
+    x = rs.random_sample((4, 3, 40, 72)).astype(np.float32)
+    x[0] *= 3e-4
+    x[1] *= 5e3
+    x[3] = 0.0
+    x = T(x)
+    onet = O.VGGUnet(3)
+    onet.load_state_dict(sd)
+    with torch.no_grad():
+        ref, _ = onet.double()(x.double())            # L2-normalised maps, like the module's
+    net = VGGUnet(3, precision='fp16x3')
+    net.load_state_dict(sd)
+    net = net.to(d)
+    with torch.no_grad():
+        feats, confs = net(x.to(d))
+        for l in range(3):
+            f = feats[l].cpu().double()
+            assert torch.isfinite(f).all()
+            for b in range(4):
+                e = (f[b] - ref[l][b]).abs().max() / ref[l][b].abs().max().clamp_min(1e-300)
+                print(f'split robustness: sample {b} level {l} rel err {e:.2e}')
+                assert e < 1e-5, (b, l, float(e))
+        f1, _ = net(x[1:2].to(d))
+        f2, _ = net(x[2:4].to(d))
+    for l in range(3):
+        assert torch.equal(f1[l][0], feats[l][1]) and torch.equal(f2[l], feats[l][2:4])
 
 
 @pytest.mark.parametrize('kw', [dict(), dict(using_weight=1), dict(use_hessian=1, damping=0.5),
