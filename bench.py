@@ -2,7 +2,7 @@
 """bench.py -- image-pairs/sec through the N-iter LM pose loop (BASELINE.json metric).
 
 One "step" = one pass of the hot path over one synthetic batch already resident in HBM:
-LM_S2GP.forward(sat, grd, mode='test') = two VGG16-U-Nets (bf16 MFMA) + 15 fused
+LM_S2GP.forward(sat, grd, mode='test') = two VGG16-U-Nets (MFMA convolutions) + 15 fused
 projection/Jacobian/normal-equation/solve steps.  Workload at N=1: BASELINE configs[1]
 (KITTI shapes, batch 32 per GPU, VGG-16 two-branch, 5 LM iters, 3-DoF, bf16).
 
@@ -13,8 +13,18 @@ projection/Jacobian/normal-equation/solve steps.  Workload at N=1: BASELINE conf
 Multi-GPU: one process per GPU; the batch shards over ranks with no data-path collective
 (every sample's solve is independent); a barrier + synchronize brackets the timed
 region and the reported time is the MAX over ranks.  Prints ONE JSON line on rank 0.
+
+Besides the headline (`value`, the precision BASELINE configs[1] names) the line carries, at N=1:
+  by_precision   the same workload in each arithmetic mode -- fp32 (exact-fp32 MFMA), fp16x3 (split fp16, fp32-class
+                 results) and bf16 -- with pairs/s, the dominant conv kernel's fraction of ITS roofline, and the measured
+                 final-pose deviation from the reference's fp64 run on the committed golden inputs (tests/golden/), in
+                 metres / radians, next to the north-star tolerance (1e-4 m / 1e-4 rad)
+  secondary      short legs for BASELINE configs[3] (Ford, 10 LM iterations) and configs[4] (1024^2 / 512x2048, fp16)
+  train          forward(train) + HIP backward + gradient all-reduce + Adam
+  cpu_baseline   the CPU oracle on this host's cores (bounded sample)
 """
 import argparse
+import glob
 import json
 import os
 import sys
@@ -24,20 +34,22 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
-# dense peaks, /opt/skills/guides/MI355X_MICROARCH.md "Chip-level parameters"
-# fp16x3: every algorithmic FLOP costs three fp16 MFMA FLOPs, so the ceiling on ALGORITHMIC FLOPs is a third of the fp16 peak
+# dense peaks, /opt/skills/guides/MI355X_MICROARCH.md "Chip-level parameters".  fp16x3: every algorithmic FLOP costs three
+# fp16 MFMA FLOPs, so the ceiling on ALGORITHMIC FLOPs is a third of the fp16 peak.
 PEAK_TFLOPS = {'bf16': 2500.0, 'fp16': 2500.0, 'fp32': 157.3, 'fp16x3': 2500.0 / 3}
 PEAK_HBM_GBS = 8000.0
-# conv FLOPs per pair, forward, live outputs at level 3: 272.4 GFLOP
-GFLOP_PER_PAIR_LIVE = 272.4
 from highlyaccurate_amd._s2gp import dead_ground_rows  # noqa: E402
+from highlyaccurate_amd import synthetic  # noqa: E402
+
+KITTI_K = [[582.9802, 0., 496.2420], [0., 482.7076, 125.0034], [0., 0., 1.]]     # models_kitti.py:657-660
 
 
 def cpu_baseline(max_seconds=30.0):
     """Time the CPU oracle (oracle/ref_cpu.py, a port of the reference's PyTorch path) on this host:
-    B=1 KITTI-shape forward(mode='test'), no_grad, fp32, all cores.  Bounded sample."""
+    B=1 KITTI-shape forward(mode='test'), no_grad, fp32.  Bounded sample."""
     from oracle import ref_cpu as O
     # measured on the MI355X host (256 logical CPUs): B=1 forward takes 1.40 / 1.21 / 1.29 / 2.58 / 204 s with
     # 8 / 16 / 32 / 64 / 256 torch threads (tests/diag/cpu_threads.py) -- oversubscription kills it, 16 is the best
@@ -62,6 +74,279 @@ def cpu_baseline(max_seconds=30.0):
                       f'torch {torch.__version__} CPU, {torch.get_num_threads()} threads'}
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+def build_net(model, precision, n_iters, dev, state=None):
+    """Random-init weights of the reference architecture: Kaiming-normal(fan_out), zero bias (torchvision's non-pretrained
+    VGG init; there is no network for the pretrained checkpoint) -- or a given state dict."""
+    from highlyaccurate_amd.models_kitti import LM_G2SP, LM_S2GP
+    from highlyaccurate_amd.models_ford import LM_S2GP_Ford
+    args = synthetic.reference_args(N_iters=n_iters, precision=precision)
+    torch.manual_seed(1234)                  # identical replicas on every rank (data-parallel training needs that)
+    net = {'kitti': LM_S2GP, 'ford': LM_S2GP_Ford, 'g2sp': LM_G2SP}[model](args)
+    if state is not None:
+        net.load_state_dict(state)
+    else:
+        for m in net.modules():
+            if isinstance(m, torch.nn.Conv2d):
+                torch.nn.init.kaiming_normal_(m.weight, mode='fan_out', nonlinearity='relu')
+                if m.bias is not None:
+                    torch.nn.init.zeros_(m.bias)
+    return net.to(dev).eval()
+
+
+def make_inputs(model, B, grd_hw, sat_a, dev, rank):
+    torch.manual_seed(1234 + rank)           # a different synthetic shard per rank (also decorrelates the re-init draws)
+    sat = torch.rand(B, 3, sat_a, sat_a, device=dev)
+    grd = torch.rand(B, 3, grd_hw[0], grd_hw[1], device=dev)
+    if model == 'ford':       # BASELINE configs[3] / SURVEY 8(d): fixed camera-to-body rotation, 112.64 m tile
+        extra = (112.64, torch.tensor([[[0., 0., 1.], [1., 0., 0.], [0., 1., 0.]]], device=dev).repeat(B, 1, 1),
+                 torch.tensor([[1.7, 0.3, -1.2]], device=dev).repeat(B, 1))
+    elif model == 'g2sp':     # left_camera_k of the 256x1024 frame
+        extra = (torch.tensor([KITTI_K], device=dev).repeat(B, 1, 1),)
+    else:
+        extra = ()
+    return sat, grd, extra
+
+
+def timed_infer(net, sat, grd, extra, steps, warmup, dist):
+    """W untimed steps, then exactly K steps bracketed by barrier + synchronize; MAX over ranks.  Returns (seconds, last output)."""
+    def step():
+        with torch.no_grad():
+            return net(sat, grd, *extra, mode='test')
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    out = None
+    for _ in range(steps):
+        out = step()
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if dist:
+        tt = torch.tensor([dt], device=sat.device, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    return dt, out
+
+
+def kernel_pass(net, sat, grd, extra, n):
+    """The same step n more times with a HIP-event pair around every kernel launch (hla_prof_*, events recorded on the launch
+    stream).  Kept out of `value`: the event pairs serialise kernel tails and cost ~9 % wall time."""
+    from highlyaccurate_amd import _lib
+    _lib.prof_enable(True)
+    t1 = time.perf_counter()
+    with torch.no_grad():
+        for _ in range(n):
+            net(sat, grd, *extra, mode='test')
+    torch.cuda.synchronize()
+    dt_ev = time.perf_counter() - t1
+    _lib.prof_enable(False)
+    return _lib.prof_fetch(), dt_ev
+
+
+def aggregate(recs):
+    agg = {}
+    for name, ms, fl, by in recs:
+        e = agg.setdefault(name, [0, 0.0, 0.0, 0.0])
+        e[0] += 1; e[1] += ms; e[2] += fl; e[3] += by
+    return agg
+
+
+_PMC_SYMBOL = {'conv3x3_kernel<MT4,NT2>': 'Li4ELi2ELi2ELi2ELb0', 'conv3x3_kernel<MT4,NT2,pool>': 'Li4ELi2ELi2ELi2ELb1',
+               'conv3x3_kernel<MT4,NT1>': 'Li4ELi1ELi2ELi2ELb0', 'conv3x3_kernel<MT4,NT1,pool>': 'Li4ELi1ELi2ELi2ELb1'}
+
+
+def load_pmc():
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (tools/make_profiles.sh: separate --pmc FETCH_SIZE /
+    --pmc WRITE_SIZE runs, gfx950 correction).  The file is stamped with the content hash of the kernel sources it was
+    measured on; a file measured on OTHER kernels is ignored (traffic = null) instead of going silently stale."""
+    from highlyaccurate_amd import _lib
+    have = _lib.load().hla_source_hash().decode()
+    for f in sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_hbm_traffic.json')), reverse=True):
+        try:
+            pm = json.load(open(f))
+        except Exception:
+            continue
+        if pm.get('_source_hash') == have:
+            return pm, os.path.relpath(f, ROOT)
+    return None, None
+
+
+def conv_roofline(agg, precision, pmc, pmc_src, headline_cfg):
+    """The dominant FLOP-carrying kernel against the dense MFMA peak of its arithmetic."""
+    dom = max((k for k in agg if agg[k][2] > 0), key=lambda k: agg[k][1])
+    n, ms, fl, by = agg[dom]
+    ach = fl / (ms * 1e-3) / 1e12
+    traffic, tsrc = None, None
+    sym = _PMC_SYMBOL.get(dom)
+    if pmc and headline_cfg and sym:
+        for kname, v in pmc.items():
+            if isinstance(v, dict) and sym in kname and ('DF16b' in kname) == (precision == 'bf16'):
+                traffic, tsrc = v['hbm_bytes_corrected'], pmc_src
+    return {'kernel': dom, 'bound': 'mfma', 'achieved': round(ach, 2), 'peak': round(PEAK_TFLOPS[precision], 1),
+            'unit': 'TFLOP/s', 'frac': round(ach / PEAK_TFLOPS[precision], 4), 'traffic': traffic,
+            'traffic_unit': 'bytes/launch', 'traffic_source': tsrc, 'launches': n, 'avg_launch_us': round(ms / n * 1e3, 2),
+            'flops_per_launch': round(fl / n / 1e9, 3), 'flops_unit': 'GFLOP (algorithmic: 2*9*Cin*Cout*pixels)'}
+
+
+def lm_roofline(agg, pmc, pmc_src):
+    """The LM accumulate kernels against HBM.  `achieved` uses COUNTER bytes (what actually crossed the HBM interface per
+    launch, committed PMC passes) over the live launch time; the algorithmic model (whole satellite map + ground half once
+    per step) over-counts -- only the ground-plane footprint of the satellite map is touched and much of it is
+    served by L2 / Infinity Cache -- so it is reported beside it, never as the achieved rate."""
+    lm = [k for k in agg if k.startswith('lm_accum')]
+    if not lm:
+        return None
+    ms = sum(agg[k][1] for k in lm)
+    n = sum(agg[k][0] for k in lm)
+    alg = sum(agg[k][3] for k in lm)
+    out = {'kernel': 'lm_accum<*>', 'bound': 'hbm', 'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'launches': n,
+           'avg_launch_us': round(ms / n * 1e3, 2), 'algorithmic_bytes_per_launch': round(alg / n),
+           'algorithmic_gbs': round(alg / (ms * 1e-3) / 1e9, 1),
+           'note': 'algorithmic_gbs is NOT an achieved bandwidth (the byte model counts the whole satellite map; a rate above the '
+                   'HBM peak only means most of it never left the caches)'}
+    cb = 0.0
+    if pmc:
+        for k in lm:
+            C = k[len('lm_accum<'):-1]
+            hit = [v for kn, v in pmc.items() if isinstance(v, dict) and f'lm_accum<{C},' in kn]
+            if not hit:
+                cb = None
+                break
+            cb += hit[0]['hbm_bytes_corrected'] * agg[k][0]
+    else:
+        cb = None
+    if cb:
+        ach = cb / (ms * 1e-3) / 1e9
+        out.update({'achieved': round(ach, 1), 'frac': round(ach / PEAK_HBM_GBS, 4), 'traffic': round(cb / n),
+                    'traffic_unit': 'bytes/launch (counter)', 'traffic_source': pmc_src,
+                    'traffic_over_algorithmic': round(cb / alg, 3)})
+    else:
+        out.update({'achieved': None, 'frac': None, 'traffic': None})
+    return out
+
+
+def pose_deviation(precision, dev):
+    """Final pose of the golden inputs (tests/golden/e2e_kitti.npz: 4 seeds x B=2, recorded from the REAL reference in fp32 and
+    fp64) in this arithmetic mode, as the worst deviation from the reference's fp64 run in metres / radians, next to the
+    reference's own fp32-vs-fp64 gap and the parity gate of SURVEY 8(c): |ours - ref64| <= max(tol, 2 |ref32 - ref64|)."""
+    g = np.load(os.path.join(ROOT, 'tests', 'golden', 'e2e_kitti.npz'), allow_pickle=False)
+    B = int(g['B'])
+    to_m, to_rad = 20.0, 10.0 * np.pi / 180.0                     # shift_range_lat/lon, rotation_range (reference defaults)
+    tol = np.array([1e-4 / to_m, 1e-4 / to_m, 1e-4 / to_rad])
+    dev_m = dev_rad = gap_m = gap_rad = 0.0
+    worst = 0.0
+    for seed in (int(s) for s in g['seeds']):
+        net = build_net('kitti', precision, 5, dev, state=synthetic.model_state(seed))
+        sat, grd, *_ = synthetic.images(seed + 100, B)
+        torch.manual_seed(seed)
+        with torch.no_grad():
+            net(sat.to(dev), grd.to(dev), mode='test')
+        ours = net.last_trace.reshape(B, -1, 3)[:, -1].double().cpu().numpy()     # final (shift_u, shift_v, theta)
+        r64, r32 = g[f'trace64_{seed}'][:, -1], g[f'trace32_{seed}'][:, -1]
+        e, gap = np.abs(ours - r64), np.abs(r32 - r64)
+        dev_m, dev_rad = max(dev_m, e[:, :2].max() * to_m), max(dev_rad, e[:, 2].max() * to_rad)
+        gap_m, gap_rad = max(gap_m, gap[:, :2].max() * to_m), max(gap_rad, gap[:, 2].max() * to_rad)
+        worst = max(worst, (e / np.maximum(tol, 2 * gap)).max())
+        del net
+    return {'final_pose_dev_shift_m': float(f'{dev_m:.3e}'), 'final_pose_dev_yaw_rad': float(f'{dev_rad:.3e}'),
+            'reference_fp32_vs_fp64_shift_m': float(f'{gap_m:.3e}'), 'reference_fp32_vs_fp64_yaw_rad': float(f'{gap_rad:.3e}'),
+            'tolerance': '1e-4 m / 1e-4 rad (north_star)', 'gate_ratio': round(float(worst), 3),
+            'meets_parity_gate': bool(worst <= 1.0),
+            'inputs': 'tests/golden/e2e_kitti.npz: 4 seeds x 2 pairs, full KITTI shapes, 15 LM steps'}
+
+
+def workload_name(model, sat_a, grd_hw, n_iters):
+    base = {'kitti': ("BASELINE configs[1]: LM_S2GP" if (sat_a, tuple(grd_hw)) == (512, (256, 1024)) else "BASELINE configs[4] sizes: LM_S2GP"),
+            'ford': "BASELINE configs[3] shapes: LM_S2GP_Ford", 'g2sp': "SURVEY 8(f).2: LM_G2SP"}[model]
+    return (base + f".forward(mode='test'), sat {sat_a}x{sat_a}, grd {grd_hw[0]}x{grd_hw[1]}, VGG-16 two-branch, level 3, "
+            f"{n_iters} LM iters x 3 levels, 3-DoF, random-init weights")
+
+
+def train_leg(net, a, sat, grd, extra, B, world, dist, dev, want_kt):
+    from highlyaccurate_amd import _lib
+    from highlyaccurate_amd.parallel import GradSync
+    net.train()
+    if dist:
+        net.grad_sync = GradSync()
+    opt = torch.optim.Adam(net.parameters(), lr=1e-4)
+    gt = [torch.rand(B, 1, device=dev) * 2 - 1 for _ in range(3)]
+    if a.model == 'ford':      # Ford_dataset.py:211 collates python floats: [B] float64
+        gt = [g[:, 0].double() for g in gt]
+
+    def tstep():
+        opt.zero_grad(set_to_none=True)
+        r = net(sat, grd, *extra, gt[0], gt[1], gt[2], mode='train')
+        r[0].backward()
+        opt.step()
+        return r[0]
+
+    def timed(nsteps):
+        for _ in range(2):          # warm-up: Adam state, caching-allocator segments for the backward workspaces
+            tstep()
+        torch.cuda.synchronize()
+        if dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        lossv = None
+        for _ in range(nsteps):
+            lossv = tstep()
+        torch.cuda.synchronize()
+        if dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+        tdt = time.perf_counter() - t1
+        if dist:
+            tt = torch.tensor([tdt], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            tdt = float(tt.item())
+        return tdt, lossv
+
+    ar0 = net.grad_sync.bytes_reduced if dist else 0
+    tdt, lossv = timed(a.train_steps)
+    ar_bytes = ((net.grad_sync.bytes_reduced - ar0) // (a.train_steps + 2)) if dist else 0
+    trecs = []
+    if not a.no_kernel_timing:  # per-kernel table from two extra steps (not part of the timing).  EVERY rank runs them --
+        if want_kt:             # a training step contains the gradient all-reduce -- but only rank 0 is instrumented
+            _lib.prof_enable(True)
+        for _ in range(2):
+            tstep()
+        torch.cuda.synchronize()
+        if want_kt:
+            _lib.prof_enable(False)
+            trecs = _lib.prof_fetch()
+    if dist:
+        dist.barrier()
+    train = {'value': round(B * world * a.train_steps / tdt, 3), 'unit': 'pairs/s', 'steps': a.train_steps,
+             'ms_per_step': round(tdt / a.train_steps * 1e3, 3), 'loss_finite': bool(torch.isfinite(lossv)),
+             'what': "forward(mode='train') + HIP backward (LM loop + both VGGs) + gradient all-reduce + Adam",
+             'allreduce_bytes_per_step': ar_bytes}
+    if a.model != 'g2sp':
+        # secondary number: the same step with args.train_ground_crop=1 (an extension: the ground branch trains on the
+        # image rows that can reach the loss; loss and gradients equal to rounding, the RETURNED confidence maps are
+        # only computed from the crop on -- DESIGN.md 3.5).  Not the default, so it is not `train.value`.
+        net.args.train_ground_crop = 1
+        cdt, _ = timed(a.train_steps)
+        net.args.train_ground_crop = 0
+        train['with_train_ground_crop'] = {'value': round(B * world * a.train_steps / cdt, 3), 'unit': 'pairs/s',
+                                           'ms_per_step': round(cdt / a.train_steps * 1e3, 3)}
+    if trecs:
+        tagg = aggregate(trecs)
+        tot = sum(v[1] for v in tagg.values())
+        train['kernels'] = {k: {'launches': v[0], 'avg_us': round(v[1] / v[0] * 1e3, 1), 'share': round(v[1] / tot, 3),
+                                'tflops': round(v[2] / (v[1] * 1e-3) / 1e12, 1) if v[2] else None}
+                            for k, v in sorted(tagg.items(), key=lambda kv: -kv[1][1])[:8]}
+    net.eval()
+    return train
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -76,6 +361,7 @@ def main():
                     help='kitti = LM_S2GP (the headline, BASELINE configs[1]); ford = LM_S2GP_Ford; g2sp = LM_G2SP')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-timing', action='store_true')
+    ap.add_argument('--no-extra-legs', action='store_true', help='skip by_precision and the secondary configs (N=1 extras)')
     ap.add_argument('--train-steps', type=int, default=6, help='extra: time this many training steps (0 = skip)')
     a = ap.parse_args()
     if a.n_iters is None:
@@ -93,6 +379,7 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
     dist = None
+    ranks_seen = 1
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
@@ -100,175 +387,85 @@ def main():
             dist.init_process_group('gloo', rank=rank, world_size=world)
         else:
             dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+        # proof that the collective backend really spans N ranks: every rank contributes 1 (and its device index)
+        one = torch.ones(2, device=dev, dtype=torch.float64)
+        one[1] = float(torch.cuda.current_device())
+        dist.all_reduce(one, op=dist.ReduceOp.SUM)
+        ranks_seen = int(one[0].item())
 
-    from types import SimpleNamespace
     from highlyaccurate_amd import _lib
-    from highlyaccurate_amd.models_kitti import LM_G2SP, LM_S2GP
-    from highlyaccurate_amd.models_ford import LM_S2GP_Ford
     _lib.load()
-    args = SimpleNamespace(level=3, N_iters=a.n_iters, using_weight=0, loss_method=0, proj='geo', Optimizer='LM',
-                           rotation_range=10.0, shift_range_lat=20.0, shift_range_lon=20.0, damping=0.1,
-                           train_damping=0, dropout=0, use_hessian=0, use_gt_depth=0, visualize=0,
-                           coe_shift_lat=100.0, coe_shift_lon=100.0, coe_heading=100.0, coe_L1=100.0, coe_L2=100.0,
-                           coe_L3=100.0, coe_L4=100.0, estimate_depth=0, precision=a.precision)
-    torch.manual_seed(1234)                  # identical replicas on every rank (data-parallel training needs that) ...
-    net = {'kitti': LM_S2GP, 'ford': LM_S2GP_Ford, 'g2sp': LM_G2SP}[a.model](args)
-    # random-init weights of the reference architecture: Kaiming-normal(fan_out), zero bias (torchvision's
-    # non-pretrained VGG init; there is no network for the pretrained checkpoint)
-    for m in net.modules():
-        if isinstance(m, torch.nn.Conv2d):
-            torch.nn.init.kaiming_normal_(m.weight, mode='fan_out', nonlinearity='relu')
-            if m.bias is not None:
-                torch.nn.init.zeros_(m.bias)
-    net = net.to(dev).eval()
-    torch.manual_seed(1234 + rank)           # ... and a different synthetic shard per rank (also decorrelates the re-init draws)
     B = a.batch
-    sat = torch.rand(B, 3, a.sat_a, a.sat_a, device=dev)
-    grd = torch.rand(B, 3, a.grd_hw[0], a.grd_hw[1], device=dev)
-
-    if a.model == 'ford':       # BASELINE configs[3] / SURVEY 8(d): fixed camera-to-body rotation, 112.64 m tile
-        extra = (112.64, torch.tensor([[[0., 0., 1.], [1., 0., 0.], [0., 1., 0.]]], device=dev).repeat(B, 1, 1),
-                 torch.tensor([[1.7, 0.3, -1.2]], device=dev).repeat(B, 1))
-    elif a.model == 'g2sp':     # left_camera_k of the 256x1024 frame (models_kitti.py:657-660 values)
-        extra = (torch.tensor([[[582.9802, 0., 496.2420], [0., 482.7076, 125.0034], [0., 0., 1.]]], device=dev).repeat(B, 1, 1),)
-    else:
-        extra = ()
-
-    def step():
-        with torch.no_grad():
-            return net(sat, grd, *extra, mode='test')
-
-    for _ in range(a.warmup):
-        step()
-    torch.cuda.synchronize()
-    if dist:
-        dist.barrier()
-    torch.cuda.synchronize()
+    net = build_net(a.model, a.precision, a.n_iters, dev)
+    sat, grd, extra = make_inputs(a.model, B, a.grd_hw, a.sat_a, dev, rank)
     want_kt = (rank == 0) and not a.no_kernel_timing
+
     # ---- the timed region: exactly K steps, no instrumentation
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        out = step()
-    torch.cuda.synchronize()
-    if dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    # ---- the same K steps once more on rank 0 with a HIP-event pair around every kernel launch (hla_prof_*, events on the
-    # launch stream): per-kernel durations for the roofline.  Kept out of `value`: the event pairs cost ~9 % wall time
-    # (measured: 8.73 vs 7.97 ms/step), which would also have made rank 0 the slowest rank of every multi-GPU run.
+    dt, out = timed_infer(net, sat, grd, extra, a.steps, a.warmup, dist)
+    # ---- the same steps once more on rank 0 with a HIP-event pair around every kernel launch: per-kernel durations for the
+    # rooflines.  Kept out of `value` (measured: 8.73 vs 7.97 ms/step), and it would make rank 0 the slowest rank of every multi-GPU run.
     recs, dt_ev = [], None
     n_ev = min(a.steps, 50)               # bound the instrumented pass (130 event pairs per step)
     if want_kt:
-        _lib.prof_enable(True)
-        t1 = time.perf_counter()
-        for _ in range(n_ev):
-            step()
-        torch.cuda.synchronize()
-        dt_ev = time.perf_counter() - t1
-        _lib.prof_enable(False)
-        recs = _lib.prof_fetch()
+        recs, dt_ev = kernel_pass(net, sat, grd, extra, n_ev)
     if dist:
         dist.barrier()
-    if dist:
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
     if not os.environ.get('HLA_BENCH_NOCHECK'):     # timing-ablation builds (tools/variants.py) produce garbage
         assert all(torch.isfinite(o).all() for o in out)
+
+    headline_cfg = (a.model == 'kitti' and B == 32 and a.sat_a == 512 and tuple(a.grd_hw) == (256, 1024) and a.n_iters == 5)
+    pmc, pmc_src = load_pmc() if rank == 0 else (None, None)
 
     # ---- extra: the training step (forward(train) + HIP backward + gradient all-reduce + Adam), same shapes
     train = None
     if a.train_steps > 0:
-      try:
-          from highlyaccurate_amd.parallel import GradSync
-          net.train()
-          if dist:
-              net.grad_sync = GradSync()
-          opt = torch.optim.Adam(net.parameters(), lr=1e-4)
-          gt = [torch.rand(B, 1, device=dev) * 2 - 1 for _ in range(3)]
-          if a.model == 'ford':      # Ford_dataset.py:211 collates python floats: [B] float64
-              gt = [g[:, 0].double() for g in gt]
+        try:
+            train = train_leg(net, a, sat, grd, extra, B, world, dist, dev, want_kt)
+        except Exception as e:      # the headline line must still be printed
+            train = {'error': repr(e)[:300]}
 
-          def tstep():
-              opt.zero_grad(set_to_none=True)
-              r = net(sat, grd, *extra, gt[0], gt[1], gt[2], mode='train')
-              r[0].backward()
-              opt.step()
-              return r[0]
-          for _ in range(2):          # warm-up: Adam state, caching-allocator segments for the backward workspaces
-              tstep()
-          torch.cuda.synchronize()
-          if dist:
-              dist.barrier()
-          torch.cuda.synchronize()
-          t1 = time.perf_counter()
-          ar0 = net.grad_sync.bytes_reduced if dist else 0
-          for _ in range(a.train_steps):
-              lossv = tstep()
-          ar_bytes = ((net.grad_sync.bytes_reduced - ar0) // a.train_steps) if dist else 0
-          torch.cuda.synchronize()
-          if dist:
-              dist.barrier()
-          torch.cuda.synchronize()
-          tdt = time.perf_counter() - t1
-          trecs = []
-          if not a.no_kernel_timing:  # per-kernel table from two extra steps (not part of the timing).  EVERY rank runs them --
-              if want_kt:             # a training step contains the gradient all-reduce -- but only rank 0 is instrumented
-                  _lib.prof_enable(True)
-              for _ in range(2):
-                  tstep()
-              torch.cuda.synchronize()
-              if want_kt:
-                  _lib.prof_enable(False)
-                  trecs = _lib.prof_fetch()
-          if dist:
-              dist.barrier()
-          if dist:
-              tt = torch.tensor([tdt], device=dev, dtype=torch.float64)
-              dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-              tdt = float(tt.item())
-          train = {'value': round(B * world * a.train_steps / tdt, 3), 'unit': 'pairs/s', 'steps': a.train_steps,
-                   'ms_per_step': round(tdt / a.train_steps * 1e3, 3), 'loss_finite': bool(torch.isfinite(lossv)),
-                   'what': "forward(mode='train') + HIP backward (LM loop + both VGGs) + gradient all-reduce + Adam",
-                   'allreduce_bytes_per_step': ar_bytes}
-          if a.model != 'g2sp':
-              # secondary number: the same step with args.train_ground_crop=1 (an extension: the ground branch trains on the
-              # image rows that can reach the loss; loss and gradients equal to rounding, the RETURNED confidence maps are
-              # only computed from the crop on -- DESIGN.md 3.5).  Not the default, so it is not `train.value`.
-              net.args.train_ground_crop = 1
-              for _ in range(2):
-                  tstep()
-              torch.cuda.synchronize()
-              if dist:
-                  dist.barrier()
-              torch.cuda.synchronize()
-              t1 = time.perf_counter()
-              for _ in range(a.train_steps):
-                  tstep()
-              torch.cuda.synchronize()
-              if dist:
-                  dist.barrier()
-              torch.cuda.synchronize()
-              cdt = time.perf_counter() - t1
-              net.args.train_ground_crop = 0
-              if dist:
-                  tt = torch.tensor([cdt], device=dev, dtype=torch.float64)
-                  dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-                  cdt = float(tt.item())
-              train['with_train_ground_crop'] = {'value': round(B * world * a.train_steps / cdt, 3), 'unit': 'pairs/s',
-                                                 'ms_per_step': round(cdt / a.train_steps * 1e3, 3)}
-          if trecs:
-              tagg = {}
-              for name, ms, fl, by in trecs:
-                  e = tagg.setdefault(name, [0, 0.0, 0.0])
-                  e[0] += 1; e[1] += ms; e[2] += fl
-              tot = sum(v[1] for v in tagg.values())
-              train['kernels'] = {k: {'launches': v[0], 'avg_us': round(v[1] / v[0] * 1e3, 1), 'share': round(v[1] / tot, 3),
-                                      'tflops': round(v[2] / (v[1] * 1e-3) / 1e12, 1) if v[2] else None}
-                                  for k, v in sorted(tagg.items(), key=lambda kv: -kv[1][1])[:8]}
-      except Exception as e:      # the headline line must still be printed
-        train = {'error': repr(e)[:300]}
+    # ---- N=1 extras: the other arithmetic modes on the same workload, and BASELINE configs[3] / [4]
+    by_precision, secondary = None, None
+    if world == 1 and headline_cfg and not a.no_extra_legs:
+        by_precision = {}
+        for p in ('fp32', 'fp16x3', 'bf16'):
+            try:
+                if p == a.precision:
+                    e = {'value': round(B * a.steps / dt, 3), 'ms_per_step': round(dt / a.steps * 1e3, 3), 'steps': a.steps}
+                    prec_recs = recs
+                else:
+                    net = None
+                    torch.cuda.empty_cache()
+                    net = build_net('kitti', p, 5, dev)
+                    k = 10 if p == 'fp32' else 20
+                    pdt, pout = timed_infer(net, sat, grd, extra, k, 3, None)
+                    assert all(torch.isfinite(o).all() for o in pout)
+                    e = {'value': round(B * k / pdt, 3), 'ms_per_step': round(pdt / k * 1e3, 3), 'steps': k}
+                    prec_recs = kernel_pass(net, sat, grd, extra, 5)[0] if not a.no_kernel_timing else []
+                e['unit'] = 'pairs/s'
+                if prec_recs:
+                    r = conv_roofline(aggregate(prec_recs), p, None, None, False)
+                    e['roofline'] = {k_: r[k_] for k_ in ('kernel', 'bound', 'achieved', 'peak', 'unit', 'frac', 'avg_launch_us')}
+                e['accuracy'] = pose_deviation(p, dev)
+                by_precision[p] = e
+            except Exception as ex:
+                by_precision[p] = {'error': repr(ex)[:300]}
+        secondary = {}
+        for tag, kw in (('configs[3] Ford', dict(model='ford', precision='bf16', n_iters=10, B=32, grd_hw=(256, 1024), sat_a=512, steps=10)),
+                        ('configs[4] hires fp16', dict(model='kitti', precision='fp16', n_iters=10, B=8, grd_hw=(512, 2048), sat_a=1024, steps=5))):
+            try:
+                net = None
+                torch.cuda.empty_cache()
+                net = build_net(kw['model'], kw['precision'], kw['n_iters'], dev)
+                s2, g2, x2 = make_inputs(kw['model'], kw['B'], kw['grd_hw'], kw['sat_a'], dev, rank)
+                sdt, sout = timed_infer(net, s2, g2, x2, kw['steps'], 2, None)
+                secondary[tag] = {'value': round(kw['B'] * kw['steps'] / sdt, 3), 'unit': 'pairs/s', 'dtype': kw['precision'],
+                                  'ms_per_step': round(sdt / kw['steps'] * 1e3, 3), 'steps': kw['steps'], 'pairs_per_gpu': kw['B'],
+                                  'finite': bool(all(torch.isfinite(o).all() for o in sout)),
+                                  'workload': workload_name(kw['model'], kw['sat_a'], kw['grd_hw'], kw['n_iters'])}
+                del s2, g2, x2
+            except Exception as ex:
+                secondary[tag] = {'error': repr(ex)[:300]}
 
     if rank == 0:
         pairs = B * world * a.steps
@@ -277,57 +474,36 @@ def main():
             'value': round(pairs / dt, 3), 'unit': 'pairs/s', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
             'ms_per_step': round(dt / a.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': a.precision, 'data': 'synthetic',
-            'config': {'workload': {'kitti': ("BASELINE configs[1]: LM_S2GP" if (a.sat_a, tuple(a.grd_hw)) == (512, (256, 1024)) else "BASELINE configs[4] sizes: LM_S2GP"), 'ford': "BASELINE configs[3] shapes: LM_S2GP_Ford",
-                                    'g2sp': "SURVEY 8(f).2: LM_G2SP"}[a.model] + f".forward(mode='test'), sat {a.sat_a}x{a.sat_a}, grd {a.grd_hw[0]}x{a.grd_hw[1]}, "
-                                   f"VGG-16 two-branch, level 3, {a.n_iters} LM iters x 3 levels, 3-DoF, random-init weights",
+            'config': {'workload': workload_name(a.model, a.sat_a, a.grd_hw, a.n_iters),
                        'pairs_per_gpu': B, 'global_batch': B * world, 'parallelism': f'batch-sharded x{world}, no collective',
                        'dead_work_skipped': 'dec3/conf3 (VGG.py:153-155,163: computed and dropped by the reference at level 3); '
                                             f'ground-image rows 0..{dead_ground_rows(grd.shape[-2]) - 1} (cannot reach the bottom-half '
                                             'rows the LM loop reads) and, layer by layer, the feature rows those rows do not '
                                             'depend on; computed rows are bit-identical, DESIGN.md 3.5)'},
         }
-        # whole-forward conv rate on the FLOPs that were actually executed (the reference's as-written count is 316.3
-        # GFLOP/pair, 272.4 without dec3/conf3)
+        if world > 1:
+            res['collective_ranks_seen'] = ranks_seen      # all-reduced count over the process group (RCCL unless rehearsing)
+            res['collective_backend'] = 'gloo (rehearsal)' if rehearse else 'nccl (RCCL)'
         if recs:
-            conv_fl = sum(fl for name, ms, fl, by in recs if name.startswith('conv'))      # over the K instrumented steps
+            agg = aggregate(recs)
+            # whole-forward conv rate on the FLOPs that were actually EXECUTED (dead rows / dead layers excluded; the
+            # reference's as-written count is 316.3 GFLOP/pair, 272.4 without dec3/conf3)
+            conv_fl = sum(v[2] for k, v in agg.items() if k.startswith('conv'))      # over the n_ev instrumented steps
             res['conv_gflop_per_pair_executed'] = round(conv_fl / (B * n_ev) / 1e9, 2)
-            res['conv_tflops_live'] = round(conv_fl / n_ev * a.steps / dt / 1e12, 2)   # this GPU, against the un-instrumented time
-        if recs:
-            agg = {}
-            for name, ms, fl, by in recs:
-                e = agg.setdefault(name, [0, 0.0, 0.0, 0.0])
-                e[0] += 1; e[1] += ms; e[2] += fl; e[3] += by
+            res['conv_tflops_executed'] = round(conv_fl / n_ev * a.steps / dt / 1e12, 2)   # this GPU, against the un-instrumented time
             tot_ms = sum(v[1] for v in agg.values())
-            kern = {k: {'launches': v[0], 'avg_us': round(v[1] / v[0] * 1e3, 2), 'share': round(v[1] / tot_ms, 4),
-                        'tflops': round(v[2] / (v[1] * 1e-3) / 1e12, 2) if v[2] else None,
-                        'gbs': round(v[3] / (v[1] * 1e-3) / 1e9, 1) if v[3] else None}
-                    for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])}
-            dom = max((k for k in agg if agg[k][2] > 0), key=lambda k: agg[k][1])
-            n, ms, fl, by = agg[dom]
-            ach = fl / (ms * 1e-3) / 1e12
-            traffic, tsrc = None, None
-            try:      # HBM bytes per launch from the committed rocprofv3 PMC passes (separate --pmc runs, gfx950 correction)
-                pm = json.load(open(os.path.join(ROOT, 'profiles', 'r01_pmc_hbm_traffic.json')))
-                sym = {'conv3x3_kernel<MT4,NT2>': 'Li4ELi2ELi2ELi2ELb0', 'conv3x3_kernel<MT4,NT2,pool>': 'Li4ELi2ELi2ELi2ELb1',
-                       'conv3x3_kernel<MT4,NT1>': 'Li4ELi1ELi2ELi2ELb0', 'conv3x3_kernel<MT4,NT1,pool>': 'Li4ELi1ELi2ELi2ELb1'}.get(dom)
-                if a.precision == 'bf16' and B == 32 and sym:
-                    for kname, v in pm.items():
-                        if sym in kname:
-                            traffic, tsrc = v['hbm_bytes_corrected'], 'profiles/r01_pmc_hbm_traffic.json'
-            except Exception:
-                pass
             res['events_pass_ms_per_step'] = round(dt_ev / n_ev * 1e3, 3)
-            res['roofline'] = {'kernel': dom, 'bound': 'mfma', 'achieved': round(ach, 2), 'peak': PEAK_TFLOPS[a.precision],
-                               'unit': 'TFLOP/s', 'frac': round(ach / PEAK_TFLOPS[a.precision], 4), 'traffic': traffic,
-                               'traffic_unit': 'bytes/launch', 'traffic_source': tsrc,
-                               'launches': n, 'avg_launch_us': round(ms / n * 1e3, 2),
-                               'flops_per_launch': round(fl / n / 1e9, 3), 'flops_unit': 'GFLOP'}
-            lm = [k for k in agg if k.startswith('lm_accum')]
-            if lm:
-                lms, lby = sum(agg[k][1] for k in lm), sum(agg[k][3] for k in lm)
-                res['lm_roofline'] = {'kernel': 'lm_accum<*>', 'bound': 'hbm', 'achieved': round(lby / (lms * 1e-3) / 1e9, 1),
-                                      'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'frac': round(lby / (lms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)}
-            res['kernels'] = kern
+            res['roofline'] = conv_roofline(agg, a.precision, pmc, pmc_src, headline_cfg)
+            lmr = lm_roofline(agg, pmc if headline_cfg else None, pmc_src)
+            if lmr:
+                res['lm_roofline'] = lmr
+            res['kernels'] = {k: {'launches': v[0], 'avg_us': round(v[1] / v[0] * 1e3, 2), 'share': round(v[1] / tot_ms, 4),
+                                  'tflops': round(v[2] / (v[1] * 1e-3) / 1e12, 2) if v[2] else None}
+                              for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])}
+        if by_precision:
+            res['by_precision'] = by_precision
+        if secondary:
+            res['secondary'] = secondary
         if train:
             res['train'] = train
         if not a.no_cpu_baseline:

@@ -310,3 +310,18 @@ def test_oracle_ablation_optimisers_match_reference_golden(opt):
     # reference's own fp32-vs-fp64 gap is 6.7e-4): tight on the first steps, within a fraction of that gap overall
     assert err[:, :3].max() < 1e-7
     assert err.max() < (1e-7 if opt == 'SGD' else 0.5 * np.abs(g[f'trace32_{opt}'] - g[f'trace64_{opt}']).max())
+
+
+def test_product_side_synthetic_generators_match_the_oracles():
+    """bench.py draws its golden-input accuracy check from highlyaccurate_amd.synthetic (the product may not import the
+    oracle); those generators must be the ones the goldens were recorded with, bit for bit."""
+    import torch
+    from highlyaccurate_amd import synthetic as S
+    from oracle import ref_cpu as O
+    assert vars(S.reference_args(N_iters=7)) == vars(O.default_args(N_iters=7))
+    a, b = S.model_state(3, bias_scale=0.02), O.synth_model_state(3, bias_scale=0.02)
+    assert list(a) == list(b) and all(torch.equal(a[k], b[k]) for k in a)
+    a, b = S.model_state(4, rotation_range=0.0), O.synth_model_state(4, rotation_range=0.0)
+    assert all(torch.equal(a[k], b[k]) for k in a) and a['damping'].dim() == 0
+    for x, y in zip(S.images(9, 2, grd_hw=(16, 32), sat_a=24), O.synth_images(9, 2, grd_hw=(16, 32), sat_a=24)):
+        assert torch.equal(x, y)

@@ -17,9 +17,16 @@ write, _ = means(sys.argv[2], 'WRITE_SIZE')
 out = {'_note': 'rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), mean per dispatch, bench.py --steps 2 (B=32, bf16). '
                 'Counter unit is KiB. Per MI355X_MICROARCH.md (HBM section) FETCH_SIZE reports half of a wide coalesced read stream on '
                 'gfx950, so hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024; WRITE_SIZE is uncalibrated.'}
+try:      # stamp with the content hash of the kernel sources: bench.py ignores a file measured on other kernels
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from highlyaccurate_amd import build as _b
+    out['_source_hash'] = _b.lib_hash()
+except Exception as e:
+    out['_source_hash'] = None
 for k in sorted(fetch, key=lambda k: -fetch[k] * nf[k]):
     if any(s in k for s in ('conv', 'lm_', 'wgrad')):
         out[k] = {'dispatches': nf[k], 'FETCH_SIZE_KiB': fetch[k], 'WRITE_SIZE_KiB': write.get(k, 0.0),
                   'hbm_bytes_corrected': (2 * fetch[k] + write.get(k, 0.0)) * 1024}
 json.dump(out, open(sys.argv[3], 'w'), indent=1)
-print(json.dumps({k: v['hbm_bytes_corrected'] for k, v in out.items() if k != '_note'}, indent=1))
+print(json.dumps({k: v['hbm_bytes_corrected'] for k, v in out.items() if isinstance(v, dict)}, indent=1))
