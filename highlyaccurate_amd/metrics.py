@@ -10,13 +10,18 @@ ANGLES = (1, 3, 5)      # degrees
 
 
 def localisation_metrics(pred_shifts, pred_headings, gt_shifts, gt_headings, shift_range_lat, shift_range_lon,
-                         rotation_range):
+                         rotation_range, reference_compat: bool = False):
     """All inputs in the model's normalised units: pred_shifts / gt_shifts [N,2] = (lat, lon), headings [N,1].
-    Returns (result, stats dict, text lines).  ``result`` is the reference's model-selection score: the percentage of
-    samples within 1 m AND 1 degree (train_kitti.py:160)."""
+    Returns (result, stats dict, text lines).  ``result`` is the model-selection score (train_kitti.py:160): the percentage
+    of samples within 1 m AND 1 degree.  The reference computes it as ``(distance < 1) & (angle_diff < 1)`` with distance
+    [N] and angle_diff [N,1], which BROADCASTS to an N x N mask (every distance paired with every angle; the score can
+    exceed 100).  The default here is the per-sample score the line means; ``reference_compat=True`` reproduces the
+    reference's number bit for bit, for anyone who must select the same best checkpoint as an existing run."""
     scale = np.array([shift_range_lat, shift_range_lon], dtype=np.float64).reshape(1, 2)
-    ps, gs = np.asarray(pred_shifts, np.float64) * scale, np.asarray(gt_shifts, np.float64) * scale      # 77-80
-    ph, gh = np.asarray(pred_headings, np.float64) * rotation_range, np.asarray(gt_headings, np.float64) * rotation_range
+    # dtypes as in the reference (77-80): shifts are multiplied by a float64 ARRAY (-> float64), headings by a python
+    # float (-> they stay in the network's float32), and every later comparison is made on those values
+    ps, gs = np.asarray(pred_shifts) * scale, np.asarray(gt_shifts) * scale
+    ph, gh = np.asarray(pred_headings) * rotation_range, np.asarray(gt_headings) * rotation_range
     distance = np.sqrt(np.sum((ps - gs) ** 2, axis=1))
     angle_diff = np.remainder(np.abs(ph - gh), 360)
     angle_diff = np.where(angle_diff > 180, 360 - angle_diff, angle_diff)
@@ -46,5 +51,33 @@ def localisation_metrics(pred_shifts, pred_headings, gt_shifts, gt_headings, shi
         i = np.sum((init_angle[:, 0] < a) & (np.abs(gs[:, 0]) < m)) / n * 100
         stats[f'lat@{m}&angle@{a}'] = (p, i)
         lines.append(f'lat within {m} & angle within {a} (pred, init): {p} {i}')
-    result = float(np.sum((distance < METRICS[0]) & (angle_diff[:, 0] < ANGLES[0])) / n * 100)
+    if reference_compat:
+        result = float(np.sum((distance < METRICS[0]) & (angle_diff < ANGLES[0])) / n * 100)      # [N] & [N,1] -> [N,N]
+    else:
+        result = float(np.sum((distance < METRICS[0]) & (angle_diff[:, 0] < ANGLES[0])) / n * 100)
     return result, stats, lines
+
+
+def write_test_results(save_path, name, epoch, duration, pred_shifts, pred_headings, gt_shifts, gt_headings,
+                       shift_range_lat, shift_range_lon, rotation_range, reference_compat: bool = False):
+    """What test1 / test2 leave on disk (train_kitti.py:77-161, 212-296; train_ford.py the same):
+      ``<save_path>/<name>_results.mat``  gt_shifts, gt_headings, pred_shifts, pred_headings in metres / degrees (line 82)
+      ``<save_path>/<name>_results.txt``  one block per call APPENDED: header, EPOCH, time per image, the recall lines
+    ``name`` is 'Test1' or 'Test2'.  Inputs in the model's normalised units.  Returns (result, stats)."""
+    import os
+    import scipy.io as scio
+    os.makedirs(save_path, exist_ok=True)
+    scale = np.array([shift_range_lat, shift_range_lon], dtype=np.float64).reshape(1, 2)
+    scio.savemat(os.path.join(save_path, f'{name}_results.mat'),
+                 {'gt_shifts': np.asarray(gt_shifts) * scale, 'gt_headings': np.asarray(gt_headings) * rotation_range,
+                  'pred_shifts': np.asarray(pred_shifts) * scale, 'pred_headings': np.asarray(pred_headings) * rotation_range})
+    result, stats, lines = localisation_metrics(pred_shifts, pred_headings, gt_shifts, gt_headings, shift_range_lat,
+                                                shift_range_lon, rotation_range, reference_compat)
+    with open(os.path.join(save_path, f'{name}_results.txt'), 'a') as f:
+        f.write('====================================\n')
+        f.write('       EPOCH: ' + str(epoch) + '\n')
+        f.write('Time per image (second): ' + str(duration) + '\n')
+        for line in lines:
+            f.write(line + '\n')
+        f.write('====================================\n')
+    return result, stats

@@ -442,6 +442,73 @@ def gen_train(mk, seed, B=1, weighted=False):
     np.savez_compressed(os.path.join(GOLD, 'train_kitti_w.npz' if weighted else 'train_kitti.npz'), **out)
 
 
+def gen_manifest(mk, mf):
+    """State-dict manifest of the REAL reference classes (key -> shape, in state_dict order) for the configurations a
+    checkpoint can come from: what `torch.save(net.state_dict())` (train_kitti.py:167-170,409-414) writes and
+    `load_state_dict` (546-554) expects.  tests/test_oracle_golden.py holds the product classes to it on CPU."""
+    import json
+    torch.Tensor.cuda = lambda self, *a, **k: self          # LM_G2SP calls .cuda() on helper tensors
+    out = {}
+    for tag, mod, cls, kw in (('LM_S2GP', mk, 'LM_S2GP', {}), ('LM_S2GP level4', mk, 'LM_S2GP', dict(level=4)),
+                              ('LM_S2GP rot0', mk, 'LM_S2GP', dict(rotation_range=0.0)),
+                              ('LM_G2SP', mk, 'LM_G2SP', {}), ('LM_S2GP_Ford', mf, 'LM_S2GP_Ford', {}),
+                              ('LM_S2GP_Ford level4', mf, 'LM_S2GP_Ford', dict(level=4))):
+        net = getattr(mod, cls)(O.default_args(**kw))
+        torch.autograd.set_detect_anomaly(False)
+        sd = net.state_dict()
+        out[tag] = {'class': cls, 'args': kw, 'n_tensors': len(sd), 'n_params': int(sum(v.numel() for v in sd.values())),
+                    'state_dict': [[k, list(v.shape), str(v.dtype)] for k, v in sd.items()]}
+        print(tag, out[tag]['n_tensors'], out[tag]['n_params'])
+    json.dump(out, open(os.path.join(GOLD, 'state_dict_manifest.json'), 'w'), indent=0)
+
+
+def gen_results():
+    """The files the REAL reference's test1() leaves on disk (train_kitti.py:34-170): Test1_results.mat and the block it
+    appends to Test1_results.txt, for prescribed predictions.  train_kitti.py is imported with its data loader and
+    tensorboard shimmed out, `load_test1_data` returns three synthetic batches and the "network" returns prescribed poses."""
+    import tempfile
+    import types
+    import scipy.io as scio
+    for name in ('torch.utils.tensorboard', 'dataLoader', 'dataLoader.KITTI_dataset'):
+        m = types.ModuleType(name)
+        sys.modules.setdefault(name, m)
+    sys.modules['torch.utils.tensorboard'].SummaryWriter = object
+    for fn in ('load_train_data', 'load_test1_data', 'load_test2_data'):
+        setattr(sys.modules['dataLoader.KITTI_dataset'], fn, None)
+    import train_kitti as tk
+    rs = np.random.RandomState(11)
+    N, bs = 24, 8
+    gt = rs.uniform(-1, 1, (N, 3)).astype(np.float32)                       # (u, v, heading), normalised
+    pred = (gt + rs.standard_normal((N, 3)) * np.array([0.04, 0.08, 0.15])).astype(np.float32)
+    batches = []
+    for i in range(0, N, bs):
+        g = torch.from_numpy(gt[i:i + bs])
+        batches.append((torch.zeros(bs, 3, 8, 8), torch.zeros(bs, 3, 3), torch.full((bs, 3, 4, 4), float(i)),
+                        g[:, 0:1].clone(), g[:, 1:2].clone(), g[:, 2:3].clone(), ['f'] * bs))
+
+    class FakeNet(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.p = torch.nn.Parameter(torch.zeros(()))
+
+        def forward(self, sat_map, grd, mode='test', **kw):
+            i = int(grd[0, 0, 0, 0].item())
+            out = torch.from_numpy(pred[i:i + bs]) + self.p
+            return out[:, 1], out[:, 0], out[:, 2]                           # (shifts_lat, shifts_lon, theta)
+
+    tk.load_test1_data = lambda *a, **k: batches
+    tk.device, tk.mini_batch = torch.device('cpu'), bs
+    args = O.default_args(direction='S2GP')
+    tmp = tempfile.mkdtemp()
+    result = tk.test1(FakeNet(), args, tmp, 1e9, 7)
+    mat = scio.loadmat(os.path.join(tmp, 'Test1_results.mat'))
+    txt = open(os.path.join(tmp, 'Test1_results.txt')).read()
+    print(txt, result)
+    np.savez_compressed(os.path.join(GOLD, 'results_kitti.npz'), gt=gt, pred=pred, result=np.float64(result), epoch=7,
+                        txt=np.frombuffer(txt.encode(), dtype=np.uint8),
+                        **{'mat_' + k: mat[k] for k in ('gt_shifts', 'gt_headings', 'pred_shifts', 'pred_headings')})
+
+
 if __name__ == '__main__':
     ap = argparse.ArgumentParser()
     ap.add_argument('--only', default='all')
@@ -453,6 +520,10 @@ if __name__ == '__main__':
     seeds = [int(s) for s in a.seeds.split(',')] if a.seeds else None
     if a.only == 'screen':
         gen_screen(mk)
+    if a.only in ('all', 'manifest'):
+        gen_manifest(mk, mf)
+    if a.only in ('all', 'results'):
+        gen_results()
     if a.only in ('all', 'kat'):
         gen_kat(mk, mf, jac, VGG)
     if a.only in ('all', 'e2e'):

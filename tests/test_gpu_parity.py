@@ -1044,6 +1044,59 @@ def test_reference_call_pattern_harness_runs():
     assert len(log) == 2 and all(np.isfinite(log))
 
 
+def test_checkpoint_round_trip_resume_and_result_files(tmp_path):
+    """the harness writes what the reference's driver writes (model_<epoch>.pth after every epoch, Test1_results.mat
+    / .txt, Model_best.pth); a checkpoint loaded in a NEW process reproduces the saved model's pose trace bit for bit;
+    --resume continues from model_<N-1>.pth; --test 1 evaluates model_1.pth."""
+    import importlib.util, os, subprocess, sys
+    import scipy.io as scio
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location('train_harness', os.path.join(root, 'tools', 'train_harness.py'))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    sp = str(tmp_path / 'ckpt')
+    common = ['--batch_size', '2', '--iters_per_epoch', '2', '--N_iters', '2', '--grd_h', '64', '--grd_w', '256', '--sat_a', '128',
+              '--precision', 'fp32', '--save_path', sp]
+    log = m.main(common + ['--epochs', '2'])
+    assert len(log) == 4 and all(np.isfinite(log))
+    for f in ('model_0.pth', 'model_1.pth', 'Test1_results.mat', 'Test1_results.txt'):
+        assert os.path.exists(os.path.join(sp, f)), f
+    mat = scio.loadmat(os.path.join(sp, 'Test1_results.mat'))
+    assert mat['pred_shifts'].shape == (4, 2) and mat['gt_headings'].shape == (4, 1)       # 2 test batches of 2
+    txt = open(os.path.join(sp, 'Test1_results.txt')).read()
+    assert txt.count('EPOCH:') == 2 and 'lat within 5 & angle within 5 (pred, init):' in txt
+    # the checkpoint in this process ...
+    from oracle import ref_cpu as O
+    from highlyaccurate_amd.models_kitti import LM_S2GP
+    d = _dev()
+    sd = torch.load(os.path.join(sp, 'model_1.pth'), map_location='cpu')
+    assert len(sd) == 49
+    net = LM_S2GP(O.default_args(N_iters=2))
+    net.load_state_dict(sd)                                  # strict
+    net = net.to(d)
+    sat, grd, *_ = O.synth_images(5, 2, grd_hw=(64, 256), sat_a=128)
+    torch.manual_seed(0)
+    with torch.no_grad():
+        net(sat.to(d), grd.to(d), mode='test')
+    here = net.last_trace.cpu().numpy()
+    # ... and in a new process
+    code = ("import sys, numpy as np, torch; sys.path.insert(0, %r); from oracle import ref_cpu as O; "
+            "from highlyaccurate_amd.models_kitti import LM_S2GP; net = LM_S2GP(O.default_args(N_iters=2)); "
+            "net.load_state_dict(torch.load(%r, map_location='cpu')); net = net.to('cuda:0'); "
+            "sat, grd, *_ = O.synth_images(5, 2, grd_hw=(64, 256), sat_a=128); torch.manual_seed(0); "
+            "torch.no_grad().__enter__(); net(sat.cuda(), grd.cuda(), mode='test'); np.save(%r, net.last_trace.cpu().numpy())"
+            % (root, os.path.join(sp, 'model_1.pth'), str(tmp_path / 'there.npy')))
+    subprocess.run([sys.executable, '-c', code], check=True, timeout=600)
+    np.testing.assert_array_equal(np.load(str(tmp_path / 'there.npy')), here)
+    # --resume 2: loads model_1.pth, runs epoch 2 only
+    log = m.main(common + ['--epochs', '3', '--resume', '2'])
+    assert len(log) == 2 and os.path.exists(os.path.join(sp, 'model_2.pth'))
+    assert open(os.path.join(sp, 'Test1_results.txt')).read().count('EPOCH:') == 3
+    # --test 1: evaluates model_1.pth, appends one more block, trains nothing
+    assert m.main(common + ['--test', '1']) == []
+    assert open(os.path.join(sp, 'Test1_results.txt')).read().count('EPOCH:') == 4
+
+
 @pytest.mark.parametrize('level', [3, 4])
 def test_ford_train_step_vs_oracle_autograd_small(level):
     """Ford model, mode='train' under autograd on a reduced shape: loss and a few gradients vs the fp64 oracle."""

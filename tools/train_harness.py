@@ -4,8 +4,11 @@
 The reference's drivers never travel, and its datasets are not available, so this harness reproduces what they DO
 with the model -- same argparse flag names and defaults (train_kitti.py:428-481), per-epoch Adam re-creation with
 lr*(1-epoch/100) (329-333), zero_grad -> forward(mode='train') -> loss.backward() -> step (351-367), the progress
-line built from the 14-tuple indices (373-406), and the test loop that calls .backward() on the test outputs
-(49-64) -- against highlyaccurate_amd.models_kitti.LM_S2GP.  Multi-GPU: torchrun, batch sharded, GradSync.
+line built from the 14-tuple indices (373-406), the test loop that calls .backward() on the test outputs (49-64) and
+what it leaves on disk -- `model_<epoch % 100>.pth` after every epoch (409-414), `Test1_results.mat` / `.txt` (82,
+97-161), `Model_best.pth` when the selection score improves (163-170), `--resume N` loading `model_<N-1>.pth` (552-554)
+and `--test 1` loading `model_1.pth` (545-548) -- against highlyaccurate_amd.models_kitti.LM_S2GP.
+Multi-GPU: torchrun, batch sharded, GradSync.
 """
 import argparse
 import os
@@ -47,7 +50,57 @@ def parse_args(argv=None):
     p.add_argument('--grd_h', type=int, default=256)
     p.add_argument('--grd_w', type=int, default=1024)
     p.add_argument('--sat_a', type=int, default=512)
+    p.add_argument('--save_path', type=str, default='', help="checkpoint / result directory (the reference's getSavePath(args)); '' = write nothing")
+    p.add_argument('--resume', type=int, default=0, help='resume from model_<resume-1>.pth and continue with epoch <resume> (train_kitti.py:552-554)')
+    p.add_argument('--test', type=int, default=0, help='1: load model_1.pth, run the test loop, write the result files, no training (545-548)')
+    p.add_argument('--test_batches', type=int, default=2)
+    p.add_argument('--reference_compat', type=int, default=0,
+                   help="1: the reference's N x N model-selection score (metrics.localisation_metrics)")
     return p.parse_args(argv)
+
+
+def test1(net, args, save_path, best_rank_result, epoch, device, gen, rank=0):
+    """train_kitti.py:34-170 on synthetic batches: eval mode, NO no_grad (the outputs carry grad and .backward() is called
+    "to release the graph"), predictions gathered on the host, result files, Model_best.pth."""
+    import numpy as np
+    from highlyaccurate_amd.metrics import localisation_metrics, write_test_results
+    net.eval()
+    pred_shifts, pred_headings, gt_shifts, gt_headings = [], [], [], []
+    t0 = time.time()
+    for _ in range(args.test_batches):
+        sat_map, grd_left_imgs, (gt_shift_u, gt_shift_v, gt_heading) = synthetic_batch(args, device, gen)
+        shifts_lat, shifts_lon, theta = net(sat_map, grd_left_imgs, mode='test')
+        shifts = torch.stack([shifts_lat, shifts_lon], dim=-1)
+        headings = theta.unsqueeze(dim=-1)
+        gt_shift = torch.cat([gt_shift_v, gt_shift_u], dim=-1)
+        if args.shift_range_lat == 0 and args.shift_range_lon == 0:
+            loss = torch.mean(headings - gt_heading)
+        else:
+            loss = torch.mean(shifts_lat - gt_shift_u)
+        loss.backward()
+        pred_shifts.append(shifts.data.cpu().numpy())
+        pred_headings.append(headings.data.cpu().numpy())
+        gt_shifts.append(gt_shift.data.cpu().numpy())
+        gt_headings.append(gt_heading.data.cpu().numpy())
+    duration = (time.time() - t0) / args.test_batches
+    ps, ph = np.concatenate(pred_shifts, 0), np.concatenate(pred_headings, 0)
+    gs, gh = np.concatenate(gt_shifts, 0), np.concatenate(gt_headings, 0)
+    rc = bool(args.reference_compat)
+    if save_path and rank == 0:
+        result, stats = write_test_results(save_path, 'Test1', epoch, duration, ps, ph, gs, gh, args.shift_range_lat,
+                                           args.shift_range_lon, args.rotation_range, reference_compat=rc)
+    else:
+        result, stats, _ = localisation_metrics(ps, ph, gs, gh, args.shift_range_lat, args.shift_range_lon,
+                                                args.rotation_range, reference_compat=rc)
+    if rank == 0:
+        print('====================================\n       EPOCH: %d\nValidation results:\nInit distance average:  %s\n'
+              'Pred distance average:  %s\nresult: %s' % (epoch, stats['init_distance_mean'], stats['pred_distance_mean'], result),
+              flush=True)
+    net.train()
+    if result > best_rank_result and save_path and rank == 0:                       # train_kitti.py:165-168
+        os.makedirs(save_path, exist_ok=True)
+        torch.save(net.state_dict(), os.path.join(save_path, 'Model_best.pth'))
+    return result
 
 
 def synthetic_batch(args, device, gen):
@@ -70,7 +123,17 @@ def main(argv=None):
         net.grad_sync = P.GradSync()
     gen = torch.Generator().manual_seed(2022 + rank)
     log = []
-    for epoch in range(args.epochs):
+    save_path = args.save_path
+    if args.test:                                                                  # train_kitti.py:545-548
+        net.load_state_dict(torch.load(os.path.join(save_path, 'model_1.pth'), map_location=device))
+        test1(net, args, save_path, 0., 0, device, gen, rank)
+        return log
+    if args.resume:                                                                # train_kitti.py:552-554
+        net.load_state_dict(torch.load(os.path.join(save_path, 'model_' + str(args.resume - 1) + '.pth'), map_location=device))
+        if rank == 0:
+            print('resume from ' + 'model_' + str(args.resume - 1) + '.pth')
+    best = 0.0
+    for epoch in range(args.resume, args.epochs):
         net.train()
         base_lr = args.lr * ((1.0 - float(epoch) / 100.0) ** 1.0)            # train_kitti.py:329
         optimizer = torch.optim.Adam(net.parameters(), lr=base_lr)           # re-created every epoch (333)
@@ -96,22 +159,13 @@ def main(argv=None):
             log.append(float(loss.item()))
             if rank == 0:
                 print(line, flush=True)
-        # test1-style loop (train_kitti.py:34-100): no no_grad(), backward on the outputs "to release the graph"
-        net.eval()
-        sat_map, grd_left_imgs, (gt_shift_u, gt_shift_v, gt_heading) = synthetic_batch(args, device, gen)
-        shifts_lat, shifts_lon, theta = net(sat_map, grd_left_imgs, mode='test')
-        loss = torch.mean(shifts_lat - gt_shift_u)
-        loss.backward()
-        from highlyaccurate_amd.metrics import localisation_metrics
-        shifts = torch.stack([shifts_lat, shifts_lon], dim=-1).data.cpu().numpy()          # train_kitti.py:55-70
-        gt_shift = torch.cat([gt_shift_v, gt_shift_u], dim=-1).data.cpu().numpy()
-        result, stats, lines = localisation_metrics(shifts, theta.unsqueeze(-1).data.cpu().numpy(), gt_shift,
-                                                    gt_heading.data.cpu().numpy(), args.shift_range_lat, args.shift_range_lon,
-                                                    args.rotation_range)                      # train_kitti.py:77-160
-        if rank == 0:
-            print('\n'.join(['====================================', '       EPOCH: ' + str(epoch), 'Validation results:',
-                             'Init distance average:  %s' % stats['init_distance_mean'],
-                             'Pred distance average:  %s' % stats['pred_distance_mean']] + lines), flush=True)
+        compNum = epoch % 100                                                      # train_kitti.py:409-414
+        if save_path and rank == 0:
+            os.makedirs(save_path, exist_ok=True)
+            torch.save(net.state_dict(), os.path.join(save_path, 'model_' + str(compNum) + '.pth'))
+        current = test1(net, args, save_path, best, epoch, device, gen, rank)      # train_kitti.py:417-419
+        if current > best:
+            best = current
     return log
 
 
