@@ -124,12 +124,15 @@ def vgg_forward_nhwc(module: 'VGGUnet', x: torch.Tensor, want_conf: bool = True,
 
 @_lib.on_device(lambda module, ctx, *a, **k: ctx['x'])
 def vgg_backward_nhwc(module: 'VGGUnet', ctx: dict, d_feats, confs=None, d_confs=None, scale_invariant: bool = False,
-                      first_row8: int = 0):
+                      first_row8: int = 0, flat: bool = False):
     """Backward of ``vgg_forward_nhwc(..., defer_norm=True, save_for_backward=True)``.
     d_feats[l]: NHWC fp32 gradient w.r.t. the L2-normalised map l.  Returns {parameter name: gradient} for the
     22 tensors that receive one at level 3 (conv0..conv14 weights+biases, conv_dec1/2 weights), plus the conf head weights
     when ``confs`` / ``d_confs`` (the forward's confidence maps and their [B,h,w] gradients) are given, plus conv_dec3.* at
-    level 4 (d_feats[3] is [B,H,W,64]: the gradient w.r.t. the zero-padded x24)."""
+    level 4 (d_feats[3] is [B,H,W,64]: the gradient w.r.t. the zero-padded x24).
+    ``flat=True``: the 18 weight / bias gradients of conv0..conv_dec2.3 are VIEWS of one contiguous fp32 buffer that the
+    wgrad kernels write into directly, and ``(grads, flat_buffer)`` is returned: a data-parallel caller all-reduces that one
+    buffer in place (parallel.GradSync) -- no gather copy before and no scatter copy after the collective."""
     lib = _lib.load()
     x, dt = ctx['x'], ctx['dt']
     B, _, H, W = x.shape
@@ -142,14 +145,19 @@ def vgg_backward_nhwc(module: 'VGGUnet', ctx: dict, d_feats, confs=None, d_confs
         cache['key'], cache['buf'] = key, buf
     sd = dict(module.named_parameters())
     grads, gs = {}, _lib.VggGrads()
+    shapes = [(name + '.weight', tuple(sd[name + '.weight'].shape)) for name in _W_ORDER[:11]] + \
+             [(name + '.bias', tuple(sd[name + '.bias'].shape)) for name in _W_ORDER[:7]]
+    sizes = [int(torch.Size(shp).numel()) for _, shp in shapes]
+    # one allocation either way; every view starts on a 16-B boundary (all sizes are multiples of 4 elements)
+    flat_buf = torch.empty(sum(sizes), device=x.device, dtype=torch.float32)
+    o = 0
+    for (key, shp), n in zip(shapes, sizes):
+        grads[key] = flat_buf[o:o + n].view(shp)
+        o += n
     for i, name in enumerate(_W_ORDER[:11]):
-        g = torch.empty_like(sd[name + '.weight'], dtype=torch.float32, memory_format=torch.contiguous_format)
-        grads[name + '.weight'] = g
-        gs.dw[i] = g.data_ptr()
+        gs.dw[i] = grads[name + '.weight'].data_ptr()
         if i < 7:
-            gb = torch.empty_like(sd[name + '.bias'], dtype=torch.float32)
-            grads[name + '.bias'] = gb
-            gs.db[i] = gb.data_ptr()
+            gs.db[i] = grads[name + '.bias'].data_ptr()
     L = ctx.get('L', 3)
     padded = {}                         # level 4: gradients of the zero-padded weights; their leading blocks are the real ones
     if L == 4:
@@ -183,7 +191,7 @@ def vgg_backward_nhwc(module: 'VGGUnet', ctx: dict, d_feats, confs=None, d_confs
     for name, g in padded.items():
         co, ci = sd[name].shape[:2]
         grads[name] = g[:co, :ci].contiguous()
-    return grads
+    return (grads, flat_buf) if flat else grads
 
 
 class VGGUnet(nn.Module):
@@ -212,11 +220,46 @@ class VGGUnet(nn.Module):
         self.conf3 = nn.Sequential(nn.ReLU(), c(16, 1, False), nn.Sigmoid())
 
     def forward(self, x):
-        feats, confs, _ = vgg_forward_nhwc(self, x, want_conf=True)
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            # an ordinary differentiable module, like the reference's (VGG.py:121-203): the backward is hla_vgg_backward
+            names = [n for n, _ in self.named_parameters()]
+            out = _VggFn.apply(self, names, x, *[p for _, p in self.named_parameters()])
+            L = len(out) // 2
+            feats, confs = list(out[:L]), list(out[L:])
+        else:
+            feats, confs, _ = vgg_forward_nhwc(self, x, want_conf=True)
         sel = _LEVEL_SEL[self.level]
         # NCHW-shaped views over the NHWC storage
         view = lambda i: (feats[i][..., :_CH[i]] if i == 3 else feats[i]).permute(0, 3, 1, 2)   # x24: 16 real of 64 stored channels
         return [view(i) for i in sel], [confs[i].unsqueeze(1) for i in sel]
+
+
+class _VggFn(torch.autograd.Function):
+    """Stand-alone VGGUnet under autograd: forward = the training-mode extractor (activations and pool argmax kept), outputs
+    the L2-normalised maps and the confidence maps; backward = hla_vgg_backward (MFMA dgrad / wgrad kernels) -> parameter
+    gradients.  The input image gets no gradient (the reference never asks for one: its images come from the DataLoader)."""
+
+    @staticmethod
+    def forward(ctx, module, names, x, *params):
+        feats, confs, inv, c = vgg_forward_nhwc(module, x, want_conf=True, defer_norm=True, save_for_backward=True)
+        B = x.shape[0]
+        # the un-deferred path scales in-kernel with one fp64 multiply per element (scale_kernel): the same arithmetic here
+        normed = [(f.double() * inv[l].view(B, 1, 1, 1)).float() for l, f in enumerate(feats)]
+        ctx.module, ctx.names, ctx.saved, ctx.confs = module, names, c, confs
+        return tuple(normed) + tuple(confs)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        c, confs = ctx.saved, ctx.confs
+        if c is None:
+            raise RuntimeError('VGGUnet: backward through the same forward twice (the saved activations were released after the '
+                               'first backward; retain_graph is not supported by the HIP backward)')
+        L = len(confs)
+        d_feats = [g if g is not None else torch.zeros_like(c['feats'][l]) for l, g in enumerate(grads[:L])]
+        d_confs = [g if g is not None else torch.zeros_like(confs[l]) for l, g in enumerate(grads[L:])]
+        g = vgg_backward_nhwc(ctx.module, c, d_feats, confs, d_confs, scale_invariant=False)
+        ctx.saved = None
+        return (None, None, None) + tuple(g.get(n) for n in ctx.names)
 
 
 def L2_norm(x):

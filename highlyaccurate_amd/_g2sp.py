@@ -174,15 +174,19 @@ class _G2sFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, d_trace, *unused):
         model = ctx.model
+        if ctx.state is None:
+            raise RuntimeError('backward through the same forward twice: the saved activations are released after the first '
+                               'backward; retain_graph is not supported by the HIP backward')
         sat_feats, grd_feats, grd_confs, camera_k, ori_hw, trace, neq, sat_inv, grd_inv, cs, cg = ctx.state
         d_sat, d_grd, d_conf, d_lam = model.lm_backward(sat_feats, grd_feats, grd_confs, camera_k, ori_hw, trace, neq, d_trace,
                                                         ctx.init_pose, sat_inv, grd_inv)
         sync = getattr(model, 'grad_sync', None)
-        g_sat = vgg_backward_nhwc(model.SatFeatureNet, cs, d_sat)
-        h1 = sync.start({'SatFeatureNet.' + k: v for k, v in g_sat.items()}) if sync else None
+        g_sat, flat_sat = vgg_backward_nhwc(model.SatFeatureNet, cs, d_sat, flat=True)
+        h1 = sync.start({'SatFeatureNet.' + k: v for k, v in g_sat.items()}, flat_sat) if sync else None
         use_w = model.using_weight and all(c is not None for c in d_conf)
-        g_grd = vgg_backward_nhwc(model.GrdFeatureNet, cg, d_grd, grd_confs if use_w else None, d_conf if use_w else None)
-        h2 = sync.start({'GrdFeatureNet.' + k: v for k, v in g_grd.items()}) if sync else None
+        g_grd, flat_grd = vgg_backward_nhwc(model.GrdFeatureNet, cg, d_grd, grd_confs if use_w else None, d_conf if use_w else None,
+                                            flat=True)
+        h2 = sync.start({'GrdFeatureNet.' + k: v for k, v in g_grd.items()}, flat_grd) if sync else None
         if sync:
             sync.finish(h1)
             sync.finish(h2)

@@ -404,6 +404,9 @@ class _LocaliseFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, d_trace, *unused):
         model = ctx.model
+        if ctx.state is None:
+            raise RuntimeError('backward through the same forward twice: the saved activations (GBs at B = 32) are released after '
+                               'the first backward; retain_graph is not supported by the HIP backward')
         sat_feats, grd_feats, grd_confs, grd_hw, trace, neq, sat_inv, grd_inv, cs, cg, keep = ctx.state
         d_sat, d_grd, d_conf, d_lam = model.lm_backward(sat_feats, grd_feats, grd_confs, grd_hw, trace, neq, d_trace, ctx.extra,
                                                    ctx.level_first, ctx.init_pose, sat_inv, grd_inv, keep)
@@ -411,15 +414,15 @@ class _LocaliseFn(torch.autograd.Function):
         # LM_update renormalises both projected maps (models_kitti.py:982-990), so the loss does not depend on the per-sample
         # scale of either extractor's output: d_feat is orthogonal to feat and the L2_norm backward needs no (x . dy) pass
         inv = getattr(model.args, 'Optimizer', 'LM') == 'LM' and os.environ.get('HLA_L2BWD_FULL', '0') != '1'
-        g_sat = vgg_backward_nhwc(model.SatFeatureNet, cs, d_sat, scale_invariant=inv)
-        h1 = sync.start({'SatFeatureNet.' + k: v for k, v in g_sat.items()}) if sync else None
+        g_sat, flat_sat = vgg_backward_nhwc(model.SatFeatureNet, cs, d_sat, scale_invariant=inv, flat=True)
+        h1 = sync.start({'SatFeatureNet.' + k: v for k, v in g_sat.items()}, flat_sat) if sync else None
         use_w = model.using_weight and all(c is not None for c in d_conf)
         # the ground maps' gradient lives in rows h_l/2.. (all the LM loop reads): the backward skips the rows above its support
         f8 = (grd_hw[0] // 8) // 2 - (grd_hw[0] - grd_feats[2].shape[1] * 2) // 8
         f8 = f8 if (inv and f8 >= 4 and model.level == 3 and os.environ.get('HLA_BWD_TRIM', '1') != '0') else 0
-        g_grd = vgg_backward_nhwc(model.GrdFeatureNet, cg, d_grd, grd_confs if use_w else None, d_conf if use_w else None,
-                                  scale_invariant=inv, first_row8=f8)
-        h2 = sync.start({'GrdFeatureNet.' + k: v for k, v in g_grd.items()}) if sync else None
+        g_grd, flat_grd = vgg_backward_nhwc(model.GrdFeatureNet, cg, d_grd, grd_confs if use_w else None, d_conf if use_w else None,
+                                            scale_invariant=inv, first_row8=f8, flat=True)
+        h2 = sync.start({'GrdFeatureNet.' + k: v for k, v in g_grd.items()}, flat_grd) if sync else None
         if sync:
             sync.finish(h1)
             sync.finish(h2)

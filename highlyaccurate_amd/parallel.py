@@ -41,36 +41,57 @@ def shard_batch(t: torch.Tensor, rank: int, world: int) -> torch.Tensor:
 
 
 class GradSync:
-    """Bucketed gradient averaging.  ``start(grads)`` flattens a {name: tensor} dict into one bucket and launches
-    an asynchronous SUM all-reduce; ``finish(handle)`` waits, divides by the world size and scatters the values
-    back into the original tensors.  Used by the model's backward (``model.grad_sync``) so that the satellite
-    branch's 9.9 MB bucket is in flight on the xGMI links while the ground branch's backward kernels run."""
+    """Bucketed gradient averaging, one bucket per network branch.
+
+    ``start(grads, flat)``: ``flat`` is the contiguous fp32 buffer the branch's wgrad kernels wrote their results into
+    (``vgg_backward_nhwc(..., flat=True)``; every tensor of ``grads`` that lies inside it is a view of it): it is summed IN
+    PLACE by one asynchronous all-reduce -- no gather copy, no scatter copy.  Tensors of ``grads`` outside ``flat`` (the
+    confidence heads, level 4's padded layers, ``damping``) and callers without a flat buffer go through a small staged
+    bucket.  ``finish(handle)`` waits and divides by the world size.  Used by the model's backward (``model.grad_sync``) so
+    that the satellite branch's 9.9 MB bucket is in flight on the xGMI links while the ground branch's backward kernels run."""
 
     def __init__(self, group=None):
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.bytes_reduced = 0
+        self.collectives = 0
 
-    def start(self, grads: dict):
+    @staticmethod
+    def _inside(t: torch.Tensor, flat: torch.Tensor) -> bool:
+        return (t.untyped_storage().data_ptr() == flat.untyped_storage().data_ptr() and t.is_contiguous()
+                and flat.data_ptr() <= t.data_ptr() and t.data_ptr() + t.numel() * 4 <= flat.data_ptr() + flat.numel() * 4)
+
+    def start(self, grads: dict, flat: torch.Tensor | None = None):
         if self.world == 1 or not grads:
             return None
-        names = sorted(grads)                         # identical order on every rank
-        flat = torch.cat([grads[n].reshape(-1).float() for n in names])
-        self.bytes_reduced += flat.numel() * 4
-        work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-        return work, flat, names, grads
+        works = []
+        rest = grads
+        if flat is not None:
+            rest = {n: g for n, g in grads.items() if not self._inside(g, flat)}
+            self.bytes_reduced += flat.numel() * 4
+            self.collectives += 1
+            works.append((dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True), flat, None, None))
+        if rest:
+            names = sorted(rest)                      # identical order on every rank
+            stage = torch.cat([rest[n].reshape(-1).float() for n in names])
+            self.bytes_reduced += stage.numel() * 4
+            self.collectives += 1
+            works.append((dist.all_reduce(stage, op=dist.ReduceOp.SUM, group=self.group, async_op=True), stage, names, rest))
+        return works
 
     def finish(self, handle):
         if handle is None:
             return
-        work, flat, names, grads = handle
-        work.wait()
-        flat.div_(self.world)
-        o = 0
-        for n in names:
-            g = grads[n]
-            g.copy_(flat[o:o + g.numel()].view_as(g))
-            o += g.numel()
+        for work, buf, names, grads in handle:
+            work.wait()
+            buf.div_(self.world)
+            if names is None:
+                continue                              # reduced in place: the gradient tensors ARE views of buf
+            o = 0
+            for n in names:
+                g = grads[n]
+                g.copy_(buf[o:o + g.numel()].view_as(g))
+                o += g.numel()
 
 
 def allreduce_module_grads(module: torch.nn.Module, group=None):

@@ -70,7 +70,8 @@ def test_vgg_small_vs_golden(kat, precision, tol):
     net = VGGUnet(3, precision=precision)
     net.load_state_dict(sd)
     net = net.to(d)
-    feats, confs = net(x.to(d))
+    with torch.no_grad():
+        feats, confs = net(x.to(d))
     for l in range(3):
         f = feats[l].cpu().numpy()
         assert f.shape == kat[f'vgg_feat64_l{l}'].shape
@@ -94,7 +95,8 @@ def test_vgg_level4_vs_golden(kat, precision, tol):
     net = VGGUnet(4, precision=precision)
     net.load_state_dict(sd)
     net = net.to(d)
-    feats, confs = net(x.to(d))
+    with torch.no_grad():
+        feats, confs = net(x.to(d))
     assert len(feats) == 4 and tuple(feats[3].shape) == (2, 16, 32, 64) and tuple(confs[3].shape) == (2, 1, 32, 64)
     for l in range(4):
         e = _rel(feats[l].cpu().numpy(), kat[f'vgg_feat64_l{l}'])
@@ -103,7 +105,8 @@ def test_vgg_level4_vs_golden(kat, precision, tol):
         assert e < tol and ec < max(tol, 2e-6), (precision, l, e, ec)
     net3 = VGGUnet(3, precision=precision)
     net3.load_state_dict(sd)
-    f3, _ = net3.to(d)(x.to(d))
+    with torch.no_grad():
+        f3, _ = net3.to(d)(x.to(d))
     if precision == 'fp32':
         for l in range(3):
             assert torch.allclose(f3[l], feats[l], rtol=0, atol=0) or _rel(f3[l].cpu().numpy(), feats[l].cpu().numpy()) < 1e-6
@@ -281,7 +284,8 @@ def test_e2e_kitti_features_vs_golden(precision):
     net = net.to(d)
     sat, grd, *_ = O.synth_images(seed + 100, B)
     for name, mod, img in (('sat', net.SatFeatureNet, sat), ('grd', net.GrdFeatureNet, grd)):
-        feats, _ = mod(img.to(d))
+        with torch.no_grad():
+            feats, _ = mod(img.to(d))
         for l in range(3):
             ref = g[f'{name}feat64_{seed}_l{l}']
             f = feats[l].contiguous().reshape(B, -1).double().cpu()       # NCHW flat order
@@ -476,7 +480,8 @@ def test_e2e_hires_config5_vs_golden():
     from oracle import ref_cpu as O
     sat, grd, *_ = O.synth_images(seed + 100, B, grd_hw=(512, 2048), sat_a=1024)
     for name, mod, img in (('sat', net.SatFeatureNet, sat), ('grd', net.GrdFeatureNet, grd)):
-        feats, _ = mod(img.to(d))
+        with torch.no_grad():
+            feats, _ = mod(img.to(d))
         for l in range(3):
             ref = g[f'{name}feat64_l{l}']
             f = feats[l].contiguous().reshape(B, -1).double().cpu()
@@ -625,6 +630,9 @@ def test_full_bench_config_runs_and_is_consistent():
     assert torch.equal(t[5:6], t5)
 
 
+_ORACLE_B32 = {}
+
+
 @pytest.mark.parametrize('precision', ['fp32', 'fp16x3', 'bf16'])
 def test_bench_batch_per_sample_vs_oracle(precision):
     """BASELINE configs[1] batch size (B = 32, what bench.py times): four samples of the batch are compared ONE BY ONE with
@@ -645,19 +653,21 @@ def test_bench_batch_per_sample_vs_oracle(precision):
         net(sat.to(d), grd.to(d), mode='test')
     trace = net.last_trace.cpu().numpy().astype(np.float64)              # [32,5,3,(u,v,theta)]
     assert np.isfinite(trace).all()
-    o32 = O.LM_S2GP(O.default_args())
-    o32.load_state_dict(sd)
-    o64 = O.LM_S2GP(O.default_args())
-    o64.load_state_dict(sd)
-    o64 = o64.double()
     for k in (0, 7, 19, 31):
-        with torch.no_grad():
-            torch.manual_seed(seed)
-            o64(sat[k:k + 1].double(), grd[k:k + 1].double(), mode='test')
-            torch.manual_seed(seed)
-            o32(sat[k:k + 1], grd[k:k + 1], mode='test')
-        t64 = torch.stack([o64.trace[1], o64.trace[0], o64.trace[2]], -1)[0].numpy()     # (lon, lat, theta) = (u, v, theta)
-        t32 = torch.stack([o32.trace[1], o32.trace[0], o32.trace[2]], -1)[0].double().numpy()
+        if (seed, k) not in _ORACLE_B32:                 # the oracle runs are shared by the three precisions
+            o32 = O.LM_S2GP(O.default_args())
+            o32.load_state_dict(sd)
+            o64 = O.LM_S2GP(O.default_args())
+            o64.load_state_dict(sd)
+            o64 = o64.double()
+            with torch.no_grad():
+                torch.manual_seed(seed)
+                o64(sat[k:k + 1].double(), grd[k:k + 1].double(), mode='test')
+                torch.manual_seed(seed)
+                o32(sat[k:k + 1], grd[k:k + 1], mode='test')
+            _ORACLE_B32[(seed, k)] = (torch.stack([o64.trace[1], o64.trace[0], o64.trace[2]], -1)[0].numpy(),   # (lon, lat, theta) = (u, v, theta)
+                                      torch.stack([o32.trace[1], o32.trace[0], o32.trace[2]], -1)[0].double().numpy())
+        t64, t32 = _ORACLE_B32[(seed, k)]
         if precision in ('fp32', 'fp16x3'):
             _pose_gate(trace[k], t64, t32, f'B=32 {precision} sample {k}')
         else:
@@ -1095,6 +1105,89 @@ def test_checkpoint_round_trip_resume_and_result_files(tmp_path):
     # --test 1: evaluates model_1.pth, appends one more block, trains nothing
     assert m.main(common + ['--test', '1']) == []
     assert open(os.path.join(sp, 'Test1_results.txt')).read().count('EPOCH:') == 4
+
+
+@pytest.mark.parametrize('level', [3, 4])
+def test_standalone_vggunet_is_differentiable_like_the_reference(level):
+    """VGGUnet used on its own (VGG.py:121-203 is an ordinary autograd module): a loss on its returned maps and confidence maps
+    back-propagates to every parameter that reaches them; gradients against the fp64 oracle's autograd."""
+    from oracle import ref_cpu as O
+    from highlyaccurate_amd.VGG import VGGUnet
+    d = _dev()
+    rs = np.random.RandomState(41)
+    sd = O.synth_vgg_state(rs, bias_scale=0.05)
+    x = T(rs.random_sample((2, 3, 32, 64)).astype(np.float32))
+    onet = O.VGGUnet(level)
+    onet.load_state_dict(sd)
+    onet = onet.double()
+    f64, c64 = onet(x.double())
+    uf = [T(rs.standard_normal(tuple(f.shape))) for f in f64]
+    uc = [T(rs.standard_normal(tuple(c.shape))) for c in c64]
+    (sum((u * f).sum() for u, f in zip(uf, f64)) + sum((u * c).sum() for u, c in zip(uc, c64))).backward()
+    ref = {k: p.grad for k, p in onet.named_parameters() if p.grad is not None}
+    net = VGGUnet(level)
+    net.load_state_dict(sd)
+    net = net.to(d)
+    feats, confs = net(x.to(d))
+    assert all(f.grad_fn is not None for f in feats) and all(c.grad_fn is not None for c in confs)
+    (sum((u.float().to(d) * f).sum() for u, f in zip(uf, feats)) + sum((u.float().to(d) * c).sum() for u, c in zip(uc, confs))).backward()
+    got = {k: p.grad for k, p in net.named_parameters() if p.grad is not None}
+    assert set(got) == set(ref), set(got) ^ set(ref)
+    worst = 0.0
+    for k in ref:
+        r = ref[k].numpy()
+        e = np.abs(got[k].cpu().double().numpy() - r).max() / max(np.abs(r).max(), 1e-30)
+        worst = max(worst, e)
+        assert e < 2e-4, (k, e)
+    print(f'standalone VGGUnet level {level}: {len(ref)} gradients, worst rel err {worst:.2e}')
+    with torch.no_grad():                                    # and without autograd it is the plain forward, same values
+        f2, c2 = net(x.to(d))
+    assert all(torch.equal(a, b) for a, b in zip(f2, feats)) and all(torch.equal(a, b) for a, b in zip(c2, confs))
+
+
+@pytest.mark.parametrize('kw', [dict(), dict(using_weight=1, train_damping=1)])
+def test_two_rank_real_model_gradients_match_full_batch(kw, tmp_path):
+    """the batch shards over ranks and the only exchange is the gradient all-reduce.  Two processes (gloo; they
+    share this box's one GPU) run LM_S2GP train steps on the two halves of a B = 4 batch with `net.grad_sync` installed, i.e.
+    through the model's own backward: bucket per branch, flat gradient buffers reduced in place, the satellite bucket in flight
+    during the ground branch's backward.  Every parameter gradient on BOTH ranks must equal the single-process B = 4 gradient
+    (to the order of the weight-gradient partial sums), and the parameters that get no gradient stay grad-less on both."""
+    import json, os, socket, subprocess, sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import dp_worker as W
+    from highlyaccurate_amd.models_kitti import LM_S2GP
+    d = _dev()
+    args, sd, batch = W.build_case(kw)
+    net = LM_S2GP(args)
+    net.load_state_dict(sd)
+    net = net.to(d).train()
+    full, loss_full = W.run(net, batch, d)
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE='2', LOCAL_RANK=str(r), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, W.__file__, str(tmp_path), json.dumps(kw)], env=env))
+    for p in procs:
+        assert p.wait(timeout=900) == 0
+    ranks = [torch.load(str(tmp_path / f'rank{r}.pt')) for r in range(2)]
+    n_live = sum(g is not None for g in full.values())
+    assert n_live == (40 if kw else 36), n_live                      # SURVEY B-8: 36 live tensors by default, +3 heads +damping
+    assert abs(0.5 * (ranks[0]['loss'] + ranks[1]['loss']) - loss_full) < 1e-4 * max(1.0, abs(loss_full))
+    worst = 0.0
+    for r in range(2):
+        assert ranks[r]['collectives'] >= 2 and ranks[r]['bytes'] >= 19_000_000     # two flat buckets (+ staged extras)
+        for k, g in full.items():
+            gr = ranks[r]['grads'][k]
+            if g is None:
+                assert gr is None, (r, k)                             # grad-less on every rank, never a zero tensor
+                continue
+            e = float((gr - g).abs().max() / g.abs().max().clamp_min(1e-30))
+            worst = max(worst, e)
+            assert e < 5e-4, (r, k, e)
+        for k in full:
+            if full[k] is not None:
+                assert torch.equal(ranks[0]['grads'][k], ranks[1]['grads'][k]), k    # the all-reduce leaves identical replicas
+    print(f'2-rank vs full-batch gradients {kw}: worst rel err {worst:.2e} over {n_live} tensors')
 
 
 @pytest.mark.parametrize('level', [3, 4])

@@ -46,6 +46,23 @@ def _worker(rank, world, port, out):
     h2 = gs.start({k: named[k].grad for k in ('2.weight', '2.bias')})
     gs.finish(h1); gs.finish(h2)
     assert named['unused'].grad is None
+    # the flat-buffer path: gradients that are views of one buffer are reduced IN PLACE by one collective, the rest is staged
+    local = {k: named[k].grad.clone() for k in ('0.weight', '0.bias', '2.weight', '2.bias')}      # already averaged: use as data
+    flat = torch.empty(sum(local[k].numel() for k in ('0.weight', '0.bias', '2.weight')))
+    views, o = {}, 0
+    for k in ('0.weight', '0.bias', '2.weight'):
+        n = local[k].numel()
+        views[k] = flat[o:o + n].view_as(local[k])
+        views[k].copy_(local[k] * (rank + 1))          # rank-dependent values: the average is 1.5x
+        o += n
+    views['2.bias'] = local['2.bias'] * (rank + 1)     # NOT inside the flat buffer
+    ptrs = {k: v.data_ptr() for k, v in views.items()}
+    gs2 = P.GradSync()
+    gs2.finish(gs2.start(views, flat))
+    assert gs2.collectives == 2 and gs2.bytes_reduced == (flat.numel() + local['2.bias'].numel()) * 4
+    for k in views:
+        assert views[k].data_ptr() == ptrs[k]
+        assert torch.allclose(views[k], local[k] * 1.5, atol=1e-7), k
     t = P.max_over_ranks(float(rank + 1), torch.device('cpu'))
     assert t == float(world)
     if rank == 0:
