@@ -83,7 +83,8 @@ def load() -> C.CDLL:
     if _lib is not None:
         return _lib
     from . import build as _b
-    if _b.lib_hash(LIB_PATH) != _b.source_hash():
+    if _b.lib_hash(LIB_PATH) != _b.source_hash() and not (os.environ.get('HLA_LIB') and os.environ.get('HLA_ALLOW_STALE') == '1'):
+        # (HLA_LIB + HLA_ALLOW_STALE=1: A/B timing of an older experiment build against the current one, tools/variants.py)
         if os.environ.get('HLA_LIB'):
             raise HlaError(f'{LIB_PATH} (HLA_LIB) was not built from the sources in {_b.CSRC}; rebuild the variant')
         if not _b.have_compiler():

@@ -200,6 +200,7 @@ template <typename E, int NT> struct RowStager {
   }
   // cooperative flush of `npx` pixels: dst points at channel cb of the first pixel; pixel stride = Cout elements
   // `mask` / `add` (optional) are indexed exactly like dst: v = (mask > 0 ? v : 0) + add, applied on the 16-B vectors
+  template <bool PLAIN = false>
   static __device__ __forceinline__ void flush(const char* stage, E* dst, int npx, int npx_valid, int Cout, int lane,
                                                const E* mask = nullptr, const E* add = nullptr) {
     const int chunks = npx * CPP;
@@ -210,9 +211,13 @@ template <typename E, int NT> struct RowStager {
       if (c0 < chunks && c < chunks) {
         const int px = c / CPP, part = c % CPP;
         if (px < npx_valid) {
+#if CONV_VARIANT == 42 || CONV_VARIANT == 43
+          uint4 v = make_uint4(px, part, lane, c0);                        // timing ablation: no LDS read-back
+#else
           uint4 v = *(const uint4*)(stage + px * PITCH + part * 16);
-          const size_t off = (size_t)px * Cout * sizeof(E) + part * 16;
-          if (mask || add) {
+#endif
+          const unsigned off = (unsigned)px * (unsigned)Cout * (unsigned)sizeof(E) + part * 16;   // < 2^20: one row segment
+          if (!PLAIN && (mask || add)) {
             E e[EPV], m[EPV], ad[EPV];
             __builtin_memcpy(e, &v, 16);
             if (mask) { const uint4 t = *(const uint4*)((const char*)mask + off); __builtin_memcpy(m, &t, 16); }
@@ -226,7 +231,11 @@ template <typename E, int NT> struct RowStager {
             }
             __builtin_memcpy(&v, e, 16);
           }
+#if CONV_VARIANT == 41 || CONV_VARIANT == 42
+          asm volatile("" :: "v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w));     // timing ablation: no global store
+#else
           *(uint4*)((char*)dst + off) = v;
+#endif
         }
       }
     }
@@ -234,9 +243,27 @@ template <typename E, int NT> struct RowStager {
 };
 
 // dsc (split mode): accumulators hold (s_x s_w) * result; 1 otherwise.  red: 8 floats of LDS.
-template <typename T, int MT, int NT, bool POOL>
+// EPI selects what is COMPILED IN.  The generic epilogue evaluates every optional output at run time (raw copy, ReLU mask,
+// gradient fan-in, pool argmax, sum-pool): 3200 instructions and 120 exec-mask branches per wave, 8.5 k cycles even with every
+// store removed (CONV_VARIANT 40-45 accounting) -- as long as two pipeline stages of MFMAs.  The forward pass only ever needs
+// two shapes of it, so those are compiled separately and picked by one kernel-uniform branch (epilogue_mode):
+enum { EPI_GENERIC = 0,   // everything, decided at run time (backward / training forward)
+       EPI_ACT = 1,       // out_act = relu(acc + bias) only
+       EPI_ACT_RAW = 2 }; // + the raw fp32 copy and its per-sample sum of squares (the three feature layers)
+__device__ __forceinline__ int epilogue_mode(const ConvArgs& a) {
+  if (a.mask_act || a.add_src || a.idx_out || a.pool_sum || !a.out_act || !a.relu_act) return EPI_GENERIC;
+  if (!a.out_raw) return a.sumsq ? EPI_GENERIC : EPI_ACT;
+  return a.sumsq ? EPI_ACT_RAW : EPI_GENERIC;
+}
+template <typename T, int MT, int NT, bool POOL, int EPI = EPI_GENERIC>
 __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[MT][NT], const ConvArgs& a, int b, int yrow0, int x0,
                                               int cb, float* red, char* stage, float dsc = 1.f) {
+  constexpr bool GEN = EPI == EPI_GENERIC;
+  const bool has_raw = GEN ? a.out_raw != nullptr : EPI == EPI_ACT_RAW;
+  const bool has_act = GEN ? a.out_act != nullptr : true;
+  const bool relu = GEN ? a.relu_act != 0 : true;
+  const bool pool_sum = GEN && a.pool_sum;
+  const bool has_sumsq = GEN ? a.sumsq != nullptr : EPI == EPI_ACT_RAW;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, x = lane & 31, g = lane >> 5;
   const int Ho = POOL ? a.H >> 1 : a.H, Wo = POOL ? a.W >> 1 : a.W;
   constexpr int NPX = POOL ? 16 : 32;
@@ -245,7 +272,13 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[MT][NT], const ConvA
   for (int j = 0; j < NT; ++j)
 #pragma unroll
     for (int q = 0; q < 4; ++q)
-      bias[j][q] = a.bias ? *(const float4*)(a.bias + cb + j * 32 + q * 8 + g * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+      bias[j][q] = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (a.bias && CONV_VARIANT != 45) {                     // (45: timing ablation without the bias loads)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) bias[j][q] = *(const float4*)(a.bias + cb + j * 32 + q * 8 + g * 4);
+  }
   const int xo0 = POOL ? x0 >> 1 : x0;
   const int nvalid = min(NPX, Wo - xo0);              // pixels of this row segment inside the image
   float ss = 0.f, mx = 0.f;
@@ -266,7 +299,7 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[MT][NT], const ConvA
           float t = acc[i][j][q * 4 + e];
           if (POOL) {
             const float u = acc[i + 1][j][q * 4 + e];
-            if (a.pool_sum) {
+            if (pool_sum) {
               t += u;
               t += __shfl_xor(t, 1, 64);
             } else {
@@ -280,7 +313,31 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[MT][NT], const ConvA
         v[j][q][0] += bias[j][q].x; v[j][q][1] += bias[j][q].y; v[j][q][2] += bias[j][q].z; v[j][q][3] += bias[j][q].w;
       }
     const size_t pix0 = ((size_t)b * Ho + yo) * Wo + xo0;
-    if (a.out_raw) {
+    // 16-bit activations: the raw fp32 row and the activation row fit side by side in the wave's stager, so one pass over the
+    // accumulators feeds both (no 32-value array kept live between two passes)
+    constexpr bool ONE_PASS = EPI == EPI_ACT_RAW && sizeof(T) == 2;
+    if constexpr (ONE_PASS) {
+      char* stage2 = stage + 32 * RowStager<float, NT>::PITCH;
+      if (!POOL || !(x & 1)) {
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const float w0 = v[j][q][0], w1 = v[j][q][1], w2 = v[j][q][2], w3 = v[j][q][3];
+            RowStager<float, NT>::put(stage, px, j * 32 + q * 8 + g * 4, w0, w1, w2, w3);
+            if (lane_ok) ss += w0 * w0 + w1 * w1 + w2 * w2 + w3 * w3;
+            RowStager<T, NT>::put(stage2, px, j * 32 + q * 8 + g * 4, fmaxf(w0, 0.f), fmaxf(w1, 0.f), fmaxf(w2, 0.f), fmaxf(w3, 0.f));
+          }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (row_ok) {
+        RowStager<float, NT>::template flush<true>(stage, a.out_raw + pix0 * a.Cout + cb, NPX, nvalid, a.Cout, lane);
+        RowStager<T, NT>::template flush<true>(stage2, (T*)a.out_act + pix0 * a.Cout + cb, NPX, nvalid, a.Cout, lane);
+      }
+      __builtin_amdgcn_sched_barrier(0);      // keep the rows apart: hoisting the next rows' arithmetic up here spills
+      continue;
+    }
+    if (has_raw) {
       if (!POOL || !(x & 1)) {
 #pragma unroll
         for (int j = 0; j < NT; ++j)
@@ -290,26 +347,30 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[MT][NT], const ConvA
             if (lane_ok) ss += v[j][q][0] * v[j][q][0] + v[j][q][1] * v[j][q][1] + v[j][q][2] * v[j][q][2] + v[j][q][3] * v[j][q][3];
           }
       }
-      if (row_ok) RowStager<float, NT>::flush(stage, a.out_raw + pix0 * a.Cout + cb, NPX, nvalid, a.Cout, lane);
+      if (row_ok) RowStager<float, NT>::template flush<true>(stage, a.out_raw + pix0 * a.Cout + cb, NPX, nvalid, a.Cout, lane);
     }
-    if (a.out_act) {
+    if (has_act) {
       if (!POOL || !(x & 1)) {
 #pragma unroll
         for (int j = 0; j < NT; ++j)
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             float w0 = v[j][q][0], w1 = v[j][q][1], w2 = v[j][q][2], w3 = v[j][q][3];
-            if (a.relu_act) { w0 = fmaxf(w0, 0.f); w1 = fmaxf(w1, 0.f); w2 = fmaxf(w2, 0.f); w3 = fmaxf(w3, 0.f); }
+            if (relu) { w0 = fmaxf(w0, 0.f); w1 = fmaxf(w1, 0.f); w2 = fmaxf(w2, 0.f); w3 = fmaxf(w3, 0.f); }
             if (Prec<T>::SPLIT && lane_ok) mx = fmaxf(fmaxf(mx, fmaxf(fabsf(w0), fabsf(w1))), fmaxf(fabsf(w2), fabsf(w3)));
             RowStager<T, NT>::put(stage, px, j * 32 + q * 8 + g * 4, w0, w1, w2, w3);
           }
       }
       const size_t o = pix0 * a.Cout + cb;
-      if (row_ok) RowStager<T, NT>::flush(stage, (T*)a.out_act + o, NPX, nvalid, a.Cout, lane,
-                                          a.mask_act ? (const T*)a.mask_act + o : nullptr,
-                                          (a.add_src && yo >= a.add_row_lo) ? (const T*)a.add_src + o : nullptr);
+      if (GEN) {
+        if (row_ok) RowStager<T, NT>::flush(stage, (T*)a.out_act + o, NPX, nvalid, a.Cout, lane,
+                                            a.mask_act ? (const T*)a.mask_act + o : nullptr,
+                                            (a.add_src && yo >= a.add_row_lo) ? (const T*)a.add_src + o : nullptr);
+      } else {
+        if (row_ok) RowStager<T, NT>::template flush<true>(stage, (T*)a.out_act + o, NPX, nvalid, a.Cout, lane);
+      }
     }
-    if (POOL && a.idx_out) {            // training only: recompute which of the 4 window positions won (2*row+col)
+    if (GEN && POOL && a.idx_out) {            // training only: recompute which of the 4 window positions won (2*row+col)
 #pragma unroll
       for (int j = 0; j < NT; ++j)
 #pragma unroll
@@ -329,13 +390,13 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[MT][NT], const ConvA
     }
   }
   const bool want_max = Prec<T>::SPLIT && a.amax_out;          // kernel-uniform
-  if (a.sumsq || want_max) {
+  if (has_sumsq || want_max) {
     ss = wave_sum_f32(ss);
     if (want_max) mx = wave_max_f32(mx);
     if (lane == 0) { red[wv] = ss; red[4 + wv] = mx; }
     __syncthreads();
     if (threadIdx.x == 0) {
-      if (a.sumsq) {
+      if (has_sumsq) {
         const int np = a.tiles_x * a.tiles_y * gridDim.y;
         const int tile = (xcd_contiguous(blockIdx.x, gridDim.x) % (a.tiles_x * a.tiles_y)) * gridDim.y + blockIdx.y;
         a.sumsq[(size_t)b * np + tile] = ((double)red[0] + (double)red[1]) + ((double)red[2] + (double)red[3]);
@@ -355,6 +416,7 @@ template <typename T, int MT, int NT, int WD>
 struct WeightRing {
   static constexpr int RS = WD + 1;
   uint4 wb[RS][2][NT];
+  uint4 pf[4];           // pixel-fragment pipeline of the non-upfront MFMA loop (lives across taps)
   const uint4* wq[NT];   // per-lane pointer to this stage's fragments of output tile j: [tap][kg][lane]
 
   __device__ __forceinline__ void prime() {
@@ -455,6 +517,37 @@ __device__ __forceinline__ void stage_mma(f32x16 (&acc)[MT][NT], const char* cur
 #pragma unroll
           for (int j = 0; j < NT; ++j) mma16<T>(acc[i][j], ring.wb[tap % RS][kg][j], pf[kg][i]);
       }
+    } else if constexpr (CONV_VARIANT != 130) {
+      // pixel fragments software-pipelined three reads ahead of the MFMAs that consume them.  (The straightforward "read the
+      // fragments of a row, multiply" order leaves every ds_read_b128 one LDS latency -- about 100 cycles -- ahead of its
+      // first MFMA with only 64 cycles of matrix work queued behind it: the pipe idled ~4 x 50 cycles per tap.)
+      constexpr int FPT = MT * 2, DEPTH = 3;               // fragments per tap: (row i, k-group kg), kg fastest
+      auto frag_ptr = [&](int f) {                          // f counts fragments within THIS tap; f >= FPT spills into the next tap
+        const int tp = tap + f / FPT, r = f % FPT;
+        return cur + (((tp / 3) * HWID + tp % 3) + (r >> 1) * HWID) * PSTR + (r & 1) * 32;
+      };
+      if (tap == 0) {
+#pragma unroll
+        for (int f = 0; f < DEPTH; ++f) ring.pf[f] = ABL_NO_LDS ? ring.wb[0][0][0] : *(const uint4*)frag_ptr(f);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int f = 0; f < FPT; ++f) {
+        const int slot = (tap * FPT + f) % (DEPTH + 1), nslot = (tap * FPT + f + DEPTH) % (DEPTH + 1);
+        if (tap * FPT + f + DEPTH < 9 * FPT) ring.pf[nslot] = ABL_NO_LDS ? ring.wb[0][0][0] : *(const uint4*)frag_ptr(f + DEPTH);
+        const int i = f >> 1, kg = f & 1;
+        if constexpr (Prec<T>::SPLIT) {
+          // kg 0: the hi pixel fragment against the hi and the lo weights; kg 1: the lo pixel fragment against the hi weights
+#pragma unroll
+          for (int c = 0; c < (kg == 0 ? 2 : 1); ++c)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) mma16<T>(acc[i][j], ring.wb[tap % RS][c][j], ring.pf[slot]);
+        } else {
+#pragma unroll
+          for (int j = 0; j < NT; ++j) mma16<T>(acc[i][j], ring.wb[tap % RS][kg][j], ring.pf[slot]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
     } else {
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -495,10 +588,11 @@ __global__ __launch_bounds__(256, (NT == 1 && !PF_UPFRONT) ? 3 : 2) void conv3x3
   __shared__ __attribute__((aligned(16))) char lds[2 * BUF];
   __shared__ float red[8];
 
-#if CONV_VARIANT == 40
+#if CONV_VARIANT >= 40 && CONV_VARIANT <= 47
   const unsigned long long t_begin = __builtin_readcyclecounter();
 #endif
-  const int t = threadIdx.x, lane = t & 63, wv = t >> 6, wm = wv / WN, wn = wv % WN;
+  // (readfirstlane: the wave index is uniform, which lets every address that depends on it live in scalar registers)
+  const int t = threadIdx.x, lane = t & 63, wv = __builtin_amdgcn_readfirstlane(t >> 6), wm = wv / WN, wn = wv % WN;
   int bid = xcd_contiguous(blockIdx.x, gridDim.x);
   const int tx = bid % a.tiles_x; bid /= a.tiles_x;
   const int ty = bid % a.tiles_y;
@@ -590,14 +684,30 @@ __global__ __launch_bounds__(256, (NT == 1 && !PF_UPFRONT) ? 3 : 2) void conv3x3
 #pragma unroll
   for (int j = 0; j < NT; ++j) ring.wq[j] = a.wpk + (size_t)(ntg0 + j) * nstage * 18 * 64 + lane;
 
+#if CONV_VARIANT >= 120 && CONV_VARIANT <= 123
+  // experiment: de-phase the CUs.  All workgroups of a generation start together, run for the same time and therefore hit their
+  // store-bound epilogues together, chip-wide (an HBM write burst while every matrix pipe idles).  Delay the workgroups of the
+  // FIRST generation by a pseudo-random fraction of a workgroup's lifetime; later generations inherit the spread.
+  {
+    const unsigned lin = blockIdx.x + blockIdx.y * gridDim.x;
+    if (gridDim.x * gridDim.y > 1024 && lin < 512) {
+      constexpr int DIV = CONV_VARIANT == 120 ? 1 : (CONV_VARIANT == 121 ? 2 : (CONV_VARIANT == 122 ? 4 : 1));
+      const unsigned key = CONV_VARIANT == 123 ? (lin >> 1) : lin;            // 123: pairs of consecutive ids share a delay
+      const unsigned h = (key * 2654435761u) >> 16;
+      const int nslot = (2 + nstage + nstage / 4) / DIV;                     // ~ a lifetime in units of 8 k cycles
+      const int n = nslot > 0 ? (int)(h % (unsigned)(nslot + 1)) : 0;
+      for (int k = 0; k < n; ++k) __builtin_amdgcn_s_sleep(127);
+    }
+  }
+#endif
   uint4 st[NPIECE];
+  ring.prime();              // the first weight fragments do not depend on the halo tile: request them ahead of it
   load_stage(0, st);
   write_stage(lds, st);
   __syncthreads();
-  ring.prime();
   stagger_priority();
 
-#if CONV_VARIANT == 40   // cycle accounting per wave: [prologue, mma, halo write, barrier wait, epilogue]
+#if CONV_VARIANT >= 40 && CONV_VARIANT <= 47   // cycle accounting per wave: [prologue, mma, halo write, barrier wait, epilogue]
   unsigned long long tc[5] = {0, 0, 0, 0, 0};
   unsigned long long t_prev = __builtin_readcyclecounter();
   tc[0] = t_prev - t_begin;
@@ -618,8 +728,24 @@ __global__ __launch_bounds__(256, (NT == 1 && !PF_UPFRONT) ? 3 : 2) void conv3x3
   }
   // the loop's last barrier guarantees nobody still reads the halo buffers: reuse them as 4 wave-private stagers
   static_assert(2 * BUF / 4 >= 32 * (NT * 32 * 4 + 16) && (2 * BUF / 4) % 16 == 0, "stager does not fit");
-  conv_epilogue<T, MT, NT, POOL>(acc, a, b, y0 + wm * MT, x0, ntg0 * 32, red, lds + wv * (2 * BUF / 4), dsc);
-#if CONV_VARIANT == 40
+#if CONV_VARIANT == 44      // timing ablation: no epilogue at all
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) asm volatile("" :: "v"(acc[i][j]));
+#else
+  {
+    char* stager = lds + wv * (2 * BUF / 4);
+    const int mode = epilogue_mode(a);      // kernel-uniform
+    // (the un-pooled 64-channel-wave-tile kernel keeps its raw-copy layers -- dec1.3 only -- on the generic epilogue: the
+    // specialised one spills ~30 registers there, measured 31 k cycles against the generic path's 21 k)
+    constexpr bool RAW_SPECIAL = POOL || NT == 1;
+    if (mode == EPI_ACT) conv_epilogue<T, MT, NT, POOL, EPI_ACT>(acc, a, b, y0 + wm * MT, x0, ntg0 * 32, red, stager, dsc);
+    else if (RAW_SPECIAL && mode == EPI_ACT_RAW) conv_epilogue<T, MT, NT, POOL, RAW_SPECIAL ? EPI_ACT_RAW : EPI_GENERIC>(acc, a, b, y0 + wm * MT, x0, ntg0 * 32, red, stager, dsc);
+    else conv_epilogue<T, MT, NT, POOL, EPI_GENERIC>(acc, a, b, y0 + wm * MT, x0, ntg0 * 32, red, stager, dsc);
+  }
+#endif
+#if CONV_VARIANT >= 40 && CONV_VARIANT <= 47
   TICK(4)
   if (a.dbg && lane == 0) {
     unsigned long long* d = a.dbg + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 4 + wv) * 5;
@@ -667,7 +793,7 @@ __global__ __launch_bounds__(256, 2) void conv02_kernel(Conv02Args a0) {
   float* in = (float*)(smem + NSG * BUF);            // [3][12][36] input patch
   __shared__ float red[8];
 
-  const int t = threadIdx.x, lane = t & 63, wv = t >> 6, wm = wv / WN, wn = wv % WN;
+  const int t = threadIdx.x, lane = t & 63, wv = __builtin_amdgcn_readfirstlane(t >> 6), wm = wv / WN, wn = wv % WN;
   int bid = blockIdx.x;                    // (the XCD-contiguous order measured 2-3 % slower for this kernel)
   const int tx = bid % a0.tiles_x; bid /= a0.tiles_x;
   const int ty = bid % a0.tiles_y;
@@ -837,10 +963,11 @@ __global__ __launch_bounds__(256, 2) void conv02_kernel(Conv02Args a0) {
   if (a0.a2_out) {   // the epilogue only reads the accumulators: run it twice, un-pooled first
     ConvArgs f = a;
     f.out_act = a0.a2_out; f.idx_out = nullptr; f.amax_out = a0.amax_a2_out;
-    conv_epilogue<T, MT, NT, false>(acc, f, b, y0 + wm * MT, x0, wn * 32, red, lds + wv * (NSG * BUF / 4), dsc2);
+    conv_epilogue<T, MT, NT, false, EPI_ACT>(acc, f, b, y0 + wm * MT, x0, wn * 32, red, lds + wv * (NSG * BUF / 4), dsc2);
     if (SPLIT) __syncthreads();     // `red` is reused by the second epilogue's maximum
   }
-  conv_epilogue<T, MT, NT, true>(acc, a, b, y0 + wm * MT, x0, wn * 32, red, lds + wv * (NSG * BUF / 4), dsc2);
+  if (a.idx_out) conv_epilogue<T, MT, NT, true, EPI_GENERIC>(acc, a, b, y0 + wm * MT, x0, wn * 32, red, lds + wv * (NSG * BUF / 4), dsc2);
+  else conv_epilogue<T, MT, NT, true, EPI_ACT>(acc, a, b, y0 + wm * MT, x0, wn * 32, red, lds + wv * (NSG * BUF / 4), dsc2);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1011,7 +1138,7 @@ static void launch_conv(hipStream_t st, ConvArgs a, bool pool) {
   const size_t es = sizeof(T), P = (size_t)a.B * (a.H - a.row_begin) * a.W, Po = pool ? P / 4 : P;
   const double flops = 2.0 * 9.0 * (a.C1 + a.C2) * a.Cout * (double)P;
   const double bytes = (double)P * ((a.up1 ? a.C1 / 4.0 : a.C1) + a.C2) * es + (double)Po * a.Cout * ((a.out_act ? es : 0) + (a.out_raw ? 4 : 0));
-#if CONV_VARIANT == 40 || CONV_VARIANT == 104
+#if (CONV_VARIANT >= 40 && CONV_VARIANT <= 47) || CONV_VARIANT == 104
   static unsigned long long* dbg = nullptr;
   static int n_reported = 0;
   if (!dbg) (void)hipMallocManaged((void**)&dbg, (size_t)1 << 26);
@@ -1062,7 +1189,7 @@ static void launch_conv(hipStream_t st, ConvArgs a, bool pool) {
             (m[0] + m[1] + m[2] + m[3] + m[4] + m[5]) / nw);
   }
 #endif
-#if CONV_VARIANT == 40
+#if CONV_VARIANT >= 40 && CONV_VARIANT <= 47
   if (n_reported++ < 40) {
     (void)hipStreamSynchronize(st);
     const size_t nw = (size_t)grid.x * grid.y * 4;
