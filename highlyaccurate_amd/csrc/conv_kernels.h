@@ -249,21 +249,25 @@ template <typename E, int NT> struct RowStager {
 // two shapes of it, so those are compiled separately and picked by one kernel-uniform branch (epilogue_mode):
 enum { EPI_GENERIC = 0,   // everything, decided at run time (backward / training forward)
        EPI_ACT = 1,       // out_act = relu(acc + bias) only
-       EPI_ACT_RAW = 2 }; // + the raw fp32 copy and its per-sample sum of squares (the three feature layers)
+       EPI_ACT_RAW = 2,   // + the raw fp32 copy and its per-sample sum of squares (the three feature layers)
+       EPI_ACT_RAW_NOBIAS = 3,    // the same for a layer without bias (the decoder's): 32 registers less
+       EPI_DGRAD = 4 };   // backward data gradient: out_act = (mask > 0 ? acc : 0) [+ add], no bias, no ReLU of its own
 __device__ __forceinline__ int epilogue_mode(const ConvArgs& a) {
+  if (a.mask_act && a.out_act && !a.relu_act && !a.bias && !a.out_raw && !a.sumsq && !a.idx_out && !a.pool_sum) return EPI_DGRAD;
   if (a.mask_act || a.add_src || a.idx_out || a.pool_sum || !a.out_act || !a.relu_act) return EPI_GENERIC;
   if (!a.out_raw) return a.sumsq ? EPI_GENERIC : EPI_ACT;
-  return a.sumsq ? EPI_ACT_RAW : EPI_GENERIC;
+  return a.sumsq ? (a.bias ? EPI_ACT_RAW : EPI_ACT_RAW_NOBIAS) : EPI_GENERIC;
 }
 template <typename T, int MT, int NT, bool POOL, int EPI = EPI_GENERIC>
 __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[MT][NT], const ConvArgs& a, int b, int yrow0, int x0,
                                               int cb, float* red, char* stage, float dsc = 1.f) {
-  constexpr bool GEN = EPI == EPI_GENERIC;
-  const bool has_raw = GEN ? a.out_raw != nullptr : EPI == EPI_ACT_RAW;
+  constexpr bool GEN = EPI == EPI_GENERIC, RAW = EPI == EPI_ACT_RAW || EPI == EPI_ACT_RAW_NOBIAS, DG = EPI == EPI_DGRAD;
+  constexpr bool NOBIAS = EPI == EPI_ACT_RAW_NOBIAS || DG;
+  const bool has_raw = GEN ? a.out_raw != nullptr : RAW;
   const bool has_act = GEN ? a.out_act != nullptr : true;
-  const bool relu = GEN ? a.relu_act != 0 : true;
+  const bool relu = GEN ? a.relu_act != 0 : !DG;
   const bool pool_sum = GEN && a.pool_sum;
-  const bool has_sumsq = GEN ? a.sumsq != nullptr : EPI == EPI_ACT_RAW;
+  const bool has_sumsq = GEN ? a.sumsq != nullptr : RAW;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, x = lane & 31, g = lane >> 5;
   const int Ho = POOL ? a.H >> 1 : a.H, Wo = POOL ? a.W >> 1 : a.W;
   constexpr int NPX = POOL ? 16 : 32;
@@ -273,7 +277,7 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[MT][NT], const ConvA
 #pragma unroll
     for (int q = 0; q < 4; ++q)
       bias[j][q] = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (a.bias && CONV_VARIANT != 45) {                     // (45: timing ablation without the bias loads)
+  if (!NOBIAS && a.bias && CONV_VARIANT != 45) {          // (45: timing ablation without the bias loads)
 #pragma unroll
     for (int j = 0; j < NT; ++j)
 #pragma unroll
@@ -310,12 +314,12 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[MT][NT], const ConvA
           if (Prec<T>::SPLIT) t *= dsc;           // exact: a power of two (and > 0, so it commutes with the pooling)
           v[j][q][e] = t;
         }
-        v[j][q][0] += bias[j][q].x; v[j][q][1] += bias[j][q].y; v[j][q][2] += bias[j][q].z; v[j][q][3] += bias[j][q].w;
+        if (!NOBIAS) { v[j][q][0] += bias[j][q].x; v[j][q][1] += bias[j][q].y; v[j][q][2] += bias[j][q].z; v[j][q][3] += bias[j][q].w; }
       }
     const size_t pix0 = ((size_t)b * Ho + yo) * Wo + xo0;
     // 16-bit activations: the raw fp32 row and the activation row fit side by side in the wave's stager, so one pass over the
     // accumulators feeds both (no 32-value array kept live between two passes)
-    constexpr bool ONE_PASS = EPI == EPI_ACT_RAW && sizeof(T) == 2;
+    constexpr bool ONE_PASS = RAW && sizeof(T) == 2;
     if constexpr (ONE_PASS) {
       char* stage2 = stage + 32 * RowStager<float, NT>::PITCH;
       if (!POOL || !(x & 1)) {
@@ -362,7 +366,7 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[MT][NT], const ConvA
           }
       }
       const size_t o = pix0 * a.Cout + cb;
-      if (GEN) {
+      if (GEN || DG) {
         if (row_ok) RowStager<T, NT>::flush(stage, (T*)a.out_act + o, NPX, nvalid, a.Cout, lane,
                                             a.mask_act ? (const T*)a.mask_act + o : nullptr,
                                             (a.add_src && yo >= a.add_row_lo) ? (const T*)a.add_src + o : nullptr);
@@ -737,11 +741,15 @@ __global__ __launch_bounds__(256, (NT == 1 && !PF_UPFRONT) ? 3 : 2) void conv3x3
   {
     char* stager = lds + wv * (2 * BUF / 4);
     const int mode = epilogue_mode(a);      // kernel-uniform
-    // (the un-pooled 64-channel-wave-tile kernel keeps its raw-copy layers -- dec1.3 only -- on the generic epilogue: the
-    // specialised one spills ~30 registers there, measured 31 k cycles against the generic path's 21 k)
+    // (in the un-pooled 64-channel-wave-tile kernel the raw-copy epilogue WITH bias spills ~30 registers -- 31 k cycles against
+    // the generic path's 21 k -- so only its bias-free form is compiled there; that is the one the model uses: dec1.3)
     constexpr bool RAW_SPECIAL = POOL || NT == 1;
     if (mode == EPI_ACT) conv_epilogue<T, MT, NT, POOL, EPI_ACT>(acc, a, b, y0 + wm * MT, x0, ntg0 * 32, red, stager, dsc);
     else if (RAW_SPECIAL && mode == EPI_ACT_RAW) conv_epilogue<T, MT, NT, POOL, RAW_SPECIAL ? EPI_ACT_RAW : EPI_GENERIC>(acc, a, b, y0 + wm * MT, x0, ntg0 * 32, red, stager, dsc);
+    else if (!Prec<T>::SPLIT && mode == EPI_DGRAD)
+      conv_epilogue<T, MT, NT, POOL, Prec<T>::SPLIT ? EPI_GENERIC : EPI_DGRAD>(acc, a, b, y0 + wm * MT, x0, ntg0 * 32, red, stager, dsc);
+    else if ((RAW_SPECIAL || sizeof(T) == 2) && mode == EPI_ACT_RAW_NOBIAS)      // (4-byte storage: two passes, spills as well)
+      conv_epilogue<T, MT, NT, POOL, (RAW_SPECIAL || sizeof(T) == 2) ? EPI_ACT_RAW_NOBIAS : EPI_GENERIC>(acc, a, b, y0 + wm * MT, x0, ntg0 * 32, red, stager, dsc);
     else conv_epilogue<T, MT, NT, POOL, EPI_GENERIC>(acc, a, b, y0 + wm * MT, x0, ntg0 * 32, red, stager, dsc);
   }
 #endif
