@@ -79,13 +79,15 @@ def _packed_weights(module: 'VGGUnet', prm, versions, dt: int, device):
 
 @_lib.on_device(lambda module, x, *a, **k: x)
 def vgg_forward_nhwc(module: 'VGGUnet', x: torch.Tensor, want_conf: bool = True, defer_norm: bool = False,
-                     save_for_backward: bool = False, first_row8: int = 0):
+                     save_for_backward: bool = False, first_row8: int = 0, feat16: bool = False):
     """Run the three-level extractor.  Returns (feats, confs, inv_norm): lists of NHWC fp32 tensors
     [B,h,w,C] and [B,h,w] (or None), and inv_norm [3,B] fp64 = 1/max(||map||, 1e-12).
     With ``defer_norm`` the maps are left un-normalised (the LM loop folds inv_norm into its sums);
     otherwise they are L2-normalised per sample like the reference's (VGG.py:172-175).
     ``first_row8`` = f > 0 promises that only rows f / 2f / 4f.. of the three maps will be read (include/hla.h): the layers
-    skip the rows nothing depends on, the rows above stay unwritten and inv_norm covers the computed rows only."""
+    skip the rows nothing depends on, the rows above stay unwritten and inv_norm covers the computed rows only.
+    ``feat16`` (bf16 / fp16 precision, ``defer_norm`` only, inference only): the raw maps are returned in the 16-bit activation
+    type instead of fp32 -- half the bytes through the HBM-bound LM loop, whose arithmetic stays fp32 / fp64."""
     _lib.require_gpu(x, 'VGGUnet input')
     if x.dim() != 4 or x.shape[1] != 3:
         raise ValueError(f'expected [B,3,H,W], got {tuple(x.shape)}')
@@ -97,8 +99,13 @@ def vgg_forward_nhwc(module: 'VGGUnet', x: torch.Tensor, want_conf: bool = True,
     prm, keep, versions = _param_table(module)
     packed = _packed_weights(module, prm, versions, dt, x.device)
     L = 4 if module.level == 4 else 3
+    fdt = torch.float32
+    if feat16:
+        if not (defer_norm and not save_for_backward and L == 3 and dt in (_lib.HLA_BF16, _lib.HLA_F16)):
+            raise ValueError("feat16 needs precision 'bf16' / 'fp16', defer_norm=True, level 3 and no save_for_backward")
+        fdt = torch.bfloat16 if dt == _lib.HLA_BF16 else torch.float16
     # level 4: x24 is stored with 64 channels, the 16 real ones first, zeros behind them (see include/hla.h)
-    feats = [torch.empty(B, H >> (3 - l), W >> (3 - l), 64 if l == 3 else _CH[l], device=x.device, dtype=torch.float32)
+    feats = [torch.empty(B, H >> (3 - l), W >> (3 - l), 64 if l == 3 else _CH[l], device=x.device, dtype=fdt)
              for l in range(L)]
     confs = [torch.empty(B, H >> (3 - l), W >> (3 - l), device=x.device, dtype=torch.float32) if want_conf else None
              for l in range(L)]
@@ -107,7 +114,8 @@ def vgg_forward_nhwc(module: 'VGGUnet', x: torch.Tensor, want_conf: bool = True,
     cp = (C.c_void_p * 4)(*([(c.data_ptr() if c is not None else 0) for c in confs] + [0] * (4 - L)))
     nbytes = lib.hla_vgg_workspace_bytes(B, H, W, L, dt)
     ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
-    flags = (_lib.HLA_VGG_WANT_CONF if want_conf else 0) | (_lib.HLA_VGG_DEFER_NORM if defer_norm else 0)
+    flags = (_lib.HLA_VGG_WANT_CONF if want_conf else 0) | (_lib.HLA_VGG_DEFER_NORM if defer_norm else 0) | \
+            (_lib.HLA_VGG_FEAT16 if feat16 else 0)
     if save_for_backward:
         if not defer_norm:
             raise ValueError('save_for_backward needs defer_norm=True (the backward works on the raw maps)')

@@ -14,9 +14,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('HLA_LIB') or os.path.join(HERE, 'libhla.so')   # HLA_LIB: experiment builds
 
 HLA_F32, HLA_BF16, HLA_F16, HLA_F16X3 = 0, 1, 2, 3
-HLA_VGG_WANT_CONF, HLA_VGG_DEFER_NORM, HLA_VGG_SAVE_FOR_BACKWARD = 1, 2, 4
+HLA_VGG_WANT_CONF, HLA_VGG_DEFER_NORM, HLA_VGG_SAVE_FOR_BACKWARD, HLA_VGG_FEAT16 = 1, 2, 4, 8
 HLA_VGG_BWD_SCALE_INVARIANT = 1
-ABI_VERSION = 13
+ABI_VERSION = 14
 
 
 class HlaError(RuntimeError):
@@ -31,7 +31,7 @@ class S2GLevel(C.Structure):
     _fields_ = [('sat_feat', C.c_void_p), ('grd_feat', C.c_void_p), ('grd_conf', C.c_void_p), ('xyz', C.c_void_p),
                 ('sat_inv_norm', C.c_void_p), ('grd_inv_norm', C.c_void_p),
                 ('A', C.c_int), ('h', C.c_int), ('w', C.c_int), ('C', C.c_int), ('row0', C.c_int), ('grd_row_skip', C.c_int),
-                ('meter_per_pixel', C.c_double), ('centre', C.c_double)]
+                ('meter_per_pixel', C.c_double), ('centre', C.c_double), ('feat_dtype', C.c_int)]
 
 
 class S2GConfig(C.Structure):

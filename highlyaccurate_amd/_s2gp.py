@@ -21,6 +21,9 @@ FORD_K_FL = [945.391406, 0.0, 855.502825, 0.0, 945.668274, 566.372868, 0.0, 0.0,
 FORD_H_FL, FORD_W_FL = 860, 1656                                                        # models_ford.py:119-120
 
 
+_FEAT_DTYPES = {torch.float32: _lib.HLA_F32, torch.bfloat16: _lib.HLA_BF16, torch.float16: _lib.HLA_F16}
+
+
 def ground_plane_table(K_ori, grd_H, grd_W, ori_H, ori_W):
     """Back-project the pixel grid onto the ground plane y = camera height
     (models_kitti.py:655-682 / models_ford.py:132-155).  Same fp32 op sequence as the reference so the
@@ -186,10 +189,10 @@ class S2GPBase(nn.Module):
             skip = h - g.shape[1]
             if not (s.shape[2] == A and s.shape[3] == Cn and tuple(tables[l].shape) == (h, w, 3) and 0 <= skip <= h // 2
                     and g.shape[0] == s.shape[0] and s.is_contiguous() and g.is_contiguous()
-                    and s.dtype == torch.float32 and g.dtype == torch.float32):
+                    and s.dtype == g.dtype and s.dtype in _FEAT_DTYPES):
                 raise ValueError(f'level {l}: inconsistent feature maps sat {tuple(s.shape)} / grd {tuple(g.shape)} '
                                  f'for a {tuple(grd_hw)} ground image')
-            lv[l].sat_feat, lv[l].grd_feat = s.data_ptr(), g.data_ptr()
+            lv[l].sat_feat, lv[l].grd_feat, lv[l].feat_dtype = s.data_ptr(), g.data_ptr(), _FEAT_DTYPES[s.dtype]
             lv[l].grd_conf = grd_confs[l].data_ptr() if (self.using_weight and grd_confs[l] is not None) else 0
             lv[l].xyz = tables[l].data_ptr()
             lv[l].sat_inv_norm = sat_inv_norm[l].data_ptr() if sat_inv_norm is not None else 0
@@ -309,7 +312,11 @@ class S2GPBase(nn.Module):
             for t in list(grd_feats) + [c for c in grd_confs if c is not None] + [grd_inv]:
                 t.record_stream(cur)
         else:
-            sat_feats, _, sat_inv = vgg_forward_nhwc(self.SatFeatureNet, sat_map, want_conf=False, defer_norm=True)
+            # reduced-precision modes, inference: the LM loop reads 16-bit feature maps (HBM-bound: half the bytes; HLA_LM_FEAT16=0
+            # keeps them fp32).  The fp32-class modes and every training path keep fp32 maps.
+            f16 = (self.SatFeatureNet.precision in ('bf16', 'fp16') and self.level == 3
+                   and os.environ.get('HLA_LM_FEAT16', '1') != '0')
+            sat_feats, _, sat_inv = vgg_forward_nhwc(self.SatFeatureNet, sat_map, want_conf=False, defer_norm=True, feat16=f16)
             grd_in = grd_img
             # (only LM_update renormalises the ground features; SGD / ADAM see the whole-map L2_norm scale, so they need every row)
             dead_ok = (not return_confs and self.level == 3 and getattr(self.args, 'Optimizer', 'LM') == 'LM'
@@ -321,7 +328,7 @@ class S2GPBase(nn.Module):
             f8 = ((grd_img.shape[-2] // 8) // 2 - skip // 8) if dead_ok else 0
             f8 = f8 if (f8 >= 4 and os.environ.get('HLA_GRD_TRIM', '1') != '0') else 0
             grd_feats, grd_confs, grd_inv = vgg_forward_nhwc(self.GrdFeatureNet, grd_in, want_conf=want_conf, defer_norm=True,
-                                                             first_row8=f8)
+                                                             first_row8=f8, feat16=f16)
         trace = self.lm_solve(sat_feats, grd_feats, grd_confs, grd_img.shape[-2:], extra, level_first, init_pose,
                               sat_inv, grd_inv)
         return trace, grd_confs

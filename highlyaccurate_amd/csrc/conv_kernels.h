@@ -23,6 +23,7 @@
 // conv02_kernel -- conv0 (3->64 on the NCHW fp32 input, K = 27 padded to 32) computed by MFMA directly into the
 //   LDS halo tile of conv2, then conv2 + pool: the 64-channel full-resolution map never touches HBM.
 #include "common.h"
+#include <type_traits>
 
 typedef __bf16 bf16;
 typedef _Float16 f16;
@@ -144,7 +145,8 @@ struct ConvArgs {
   const uint4* wpk;   // fragment-packed weights
   const float* bias;  // [Cout] or null
   void* out_act;      // NHWC T [B,Ho,Wo,Cout] (post-ReLU when relu_act) or null
-  float* out_raw;     // NHWC fp32 (pre-ReLU) or null
+  float* out_raw;     // NHWC fp32 (pre-ReLU) or null; T elements instead when raw16 (HLA_VGG_FEAT16)
+  int raw16;
   double* sumsq;      // [B, tiles_per_img * gridDim.y] sum of squares of out_raw, or null
   int C1, C2, up1;
   int B, H, W, Cout;
@@ -258,9 +260,12 @@ __device__ __forceinline__ int epilogue_mode(const ConvArgs& a) {
   if (!a.out_raw) return a.sumsq ? EPI_GENERIC : EPI_ACT;
   return a.sumsq ? (a.bias ? EPI_ACT_RAW : EPI_ACT_RAW_NOBIAS) : EPI_GENERIC;
 }
-template <typename T, int MT, int NT, bool POOL, int EPI = EPI_GENERIC>
+// R16: the raw copy is written in T (16-bit activation types only) instead of fp32; its sum of squares is that of the
+// ROUNDED values, so that inv_norm normalises exactly the map the LM loop will read.
+template <typename T, int MT, int NT, bool POOL, int EPI = EPI_GENERIC, bool R16 = false>
 __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[MT][NT], const ConvArgs& a, int b, int yrow0, int x0,
                                               int cb, float* red, char* stage, float dsc = 1.f) {
+  using RawT = std::conditional_t<R16, T, float>;
   constexpr bool GEN = EPI == EPI_GENERIC, RAW = EPI == EPI_ACT_RAW || EPI == EPI_ACT_RAW_NOBIAS, DG = EPI == EPI_DGRAD;
   constexpr bool NOBIAS = EPI == EPI_ACT_RAW_NOBIAS || DG;
   const bool has_raw = GEN ? a.out_raw != nullptr : RAW;
@@ -268,7 +273,12 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[MT][NT], const ConvA
   const bool relu = GEN ? a.relu_act != 0 : !DG;
   const bool pool_sum = GEN && a.pool_sum;
   const bool has_sumsq = GEN ? a.sumsq != nullptr : RAW;
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, x = lane & 31, g = lane >> 5;
+  // The thread index is made opaque here so that nothing derived from it (stager addresses, lane offsets, masks) can be
+  // hoisted above the main loop: with several epilogue forms compiled into one kernel that hoisting cost 18-50 spilled
+  // registers in the 243-register main loop.
+  int tid = threadIdx.x;
+  asm volatile("" : "+v"(tid));
+  const int lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6), x = lane & 31, g = lane >> 5;
   const int Ho = POOL ? a.H >> 1 : a.H, Wo = POOL ? a.W >> 1 : a.W;
   constexpr int NPX = POOL ? 16 : 32;
   float4 bias[NT][4];
@@ -321,21 +331,22 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[MT][NT], const ConvA
     // accumulators feeds both (no 32-value array kept live between two passes)
     constexpr bool ONE_PASS = RAW && sizeof(T) == 2;
     if constexpr (ONE_PASS) {
-      char* stage2 = stage + 32 * RowStager<float, NT>::PITCH;
+      char* stage2 = stage + 32 * RowStager<RawT, NT>::PITCH;
       if (!POOL || !(x & 1)) {
 #pragma unroll
         for (int j = 0; j < NT; ++j)
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
-            const float w0 = v[j][q][0], w1 = v[j][q][1], w2 = v[j][q][2], w3 = v[j][q][3];
-            RowStager<float, NT>::put(stage, px, j * 32 + q * 8 + g * 4, w0, w1, w2, w3);
+            float w0 = v[j][q][0], w1 = v[j][q][1], w2 = v[j][q][2], w3 = v[j][q][3];
+            if (R16) { w0 = (float)(T)w0; w1 = (float)(T)w1; w2 = (float)(T)w2; w3 = (float)(T)w3; }
+            RowStager<RawT, NT>::put(stage, px, j * 32 + q * 8 + g * 4, w0, w1, w2, w3);
             if (lane_ok) ss += w0 * w0 + w1 * w1 + w2 * w2 + w3 * w3;
             RowStager<T, NT>::put(stage2, px, j * 32 + q * 8 + g * 4, fmaxf(w0, 0.f), fmaxf(w1, 0.f), fmaxf(w2, 0.f), fmaxf(w3, 0.f));
           }
       }
       __builtin_amdgcn_sched_barrier(0);
       if (row_ok) {
-        RowStager<float, NT>::template flush<true>(stage, a.out_raw + pix0 * a.Cout + cb, NPX, nvalid, a.Cout, lane);
+        RowStager<RawT, NT>::template flush<true>(stage, (RawT*)a.out_raw + pix0 * a.Cout + cb, NPX, nvalid, a.Cout, lane);
         RowStager<T, NT>::template flush<true>(stage2, (T*)a.out_act + pix0 * a.Cout + cb, NPX, nvalid, a.Cout, lane);
       }
       __builtin_amdgcn_sched_barrier(0);      // keep the rows apart: hoisting the next rows' arithmetic up here spills
@@ -399,7 +410,7 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[MT][NT], const ConvA
     if (want_max) mx = wave_max_f32(mx);
     if (lane == 0) { red[wv] = ss; red[4 + wv] = mx; }
     __syncthreads();
-    if (threadIdx.x == 0) {
+    if (tid == 0) {
       if (has_sumsq) {
         const int np = a.tiles_x * a.tiles_y * gridDim.y;
         const int tile = (xcd_contiguous(blockIdx.x, gridDim.x) % (a.tiles_x * a.tiles_y)) * gridDim.y + blockIdx.y;
@@ -420,7 +431,8 @@ template <typename T, int MT, int NT, int WD>
 struct WeightRing {
   static constexpr int RS = WD + 1;
   uint4 wb[RS][2][NT];
-  uint4 pf[4];           // pixel-fragment pipeline of the non-upfront MFMA loop (lives across taps)
+  static constexpr int PFD = NT == 1 ? 6 : 3;   // pixel fragments in flight ahead of the MFMAs (one MFMA per fragment at NT = 1)
+  uint4 pf[PFD + 1];     // pixel-fragment pipeline of the non-upfront MFMA loop (lives across taps)
   const uint4* wq[NT];   // per-lane pointer to this stage's fragments of output tile j: [tap][kg][lane]
 
   __device__ __forceinline__ void prime() {
@@ -525,7 +537,7 @@ __device__ __forceinline__ void stage_mma(f32x16 (&acc)[MT][NT], const char* cur
       // pixel fragments software-pipelined three reads ahead of the MFMAs that consume them.  (The straightforward "read the
       // fragments of a row, multiply" order leaves every ds_read_b128 one LDS latency -- about 100 cycles -- ahead of its
       // first MFMA with only 64 cycles of matrix work queued behind it: the pipe idled ~4 x 50 cycles per tap.)
-      constexpr int FPT = MT * 2, DEPTH = 3;               // fragments per tap: (row i, k-group kg), kg fastest
+      constexpr int FPT = MT * 2, DEPTH = WeightRing<T, MT, NT, WD>::PFD;   // fragments per tap: (row i, k-group kg), kg fastest
       auto frag_ptr = [&](int f) {                          // f counts fragments within THIS tap; f >= FPT spills into the next tap
         const int tp = tap + f / FPT, r = f % FPT;
         return cur + (((tp / 3) * HWID + tp % 3) + (r >> 1) * HWID) * PSTR + (r & 1) * 32;
@@ -584,7 +596,7 @@ __device__ __forceinline__ void stage_mma(f32x16 (&acc)[MT][NT], const char* cur
 }
 
 template <typename T, int MT, int NT, int WM, int WN, bool POOL, int WD, bool PF_UPFRONT>
-__global__ __launch_bounds__(256, (NT == 1 && !PF_UPFRONT) ? 3 : 2) void conv3x3_kernel(ConvArgs a) {
+__global__ __launch_bounds__(256, (NT == 1 && !PF_UPFRONT && (CONV_VARIANT == 50 || CONV_VARIANT == 51 || CONV_VARIANT == 132)) ? 3 : 2) void conv3x3_kernel(ConvArgs a) {
   static_assert(WM * WN == 4, "4 waves per block");
   constexpr int EPL = 16 / sizeof(T), KC = SB / sizeof(T);     // channels per stage: 32 (bf16) / 16 (fp32)
   constexpr int TH = WM * MT, HPIX = (TH + 2) * HWID, BUF = HPIX * PSTR;
@@ -744,7 +756,14 @@ __global__ __launch_bounds__(256, (NT == 1 && !PF_UPFRONT) ? 3 : 2) void conv3x3
     // (in the un-pooled 64-channel-wave-tile kernel the raw-copy epilogue WITH bias spills ~30 registers -- 31 k cycles against
     // the generic path's 21 k -- so only its bias-free form is compiled there; that is the one the model uses: dec1.3)
     constexpr bool RAW_SPECIAL = POOL || NT == 1;
+    constexpr bool T16 = sizeof(T) == 2;
     if (mode == EPI_ACT) conv_epilogue<T, MT, NT, POOL, EPI_ACT>(acc, a, b, y0 + wm * MT, x0, ntg0 * 32, red, stager, dsc);
+    // (16-bit raw copy, HLA_VGG_FEAT16: only the three feature layers ask for it -- conv14: pooled + bias; dec1.3 / dec2.3:
+    // no bias -- and exactly those forms are compiled)
+    else if (T16 && RAW_SPECIAL && a.raw16 && mode == EPI_ACT_RAW)
+      conv_epilogue<T, MT, NT, POOL, (T16 && RAW_SPECIAL) ? EPI_ACT_RAW : EPI_GENERIC, T16 && RAW_SPECIAL>(acc, a, b, y0 + wm * MT, x0, ntg0 * 32, red, stager, dsc);
+    else if (T16 && a.raw16 && mode == EPI_ACT_RAW_NOBIAS)
+      conv_epilogue<T, MT, NT, POOL, T16 ? EPI_ACT_RAW_NOBIAS : EPI_GENERIC, T16>(acc, a, b, y0 + wm * MT, x0, ntg0 * 32, red, stager, dsc);
     else if (RAW_SPECIAL && mode == EPI_ACT_RAW) conv_epilogue<T, MT, NT, POOL, RAW_SPECIAL ? EPI_ACT_RAW : EPI_GENERIC>(acc, a, b, y0 + wm * MT, x0, ntg0 * 32, red, stager, dsc);
     else if (!Prec<T>::SPLIT && mode == EPI_DGRAD)
       conv_epilogue<T, MT, NT, POOL, Prec<T>::SPLIT ? EPI_GENERIC : EPI_DGRAD>(acc, a, b, y0 + wm * MT, x0, ntg0 * 32, red, stager, dsc);
@@ -1157,8 +1176,10 @@ static void launch_conv(hipStream_t st, ConvArgs a, bool pool) {
   // Cout == 64 : block = 8x32 pixels x  64 channels, waves 2 x 2,       wave tile 128 px x 32 ch, weights 2 taps ahead
 #if CONV_VARIANT == 50 || CONV_VARIANT == 51
 #define SMALL_OPT 1, false     // 154 VGPRs -> 3 waves/SIMD, 3 blocks/CU (LDS 3 x 54,416 B fits the 160 KiB)
+#elif CONV_VARIANT == 133
+#define SMALL_OPT 2, true      // the former default: all fragments of a tap requested up front (960 -> 906 TF)
 #else
-#define SMALL_OPT 2, true
+#define SMALL_OPT 2, false     // the pipelined fragment loop, six ds_reads ahead (132: the same at 3 waves/SIMD -- spills, 690 TF)
 #endif
 #if CONV_VARIANT >= 100 && CONV_VARIANT <= 109   // experiment (negative result): weights through LDS
   if (big && !a.unpool_idx) {

@@ -357,8 +357,10 @@ extern "C" int hla_s2g_lm_solve_bwd(const hla_s2g_config* cfg, const hla_s2g_lev
   HLA_REQUIRE(cfg && cfg->optimizer >= 0 && cfg->optimizer <= 3, "hla_s2g_lm_solve_bwd: optimizer must be 0 (LM), 1 (SGD), 2 (ADAM) or 3 (GN)");
   const int rc = hla_s2g_validate("hla_s2g_lm_solve_bwd", cfg, lv, R_FL, T_FL, B);
   if (rc) return rc;
-  for (int l = 0; l < cfg->n_levels; ++l)
+  for (int l = 0; l < cfg->n_levels; ++l) {
     HLA_REQUIRE(gr[l].d_sat_feat && gr[l].d_grd_feat, "hla_s2g_lm_solve_bwd: level %d gradient buffers missing", l);
+    HLA_REQUIRE(lv[l].feat_dtype == HLA_F32, "hla_s2g_lm_solve_bwd: level %d: the backward needs fp32 feature maps", l);
+  }
   size_t off[5];
   const size_t need = bwd_layout(cfg, lv, B, off);
   if (workspace_bytes < need) {
@@ -412,7 +414,7 @@ extern "C" int hla_s2g_lm_solve_bwd(const hla_s2g_config* cfg, const hla_s2g_lev
     hla_prof_end(st);
 
     BwdAccumArgs aa{};
-    aa.sat = v.sat_feat; aa.grd = v.grd_feat; aa.conf = v.grd_conf; aa.xyz = v.xyz; aa.coef = coef; aa.adj = adj;
+    aa.sat = (const float*)v.sat_feat; aa.grd = (const float*)v.grd_feat; aa.conf = v.grd_conf; aa.xyz = v.xyz; aa.coef = coef; aa.adj = adj;
     aa.sat_inv = v.sat_inv_norm; aa.grd_inv = v.grd_inv_norm;
     aa.d_sat = gr[l].d_sat_feat; aa.d_grd = gr[l].d_grd_feat; aa.d_conf = gr[l].d_grd_conf; aa.part = part;
     aa.A = v.A; aa.h = v.h; aa.w = v.w; aa.row0 = v.row0; aa.npix = (v.h - v.row0) * v.w;

@@ -245,6 +245,7 @@ extern "C" int hla_g2s_lm_solve(const hla_s2g_config* cfg, const hla_s2g_level* 
     const int C = lv[l].C;
     HLA_REQUIRE(C == 256 || C == 128 || C == 64, "hla_g2s_lm_solve: unsupported channel count %d", C);
     HLA_REQUIRE(lv[l].sat_feat && lv[l].grd_feat, "hla_g2s_lm_solve: level %d has null maps", l);
+    HLA_REQUIRE(lv[l].feat_dtype == HLA_F32, "hla_g2s_lm_solve: level %d: fp32 feature maps only", l);
     HLA_REQUIRE(!cfg->using_weight || lv[l].grd_conf, "hla_g2s_lm_solve: using_weight needs grd_conf");
     HLA_REQUIRE(lv[l].grd_row_skip == 0, "hla_g2s_lm_solve: the whole ground map is sampled (grd_row_skip must be 0)");
     HLA_REQUIRE((size_t)lv[l].h * lv[l].w * C < (1u << 31), "hla_g2s_lm_solve: ground map too large");
@@ -279,7 +280,7 @@ extern "C" int hla_g2s_lm_solve(const hla_s2g_config* cfg, const hla_s2g_level* 
     const int l = k % L, it = k / L;
     const hla_s2g_level& v = lv[l];
     G2sAccumArgs aa{};
-    aa.src = v.grd_feat; aa.fix = v.sat_feat; aa.conf = v.grd_conf; aa.coef = coef; aa.part = part;
+    aa.src = (const float*)v.grd_feat; aa.fix = (const float*)v.sat_feat; aa.conf = v.grd_conf; aa.coef = coef; aa.part = part;
     aa.A = v.A; aa.h = v.h; aa.w = v.w; aa.ctr = v.A / 2; aa.npix = v.A * v.A;
     aa.TP = lm_pick_tile(aa.npix); aa.nt = (aa.npix + aa.TP - 1) / aa.TP; aa.B = B;
     aa.xcd_affine = (B >= 8) ? 1 : 0;
@@ -657,7 +658,7 @@ extern "C" int hla_g2s_lm_solve_bwd(const hla_s2g_config* cfg, const hla_s2g_lev
     hla_prof_end(st);
 
     G2sBwdAccumArgs aa{};
-    aa.src = v.grd_feat; aa.fix = v.sat_feat; aa.conf = v.grd_conf; aa.coef = coef; aa.adj = adj;
+    aa.src = (const float*)v.grd_feat; aa.fix = (const float*)v.sat_feat; aa.conf = v.grd_conf; aa.coef = coef; aa.adj = adj;
     aa.src_inv = v.grd_inv_norm; aa.fix_inv = v.sat_inv_norm;
     aa.d_src = gr[l].d_grd_feat; aa.d_fix = gr[l].d_sat_feat; aa.d_conf = gr[l].d_grd_conf; aa.part = part;
     aa.A = v.A; aa.h = v.h; aa.w = v.w; aa.ctr = v.A / 2; aa.npix = v.A * v.A;

@@ -14,116 +14,6 @@
 //                and the projection coefficients of the NEXT step (so no extra launch for them).
 #include "lm_common.h"
 
-struct AccumArgs {
-  const float* sat;   // [B,A,A,C]
-  const float* grd;   // [B,h,w,C]
-  const float* conf;  // [B,h,w] or null
-  const float* xyz;   // [h,w,3]
-  const double* coef; // [B,COEF_N]
-  double* part;       // [B,nt,PART_N]
-  int A, h, w, row0, npix, TP, nt, B, xcd_affine;
-  int hs, rskip;      // stored rows of grd/conf (h - grd_row_skip) and the skip itself
-  const unsigned char* keep;   // dropout: [npix] of this step, 1 = pixel takes part; or null
-};
-
-template <int C, bool USE_W>
-__global__ __launch_bounds__(256) void lm_accum(AccumArgs a) {
-  __shared__ PixParam pp[MAX_TP];
-  __shared__ float red[4][14];
-  int b, tile;
-  if (!lm_block_map(a.xcd_affine, a.nt, a.B, b, tile)) return;
-  const int t = threadIdx.x;
-  const int p0 = tile * a.TP;
-  const int np = min(a.TP, a.npix - p0);
-  const double* cf = a.coef + (size_t)b * COEF_N;
-
-  if (t < np) {
-    const int p = p0 + t;
-    const int r = a.row0 + p / a.w, c = p % a.w;
-    const float cw = USE_W ? a.conf[((size_t)b * a.hs + (r - a.rskip)) * a.w + c] : 1.f;
-    PixParam P = lm_pixel<C>(cf, a.xyz + ((size_t)r * a.w + c) * 3, a.A, cw);
-    if (a.keep && !a.keep[p]) {          // dropped by args.dropout: the pixel leaves every sum (models_kitti.py:968-974)
-      P.wx0 = P.wx1 = P.wy0 = P.wy1 = 0.f; P.off = P.dxo = P.dyo = 0; P.j2u = P.j2v = 0.f; P.gm = P.wt = P.m = 0.f;
-    }
-    pp[t] = P;
-  }
-  __syncthreads();
-
-  const float j0u = (float)cf[8], j0v = (float)cf[9], j1u = (float)cf[10], j1v = (float)cf[11];
-  constexpr int LPP = C / 4;          // lanes per pixel (16 B of channels per lane)
-  constexpr int PPW = 64 / LPP;       // pixels per wave-iteration
-  const int lane = t & 63, wave = t >> 6;
-  const int sub = lane / LPP, cl = (lane % LPP) * 4;
-  const float* satb = a.sat + (size_t)b * a.A * a.A * C + cl;
-  const float* grdb = a.grd + ((size_t)b * a.hs * a.w + (size_t)(a.row0 - a.rskip) * a.w + p0) * C + cl;
-
-  float aS = 0, aG = 0, h00 = 0, h01 = 0, h02 = 0, h11 = 0, h12 = 0, h22 = 0;
-  float u0 = 0, u1 = 0, u2 = 0, v0 = 0, v1 = 0, v2 = 0;
-
-#pragma unroll 2
-  for (int i = wave * PPW + sub; i < np; i += 4 * PPW) {
-    const PixParam P = pp[i];
-    const float4 t00 = *(const float4*)(satb + P.off);
-    const float4 t01 = *(const float4*)(satb + P.off + P.dxo);
-    const float4 t10 = *(const float4*)(satb + P.off + P.dyo);
-    const float4 t11 = *(const float4*)(satb + P.off + P.dyo + P.dxo);
-    const float4 gg = *(const float4*)(grdb + (size_t)i * C);
-    const float a00[4] = {t00.x, t00.y, t00.z, t00.w}, a01[4] = {t01.x, t01.y, t01.z, t01.w};
-    const float a10[4] = {t10.x, t10.y, t10.z, t10.w}, a11[4] = {t11.x, t11.y, t11.z, t11.w};
-    const float ag[4] = {gg.x, gg.y, gg.z, gg.w};
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const float top = P.wx0 * a00[e] + P.wx1 * a01[e];
-      const float bot = P.wx0 * a10[e] + P.wx1 * a11[e];
-      const float s = P.wy0 * top + P.wy1 * bot;
-      const float dsy = bot - top;
-      const float dsx = P.wy0 * (a01[e] - a00[e]) + P.wy1 * (a11[e] - a10[e]);
-      const float g = ag[e] * P.gm;
-      const float J0 = dsx * j0u + dsy * j0v;
-      const float J1 = dsx * j1u + dsy * j1v;
-      const float J2 = dsx * P.j2u + dsy * P.j2v;
-      const float W0 = USE_W ? J0 * P.wt : J0, W1 = USE_W ? J1 * P.wt : J1, W2 = USE_W ? J2 * P.wt : J2;
-      aS += s * s; aG += g * g;
-      h00 += W0 * J0; h01 += W0 * J1; h02 += W0 * J2; h11 += W1 * J1; h12 += W1 * J2; h22 += W2 * J2;
-      u0 += W0 * s; u1 += W1 * s; u2 += W2 * s;
-      v0 += W0 * g; v1 += W1 * g; v2 += W2 * g;
-    }
-  }
-
-  float acc[14] = {aS, aG, h00, h01, h02, h11, h12, h22, u0, u1, u2, v0, v1, v2};
-#pragma unroll
-  for (int k = 0; k < 14; ++k) acc[k] = wave_sum_f32(acc[k]);
-  if (lane == 0) {
-#pragma unroll
-    for (int k = 0; k < 14; ++k) red[wave][k] = acc[k];
-  }
-  __syncthreads();
-  if (t < PART_N) {
-    double v = 0.0;
-    if (t < 14) v = ((double)red[0][t] + (double)red[1][t]) + ((double)red[2][t] + (double)red[3][t]);
-    a.part[((size_t)b * a.nt + tile) * PART_N + t] = v;
-  }
-}
-
-// ---------------------------------------------------------------------------------------------
-// hla_s2g_config.count_in_view: the quantity jacobian.py:172 asserts on -- how many pixels of the WHOLE level map (all rows,
-// whatever their z > 0 mask) have satellite coordinates inside the map.  Geometry only; one thread per pixel.
-__global__ __launch_bounds__(256) void lm_inview_kernel(const double* __restrict__ coef, const float* __restrict__ xyz, int A,
-                                                        int npix, int* __restrict__ count) {
-  const int b = blockIdx.y, p = blockIdx.x * 256 + threadIdx.x;
-  const double* cf = coef + (size_t)b * COEF_N;
-  int in = 0;
-  if (p < npix) {
-    const double X = xyz[(size_t)p * 3], Y = xyz[(size_t)p * 3 + 1], Z = xyz[(size_t)p * 3 + 2];
-    const double u = cf[0] * X + cf[1] * Y + cf[2] * Z + cf[3];
-    const double v = cf[4] * X + cf[5] * Y + cf[6] * Z + cf[7];
-    const double lim = (double)(A - 1);
-    in = ((u >= 0.0) && (u <= lim) && (v >= 0.0) && (v <= lim)) ? 1 : 0;
-  }
-  const unsigned long long m = __ballot(in);
-  if ((threadIdx.x & 63) == 0 && m) atomicAdd(count + b, __popcll(m));
-}
-
 struct SolveArgs {
   const double* part;    // [B,nt,PART_N] of the step being closed, or null (init launch)
   const double* sat_inv; // [B] or null: feature maps are stored un-normalised, sums are rescaled here
@@ -146,8 +36,10 @@ struct SolveArgs {
   LmGeom next;           // geometry of the level the NEXT step runs on
 };
 
-__global__ __launch_bounds__(64) void lm_solve(SolveArgs a) {
-  const int b = blockIdx.x, lane = threadIdx.x;
+// One wave closes a step for sample b.  COHERENT: the tile partials were written by OTHER workgroups of the same launch
+// (the fused accumulate + solve kernel): read them with agent-scope (sc1) loads, which bypass this CU's L1.
+template <bool COHERENT>
+__device__ __forceinline__ void lm_solve_body(const SolveArgs& a, int b, int lane) {
   float su = a.pose[b * 3 + 0], sv = a.pose[b * 3 + 1], th = a.pose[b * 3 + 2];
 
   if (a.part) {
@@ -157,7 +49,8 @@ __global__ __launch_bounds__(64) void lm_solve(SolveArgs a) {
     for (int i = lane; i < a.nt; i += 64) {
       const double* p = a.part + ((size_t)b * a.nt + i) * PART_N;
 #pragma unroll
-      for (int k = 0; k < 14; ++k) s[k] += p[k];
+      for (int k = 0; k < 14; ++k)
+        s[k] += COHERENT ? __hip_atomic_load(p + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : p[k];
     }
 #pragma unroll
     for (int k = 0; k < 14; ++k) s[k] = wave_sum_f64(s[k]);
@@ -207,6 +100,194 @@ __global__ __launch_bounds__(64) void lm_solve(SolveArgs a) {
                     a.coef + (size_t)b * COEF_N);
 }
 
+// stand-alone launch: the coefficients of step 0 (part == null)
+__global__ __launch_bounds__(64) void lm_solve(SolveArgs a) { lm_solve_body<false>(a, blockIdx.x, threadIdx.x); }
+
+struct AccumArgs {
+  const void* sat;    // [B,A,A,C]  F elements (fp32, or bf16 / fp16 in the reduced-precision inference modes)
+  const void* grd;    // [B,h,w,C]
+  const float* conf;  // [B,h,w] or null
+  const float* xyz;   // [h,w,3]
+  const double* coef; // [B,COEF_N]
+  double* part;       // [B,nt,PART_N]
+  int A, h, w, row0, npix, TP, nt, B, xcd_affine;
+  int hs, rskip;      // stored rows of grd/conf (h - grd_row_skip) and the skip itself
+  const unsigned char* keep;   // dropout: [npix] of this step, 1 = pixel takes part; or null
+  unsigned* ticket;   // [B] arrival counters of this step (zeroed before the loop): the LAST tile of a sample closes the step
+};
+
+// element e (compile-time after unrolling) of a 16-byte vector of F, as fp32
+template <typename F> __device__ __forceinline__ float lm_elem(const uint4& v, int e);
+template <> __device__ __forceinline__ float lm_elem<float>(const uint4& v, int e) {
+  return __uint_as_float(e == 0 ? v.x : e == 1 ? v.y : e == 2 ? v.z : v.w);
+}
+template <> __device__ __forceinline__ float lm_elem<__bf16>(const uint4& v, int e) {      // bf16 -> fp32 is a 16-bit shift
+  const unsigned w = (e >> 1) == 0 ? v.x : (e >> 1) == 1 ? v.y : (e >> 1) == 2 ? v.z : v.w;
+  return __uint_as_float((e & 1) ? (w & 0xffff0000u) : (w << 16));
+}
+template <> __device__ __forceinline__ float lm_elem<_Float16>(const uint4& v, int e) {
+  typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+  const unsigned w = (e >> 1) == 0 ? v.x : (e >> 1) == 1 ? v.y : (e >> 1) == 2 ? v.z : v.w;
+  return (float)__builtin_bit_cast(h2, w)[e & 1];
+}
+
+// The last tile of a sample to finish (an arrival ticket per sample) reduces the sample's tile partials in fixed order and
+// closes the step: no separate solve launch.  Publication follows the write-through recipe of cdna_hip_programming.md
+// Guideline 16: 8-byte agent-scope (sc1) stores of the partials -> s_waitcnt vmcnt(0) -> relaxed agent-scope ticket; the
+// last arriver reads with agent-scope loads.  Which tile arrives last never changes a bit of the result.
+// (6 waves per SIMD = 80 registers: what the gather loop needs; the closing solve, one wave per sample, may spill a little)
+#ifndef CONV_VARIANT
+#define CONV_VARIANT 0
+#endif
+#if CONV_VARIANT == 140      // experiments: more loads in flight per wave, fewer waves
+#define LM_OCC 4
+#define LM_UNROLL(F) (sizeof(F) == 4 ? 4 : 2)
+#elif CONV_VARIANT == 141
+#define LM_OCC 8
+#define LM_UNROLL(F) 1
+#elif CONV_VARIANT == 142
+#define LM_OCC 3
+#define LM_UNROLL(F) (sizeof(F) == 4 ? 4 : 4)
+#else
+#define LM_OCC 6
+#define LM_UNROLL(F) (sizeof(F) == 4 ? 2 : 1)
+#endif
+template <int C, bool USE_W, typename F>
+__global__ __launch_bounds__(256, LM_OCC) void lm_accum(AccumArgs a, SolveArgs sa) {
+  __shared__ PixParam pp[MAX_TP];
+  __shared__ float red[4][14];
+  __shared__ double redd[14];
+  int b, tile;
+  if (!lm_block_map(a.xcd_affine, a.nt, a.B, b, tile)) return;
+  const int t = threadIdx.x;
+  const int p0 = tile * a.TP;
+  const int np = min(a.TP, a.npix - p0);
+  const double* cf = a.coef + (size_t)b * COEF_N;
+
+  if (t < np) {
+    const int p = p0 + t;
+    const int r = a.row0 + p / a.w, c = p % a.w;
+    const float cw = USE_W ? a.conf[((size_t)b * a.hs + (r - a.rskip)) * a.w + c] : 1.f;
+    PixParam P = lm_pixel<C>(cf, a.xyz + ((size_t)r * a.w + c) * 3, a.A, cw);
+    if (a.keep && !a.keep[p]) {          // dropped by args.dropout: the pixel leaves every sum (models_kitti.py:968-974)
+      P.wx0 = P.wx1 = P.wy0 = P.wy1 = 0.f; P.off = P.dxo = P.dyo = 0; P.j2u = P.j2v = 0.f; P.gm = P.wt = P.m = 0.f;
+    }
+    pp[t] = P;
+  }
+  __syncthreads();
+
+  const float j0u = (float)cf[8], j0v = (float)cf[9], j1u = (float)cf[10], j1v = (float)cf[11];
+  constexpr int EPL = 16 / (int)sizeof(F);   // channels per lane (16 B)
+  constexpr int LPP = C / EPL;        // lanes per pixel
+  constexpr int PPW = 64 / LPP;       // pixels per wave-iteration
+  const int lane = t & 63, wave = t >> 6;
+  const int sub = lane / LPP, cl = (lane % LPP) * EPL;
+  const F* satb = (const F*)a.sat + (size_t)b * a.A * a.A * C + cl;
+  const F* grdb = (const F*)a.grd + ((size_t)b * a.hs * a.w + (size_t)(a.row0 - a.rskip) * a.w + p0) * C + cl;
+
+  // With J_a = dsx*a_u + dsy*a_v (a = u, v, theta) and only the theta row's (a_u, a_v) = (j2u, j2v) varying per pixel, every
+  // normal-equation sum is a combination of CHANNEL sums of a pixel -- Sxx = sum dsx^2, Sxy, Syy, Sxs = sum dsx*s, Sys, Sxg, Syg --
+  // with per-pixel (j2u, j2v, weight) or per-sample (j0*, j1*) coefficients.  So the inner loop only forms those nine channel
+  // sums (9 FMAs per element instead of 6 for the J's + 14), the per-pixel step folds in what varies per pixel, and the
+  // per-sample coefficients are applied once per block, in fp64, after the reduction:
+  //   T1..3 = sum w (Sxx, Sxy, Syy)        B1 = sum w (j2u Sxx + j2v Sxy)   B2 = sum w (j2u Sxy + j2v Syy)
+  //   Q = sum (j2u b1 + j2v b2) = H22      U1,2 = sum w (Sxs, Sys)   U3 = sum w (j2u Sxs + j2v Sys)   V likewise with g
+  float aS = 0, aG = 0, T1 = 0, T2 = 0, T3 = 0, B1 = 0, B2 = 0, Q = 0, U1 = 0, U2 = 0, U3 = 0, V1 = 0, V2 = 0, V3 = 0;
+
+#pragma unroll LM_UNROLL(F)
+  for (int i = wave * PPW + sub; i < np; i += 4 * PPW) {
+    const PixParam P = pp[i];
+    const uint4 t00 = *(const uint4*)(satb + P.off);
+    const uint4 t01 = *(const uint4*)(satb + P.off + P.dxo);
+    const uint4 t10 = *(const uint4*)(satb + P.off + P.dyo);
+    const uint4 t11 = *(const uint4*)(satb + P.off + P.dyo + P.dxo);
+    const uint4 gg = *(const uint4*)(grdb + (size_t)i * C);
+    float Sxx = 0, Sxy = 0, Syy = 0, Sxs = 0, Sys = 0, Sxg = 0, Syg = 0, Sss = 0, Sgg = 0;
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) {
+      const float c00 = lm_elem<F>(t00, e), c01 = lm_elem<F>(t01, e), c10 = lm_elem<F>(t10, e), c11 = lm_elem<F>(t11, e);
+      const float top = P.wx0 * c00 + P.wx1 * c01;
+      const float bot = P.wx0 * c10 + P.wx1 * c11;
+      const float s = P.wy0 * top + P.wy1 * bot;
+      const float dsy = bot - top;
+      const float dsx = P.wy0 * (c01 - c00) + P.wy1 * (c11 - c10);
+      const float g = lm_elem<F>(gg, e) * P.gm;
+      Sxx += dsx * dsx; Sxy += dsx * dsy; Syy += dsy * dsy;
+      Sxs += dsx * s; Sys += dsy * s; Sxg += dsx * g; Syg += dsy * g;
+      Sss += s * s; Sgg += g * g;
+    }
+    aS += Sss; aG += Sgg;
+    if (USE_W) { Sxx *= P.wt; Sxy *= P.wt; Syy *= P.wt; Sxs *= P.wt; Sys *= P.wt; Sxg *= P.wt; Syg *= P.wt; }
+    T1 += Sxx; T2 += Sxy; T3 += Syy;
+    const float b1 = P.j2u * Sxx + P.j2v * Sxy, b2 = P.j2u * Sxy + P.j2v * Syy;
+    B1 += b1; B2 += b2;
+    Q += P.j2u * b1 + P.j2v * b2;
+    U1 += Sxs; U2 += Sys; U3 += P.j2u * Sxs + P.j2v * Sys;
+    V1 += Sxg; V2 += Syg; V3 += P.j2u * Sxg + P.j2v * Syg;
+  }
+
+  float acc[14] = {aS, aG, T1, T2, T3, B1, B2, Q, U1, U2, U3, V1, V2, V3};
+#pragma unroll
+  for (int k = 0; k < 14; ++k) acc[k] = wave_sum_f32(acc[k]);
+  if (lane == 0) {
+#pragma unroll
+    for (int k = 0; k < 14; ++k) red[wave][k] = acc[k];
+  }
+  __syncthreads();
+  if (t < 14) redd[t] = ((double)red[0][t] + (double)red[1][t]) + ((double)red[2][t] + (double)red[3][t]);
+  __syncthreads();
+  if (wave != 0) return;
+  if (t < PART_N) {
+    // the per-sample rows of d(uv)/d(pose): fp32 values (the gather used to apply them in fp32), combined in fp64
+    const double au = (double)j0u, av = (double)j0v, bu = (double)j1u, bv = (double)j1v;
+    const double t1 = redd[2], t2 = redd[3], t3 = redd[4], b1 = redd[5], b2 = redd[6];
+    double v = 0.0;
+    switch (t) {
+      case 0: v = redd[0]; break;                                             // sum s^2
+      case 1: v = redd[1]; break;                                             // sum g^2
+      case 2: v = au * au * t1 + 2.0 * au * av * t2 + av * av * t3; break;    // H00
+      case 3: v = au * bu * t1 + (au * bv + av * bu) * t2 + av * bv * t3; break;   // H01
+      case 4: v = au * b1 + av * b2; break;                                   // H02
+      case 5: v = bu * bu * t1 + 2.0 * bu * bv * t2 + bv * bv * t3; break;    // H11
+      case 6: v = bu * b1 + bv * b2; break;                                   // H12
+      case 7: v = redd[7]; break;                                             // H22
+      case 8: v = au * redd[8] + av * redd[9]; break;                         // J^T W s
+      case 9: v = bu * redd[8] + bv * redd[9]; break;
+      case 10: v = redd[10]; break;
+      case 11: v = au * redd[11] + av * redd[12]; break;                      // J^T W g
+      case 12: v = bu * redd[11] + bv * redd[12]; break;
+      case 13: v = redd[13]; break;
+      default: break;
+    }
+    __hip_atomic_store(a.part + ((size_t)b * a.nt + tile) * PART_N + t, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the partials have left this CU before the ticket is drawn
+  unsigned old = 0;
+  if (lane == 0) old = __hip_atomic_fetch_add(a.ticket + b, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  old = __builtin_amdgcn_readfirstlane(old);
+  if (old + 1 != (unsigned)a.nt) return;
+  lm_solve_body<true>(sa, b, lane);
+}
+
+// ---------------------------------------------------------------------------------------------
+// hla_s2g_config.count_in_view: the quantity jacobian.py:172 asserts on -- how many pixels of the WHOLE level map (all rows,
+// whatever their z > 0 mask) have satellite coordinates inside the map.  Geometry only; one thread per pixel.
+__global__ __launch_bounds__(256) void lm_inview_kernel(const double* __restrict__ coef, const float* __restrict__ xyz, int A,
+                                                        int npix, int* __restrict__ count) {
+  const int b = blockIdx.y, p = blockIdx.x * 256 + threadIdx.x;
+  const double* cf = coef + (size_t)b * COEF_N;
+  int in = 0;
+  if (p < npix) {
+    const double X = xyz[(size_t)p * 3], Y = xyz[(size_t)p * 3 + 1], Z = xyz[(size_t)p * 3 + 2];
+    const double u = cf[0] * X + cf[1] * Y + cf[2] * Z + cf[3];
+    const double v = cf[4] * X + cf[5] * Y + cf[6] * Z + cf[7];
+    const double lim = (double)(A - 1);
+    in = ((u >= 0.0) && (u <= lim) && (v >= 0.0) && (v <= lim)) ? 1 : 0;
+  }
+  const unsigned long long m = __ballot(in);
+  if ((threadIdx.x & 63) == 0 && m) atomicAdd(count + b, __popcll(m));
+}
+
 // ---------------------------------------------------------------------------------------------
 static size_t ws_layout(const hla_s2g_config* cfg, const hla_s2g_level* lv, int B, size_t* off_coef, size_t* off_pose,
                         size_t* off_part) {
@@ -220,6 +301,7 @@ static size_t ws_layout(const hla_s2g_config* cfg, const hla_s2g_level* lv, int 
   *off_coef = o; o += hla_align_up((size_t)B * COEF_N * sizeof(double), 256);
   *off_pose = o; o += hla_align_up((size_t)B * 3 * sizeof(float), 256);
   *off_part = o; o += hla_align_up((size_t)B * max_nt * PART_N * sizeof(double), 256);
+  o += hla_align_up((size_t)B * cfg->n_levels * cfg->n_iters * sizeof(unsigned), 256);   // arrival tickets, one per step and sample
   o += hla_align_up((size_t)B * cfg->n_levels * cfg->n_iters * sizeof(int), 256);   // in-view counts (count_in_view)
   o += hla_align_up((size_t)B * 6 * sizeof(double), 256);      // ADAM moments (last region)
   return o;
@@ -230,14 +312,20 @@ extern "C" size_t hla_s2g_workspace_bytes(const hla_s2g_config* cfg, const hla_s
   return ws_layout(cfg, levels, B, &a, &b, &c);
 }
 
-template <bool W>
-static void launch_accum(int C, dim3 grid, hipStream_t st, const AccumArgs& a) {
+template <bool W, typename F>
+static void launch_accum_f(int C, dim3 grid, hipStream_t st, const AccumArgs& a, const SolveArgs& sa) {
   switch (C) {
-    case 256: hipLaunchKernelGGL((lm_accum<256, W>), grid, dim3(256), 0, st, a); break;
-    case 128: hipLaunchKernelGGL((lm_accum<128, W>), grid, dim3(256), 0, st, a); break;
-    case 64: hipLaunchKernelGGL((lm_accum<64, W>), grid, dim3(256), 0, st, a); break;
-    case 16: hipLaunchKernelGGL((lm_accum<16, W>), grid, dim3(256), 0, st, a); break;
+    case 256: hipLaunchKernelGGL((lm_accum<256, W, F>), grid, dim3(256), 0, st, a, sa); break;
+    case 128: hipLaunchKernelGGL((lm_accum<128, W, F>), grid, dim3(256), 0, st, a, sa); break;
+    case 64: hipLaunchKernelGGL((lm_accum<64, W, F>), grid, dim3(256), 0, st, a, sa); break;
+    case 16: hipLaunchKernelGGL((lm_accum<16, W, F>), grid, dim3(256), 0, st, a, sa); break;
   }
+}
+template <bool W>
+static void launch_accum(int C, int feat_dtype, dim3 grid, hipStream_t st, const AccumArgs& a, const SolveArgs& sa) {
+  if (feat_dtype == HLA_BF16) launch_accum_f<W, __bf16>(C, grid, st, a, sa);
+  else if (feat_dtype == HLA_F16) launch_accum_f<W, _Float16>(C, grid, st, a, sa);
+  else launch_accum_f<W, float>(C, grid, st, a, sa);
 }
 
 int hla_s2g_validate(const char* who, const hla_s2g_config* cfg, const hla_s2g_level* lv, const float* R_FL,
@@ -249,6 +337,8 @@ int hla_s2g_validate(const char* who, const hla_s2g_config* cfg, const hla_s2g_l
   for (int l = 0; l < cfg->n_levels; ++l) {
     const int C = lv[l].C;
     HLA_REQUIRE(C == 256 || C == 128 || C == 64 || C == 16, "%s: unsupported channel count %d", who, C);
+    HLA_REQUIRE(lv[l].feat_dtype == HLA_F32 || lv[l].feat_dtype == HLA_BF16 || lv[l].feat_dtype == HLA_F16,
+                "%s: level %d feat_dtype must be HLA_F32, HLA_BF16 or HLA_F16", who, l);
     HLA_REQUIRE(lv[l].sat_feat && lv[l].grd_feat && lv[l].xyz, "%s: level %d has null maps", who, l);
     HLA_REQUIRE(!cfg->using_weight || lv[l].grd_conf, "%s: using_weight needs grd_conf", who);
     HLA_REQUIRE(lv[l].row0 >= 0 && lv[l].row0 < lv[l].h, "%s: bad row0", who);
@@ -298,6 +388,8 @@ extern "C" int hla_s2g_lm_solve(const hla_s2g_config* cfg, const hla_s2g_level* 
 
   double* adam = (double*)(ws + need - hla_align_up((size_t)B * 6 * sizeof(double), 256));
   int* in_view = (int*)((char*)adam - hla_align_up((size_t)B * steps * sizeof(int), 256));
+  unsigned* ticket = (unsigned*)((char*)in_view - hla_align_up((size_t)B * steps * sizeof(unsigned), 256));
+  HLA_CHECK_HIP(hipMemsetAsync(ticket, 0, (size_t)B * steps * sizeof(unsigned), st));
   const bool count = cfg->count_in_view && normal_eq;
   if (count) HLA_CHECK_HIP(hipMemsetAsync(in_view, 0, (size_t)B * steps * sizeof(int), st));
   if (cfg->optimizer == 2) HLA_CHECK_HIP(hipMemsetAsync(adam, 0, (size_t)B * 6 * sizeof(double), st));
@@ -327,12 +419,8 @@ extern "C" int hla_s2g_lm_solve(const hla_s2g_config* cfg, const hla_s2g_level* 
     aa.TP = lm_pick_tile(aa.npix); aa.nt = (aa.npix + aa.TP - 1) / aa.TP; aa.B = B;
     aa.xcd_affine = (B >= 8) ? 1 : 0;
     const int nblk = aa.xcd_affine ? 8 * ((B + 7) / 8) * aa.nt : B * aa.nt;
-    hla_prof_begin(v.C == 256 ? K_LM256 : v.C == 128 ? K_LM128 : v.C == 64 ? K_LM64 : K_LM16, 0,
-                   (double)B * ((double)v.A * v.A + (double)aa.npix) * v.C * 4.0, st);
-    if (cfg->using_weight && newton) launch_accum<true>(v.C, dim3(nblk), st, aa);   // SGD / ADAM ignore the confidence
-    else launch_accum<false>(v.C, dim3(nblk), st, aa);
-    hla_prof_end(st);
-
+    aa.ticket = ticket + (size_t)k * B;
+    // the step's closing solve runs inside the same launch (last tile of each sample): its arguments
     sa.t = k;
     sa.part = part; sa.nt = aa.nt; sa.sat_inv = v.sat_inv_norm; sa.grd_inv = v.grd_inv_norm;
     sa.trace_out = trace + ((size_t)it * L + l) * 3; sa.trace_stride = N * L * 3;
@@ -341,8 +429,11 @@ extern "C" int hla_s2g_lm_solve(const hla_s2g_config* cfg, const hla_s2g_level* 
     sa.in_view = count ? in_view + (size_t)k * B : nullptr;
     if (k + 1 < steps) { sa.coef = coef; sa.next = geom(step_level(k + 1)); }
     else sa.coef = nullptr;
-    hla_prof_begin(K_LMSOLVE, 0, (double)B * aa.nt * PART_N * 8.0, st);
-    hipLaunchKernelGGL(lm_solve, dim3(B), dim3(64), 0, st, sa);
+    const double esz = v.feat_dtype == HLA_F32 ? 4.0 : 2.0;
+    hla_prof_begin(v.C == 256 ? K_LM256 : v.C == 128 ? K_LM128 : v.C == 64 ? K_LM64 : K_LM16, 0,
+                   (double)B * ((double)v.A * v.A + (double)aa.npix) * v.C * esz, st);
+    if (cfg->using_weight && newton) launch_accum<true>(v.C, v.feat_dtype, dim3(nblk), st, aa, sa);   // SGD / ADAM ignore the confidence
+    else launch_accum<false>(v.C, v.feat_dtype, dim3(nblk), st, aa, sa);
     hla_prof_end(st);
   }
   HLA_CHECK_HIP(hipGetLastError());

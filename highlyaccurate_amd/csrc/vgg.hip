@@ -2,6 +2,9 @@
 #include "conv_kernels.h"
 #include "vgg_layers.h"
 #include <type_traits>
+#ifndef CONV02_UPFRONT
+#define CONV02_UPFRONT (CONV_VARIANT == 134)    // false: the pipelined fragment loop (621 -> 594 us); 134 = the former default
+#endif
 
 template <typename T>
 void vgg_pack_all(const hla_vgg_params* prm, char* packed, int dtype, hipStream_t st) {
@@ -32,7 +35,7 @@ void vgg_pack_all(const hla_vgg_params* prm, char* packed, int dtype, hipStream_
 }
 
 template <typename T>
-int vgg_forward_t(const float* x, const hla_vgg_params* prm, const char* packed, int dtype, float* const feat[4],
+int vgg_forward_t(const float* x, const hla_vgg_params* prm, const char* packed, int dtype, void* const feat[4],
                          float* const conf[4], double* inv_norm, char* ws, const VggPlan& pl, int B, int H, int W,
                          int flags, int first_row8, hipStream_t st) {
   const bool level4 = pl.x2r != 0;
@@ -59,22 +62,23 @@ int vgg_forward_t(const float* x, const hla_vgg_params* prm, const char* packed,
     constexpr int lds_bytes = conv02_lds_bytes<T>();
     static HlaPerDeviceOnce attr_once;
     HLA_CHECK_HIP(attr_once.run([] {
-      return hipFuncSetAttribute((const void*)conv02_kernel<T, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+      return hipFuncSetAttribute((const void*)conv02_kernel<T, 2, CONV02_UPFRONT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
     }));
     hla_prof_begin(K_CONV02, 2.0 * 9 * (3 + 64) * 64 * P, P * (3 * 4 + 16 * sizeof(T)), st);
-    hipLaunchKernelGGL((conv02_kernel<T, 2, true>), dim3(a.tiles_x * a.tiles_y * B), dim3(256), lds_bytes, st, a);
+    hipLaunchKernelGGL((conv02_kernel<T, 2, CONV02_UPFRONT>), dim3(a.tiles_x * a.tiles_y * B), dim3(256), lds_bytes, st, a);
     hla_prof_end(st);
   }
   const bool train = flags & HLA_VGG_SAVE_FOR_BACKWARD;
   int np_used[4] = {pl.np[0], pl.np[1], pl.np[2], pl.np[3]};
   auto conv = [&](int l, const void* s1, int C1, int H_, int W_h, void* act, int relu, bool pool, const void* s2 = nullptr,
-                  int C2 = 0, int up1 = 0, float* raw = nullptr, double* ss = nullptr, unsigned char* idx = nullptr,
+                  int C2 = 0, int up1 = 0, void* raw = nullptr, double* ss = nullptr, unsigned char* idx = nullptr,
                   int row_begin = 0, int norm_level = -1) {
     ConvArgs a{};
     a.idx_out = train ? idx : nullptr;
     a.src1 = s1; a.src2 = s2; a.C1 = C1; a.C2 = C2; a.up1 = up1; a.wpk = W_(l);
     a.bias = kLayers[l].has_bias ? prm->b[l] : nullptr;
-    a.out_act = act; a.out_raw = raw; a.sumsq = ss; a.B = B; a.H = H_; a.W = W_h; a.Cout = kLayers[l].cout;
+    a.out_act = act; a.out_raw = (float*)raw; a.sumsq = ss; a.B = B; a.H = H_; a.W = W_h; a.Cout = kLayers[l].cout;
+    a.raw16 = (raw && (flags & HLA_VGG_FEAT16)) ? 1 : 0;
     a.relu_act = relu;
     a.row_begin = row_begin < 0 ? 0 : row_begin;
     if (SPLIT) {      // which per-sample maxima the layer reads (its one or two sources) and writes (its activation output)
@@ -150,7 +154,7 @@ int vgg_forward_t(const float* x, const hla_vgg_params* prm, const char* packed,
       int bps = (int)(per[l] / 4 / 256 / 4);
       bps = bps < 1 ? 1 : (bps > 64 ? 64 : bps);
       hla_prof_begin(K_L2NORM, 0, (double)B * per[l] * 8, st);
-      hipLaunchKernelGGL(scale_kernel, dim3(B * bps), dim3(256), 0, st, feat[l], inv + (size_t)l * B, per[l], bps);
+      hipLaunchKernelGGL(scale_kernel, dim3(B * bps), dim3(256), 0, st, (float*)feat[l], inv + (size_t)l * B, per[l], bps);
       hla_prof_end(st);
     }
   }
@@ -160,13 +164,13 @@ int vgg_forward_t(const float* x, const hla_vgg_params* prm, const char* packed,
 
 #if HLA_TU_DTYPE >= 0
 template void vgg_pack_all<TuT>(const hla_vgg_params* prm, char* packed, int dtype, hipStream_t st);
-template int vgg_forward_t<TuT>(const float* x, const hla_vgg_params* prm, const char* packed, int dtype, float* const feat[4],
+template int vgg_forward_t<TuT>(const float* x, const hla_vgg_params* prm, const char* packed, int dtype, void* const feat[4],
                               float* const conf[4], double* inv_norm, char* ws, const VggPlan& pl, int B, int H, int W,
                               int flags, int first_row8, hipStream_t st);
 #else
 #define HLA_EXTERN_T(T) \
   extern template void vgg_pack_all<T>(const hla_vgg_params* prm, char* packed, int dtype, hipStream_t st); \
-  extern template int vgg_forward_t<T>(const float* x, const hla_vgg_params* prm, const char* packed, int dtype, float* const feat[4],                               float* const conf[4], double* inv_norm, char* ws, const VggPlan& pl, int B, int H, int W,                               int flags, int first_row8, hipStream_t st);
+  extern template int vgg_forward_t<T>(const float* x, const hla_vgg_params* prm, const char* packed, int dtype, void* const feat[4],                               float* const conf[4], double* inv_norm, char* ws, const VggPlan& pl, int B, int H, int W,                               int flags, int first_row8, hipStream_t st);
 HLA_EXTERN_T(float) HLA_EXTERN_T(bf16) HLA_EXTERN_T(f16) HLA_EXTERN_T(split32)
 
 extern "C" size_t hla_vgg_packed_weight_bytes(int dtype) {
@@ -191,7 +195,7 @@ extern "C" size_t hla_vgg_workspace_bytes(int B, int H, int W, int level, int dt
 }
 
 extern "C" int hla_vgg_forward(const float* x, const hla_vgg_params* params, const void* packed_weights,
-                               float* const feat[4], float* const conf[4], double* inv_norm, void* workspace,
+                               void* const feat[4], float* const conf[4], double* inv_norm, void* workspace,
                                size_t workspace_bytes, int B, int H, int W, int level, int dtype, int flags,
                                int first_row8, hla_stream_t stream) {
   HLA_REQUIRE(x && params && packed_weights && feat && workspace, "hla_vgg_forward: null argument");
@@ -203,6 +207,9 @@ extern "C" int hla_vgg_forward(const float* x, const hla_vgg_params* params, con
               "hla_vgg_forward: level 4 needs feat[3] ([B,H,W,64], 16 real channels) and the zero-padded conv_dec3 weights in w[11], w[12]");
   HLA_REQUIRE(level == 3 || !(flags & HLA_VGG_WANT_CONF) || !conf || !conf[3] || params->w[16], "hla_vgg_forward: conf[3] needs w[16]");
   HLA_REQUIRE(!(flags & HLA_VGG_DEFER_NORM) || inv_norm, "hla_vgg_forward: HLA_VGG_DEFER_NORM needs inv_norm");
+  HLA_REQUIRE(!(flags & HLA_VGG_FEAT16) || ((dtype == HLA_BF16 || dtype == HLA_F16) && (flags & HLA_VGG_DEFER_NORM) &&
+                                            !(flags & HLA_VGG_SAVE_FOR_BACKWARD) && level == 3),
+              "hla_vgg_forward: HLA_VGG_FEAT16 needs dtype HLA_BF16 / HLA_F16, HLA_VGG_DEFER_NORM, level 3 and no HLA_VGG_SAVE_FOR_BACKWARD");
   HLA_REQUIRE(first_row8 == 0 || (first_row8 >= 4 && first_row8 < H / 8), "hla_vgg_forward: first_row8 must be 0 or in [4, H/8)");
   VggPlan pl;
   vgg_plan(B, H, W, dtype, (flags & HLA_VGG_SAVE_FOR_BACKWARD) != 0, &pl, level == 4);

@@ -58,7 +58,7 @@ const char* hla_last_error(void);
  * with its own struct sizes (ctypes structs are positional: a mismatch corrupts silently).  highlyaccurate_amd/_lib.py
  * does both at load time, and rebuilds or refuses a binary whose hla_source_hash() is not the hash of the sources
  * next to it (the library is git-ignored but shipped prebuilt). */
-#define HLA_ABI_VERSION 13
+#define HLA_ABI_VERSION 14
 int hla_abi_version(void);
 const char* hla_source_hash(void); /* sha256 (hex) of the csrc sources, this header and the compiler flags at build time */
 typedef enum hla_struct_id {
@@ -85,8 +85,11 @@ enum {
   HLA_VGG_WANT_CONF = 1,   /* compute the confidence maps (VGG.py:160-163)                              */
   HLA_VGG_DEFER_NORM = 2,  /* leave feat[] un-normalised and only report inv_norm (the LM loop folds the
                               scale into its normal equations: one full read+write pass less per map)  */
-  HLA_VGG_SAVE_FOR_BACKWARD = 4 /* training: also keep relu(conv0) and the three max-pool argmax maps in the
+  HLA_VGG_SAVE_FOR_BACKWARD = 4, /* training: also keep relu(conv0) and the three max-pool argmax maps in the
                               workspace; the caller keeps the workspace alive until hla_vgg_backward   */
+  HLA_VGG_FEAT16 = 8       /* dtype HLA_BF16 / HLA_F16 only, needs HLA_VGG_DEFER_NORM: feat[] are written in the 16-bit
+                              activation type instead of fp32 (inv_norm is that of the rounded maps); not with
+                              HLA_VGG_SAVE_FOR_BACKWARD.  For hla_s2g_lm_solve with hla_s2g_level.feat_dtype set */
 };
 
 /* Weights are re-laid-out once into MFMA fragment order (bf16 or fp32) and reused until they change.
@@ -114,7 +117,7 @@ size_t hla_vgg_workspace_bytes(int B, int H, int W, int level, int dtype);
  *          those depend on; rows above are left unwritten, and inv_norm covers the computed rows only (usable only where
  *          the per-sample scale cancels, as in LM_update).  conf[l], if requested, is likewise only valid from rows
  *          f / 2f / 4f on.  Ignored (treated as 0) at level 4 and with HLA_VGG_SAVE_FOR_BACKWARD.                */
-int hla_vgg_forward(const float* x, const hla_vgg_params* params, const void* packed_weights, float* const feat[4],
+int hla_vgg_forward(const float* x, const hla_vgg_params* params, const void* packed_weights, void* const feat[4],
                     float* const conf[4], double* inv_norm, void* workspace, size_t workspace_bytes, int B, int H,
                     int W, int level, int dtype, int flags, int first_row8, hla_stream_t stream);
 
@@ -193,8 +196,8 @@ int hla_grid_sample(const float* image, const float* optical, const float* jac, 
  *   Ford   models_ford.py:173-466,  loop 682-835
  * ------------------------------------------------------------------------- */
 typedef struct hla_s2g_level {
-  const float* sat_feat; /* [B,A,A,C]  NHWC fp32 */
-  const float* grd_feat; /* [B,h-grd_row_skip,w,C]  NHWC fp32 (rows grd_row_skip..h-1 of the level's map) */
+  const void* sat_feat;  /* [B,A,A,C]  NHWC, elements of feat_dtype */
+  const void* grd_feat;  /* [B,h-grd_row_skip,w,C]  NHWC, same element type (rows grd_row_skip..h-1 of the level's map) */
   const float* grd_conf; /* [B,h-grd_row_skip,w] fp32 or NULL (needed iff using_weight) */
   const float* xyz;      /* [h,w,3] fp32 ground-plane points in the camera frame
                             (models_kitti.py:655-682 / models_ford.py:110-155) */
@@ -207,6 +210,9 @@ typedef struct hla_s2g_level {
                             receptive field reaches it and nothing above -- see DESIGN.md "dead rows"; 0 = full map */
   double meter_per_pixel;/* metres per satellite-feature pixel at this level */
   double centre;         /* A/2 (KITTI, float) or A//2 (Ford, integer) */
+  int feat_dtype;        /* element type of sat_feat / grd_feat: HLA_F32 (always for the backward and for hla_g2s_*), or HLA_BF16 /
+                            HLA_F16: the 16-bit maps hla_vgg_forward writes with HLA_VGG_FEAT16 (inference in the reduced-precision
+                            modes: half the bytes through the HBM-bound LM loop; all LM arithmetic stays fp32 / fp64) */
 } hla_s2g_level;
 
 typedef struct hla_s2g_config {
