@@ -215,7 +215,7 @@ def lm_roofline(agg, pmc, pmc_src):
     if pmc:
         for k in lm:
             C = k[len('lm_accum<'):-1]
-            hit = [v for kn, v in pmc.items() if isinstance(v, dict) and f'lm_accum<{C},' in kn]
+            hit = [v for kn, v in pmc.items() if isinstance(v, dict) and (f'lm_accum<{C},' in kn or f'lm_accumILi{C}E' in kn)]
             if not hit:
                 cb = None
                 break
