@@ -370,6 +370,27 @@ def test_reduced_precision_pose_deviation_reported(precision):
     assert np.isfinite(trace).all() and err[..., :2].max() < lim_s and err[..., 2].max() < lim_y, (err[..., :2].max(), err[..., 2].max())
 
 
+def test_lm_feat16_opt_in_stays_close_to_the_default():
+    """args.lm_feat16 = 1 (HLA_VGG_FEAT16 + hla_s2g_level.feat_dtype): the LM loop reads bf16 / fp16 feature maps.  Off by
+    default (-1 % step time against a much larger worst-case pose deviation); when asked for it must run the 16-bit
+    kernels and stay within the reduced-precision limits on the golden seed."""
+    g = load_golden('e2e_kitti.npz')
+    seed, B = int(g['seeds'][0]), int(g['B'])
+    for precision in ('bf16', 'fp16'):
+        net, _ = _run_kitti(seed, B, precision=precision, lm_feat16=1)
+        trace = _exec_order(net.last_trace, 0).cpu().numpy().astype(np.float64)
+        err = np.abs(trace - g[f'trace64_{seed}'])
+        print(f'{precision} + 16-bit LM maps: shift {err[..., :2].max():.3e} yaw {err[..., 2].max():.3e}')
+        lim_s, lim_y = REDUCED_LIMITS[precision]
+        assert np.isfinite(trace).all() and err[..., :2].max() < 2 * lim_s and err[..., 2].max() < 2 * lim_y
+        net2, _ = _run_kitti(seed, B, precision=precision)
+        assert not torch.equal(net.last_trace, net2.last_trace)        # it really is a different (16-bit) data path
+    with pytest.raises(ValueError):                                     # fp32-class modes keep fp32 maps: asking for more is an error
+        from oracle import ref_cpu as O
+        from highlyaccurate_amd.VGG import VGGUnet, vgg_forward_nhwc
+        vgg_forward_nhwc(VGGUnet(3, precision='fp16x3').to(_dev()), torch.rand(1, 3, 32, 64, device=_dev()), defer_norm=True, feat16=True)
+
+
 @pytest.mark.parametrize('opt', ['SGD', 'ADAM'])
 def test_e2e_ablation_optimisers_vs_golden(opt):
     """Optimizer='SGD' / 'ADAM', the reference's ablation updaters (forward only): 15-step trace vs the reference."""
