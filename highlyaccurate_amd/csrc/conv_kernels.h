@@ -806,8 +806,13 @@ struct Conv02Args {
   unsigned* amax_a2_out;   // likewise for a2_out (level 4), or null
 };
 
+// conv0's 64 output channels are conv2's K.  With 2-byte activations they are two 32-channel stages = 54 KB of halo tile and
+// two workgroups fit a CU; with 4-byte ones (exact fp32, split fp16) they would be four 16-channel stages = 109 KB, one
+// workgroup per CU with nothing to overlap its phases -- so those types produce and consume them in TWO ROUNDS of 32 channels
+// through the same two buffers (conv0 is computed per 32-channel half anyway: the same MFMA work, one more barrier).
+template <typename T> constexpr int conv02_rounds() { return (CONV_VARIANT != 160 && sizeof(T) == 4) ? 2 : 1; }
 template <typename T> constexpr int conv02_lds_bytes() {
-  return (64 * (int)sizeof(T) / SB) * (10 * HWID * PSTR) + 3 * 12 * 36 * 4;
+  return (64 * (int)sizeof(T) / SB) / conv02_rounds<T>() * (10 * HWID * PSTR) + 3 * 12 * 36 * 4;
 }
 
 template <typename T, int WD, bool PF_UPFRONT>
@@ -815,9 +820,10 @@ __global__ __launch_bounds__(256, 2) void conv02_kernel(Conv02Args a0) {
   constexpr bool SPLIT = Prec<T>::SPLIT;
   constexpr int EPL = Prec<T>::CEPL, KC = SB / sizeof(T), NSG = 64 / KC, NFRAG = 32 / (2 * EPL), NH = SPLIT ? 2 : 1;
   constexpr int MT = 4, NT = 1, WN = 2, TH = 8, HPIX = (TH + 2) * HWID, BUF = HPIX * PSTR, IW = 36, IH = 12;
+  constexpr int ROUNDS = conv02_rounds<T>(), SPR = NSG / ROUNDS, JPR = 2 / ROUNDS;   // stages / 32-channel halves per round
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* lds = smem;                                  // NSG halo buffers (all of conv0's 64 channels)
-  float* in = (float*)(smem + NSG * BUF);            // [3][12][36] input patch
+  char* lds = smem;                                  // SPR halo buffers (conv0's channels of the current round)
+  float* in = (float*)(smem + SPR * BUF);            // [3][12][36] input patch
   __shared__ float red[8];
 
   const int t = threadIdx.x, lane = t & 63, wv = __builtin_amdgcn_readfirstlane(t >> 6), wm = wv / WN, wn = wv % WN;
@@ -880,13 +886,24 @@ __global__ __launch_bounds__(256, 2) void conv02_kernel(Conv02Args a0) {
     d0 = 1.f / (s_in * a0.wtail[0]);
     dsc2 = 1.f / (s_a0 * a0.wtail[1]);
   }
+  // conv2's accumulators and weight stream live across the rounds
+  f32x16 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][0][r] = 0.f;
+  const int aoff = ((wm * MT) * HWID + x) * PSTR + g * 16;
+#pragma unroll
+  for (int rd = 0; rd < ROUNDS; ++rd) {
+  const int j0 = rd * JPR;                           // first 32-channel half of conv0's output this round produces
+  if (rd > 0) __syncthreads();                       // the previous round's MFMAs are done with the buffers
   for (int m = wv; m * 32 < (CONV_VARIANT == 95 ? 0 : HPIX); m += 4) {   // (ablation 95: no conv0 phase)
     const int p = m * 32 + x, pc = p < HPIX ? p : HPIX - 1;
     const int hy = pc / HWID, hx = pc - hy * HWID;
     const float* ib = in + hy * IW + hx;
     f32x16 c0[2];
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = j0; j < j0 + JPR; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) c0[j][r] = 0.f;
 #pragma unroll
@@ -909,7 +926,7 @@ __global__ __launch_bounds__(256, 2) void conv02_kernel(Conv02Args a0) {
         split4(ev[4], ev[5], ev[6], ev[7], s_in, h1, l1);
         const uint4 phi = make_uint4(h0.x, h0.y, h1.x, h1.y), plo = make_uint4(l0.x, l0.y, l1.x, l1.y);
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = j0; j < j0 + JPR; ++j) {
           mma16<T>(c0[j], wf0[j][f][0], phi);
           mma16<T>(c0[j], wf0[j][f][NH - 1], phi);
           mma16<T>(c0[j], wf0[j][f][0], plo);
@@ -920,7 +937,7 @@ __global__ __launch_bounds__(256, 2) void conv02_kernel(Conv02Args a0) {
         for (int jj = 0; jj < EPL; ++jj) e[jj] = (T)ev[jj];
         const uint4 pf = __builtin_bit_cast(uint4, e);
 #pragma unroll
-        for (int j = 0; j < 2; ++j) mma16<T>(c0[j], wf0[j][f][0], pf);
+        for (int j = j0; j < j0 + JPR; ++j) mma16<T>(c0[j], wf0[j][f][0], pf);
       }
     }
     // conv2 zero-pads conv0's OUTPUT map: halo pixels outside the image are 0, not conv0 of padded input
@@ -928,10 +945,10 @@ __global__ __launch_bounds__(256, 2) void conv02_kernel(Conv02Args a0) {
     const bool inside = yy >= 0 && yy < a0.H && xx >= 0 && xx < a0.W;
     if (p < HPIX) {
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
+      for (int j = j0; j < j0 + JPR; ++j)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          const int co = j * 32 + q * 8 + g * 4;
+          const int co = j * 32 + q * 8 + g * 4, sl = co / KC - rd * SPR;      // channel, its stage buffer within this round
           const float4 bb = bias0[j][q];
           float v0 = fmaxf(c0[j][q * 4 + 0] * d0 + bb.x, 0.f), v1 = fmaxf(c0[j][q * 4 + 1] * d0 + bb.y, 0.f);
           float v2 = fmaxf(c0[j][q * 4 + 2] * d0 + bb.z, 0.f), v3 = fmaxf(c0[j][q * 4 + 3] * d0 + bb.w, 0.f);
@@ -939,11 +956,11 @@ __global__ __launch_bounds__(256, 2) void conv02_kernel(Conv02Args a0) {
           if constexpr (SPLIT) {
             uint2 hi, lo;
             split4(v0, v1, v2, v3, s_a0, hi, lo);
-            char* px = lds + (co / KC) * BUF + p * PSTR + (co % KC) * 2;
+            char* px = lds + sl * BUF + p * PSTR + (co % KC) * 2;
             *(uint2*)px = hi;
             *(uint2*)(px + 32) = lo;
           } else {
-            store4((T*)(lds + (co / KC) * BUF + p * PSTR) + (co % KC), v0, v1, v2, v3);
+            store4((T*)(lds + sl * BUF + p * PSTR) + (co % KC), v0, v1, v2, v3);
           }
         }
     }
@@ -951,12 +968,12 @@ __global__ __launch_bounds__(256, 2) void conv02_kernel(Conv02Args a0) {
   __syncthreads();
 
   if (a0.a0_out) {     // training: the backward pass needs relu(conv0) (conv2's wgrad input and ReLU mask)
-    constexpr int PPP = 64 * (int)sizeof(T) / 16;          // 16-B pieces per pixel over all stages
+    constexpr int PPP = 64 * (int)sizeof(T) / 16 / ROUNDS;          // 16-B pieces per pixel over this round's stages
     for (int e = t; e < TH * 32 * PPP; e += 256) {
       const int pxl = e / PPP, piece = e % PPP, sgi = piece / 4, part = piece % 4;
       const int r = pxl / 32, c = pxl % 32, yy = y0 + r, xx = x0 + c;
       if (yy < a0.H && xx < a0.W) {
-        char* dst = (char*)a0.a0_out + (((size_t)b * a0.H + yy) * a0.W + xx) * 64 * sizeof(T) + piece * 16;
+        char* dst = (char*)a0.a0_out + (((size_t)b * a0.H + yy) * a0.W + xx) * 64 * sizeof(T) + (rd * PPP + piece) * 16;
         const char* px = lds + sgi * BUF + ((r + 1) * HWID + c + 1) * PSTR;
         if constexpr (SPLIT) {      // what conv2 actually consumes: (hi + lo) / s, 23 of relu(conv0)'s 24 significand bits
           const f16x4 h = __builtin_bit_cast(f16x4, *(const uint2*)(px + part * 8));
@@ -971,17 +988,12 @@ __global__ __launch_bounds__(256, 2) void conv02_kernel(Conv02Args a0) {
     }
   }
 
-  // phase C: conv2 over the NSG resident stages (no further loads, no barriers)
-  f32x16 acc[MT][NT];
-#pragma unroll
-  for (int i = 0; i < MT; ++i)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[i][0][r] = 0.f;
-  const int aoff = ((wm * MT) * HWID + x) * PSTR + g * 16;
-  stagger_priority();
+  // phase C: conv2 over this round's resident stages (no further loads, no barriers)
+  if (rd == 0) stagger_priority();
 #pragma unroll 1
-  for (int sg = 0; sg < (CONV_VARIANT == 96 ? 0 : NSG); ++sg)   // (ablation 96: no conv2 MFMA loop)
+  for (int sg = 0; sg < (CONV_VARIANT == 96 ? 0 : SPR); ++sg)   // (ablation 96: no conv2 MFMA loop)
     stage_mma<T, MT, NT, WD, PF_UPFRONT>(acc, lds + sg * BUF + aoff, ring, [](int) {});
+  }     // rounds
 
   ConvArgs a{};
   a.bias = a0.b2; a.out_act = a0.out_act; a.B = a0.B; a.H = a0.H; a.W = a0.W; a.Cout = 64; a.relu_act = 1;
@@ -990,11 +1002,11 @@ __global__ __launch_bounds__(256, 2) void conv02_kernel(Conv02Args a0) {
   if (a0.a2_out) {   // the epilogue only reads the accumulators: run it twice, un-pooled first
     ConvArgs f = a;
     f.out_act = a0.a2_out; f.idx_out = nullptr; f.amax_out = a0.amax_a2_out;
-    conv_epilogue<T, MT, NT, false, EPI_ACT>(acc, f, b, y0 + wm * MT, x0, wn * 32, red, lds + wv * (NSG * BUF / 4), dsc2);
+    conv_epilogue<T, MT, NT, false, EPI_ACT>(acc, f, b, y0 + wm * MT, x0, wn * 32, red, lds + wv * (SPR * BUF / 4), dsc2);
     if (SPLIT) __syncthreads();     // `red` is reused by the second epilogue's maximum
   }
-  if (a.idx_out) conv_epilogue<T, MT, NT, true, EPI_GENERIC>(acc, a, b, y0 + wm * MT, x0, wn * 32, red, lds + wv * (NSG * BUF / 4), dsc2);
-  else conv_epilogue<T, MT, NT, true, EPI_ACT>(acc, a, b, y0 + wm * MT, x0, wn * 32, red, lds + wv * (NSG * BUF / 4), dsc2);
+  if (a.idx_out) conv_epilogue<T, MT, NT, true, EPI_GENERIC>(acc, a, b, y0 + wm * MT, x0, wn * 32, red, lds + wv * (SPR * BUF / 4), dsc2);
+  else conv_epilogue<T, MT, NT, true, EPI_ACT>(acc, a, b, y0 + wm * MT, x0, wn * 32, red, lds + wv * (SPR * BUF / 4), dsc2);
 }
 
 // ---------------------------------------------------------------------------------------------
