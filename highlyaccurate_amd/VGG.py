@@ -103,7 +103,7 @@ def vgg_forward_nhwc(module: 'VGGUnet', x: torch.Tensor, want_conf: bool = True,
     if feat16:
         if not (defer_norm and not save_for_backward and L == 3 and dt in (_lib.HLA_BF16, _lib.HLA_F16)):
             raise ValueError("feat16 needs precision 'bf16' / 'fp16', defer_norm=True, level 3 and no save_for_backward")
-        fdt = torch.bfloat16 if dt == _lib.HLA_BF16 else torch.float16
+        fdt = torch.float16         # (also in bf16 mode: the raw maps are written as fp16, saturating)
     # level 4: x24 is stored with 64 channels, the 16 real ones first, zeros behind them (see include/hla.h)
     feats = [torch.empty(B, H >> (3 - l), W >> (3 - l), 64 if l == 3 else _CH[l], device=x.device, dtype=fdt)
              for l in range(L)]

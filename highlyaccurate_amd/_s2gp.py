@@ -312,11 +312,13 @@ class S2GPBase(nn.Module):
             for t in list(grd_feats) + [c for c in grd_confs if c is not None] + [grd_inv]:
                 t.record_stream(cur)
         else:
-            # Opt-in (args.lm_feat16 / HLA_LM_FEAT16=1), reduced-precision inference modes only: the LM loop reads 16-bit feature
-            # maps.  Measured on MI355X: the accumulate kernels are latency- not bandwidth-bound (halving the bytes takes 4 % off
-            # them, 1 % off the step) while the worst golden seed's final pose moves from 0.02 m to 0.46 m -- so it is OFF by default.
+            # Reduced-precision inference modes: the LM loop reads fp16 feature maps (written saturating by the three feature
+            # layers' epilogues; also in bf16 mode: bf16's 8 significand bits moved the worst golden seed's pose 23x, fp16's 11
+            # move it 1.6x).  With the gather loop written on channel PAIRS (lm_solve.hip) the accumulate kernels are VALU-bound on
+            # 16-bit maps and 30 % faster than on fp32 ones: +7 % pairs/s.  args.lm_feat16 = 0 / HLA_LM_FEAT16=0 keeps fp32 maps;
+            # the fp32-class modes and every training path always do.
             f16 = (self.SatFeatureNet.precision in ('bf16', 'fp16') and self.level == 3
-                   and (bool(getattr(self.args, 'lm_feat16', 0)) or os.environ.get('HLA_LM_FEAT16', '0') == '1'))
+                   and bool(getattr(self.args, 'lm_feat16', 1)) and os.environ.get('HLA_LM_FEAT16', '1') != '0')
             sat_feats, _, sat_inv = vgg_forward_nhwc(self.SatFeatureNet, sat_map, want_conf=False, defer_norm=True, feat16=f16)
             grd_in = grd_img
             # (only LM_update renormalises the ground features; SGD / ADAM see the whole-map L2_norm scale, so they need every row)

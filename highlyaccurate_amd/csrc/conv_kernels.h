@@ -260,12 +260,12 @@ __device__ __forceinline__ int epilogue_mode(const ConvArgs& a) {
   if (!a.out_raw) return a.sumsq ? EPI_GENERIC : EPI_ACT;
   return a.sumsq ? (a.bias ? EPI_ACT_RAW : EPI_ACT_RAW_NOBIAS) : EPI_GENERIC;
 }
-// R16: the raw copy is written in T (16-bit activation types only) instead of fp32; its sum of squares is that of the
+// R16: the raw copy is written in fp16 (16-bit activation types only) instead of fp32; its sum of squares is that of the
 // ROUNDED values, so that inv_norm normalises exactly the map the LM loop will read.
 template <typename T, int MT, int NT, bool POOL, int EPI = EPI_GENERIC, bool R16 = false>
 __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[MT][NT], const ConvArgs& a, int b, int yrow0, int x0,
                                               int cb, float* red, char* stage, float dsc = 1.f) {
-  using RawT = std::conditional_t<R16, T, float>;
+  using RawT = std::conditional_t<R16, f16, float>;      // 16-bit raw maps are fp16 also in bf16 mode: 11 significand bits for the LM loop
   constexpr bool GEN = EPI == EPI_GENERIC, RAW = EPI == EPI_ACT_RAW || EPI == EPI_ACT_RAW_NOBIAS, DG = EPI == EPI_DGRAD;
   constexpr bool NOBIAS = EPI == EPI_ACT_RAW_NOBIAS || DG;
   const bool has_raw = GEN ? a.out_raw != nullptr : RAW;
@@ -338,7 +338,10 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[MT][NT], const ConvA
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             float w0 = v[j][q][0], w1 = v[j][q][1], w2 = v[j][q][2], w3 = v[j][q][3];
-            if (R16) { w0 = (float)(T)w0; w1 = (float)(T)w1; w2 = (float)(T)w2; w3 = (float)(T)w3; }
+            if (R16) {      // saturate instead of overflowing to inf, then take the value the LM loop will read
+              w0 = (float)(f16)fminf(fmaxf(w0, -65504.f), 65504.f); w1 = (float)(f16)fminf(fmaxf(w1, -65504.f), 65504.f);
+              w2 = (float)(f16)fminf(fmaxf(w2, -65504.f), 65504.f); w3 = (float)(f16)fminf(fmaxf(w3, -65504.f), 65504.f);
+            }
             RowStager<RawT, NT>::put(stage, px, j * 32 + q * 8 + g * 4, w0, w1, w2, w3);
             if (lane_ok) ss += w0 * w0 + w1 * w1 + w2 * w2 + w3 * w3;
             RowStager<T, NT>::put(stage2, px, j * 32 + q * 8 + g * 4, fmaxf(w0, 0.f), fmaxf(w1, 0.f), fmaxf(w2, 0.f), fmaxf(w3, 0.f));

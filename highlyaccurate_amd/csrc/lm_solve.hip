@@ -116,19 +116,32 @@ struct AccumArgs {
   unsigned* ticket;   // [B] arrival counters of this step (zeroed before the loop): the LAST tile of a sample closes the step
 };
 
-// element e (compile-time after unrolling) of a 16-byte vector of F, as fp32
-template <typename F> __device__ __forceinline__ float lm_elem(const uint4& v, int e);
-template <> __device__ __forceinline__ float lm_elem<float>(const uint4& v, int e) {
-  return __uint_as_float(e == 0 ? v.x : e == 1 ? v.y : e == 2 ? v.z : v.w);
+// channel pair ep (compile-time after unrolling) of a 16-byte vector of F, as two fp32 in ADJACENT registers: the gather loop is
+// written on such pairs so that it compiles to v_pk_{mul,add,fma}_f32 without operand shuffling.  (Left to itself the SLP
+// vectoriser paired unrelated scalars: a third of the loop was v_mov_b32, and the kernel is VALU-issue-bound -- 80 % VALU busy.)
+typedef float lm_f2 __attribute__((ext_vector_type(2)));
+template <typename F> __device__ __forceinline__ lm_f2 lm_pair(const uint4& v, int ep);
+template <> __device__ __forceinline__ lm_f2 lm_pair<float>(const uint4& v, int ep) {
+  lm_f2 r;
+  r.x = __uint_as_float(ep == 0 ? v.x : v.z);
+  r.y = __uint_as_float(ep == 0 ? v.y : v.w);
+  return r;
 }
-template <> __device__ __forceinline__ float lm_elem<__bf16>(const uint4& v, int e) {      // bf16 -> fp32 is a 16-bit shift
-  const unsigned w = (e >> 1) == 0 ? v.x : (e >> 1) == 1 ? v.y : (e >> 1) == 2 ? v.z : v.w;
-  return __uint_as_float((e & 1) ? (w & 0xffff0000u) : (w << 16));
+template <> __device__ __forceinline__ lm_f2 lm_pair<__bf16>(const uint4& v, int ep) {      // bf16 -> fp32 is a 16-bit shift
+  const unsigned w = ep == 0 ? v.x : ep == 1 ? v.y : ep == 2 ? v.z : v.w;
+  lm_f2 r;
+  r.x = __uint_as_float(w << 16);
+  r.y = __uint_as_float(w & 0xffff0000u);
+  return r;
 }
-template <> __device__ __forceinline__ float lm_elem<_Float16>(const uint4& v, int e) {
+template <> __device__ __forceinline__ lm_f2 lm_pair<_Float16>(const uint4& v, int ep) {
   typedef _Float16 h2 __attribute__((ext_vector_type(2)));
-  const unsigned w = (e >> 1) == 0 ? v.x : (e >> 1) == 1 ? v.y : (e >> 1) == 2 ? v.z : v.w;
-  return (float)__builtin_bit_cast(h2, w)[e & 1];
+  const unsigned w = ep == 0 ? v.x : ep == 1 ? v.y : ep == 2 ? v.z : v.w;
+  const h2 h = __builtin_bit_cast(h2, w);
+  lm_f2 r;
+  r.x = (float)h[0];
+  r.y = (float)h[1];
+  return r;
 }
 
 // The last tile of a sample to finish (an arrival ticket per sample) reduces the sample's tile partials in fixed order and
@@ -194,7 +207,8 @@ __global__ __launch_bounds__(256, LM_OCC) void lm_accum(AccumArgs a, SolveArgs s
   //   Q = sum (j2u b1 + j2v b2) = H22      U1,2 = sum w (Sxs, Sys)   U3 = sum w (j2u Sxs + j2v Sys)   V likewise with g
   float aS = 0, aG = 0, T1 = 0, T2 = 0, T3 = 0, B1 = 0, B2 = 0, Q = 0, U1 = 0, U2 = 0, U3 = 0, V1 = 0, V2 = 0, V3 = 0;
 
-#pragma unroll LM_UNROLL(F)
+  constexpr int UNR = LM_UNROLL(F);
+#pragma unroll UNR
   for (int i = wave * PPW + sub; i < np; i += 4 * PPW) {
     const PixParam P = pp[i];
     const uint4 t00 = *(const uint4*)(satb + P.off);
@@ -202,20 +216,23 @@ __global__ __launch_bounds__(256, LM_OCC) void lm_accum(AccumArgs a, SolveArgs s
     const uint4 t10 = *(const uint4*)(satb + P.off + P.dyo);
     const uint4 t11 = *(const uint4*)(satb + P.off + P.dyo + P.dxo);
     const uint4 gg = *(const uint4*)(grdb + (size_t)i * C);
-    float Sxx = 0, Sxy = 0, Syy = 0, Sxs = 0, Sys = 0, Sxg = 0, Syg = 0, Sss = 0, Sgg = 0;
+    lm_f2 xx = {0.f, 0.f}, xy = xx, yy = xx, xs = xx, ys = xx, xg = xx, yg = xx, ss2 = xx, gg2 = xx;
 #pragma unroll
-    for (int e = 0; e < EPL; ++e) {
-      const float c00 = lm_elem<F>(t00, e), c01 = lm_elem<F>(t01, e), c10 = lm_elem<F>(t10, e), c11 = lm_elem<F>(t11, e);
-      const float top = P.wx0 * c00 + P.wx1 * c01;
-      const float bot = P.wx0 * c10 + P.wx1 * c11;
-      const float s = P.wy0 * top + P.wy1 * bot;
-      const float dsy = bot - top;
-      const float dsx = P.wy0 * (c01 - c00) + P.wy1 * (c11 - c10);
-      const float g = lm_elem<F>(gg, e) * P.gm;
-      Sxx += dsx * dsx; Sxy += dsx * dsy; Syy += dsy * dsy;
-      Sxs += dsx * s; Sys += dsy * s; Sxg += dsx * g; Syg += dsy * g;
-      Sss += s * s; Sgg += g * g;
+    for (int ep = 0; ep < EPL / 2; ++ep) {
+      const lm_f2 c00 = lm_pair<F>(t00, ep), c01 = lm_pair<F>(t01, ep), c10 = lm_pair<F>(t10, ep), c11 = lm_pair<F>(t11, ep);
+      const lm_f2 top = P.wx0 * c00 + P.wx1 * c01;
+      const lm_f2 bot = P.wx0 * c10 + P.wx1 * c11;
+      const lm_f2 s = P.wy0 * top + P.wy1 * bot;
+      const lm_f2 dsy = bot - top;
+      const lm_f2 dsx = P.wy0 * (c01 - c00) + P.wy1 * (c11 - c10);
+      const lm_f2 g = lm_pair<F>(gg, ep) * P.gm;
+      xx += dsx * dsx; xy += dsx * dsy; yy += dsy * dsy;
+      xs += dsx * s; ys += dsy * s; xg += dsx * g; yg += dsy * g;
+      ss2 += s * s; gg2 += g * g;
     }
+    float Sxx = xx.x + xx.y, Sxy = xy.x + xy.y, Syy = yy.x + yy.y, Sxs = xs.x + xs.y, Sys = ys.x + ys.y;
+    float Sxg = xg.x + xg.y, Syg = yg.x + yg.y;
+    const float Sss = ss2.x + ss2.y, Sgg = gg2.x + gg2.y;
     aS += Sss; aG += Sgg;
     if (USE_W) { Sxx *= P.wt; Sxy *= P.wt; Syy *= P.wt; Sxs *= P.wt; Sys *= P.wt; Sxg *= P.wt; Syg *= P.wt; }
     T1 += Sxx; T2 += Sxy; T3 += Syy;

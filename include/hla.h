@@ -87,8 +87,8 @@ enum {
                               scale into its normal equations: one full read+write pass less per map)  */
   HLA_VGG_SAVE_FOR_BACKWARD = 4, /* training: also keep relu(conv0) and the three max-pool argmax maps in the
                               workspace; the caller keeps the workspace alive until hla_vgg_backward   */
-  HLA_VGG_FEAT16 = 8       /* dtype HLA_BF16 / HLA_F16 only, needs HLA_VGG_DEFER_NORM: feat[] are written in the 16-bit
-                              activation type instead of fp32 (inv_norm is that of the rounded maps); not with
+  HLA_VGG_FEAT16 = 8       /* dtype HLA_BF16 / HLA_F16 only, needs HLA_VGG_DEFER_NORM: feat[] are written as fp16 (saturating; also
+                              in bf16 mode) instead of fp32 (inv_norm is that of the rounded maps); not with
                               HLA_VGG_SAVE_FOR_BACKWARD.  For hla_s2g_lm_solve with hla_s2g_level.feat_dtype set */
 };
 
