@@ -3,6 +3,7 @@ sizes (multiples of 8, mostly not of the conv / LM tiles), model family, level, 
 Forward poses and, every other case, the training-step loss + parameter gradients.
 
     python tests/diag/fuzz_e2e.py [n_cases] [first_seed]
+    HLA_FUZZ_PRECISION=fp16x3 python tests/diag/fuzz_e2e.py ...     # the other fp32-class mode (same bounds)
 
 A diagnostic, not part of the pytest suite (the oracle side takes a few seconds per case).  Prints one line per case
 and exits non-zero when a case exceeds its bound.
@@ -40,6 +41,7 @@ def one_case(seed):
         lf = 0
     train = seed % 2 == 1
     args = O.default_args(**kw)
+    args.precision = os.environ.get('HLA_FUZZ_PRECISION', 'fp32')
     sd = O.synth_model_state(seed, bias_scale=0.02, rotation_range=10.0 if ford else args.rotation_range)
     if kw['train_damping']:
         sd['damping'] = torch.from_numpy(rs.uniform(-1, 1, tuple(sd['damping'].shape))).float()
