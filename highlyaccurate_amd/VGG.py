@@ -11,6 +11,7 @@ Differences a caller can observe:
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import torch
 import torch.nn as nn
@@ -132,7 +133,7 @@ def vgg_forward_nhwc(module: 'VGGUnet', x: torch.Tensor, want_conf: bool = True,
 
 @_lib.on_device(lambda module, ctx, *a, **k: ctx['x'])
 def vgg_backward_nhwc(module: 'VGGUnet', ctx: dict, d_feats, confs=None, d_confs=None, scale_invariant: bool = False,
-                      first_row8: int = 0, flat: bool = False):
+                      first_row8: int = 0, flat: bool = False, dense: bool = False):
     """Backward of ``vgg_forward_nhwc(..., defer_norm=True, save_for_backward=True)``.
     d_feats[l]: NHWC fp32 gradient w.r.t. the L2-normalised map l.  Returns {parameter name: gradient} for the
     22 tensors that receive one at level 3 (conv0..conv14 weights+biases, conv_dec1/2 weights), plus the conf head weights
@@ -140,7 +141,9 @@ def vgg_backward_nhwc(module: 'VGGUnet', ctx: dict, d_feats, confs=None, d_confs
     level 4 (d_feats[3] is [B,H,W,64]: the gradient w.r.t. the zero-padded x24).
     ``flat=True``: the 18 weight / bias gradients of conv0..conv_dec2.3 are VIEWS of one contiguous fp32 buffer that the
     wgrad kernels write into directly, and ``(grads, flat_buffer)`` is returned: a data-parallel caller all-reduces that one
-    buffer in place (parallel.GradSync) -- no gather copy before and no scatter copy after the collective."""
+    buffer in place (parallel.GradSync) -- no gather copy before and no scatter copy after the collective.
+    With ``scale_invariant`` the call skips every tile whose gradient is zero because the d_feats are (include/hla.h,
+    HLA_VGG_BWD_SCALE_INVARIANT); ``dense=True`` (or HLA_VGG_BWD_DENSE=1 in the environment) visits all of them (A/B, tests)."""
     lib = _lib.load()
     x, dt = ctx['x'], ctx['dt']
     B, _, H, W = x.shape
@@ -194,7 +197,9 @@ def vgg_backward_nhwc(module: 'VGGUnet', ctx: dict, d_feats, confs=None, d_confs
     ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
     rc = lib.hla_vgg_backward(_lib.ptr(x), C.byref(prm), _lib.ptr(cache['buf']), _lib.ptr(ctx['ws']), fp, _lib.ptr(ctx['inv_norm']),
                               dp, cp, dcp, C.byref(gs), _lib.ptr(ws), nbytes, B, H, W, L, dt,
-                              _lib.HLA_VGG_BWD_SCALE_INVARIANT if scale_invariant else 0, int(first_row8), _lib.stream_ptr())
+                              (_lib.HLA_VGG_BWD_SCALE_INVARIANT if scale_invariant else 0)
+                              | (_lib.HLA_VGG_BWD_DENSE if dense or os.environ.get('HLA_VGG_BWD_DENSE') == '1' else 0),
+                              int(first_row8), _lib.stream_ptr())
     _lib.check(rc, 'hla_vgg_backward')
     for name, g in padded.items():
         co, ci = sd[name].shape[:2]

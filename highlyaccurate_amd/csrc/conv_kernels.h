@@ -157,6 +157,7 @@ struct ConvArgs {
   int src_row_lo;     // source rows above this one (in THIS launch's full-resolution row coordinates) read as zero: the
                       // backward's gradient maps are exactly zero -- and unwritten -- above their first row
   int add_row_lo;     // likewise for add_src, in output row coordinates
+  const int* dyn;     // device-side bounds of a data-dependent launch (ConvDyn), or null: see below
   // --- training / backward extras (all optional) ---
   const unsigned char* unpool_idx;  // src1 is a max-pooled map's gradient at half resolution [B,H/2,W/2,C1] and this is
                                     // the forward argmax (0..3): the loader routes it to full resolution (virtual unpool)
@@ -171,6 +172,17 @@ struct ConvArgs {
   unsigned* amax_out;               // [B] atomicMax target for max |out_act| per sample (zeroed before the forward), or null
   const float* wscale;              // the power-of-two scale baked into wpk (device scalar written by the packer)
 };
+
+// Data-dependent trimming (the backward of a branch whose incoming gradient has a small footprint, vgg_backward.hip): three
+// half-open pixel boxes {y0, y1, x0, x1} in DEVICE memory, written by an earlier kernel on the same stream.  A tile that does
+// not meet `out` exits at once (its output is never read: it lies outside every consumer's `src` box); the sources read as
+// zero outside `src`, add_src outside `add`.
+struct ConvDyn {
+  int out[4];         // in this launch's full-resolution coordinates (before a POOL epilogue)
+  int src[4];         // in this launch's full-resolution coordinates (after a virtual 2x upsample / unpool)
+  int add[4];         // in output coordinates
+};
+struct PixBox { int y0, y1, x0, x1; };
 
 constexpr int HWID = 34;   // halo tile width in pixels
 constexpr int SB = 64;     // bytes of channels per pixel per pipeline stage
@@ -204,7 +216,8 @@ template <typename E, int NT> struct RowStager {
   // `mask` / `add` (optional) are indexed exactly like dst: v = (mask > 0 ? v : 0) + add, applied on the 16-B vectors
   template <bool PLAIN = false>
   static __device__ __forceinline__ void flush(const char* stage, E* dst, int npx, int npx_valid, int Cout, int lane,
-                                               const E* mask = nullptr, const E* add = nullptr) {
+                                               const E* mask = nullptr, const E* add = nullptr,
+                                               int add_px_lo = 0, int add_px_hi = 1 << 30) {
     const int chunks = npx * CPP;
     constexpr int EPV = 16 / (int)sizeof(E);
 #pragma unroll
@@ -223,12 +236,13 @@ template <typename E, int NT> struct RowStager {
             E e[EPV], m[EPV], ad[EPV];
             __builtin_memcpy(e, &v, 16);
             if (mask) { const uint4 t = *(const uint4*)((const char*)mask + off); __builtin_memcpy(m, &t, 16); }
-            if (add) { const uint4 t = *(const uint4*)((const char*)add + off); __builtin_memcpy(ad, &t, 16); }
+            const bool addp = add && px >= add_px_lo && px < add_px_hi;
+            if (addp) { const uint4 t = *(const uint4*)((const char*)add + off); __builtin_memcpy(ad, &t, 16); }
 #pragma unroll
             for (int k = 0; k < EPV; ++k) {
               float f = (float)e[k];
               if (mask && !((float)m[k] > 0.f)) f = 0.f;
-              if (add) f += (float)ad[k];
+              if (addp) f += (float)ad[k];
               e[k] = (E)f;
             }
             __builtin_memcpy(&v, e, 16);
@@ -264,7 +278,8 @@ __device__ __forceinline__ int epilogue_mode(const ConvArgs& a) {
 // ROUNDED values, so that inv_norm normalises exactly the map the LM loop will read.
 template <typename T, int MT, int NT, bool POOL, int EPI = EPI_GENERIC, bool R16 = false>
 __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[MT][NT], const ConvArgs& a, int b, int yrow0, int x0,
-                                              int cb, float* red, char* stage, float dsc = 1.f) {
+                                              int cb, float* red, char* stage, float dsc = 1.f,
+                                              PixBox addb = PixBox{0, 1 << 30, 0, 1 << 30}) {
   using RawT = std::conditional_t<R16, f16, float>;      // 16-bit raw maps are fp16 also in bf16 mode: 11 significand bits for the LM loop
   constexpr bool GEN = EPI == EPI_GENERIC, RAW = EPI == EPI_ACT_RAW || EPI == EPI_ACT_RAW_NOBIAS, DG = EPI == EPI_DGRAD;
   constexpr bool NOBIAS = EPI == EPI_ACT_RAW_NOBIAS || DG;
@@ -383,7 +398,8 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[MT][NT], const ConvA
       if (GEN || DG) {
         if (row_ok) RowStager<T, NT>::flush(stage, (T*)a.out_act + o, NPX, nvalid, a.Cout, lane,
                                             a.mask_act ? (const T*)a.mask_act + o : nullptr,
-                                            (a.add_src && yo >= a.add_row_lo) ? (const T*)a.add_src + o : nullptr);
+                                            (a.add_src && yo >= max(a.add_row_lo, addb.y0) && yo < addb.y1) ? (const T*)a.add_src + o : nullptr,
+                                            addb.x0 - xo0, addb.x1 - xo0);
       } else {
         if (row_ok) RowStager<T, NT>::template flush<true>(stage, (T*)a.out_act + o, NPX, nvalid, a.Cout, lane);
       }
@@ -617,6 +633,13 @@ __global__ __launch_bounds__(256, (NT == 1 && !PF_UPFRONT && (CONV_VARIANT == 50
   const int ty = bid % a.tiles_y;
   const int b = bid / a.tiles_y;
   const int y0 = a.row_begin + ty * TH, x0 = tx * 32;
+  // source / fan-in bounds: the image (and the caller's static first rows), narrowed by the device-side boxes if there are any
+  int sy0 = a.src_row_lo, sy1 = a.H, sx0 = 0, sx1 = a.W;
+  if (a.dyn) {                              // kernel-uniform; the twelve ints are scalar loads
+    const ConvDyn& d = *(const ConvDyn*)a.dyn;
+    if (y0 >= d.out[1] || y0 + TH <= d.out[0] || x0 >= d.out[3] || x0 + 32 <= d.out[2]) return;
+    sy0 = max(sy0, d.src[0]); sy1 = min(sy1, d.src[1]); sx0 = max(sx0, d.src[2]); sx1 = min(sx1, d.src[3]);
+  }
   const int nstage = (a.C1 + a.C2) / KC;
   const int part = t & 3, pbase = t >> 2;   // 256 % 4 == 0: a thread always moves the same 16-B part of a pixel
   float sx = 1.f, dsc = 1.f;                // split mode: activation scale of this sample, 1 / (activation scale * weight scale)
@@ -641,7 +664,7 @@ __global__ __launch_bounds__(256, (NT == 1 && !PF_UPFRONT && (CONV_VARIANT == 50
       const int hy = pix / HWID, hx = pix - hy * HWID;
       const int y = y0 - 1 + hy, x = x0 - 1 + hx;
       uint4 v = make_uint4(0, 0, 0, 0);
-      if (pix < HPIX && y >= a.src_row_lo && y < a.H && x >= 0 && x < a.W) {
+      if (pix < HPIX && y >= sy0 && y < sy1 && x >= sx0 && x < sx1) {
         const size_t e0 = (((size_t)b * Hs + (y >> sh)) * Ws + (x >> sh)) * Cs + coff;
         v = *(const uint4*)(src + e0);
         if (a.unpool_idx) {          // keep only the elements whose forward argmax is this (y&1, x&1) position
@@ -756,23 +779,28 @@ __global__ __launch_bounds__(256, (NT == 1 && !PF_UPFRONT && (CONV_VARIANT == 50
   {
     char* stager = lds + wv * (2 * BUF / 4);
     const int mode = epilogue_mode(a);      // kernel-uniform
+    PixBox addb{a.add_row_lo, 1 << 30, 0, 1 << 30};
+    if (a.dyn) {
+      const ConvDyn& d = *(const ConvDyn*)a.dyn;
+      addb = PixBox{max(addb.y0, d.add[0]), d.add[1], d.add[2], d.add[3]};
+    }
     // (in the un-pooled 64-channel-wave-tile kernel the raw-copy epilogue WITH bias spills ~30 registers -- 31 k cycles against
     // the generic path's 21 k -- so only its bias-free form is compiled there; that is the one the model uses: dec1.3)
     constexpr bool RAW_SPECIAL = POOL || NT == 1;
     constexpr bool T16 = sizeof(T) == 2;
-    if (mode == EPI_ACT) conv_epilogue<T, MT, NT, POOL, EPI_ACT>(acc, a, b, y0 + wm * MT, x0, ntg0 * 32, red, stager, dsc);
+    if (mode == EPI_ACT) conv_epilogue<T, MT, NT, POOL, EPI_ACT>(acc, a, b, y0 + wm * MT, x0, ntg0 * 32, red, stager, dsc, addb);
     // (16-bit raw copy, HLA_VGG_FEAT16: only the three feature layers ask for it -- conv14: pooled + bias; dec1.3 / dec2.3:
     // no bias -- and exactly those forms are compiled)
     else if (T16 && RAW_SPECIAL && a.raw16 && mode == EPI_ACT_RAW)
-      conv_epilogue<T, MT, NT, POOL, (T16 && RAW_SPECIAL) ? EPI_ACT_RAW : EPI_GENERIC, T16 && RAW_SPECIAL>(acc, a, b, y0 + wm * MT, x0, ntg0 * 32, red, stager, dsc);
+      conv_epilogue<T, MT, NT, POOL, (T16 && RAW_SPECIAL) ? EPI_ACT_RAW : EPI_GENERIC, T16 && RAW_SPECIAL>(acc, a, b, y0 + wm * MT, x0, ntg0 * 32, red, stager, dsc, addb);
     else if (T16 && a.raw16 && mode == EPI_ACT_RAW_NOBIAS)
-      conv_epilogue<T, MT, NT, POOL, T16 ? EPI_ACT_RAW_NOBIAS : EPI_GENERIC, T16>(acc, a, b, y0 + wm * MT, x0, ntg0 * 32, red, stager, dsc);
-    else if (RAW_SPECIAL && mode == EPI_ACT_RAW) conv_epilogue<T, MT, NT, POOL, RAW_SPECIAL ? EPI_ACT_RAW : EPI_GENERIC>(acc, a, b, y0 + wm * MT, x0, ntg0 * 32, red, stager, dsc);
+      conv_epilogue<T, MT, NT, POOL, T16 ? EPI_ACT_RAW_NOBIAS : EPI_GENERIC, T16>(acc, a, b, y0 + wm * MT, x0, ntg0 * 32, red, stager, dsc, addb);
+    else if (RAW_SPECIAL && mode == EPI_ACT_RAW) conv_epilogue<T, MT, NT, POOL, RAW_SPECIAL ? EPI_ACT_RAW : EPI_GENERIC>(acc, a, b, y0 + wm * MT, x0, ntg0 * 32, red, stager, dsc, addb);
     else if (!Prec<T>::SPLIT && mode == EPI_DGRAD)
-      conv_epilogue<T, MT, NT, POOL, Prec<T>::SPLIT ? EPI_GENERIC : EPI_DGRAD>(acc, a, b, y0 + wm * MT, x0, ntg0 * 32, red, stager, dsc);
+      conv_epilogue<T, MT, NT, POOL, Prec<T>::SPLIT ? EPI_GENERIC : EPI_DGRAD>(acc, a, b, y0 + wm * MT, x0, ntg0 * 32, red, stager, dsc, addb);
     else if ((RAW_SPECIAL || sizeof(T) == 2) && mode == EPI_ACT_RAW_NOBIAS)      // (4-byte storage: two passes, spills as well)
-      conv_epilogue<T, MT, NT, POOL, (RAW_SPECIAL || sizeof(T) == 2) ? EPI_ACT_RAW_NOBIAS : EPI_GENERIC>(acc, a, b, y0 + wm * MT, x0, ntg0 * 32, red, stager, dsc);
-    else conv_epilogue<T, MT, NT, POOL, EPI_GENERIC>(acc, a, b, y0 + wm * MT, x0, ntg0 * 32, red, stager, dsc);
+      conv_epilogue<T, MT, NT, POOL, (RAW_SPECIAL || sizeof(T) == 2) ? EPI_ACT_RAW_NOBIAS : EPI_GENERIC>(acc, a, b, y0 + wm * MT, x0, ntg0 * 32, red, stager, dsc, addb);
+    else conv_epilogue<T, MT, NT, POOL, EPI_GENERIC>(acc, a, b, y0 + wm * MT, x0, ntg0 * 32, red, stager, dsc, addb);
   }
 #endif
 #if CONV_VARIANT >= 40 && CONV_VARIANT <= 47

@@ -49,6 +49,7 @@ template <> __device__ __forceinline__ uint4 frag_ones<f16>() { return make_uint
 template <> __device__ __forceinline__ uint4 frag_ones<float>() { return make_uint4(0x3F800000u, 0x3F800000u, 0x3F800000u, 0x3F800000u); }
 
 // ---------------------------------------------------------------------------------------------
+constexpr int WG_TH = 4;                                  // pixel tile of the weight-gradient kernels: 4 rows x 32 px
 struct WgradArgs {
   const void* x1; const void* x2;      // conv input (stored post-ReLU activations); virtual upsample+concat as forward
   const void* g;                       // d(loss)/d(conv output) NHWC T [B,H,W,Cout], or the pooled map's gradient
@@ -57,9 +58,32 @@ struct WgradArgs {
   float* bpart;                        // [KS][Cout] partial bias gradients, or null
   int C1, C2, up1, B, H, W, Cout, Cin, tiles_x, tiles_y, ntile, KS;
   int row_begin;                       // first pixel row that carries gradient (even with g_unpool); rows above are skipped
+  const int* dyn;                      // device-side box {y0, y1, x0, x1} outside which g is zero (and unwritten), in this launch's
+                                       // pixel coordinates, or null: only the tiles that meet it are visited
 };
 
-constexpr int WG_TH = 4;                                  // pixel tile: 4 rows x 32 px
+// tile enumeration of the weight-gradient kernels, restricted to the tiles that meet the gradient's box
+struct WgTiles {
+  int tx_lo, ntx, ty_lo, nty, ntile, gy0, gy1, gx0, gx1;
+  __device__ __forceinline__ WgTiles(const int* dyn, int H, int W, int row_begin, int tiles_x, int tiles_y, int ntile_all, int B)
+      : tx_lo(0), ntx(tiles_x), ty_lo(0), nty(tiles_y), ntile(ntile_all), gy0(0), gy1(H), gx0(0), gx1(W) {
+    if (!dyn) return;
+    gy0 = max(dyn[0], 0); gy1 = min(dyn[1], H); gx0 = max(dyn[2], 0); gx1 = min(dyn[3], W);
+    if (gy0 >= gy1 || gx0 >= gx1) { ntile = 0; ntx = nty = 1; return; }
+    tx_lo = gx0 / 32; ntx = (gx1 + 31) / 32 - tx_lo;
+    ty_lo = max(gy0 - row_begin, 0) / WG_TH;
+    nty = min((gy1 - row_begin + WG_TH - 1) / WG_TH, tiles_y) - ty_lo;
+    if (nty <= 0) { ntile = 0; ntx = nty = 1; return; }
+    ntile = B * ntx * nty;
+  }
+  __device__ __forceinline__ void origin(int tile, int row_begin, int& b, int& y0, int& x0) const {
+    int q = tile;
+    x0 = (tx_lo + q % ntx) * 32; q /= ntx;
+    y0 = row_begin + (ty_lo + q % nty) * WG_TH;
+    b = q / nty;
+  }
+};
+
 template <typename T> constexpr int wg_stride() { return 64 * (int)sizeof(T) + 16; }
 template <typename T> constexpr int wg_lds_bytes() { return ((WG_TH + 2) * HWID + WG_TH * 32) * wg_stride<T>(); }
 
@@ -96,12 +120,8 @@ __global__ __launch_bounds__(256, CONV_VARIANT == 73 ? 1 : 2) void wgrad_kernel(
   const int part = t % PPX, pix0 = t / PPX;
   uint4 xr[NX], gr[NG];
   unsigned long long gid[NG];
-  auto tile_origin = [&](int tile, int& b, int& y0, int& x0) {
-    int q = tile;
-    x0 = (q % a.tiles_x) * 32; q /= a.tiles_x;
-    y0 = a.row_begin + (q % a.tiles_y) * WG_TH;
-    b = q / a.tiles_y;
-  };
+  const WgTiles tl(a.dyn, a.H, a.W, a.row_begin, a.tiles_x, a.tiles_y, a.ntile, a.B);
+  auto tile_origin = [&](int tile, int& b, int& y0, int& x0) { tl.origin(tile, a.row_begin, b, y0, x0); };
   auto load_x = [&](int tile, int lo, int hi) {
     int b, y0, x0;
     tile_origin(tile, b, y0, x0);
@@ -126,7 +146,7 @@ __global__ __launch_bounds__(256, CONV_VARIANT == 73 ? 1 : 2) void wgrad_kernel(
       const int y = y0 + pix / 32, x = x0 + pix % 32;
       uint4 v = make_uint4(0, 0, 0, 0);
       unsigned long long id = 0;
-      if (y < a.H && x < a.W) {
+      if (y >= tl.gy0 && y < tl.gy1 && x >= tl.gx0 && x < tl.gx1) {
         const size_t e0 = (((size_t)b * Hg + (y >> gsh)) * Wg + (x >> gsh)) * a.Cout + co0 + part * EPL;
         v = *(const uint4*)((const T*)a.g + e0);
         if (a.g_unpool) __builtin_memcpy(&id, a.g_unpool + e0, EPL);
@@ -164,8 +184,8 @@ __global__ __launch_bounds__(256, CONV_VARIANT == 73 ? 1 : 2) void wgrad_kernel(
     }
   };
 
-  if (PREFETCH && ks < a.ntile) { load_x(ks, 0, NX); load_g(ks, 0, NG); }
-  for (int tile = ks; tile < a.ntile; tile += a.KS) {
+  if (PREFETCH && ks < tl.ntile) { load_x(ks, 0, NX); load_g(ks, 0, NG); }
+  for (int tile = ks; tile < tl.ntile; tile += a.KS) {
     const bool ld = !PREFETCH && !(CONV_VARIANT == 70 && tile != ks);        // (ablation 70: loads for the first tile only)
     if (sizeof(T) == 2) {
       if (ld) { load_x(tile, 0, NX); load_g(tile, 0, NG); }
@@ -180,7 +200,7 @@ __global__ __launch_bounds__(256, CONV_VARIANT == 73 ? 1 : 2) void wgrad_kernel(
       for (int lo = 0; lo < NG; lo += 4) { if (ld) load_g(tile, lo, lo + 4); store_g(tile, lo, lo + 4); }
     }
     __syncthreads();
-    if (PREFETCH && tile + a.KS < a.ntile) { load_x(tile + a.KS, 0, NX); load_g(tile + a.KS, 0, NG); }
+    if (PREFETCH && tile + a.KS < tl.ntile) { load_x(tile + a.KS, 0, NX); load_g(tile + a.KS, 0, NG); }
     // G fragments of the whole tile stay in registers; every X fragment (halo row rho, column shift kx, K-step kk) is
     // fetched ONCE and feeds the up to three taps ky with r = rho - ky inside the tile  (halves the LDS reads per MFMA)
     // (K-steps are taken two at a time so that the resident G fragments cost 32 VGPRs for every dtype)
@@ -232,6 +252,7 @@ struct Wgrad0Args {
   float* bpart;          // [KS][2][64]
   int B, H, W, tiles_x, tiles_y, ntile, KS;
   int row_begin;         // first pixel row that carries gradient
+  const int* dyn;        // as WgradArgs::dyn
 };
 
 template <typename T>
@@ -249,12 +270,10 @@ __global__ __launch_bounds__(256) void wgrad0_kernel(Wgrad0Args a) {
   const uint4 ones = frag_ones<T>();
   const int j = lane & 31, g5 = lane >> 5;            // B operand: column j = k index (c, ky, kx)
   const int jc = j < 27 ? j / 9 : 0, jky = (j % 9) / 3, jkx = j % 3;
-  for (int tile = ks; tile < a.ntile; tile += a.KS) {
-    int q = tile;
-    const int tx = q % a.tiles_x; q /= a.tiles_x;
-    const int ty = q % a.tiles_y;
-    const int b = q / a.tiles_y;
-    const int y0 = a.row_begin + ty * WG_TH, x0 = tx * 32;
+  const WgTiles tl(a.dyn, a.H, a.W, a.row_begin, a.tiles_x, a.tiles_y, a.ntile, a.B);
+  for (int tile = ks; tile < tl.ntile; tile += a.KS) {
+    int b, y0, x0;
+    tl.origin(tile, a.row_begin, b, y0, x0);
     __syncthreads();
     for (int e = t; e < 3 * (WG_TH + 2) * IW; e += 256) {
       const int c = e / ((WG_TH + 2) * IW), r = e % ((WG_TH + 2) * IW), iy = r / IW, ix = r % IW;
@@ -267,7 +286,8 @@ __global__ __launch_bounds__(256) void wgrad0_kernel(Wgrad0Args a) {
       const int pix = e / PPX, part = e % PPX;
       const int y = y0 + pix / 32, x = x0 + pix % 32;
       uint4 v = make_uint4(0, 0, 0, 0);
-      if (y < a.H && x < a.W) v = *(const uint4*)((const T*)a.g + (((size_t)b * a.H + y) * a.W + x) * 64 + part * EPL);
+      if (y >= tl.gy0 && y < tl.gy1 && x >= tl.gx0 && x < tl.gx1)
+        v = *(const uint4*)((const T*)a.g + (((size_t)b * a.H + y) * a.W + x) * 64 + part * EPL);
       *(uint4*)(Gs + pix * STR + part * 16) = v;
     }
     __syncthreads();
@@ -369,10 +389,13 @@ static __global__ __launch_bounds__(256) void l2bwd_dot_kernel(const float* __re
   if (threadIdx.x == 0) part[(size_t)b * nblk + k] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
 }
 
+// `box` (optional, ORTHO only): the bounding box of the pixels where dy is not exactly zero, over the whole batch, kept as four
+// atomicMax targets {-y0, y1, -x0, x1} (memset to 0x80 bytes = "nothing yet") -- the seed of the data-dependent trimming below.
 template <typename T, bool ORTHO>
 __global__ __launch_bounds__(256) void l2bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                           const double* __restrict__ part, const double* __restrict__ inv,
-                                                          T* __restrict__ out, size_t per_sample, int nblk) {
+                                                          T* __restrict__ out, size_t per_sample, int nblk,
+                                                          int* __restrict__ box = nullptr, int C = 1, int Wl = 1) {
   const int b = blockIdx.x / nblk, k = blockIdx.x % nblk;
   double dot = 0.0;
   if (!ORTHO)
@@ -382,13 +405,27 @@ __global__ __launch_bounds__(256) void l2bwd_apply_kernel(const float* __restric
   const float4* px = (const float4*)(x + (size_t)b * per_sample);
   const float4* pd = (const float4*)(dy + (size_t)b * per_sample);
   T* po = out + (size_t)b * per_sample;
+  int m[4] = {INT_MIN, INT_MIN, INT_MIN, INT_MIN};
   for (size_t i = (size_t)k * 256 + threadIdx.x; i < per_sample / 4; i += (size_t)nblk * 256) {
     const float4 v = pd[i];
     if (ORTHO) {       // HLA_VGG_BWD_SCALE_INVARIANT: x . dy = 0 analytically, dx = dy / ||x||; x is not read
       store4(po + i * 4, c1 * v.x, c1 * v.y, c1 * v.z, c1 * v.w);
+      if (box && (v.x != 0.f || v.y != 0.f || v.z != 0.f || v.w != 0.f)) {
+        const int pix = (int)(i * 4 / (unsigned)C), py = pix / Wl, pxx = pix - py * Wl;
+        m[0] = max(m[0], -py); m[1] = max(m[1], py + 1); m[2] = max(m[2], -pxx); m[3] = max(m[3], pxx + 1);
+      }
     } else {
       const float4 u = px[i];
       store4(po + i * 4, c1 * v.x - c3 * u.x, c1 * v.y - c3 * u.y, c1 * v.z - c3 * u.z, c1 * v.w - c3 * u.w);
+    }
+  }
+  if (ORTHO && box) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) m[q] = max(m[q], __shfl_xor(m[q], o, 64));
+      // (the plain read only filters: a stale value costs one redundant atomic, never a missed one)
+      if ((threadIdx.x & 63) == 0 && m[q] > __hip_atomic_load(box + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(box + q, m[q]);
     }
   }
 }
@@ -494,9 +531,87 @@ __global__ __launch_bounds__(256) void conf_bwd_kernel(const T* __restrict__ act
 
 // ---------------------------------------------------------------------------------------------
 // host
+// ---------------------------------------------------------------------------------------------
+// Data-dependent trimming.  The satellite branch's incoming gradient is what the LM loop's bilinear taps scattered: for KITTI
+// geometry that is ~10 % of the texels, all of them inside less than half of the map's columns (the camera looks along +u).
+// l2bwd_apply records the bounding box of the non-zero gradient of each returned map; the kernel below pushes the three boxes
+// through the layer graph exactly like the static first rows further down (a 3x3 conv widens a box by one pixel, the 2x
+// upsample's sum-pool halves it, an unpool doubles it, a fan-in is a union) and writes one ConvDyn per data-gradient launch
+// and one box per weight-gradient launch.  Nothing is promised by the caller and nothing is approximated: outside its box a
+// gradient map is exactly zero, so skipping those tiles changes no value (only the weight-gradient summation order).
+enum { DC_10, DC_9U, DC_9S, DC_8, DC_7U, DC_7S, DC_6, DC_5, DC_4, DC_3, DC_2, DC_1, DC_N };
+enum { DW_10, DW_9, DW_8, DW_7, DW_6, DW_5, DW_4, DW_3, DW_2, DW_1, DW_0, DW_N };
+constexpr int DYN_RAW = 0, DYN_CONV = 16, DYN_WG = DYN_CONV + 12 * DC_N, DYN_INTS = DYN_WG + 4 * DW_N;
+
+struct Bx { int y0, y1, x0, x1; };
+__device__ __forceinline__ bool bx_empty(const Bx& b) { return b.y0 >= b.y1 || b.x0 >= b.x1; }
+__device__ __forceinline__ Bx bx_clip(Bx b, int Hn, int Wn) {
+  b.y0 = max(b.y0, 0); b.y1 = min(b.y1, Hn); b.x0 = max(b.x0, 0); b.x1 = min(b.x1, Wn);
+  return bx_empty(b) ? Bx{0, 0, 0, 0} : b;
+}
+__device__ __forceinline__ Bx bx_grow(const Bx& b, int Hn, int Wn) {
+  return bx_empty(b) ? Bx{0, 0, 0, 0} : bx_clip(Bx{b.y0 - 1, b.y1 + 1, b.x0 - 1, b.x1 + 1}, Hn, Wn);
+}
+__device__ __forceinline__ Bx bx_down2(const Bx& b) { return bx_empty(b) ? Bx{0, 0, 0, 0} : Bx{b.y0 >> 1, (b.y1 + 1) >> 1, b.x0 >> 1, (b.x1 + 1) >> 1}; }
+__device__ __forceinline__ Bx bx_up2(const Bx& b) { return Bx{2 * b.y0, 2 * b.y1, 2 * b.x0, 2 * b.x1}; }
+__device__ __forceinline__ Bx bx_union(const Bx& a, const Bx& b) {
+  if (bx_empty(a)) return b;
+  if (bx_empty(b)) return a;
+  return Bx{min(a.y0, b.y0), max(a.y1, b.y1), min(a.x0, b.x0), max(a.x1, b.x1)};
+}
+
+static __global__ void bwd_boxes_kernel(int* __restrict__ dyn, int H, int W) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const int H2 = H / 2, W2 = W / 2, H4 = H / 4, W4 = W / 4, H8 = H / 8, W8 = W / 8;
+  Bx lb[3];
+  const int hs[3] = {H8, H4, H2}, ws[3] = {W8, W4, W2};
+  for (int l = 0; l < 3; ++l) {
+    const int* r = dyn + DYN_RAW + 4 * l;        // {-y0, y1, -x0, x1}; untouched = 0x80808080
+    lb[l] = r[1] < 0 ? Bx{0, 0, 0, 0} : bx_clip(Bx{-r[0], r[1], -r[2], r[3]}, hs[l], ws[l]);
+  }
+  const Bx none{0, 0, 0, 0};
+  const Bx g_x21 = lb[2];                                          // H/2
+  const Bx g_d2a = bx_grow(g_x21, H2, W2);
+  const Bx c9 = bx_grow(g_d2a, H2, W2);                            // conv_dec2.1^T of g_d2a, still at H/2
+  const Bx g_x18 = bx_union(lb[1], bx_down2(c9));                  // H/4
+  const Bx g_d1a = bx_grow(g_x18, H4, W4);
+  const Bx c7 = bx_grow(g_d1a, H4, W4);
+  const Bx g_x15 = bx_union(lb[0], bx_down2(c7));                  // H/8
+  const Bx u15 = bx_up2(g_x15);                                    // H/4 (virtual unpool)
+  const Bx g_a12 = bx_grow(u15, H4, W4);
+  const Bx g_a10 = bx_grow(g_a12, H4, W4);
+  const Bx g_x8 = bx_union(bx_grow(g_a10, H4, W4), c7);            // + the x8 skip branch (g_x8p = c7)
+  const Bx u8 = bx_up2(g_x8);                                      // H/2
+  const Bx g_a5 = bx_grow(u8, H2, W2);
+  const Bx g_x3 = bx_union(bx_grow(g_a5, H2, W2), c9);             // + the x3 skip branch (g_x3p = c9)
+  const Bx u3 = bx_up2(g_x3);                                      // H
+  const Bx g_a0 = bx_grow(u3, H, W);
+  auto conv = [&](int i, const Bx& out, const Bx& src, const Bx& add) {
+    int* d = dyn + DYN_CONV + 12 * i;
+    d[0] = out.y0; d[1] = out.y1; d[2] = out.x0; d[3] = out.x1;
+    d[4] = src.y0; d[5] = src.y1; d[6] = src.x0; d[7] = src.x1;
+    d[8] = add.y0; d[9] = add.y1; d[10] = add.x0; d[11] = add.x1;
+  };
+  auto wg = [&](int i, const Bx& g) { int* d = dyn + DYN_WG + 4 * i; d[0] = g.y0; d[1] = g.y1; d[2] = g.x0; d[3] = g.x1; };
+  conv(DC_10, g_d2a, g_x21, none);
+  conv(DC_9U, bx_up2(g_x18), g_d2a, Bx{0, H4, 0, W4});             // (sum-pooled launch: `out` in H/2 coordinates; l2_18 is dense)
+  conv(DC_9S, c9, g_d2a, none);
+  conv(DC_8, g_d1a, g_x18, none);
+  conv(DC_7U, bx_up2(g_x15), g_d1a, Bx{0, H8, 0, W8});
+  conv(DC_7S, c7, g_d1a, none);
+  conv(DC_6, g_a12, u15, none);
+  conv(DC_5, g_a10, g_a12, none);
+  conv(DC_4, g_x8, g_a10, c7);
+  conv(DC_3, g_a5, u8, none);
+  conv(DC_2, g_x3, g_a5, c9);
+  conv(DC_1, g_a0, u3, none);
+  wg(DW_10, g_x21); wg(DW_9, g_d2a); wg(DW_8, g_x18); wg(DW_7, g_d1a); wg(DW_6, u15); wg(DW_5, g_a12);
+  wg(DW_4, g_a10); wg(DW_3, u8); wg(DW_2, g_a5); wg(DW_1, u3); wg(DW_0, g_a0);
+}
+
 struct BwdPlan {
   size_t g_x21, g_d2a, g_x18, l2_18, g_d1a, g_x15, l2_15, g_a12, g_a10, g_x8, g_x8p, g_a5, g_x3, g_x3p, g_a0;
-  size_t dot, part, bpart, dz;
+  size_t dot, part, bpart, dz, dyn;
   size_t g_x24, g_d3a, g_x2p, g_c2, l2_21;      // level 4 only
   size_t total;
 };
@@ -535,6 +650,7 @@ static void bwd_plan(int B, int H, int W, int dtype, BwdPlan* p, bool level4 = f
   p->part = take(maxpart);
   p->bpart = take((size_t)2048 * 256 * 4);
   p->dz = take((level4 ? P : P / 4) * sizeof(float));
+  p->dyn = take(DYN_INTS * sizeof(int));
   p->g_x24 = p->g_d3a = p->g_x2p = p->g_c2 = p->l2_21 = 0;
   if (level4) {
     p->g_x24 = take(P * 64 * es); p->g_d3a = take(P * 64 * es); p->g_x2p = take(P * 64 * es); p->g_c2 = take(P * 64 * es);
@@ -576,14 +692,21 @@ int vgg_backward_t(const float* x, const hla_vgg_params* prm, const char* packed
                          (size_t)H * W * 64};
   // at level 4 x21 also feeds conv_dec3, so its L2-norm gradient goes to a side buffer and is merged by that dgrad's epilogue
   void* l2out[4] = {G(bp.l2_15), G(bp.l2_18), level4 ? G(bp.l2_21) : G(bp.g_x21), G(bp.g_x24)};
+  // data-dependent trimming (see bwd_boxes_kernel): needs exact zeros outside the support, i.e. the one-pass L2 backward, and
+  // no confidence-head gradient (which is dense)
+  const bool dynamic = !level4 && (flags & HLA_VGG_BWD_SCALE_INVARIANT) && !(flags & HLA_VGG_BWD_DENSE) && !(conf && d_conf);
+  int* dynp = (int*)(bw + bp.dyn);
+  if (dynamic) HLA_CHECK_HIP(hipMemsetAsync(dynp + DYN_RAW, 0x80, 12 * sizeof(int), st));
   for (int l = 0; l < NL; ++l) {
     int nblk = (int)(per[l] / 4 / 256 / 8);
     nblk = nblk < 1 ? 1 : (nblk > 64 ? 64 : nblk);
     double* part = (double*)(bw + bp.dot);
     if (flags & HLA_VGG_BWD_SCALE_INVARIANT) {
       hla_prof_begin(K_ELEMWISE, 0, (double)B * per[l] * (4 + sizeof(T)), st);
+      const int Cl[4] = {256, 128, 64, 64};
       hipLaunchKernelGGL((l2bwd_apply_kernel<T, true>), dim3(B * nblk), dim3(256), 0, st, feat[l], d_feat[l], part,
-                         inv_norm + (size_t)l * B, (T*)l2out[l], per[l], nblk);
+                         inv_norm + (size_t)l * B, (T*)l2out[l], per[l], nblk, dynamic ? dynp + DYN_RAW + 4 * l : (int*)nullptr,
+                         Cl[l], W >> (3 - l));
     } else {
       hla_prof_begin(K_ELEMWISE, 0, (double)B * per[l] * (16 + sizeof(T)), st);
       hipLaunchKernelGGL(l2bwd_dot_kernel, dim3(B * nblk), dim3(256), 0, st, feat[l], d_feat[l], part, per[l], nblk);
@@ -592,6 +715,8 @@ int vgg_backward_t(const float* x, const hla_vgg_params* prm, const char* packed
     }
     hla_prof_end(st);
   }
+
+  if (dynamic) hipLaunchKernelGGL(bwd_boxes_kernel, dim3(1), dim3(64), 0, st, dynp, H, W);
 
   // ---- confidence heads (only the ground branch with using_weight=1 ever has d_conf): adds into the raw-map gradients
   if (conf && d_conf) {
@@ -619,8 +744,9 @@ int vgg_backward_t(const float* x, const hla_vgg_params* prm, const char* packed
   // ---- helpers
   // data gradient of layer l restricted to its input channels [c0, c0+n): a forward conv on the transposed weights
   auto dgrad = [&](int l, int c0, int n, const void* gsrc, const unsigned char* unpool, int Hout, int Wout, void* out,
-                   const void* mask, const void* add, bool pool_sum, int row_begin = 0, int src_lo = 0, int add_lo = 0) {
+                   const void* mask, const void* add, bool pool_sum, int row_begin = 0, int src_lo = 0, int add_lo = 0, int dc = -1) {
     ConvArgs a{};
+    a.dyn = (dynamic && dc >= 0) ? dynp + DYN_CONV + 12 * dc : nullptr;
     a.src1 = gsrc; a.C1 = kLayers[l].cout; a.unpool_idx = unpool;
     const int nstage = kLayers[l].cout / KC;
     a.wpk = (const uint4*)(packedT + packed_offset(l, dtype)) + (size_t)(c0 / 32) * nstage * 18 * 64;
@@ -630,8 +756,9 @@ int vgg_backward_t(const float* x, const hla_vgg_params* prm, const char* packed
     launch_conv<T>(st, a, pool_sum);
   };
   auto wgrad = [&](int l, const void* x1, int C1, const void* x2, int C2, int up1, const void* g, const unsigned char* unpool,
-                   int Hout, int Wout, int row_begin = 0) {
+                   int Hout, int Wout, int row_begin = 0, int dw = -1) {
     WgradArgs a{};
+    a.dyn = (dynamic && dw >= 0) ? dynp + DYN_WG + 4 * dw : nullptr;
     a.x1 = x1; a.x2 = x2; a.C1 = C1; a.C2 = C2; a.up1 = up1; a.g = g; a.g_unpool = unpool;
     a.B = B; a.H = Hout; a.W = Wout; a.Cout = kLayers[l].cout; a.Cin = kLayers[l].cin;
     a.row_begin = row_begin > 0 ? row_begin : 0;
@@ -692,29 +819,29 @@ int vgg_backward_t(const float* x, const hla_vgg_params* prm, const char* packed
   const int n_x3 = nn(n_a5 - 1);                        // H/2
   const int n_a0 = nn(2 * n_x3 - 1);                    // H
   // ---- decoder 2 (VGG.py:148-151)
-  dgrad(10, 0, 64, G(bp.g_x21), nullptr, H2, W2, G(bp.g_d2a), F(fp.d2a), nullptr, false, n_d2a, 0, 0);
-  wgrad(10, F(fp.d2a), 64, nullptr, 0, 0, G(bp.g_x21), nullptr, H2, W2, n_x21);
-  dgrad(9, 0, 128, G(bp.g_d2a), nullptr, H2, W2, G(bp.g_x18), F(fp.x18r), G(bp.l2_18), true, rb_up18, n_d2a, 0);   // up(x18) branch
-  dgrad(9, 128, 64, G(bp.g_d2a), nullptr, H2, W2, G(bp.g_x3p), F(fp.x3), nullptr, false, n_x3p, n_d2a, 0);          // x3 skip branch
-  wgrad(9, F(fp.x18r), 128, F(fp.x3), 64, 1, G(bp.g_d2a), nullptr, H2, W2, n_d2a);
+  dgrad(10, 0, 64, G(bp.g_x21), nullptr, H2, W2, G(bp.g_d2a), F(fp.d2a), nullptr, false, n_d2a, 0, 0, DC_10);
+  wgrad(10, F(fp.d2a), 64, nullptr, 0, 0, G(bp.g_x21), nullptr, H2, W2, n_x21, DW_10);
+  dgrad(9, 0, 128, G(bp.g_d2a), nullptr, H2, W2, G(bp.g_x18), F(fp.x18r), G(bp.l2_18), true, rb_up18, n_d2a, 0, DC_9U);   // up(x18) branch
+  dgrad(9, 128, 64, G(bp.g_d2a), nullptr, H2, W2, G(bp.g_x3p), F(fp.x3), nullptr, false, n_x3p, n_d2a, 0, DC_9S);          // x3 skip branch
+  wgrad(9, F(fp.x18r), 128, F(fp.x3), 64, 1, G(bp.g_d2a), nullptr, H2, W2, n_d2a, DW_9);
   // ---- decoder 1 (VGG.py:144-146)
-  dgrad(8, 0, 128, G(bp.g_x18), nullptr, H4, W4, G(bp.g_d1a), F(fp.d1a), nullptr, false, n_d1a, n_x18, 0);
-  wgrad(8, F(fp.d1a), 128, nullptr, 0, 0, G(bp.g_x18), nullptr, H4, W4, n_x18);
-  dgrad(7, 0, 256, G(bp.g_d1a), nullptr, H4, W4, G(bp.g_x15), F(fp.x15r), G(bp.l2_15), true, rb_up15, n_d1a, 0);   // up(x15) branch
-  dgrad(7, 256, 128, G(bp.g_d1a), nullptr, H4, W4, G(bp.g_x8p), F(fp.x8), nullptr, false, n_x8p, n_d1a, 0);        // x8 skip branch
-  wgrad(7, F(fp.x15r), 256, F(fp.x8), 128, 1, G(bp.g_d1a), nullptr, H4, W4, n_d1a);
+  dgrad(8, 0, 128, G(bp.g_x18), nullptr, H4, W4, G(bp.g_d1a), F(fp.d1a), nullptr, false, n_d1a, n_x18, 0, DC_8);
+  wgrad(8, F(fp.d1a), 128, nullptr, 0, 0, G(bp.g_x18), nullptr, H4, W4, n_x18, DW_8);
+  dgrad(7, 0, 256, G(bp.g_d1a), nullptr, H4, W4, G(bp.g_x15), F(fp.x15r), G(bp.l2_15), true, rb_up15, n_d1a, 0, DC_7U);   // up(x15) branch
+  dgrad(7, 256, 128, G(bp.g_d1a), nullptr, H4, W4, G(bp.g_x8p), F(fp.x8), nullptr, false, n_x8p, n_d1a, 0, DC_7S);        // x8 skip branch
+  wgrad(7, F(fp.x15r), 256, F(fp.x8), 128, 1, G(bp.g_d1a), nullptr, H4, W4, n_d1a, DW_7);
   // ---- encoder block 2 (VGG.py:136-141); conv14 is followed by the pool (no ReLU in between)
-  dgrad(6, 0, 256, G(bp.g_x15), idx15, H4, W4, G(bp.g_a12), F(fp.a12), nullptr, false, n_a12, 2 * n_x15, 0);
-  wgrad(6, F(fp.a12), 256, nullptr, 0, 0, G(bp.g_x15), idx15, H4, W4, 2 * n_x15);
-  dgrad(5, 0, 256, G(bp.g_a12), nullptr, H4, W4, G(bp.g_a10), F(fp.a10), nullptr, false, n_a10, n_a12, 0);
-  wgrad(5, F(fp.a10), 256, nullptr, 0, 0, G(bp.g_a12), nullptr, H4, W4, n_a12);
-  dgrad(4, 0, 128, G(bp.g_a10), nullptr, H4, W4, G(bp.g_x8), F(fp.x8), G(bp.g_x8p), false, n_x8, n_a10, n_x8p);
-  wgrad(4, F(fp.x8), 128, nullptr, 0, 0, G(bp.g_a10), nullptr, H4, W4, n_a10);
+  dgrad(6, 0, 256, G(bp.g_x15), idx15, H4, W4, G(bp.g_a12), F(fp.a12), nullptr, false, n_a12, 2 * n_x15, 0, DC_6);
+  wgrad(6, F(fp.a12), 256, nullptr, 0, 0, G(bp.g_x15), idx15, H4, W4, 2 * n_x15, DW_6);
+  dgrad(5, 0, 256, G(bp.g_a12), nullptr, H4, W4, G(bp.g_a10), F(fp.a10), nullptr, false, n_a10, n_a12, 0, DC_5);
+  wgrad(5, F(fp.a10), 256, nullptr, 0, 0, G(bp.g_a12), nullptr, H4, W4, n_a12, DW_5);
+  dgrad(4, 0, 128, G(bp.g_a10), nullptr, H4, W4, G(bp.g_x8), F(fp.x8), G(bp.g_x8p), false, n_x8, n_a10, n_x8p, DC_4);
+  wgrad(4, F(fp.x8), 128, nullptr, 0, 0, G(bp.g_a10), nullptr, H4, W4, n_a10, DW_4);
   // ---- encoder block 1
-  dgrad(3, 0, 128, G(bp.g_x8), idx8, H2, W2, G(bp.g_a5), F(fp.a5), nullptr, false, n_a5, 2 * n_x8, 0);
-  wgrad(3, F(fp.a5), 128, nullptr, 0, 0, G(bp.g_x8), idx8, H2, W2, 2 * n_x8);
-  dgrad(2, 0, 64, G(bp.g_a5), nullptr, H2, W2, G(bp.g_x3), F(fp.x3), G(bp.g_x3p), false, n_x3, n_a5, n_x3p);
-  wgrad(2, F(fp.x3), 64, nullptr, 0, 0, G(bp.g_a5), nullptr, H2, W2, n_a5);
+  dgrad(3, 0, 128, G(bp.g_x8), idx8, H2, W2, G(bp.g_a5), F(fp.a5), nullptr, false, n_a5, 2 * n_x8, 0, DC_3);
+  wgrad(3, F(fp.a5), 128, nullptr, 0, 0, G(bp.g_x8), idx8, H2, W2, 2 * n_x8, DW_3);
+  dgrad(2, 0, 64, G(bp.g_a5), nullptr, H2, W2, G(bp.g_x3), F(fp.x3), G(bp.g_x3p), false, n_x3, n_a5, n_x3p, DC_2);
+  wgrad(2, F(fp.x3), 64, nullptr, 0, 0, G(bp.g_a5), nullptr, H2, W2, n_a5, DW_2);
   // ---- encoder block 0
   if (level4) {      // the conv2 output also fed conv_dec3: materialise unpool(g_x3) + skip gradient once
     const size_t n = (size_t)B * H * W * (64 * sizeof(T) / 16);
@@ -725,13 +852,14 @@ int vgg_backward_t(const float* x, const hla_vgg_params* prm, const char* packed
     dgrad(1, 0, 64, G(bp.g_c2), nullptr, H, W, G(bp.g_a0), F(fp.a0), nullptr, false);
     wgrad(1, F(fp.a0), 64, nullptr, 0, 0, G(bp.g_c2), nullptr, H, W);
   } else {
-    dgrad(1, 0, 64, G(bp.g_x3), idx3, H, W, G(bp.g_a0), F(fp.a0), nullptr, false, n_a0, 2 * n_x3, 0);
-    wgrad(1, F(fp.a0), 64, nullptr, 0, 0, G(bp.g_x3), idx3, H, W, 2 * n_x3);
+    dgrad(1, 0, 64, G(bp.g_x3), idx3, H, W, G(bp.g_a0), F(fp.a0), nullptr, false, n_a0, 2 * n_x3, 0, DC_1);
+    wgrad(1, F(fp.a0), 64, nullptr, 0, 0, G(bp.g_x3), idx3, H, W, 2 * n_x3, DW_1);
   }
   {
     Wgrad0Args a{};
     a.x = x; a.g = G(bp.g_a0); a.B = B; a.H = H; a.W = W;
     a.row_begin = level4 ? 0 : n_a0;
+    a.dyn = dynamic ? dynp + DYN_WG + 4 * DW_0 : nullptr;
     a.tiles_x = (W + 31) / 32; a.tiles_y = (H - a.row_begin + WG_TH - 1) / WG_TH; a.ntile = B * a.tiles_x * a.tiles_y;
     a.KS = a.ntile < 1024 ? a.ntile : 1024;
     a.part = (float*)(bw + bp.part); a.bpart = (float*)(bw + bp.bpart);

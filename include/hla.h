@@ -58,7 +58,7 @@ const char* hla_last_error(void);
  * with its own struct sizes (ctypes structs are positional: a mismatch corrupts silently).  highlyaccurate_amd/_lib.py
  * does both at load time, and rebuilds or refuses a binary whose hla_source_hash() is not the hash of the sources
  * next to it (the library is git-ignored but shipped prebuilt). */
-#define HLA_ABI_VERSION 14
+#define HLA_ABI_VERSION 15
 int hla_abi_version(void);
 const char* hla_source_hash(void); /* sha256 (hex) of the csrc sources, this header and the compiler flags at build time */
 typedef enum hla_struct_id {
@@ -149,12 +149,17 @@ size_t hla_vgg_bwd_workspace_bytes(int B, int H, int W, int level, int dtype);
  *                  scale (LM_update renormalises both maps, models_kitti.py:982-990), so d_feat[l] is orthogonal to feat[l]
  *                  and the L2_norm Jacobian  dx = a*dy - a^3 (x.dy) x  (a = 1/||x||) reduces to a*dy: the (x.dy) pass and the
  *                  re-read of feat are skipped.  (In the reference that dot product is fp32 rounding noise, ~1e-7 |x||dy|.)
+ *                  With this flag (level 3, no d_conf) the call also finds the bounding box of the pixels where each
+ *                  d_feat[l] is not exactly zero and skips every tile of every data- and weight-gradient launch whose
+ *                  gradient is zero as a consequence (the satellite maps' gradient covers ~10 % of the texels inside
+ *                  half of the columns).  Values do not change; HLA_VGG_BWD_DENSE switches it off.
  * first_row8       0, or f in [4, H/8): a promise that d_feat[0] / d_feat[1] / d_feat[2] (and d_conf) are zero above rows
  *                  f / 2f / 4f -- the LM loop only reads rows h_l/2.. of the ground maps, so that is where its gradient
  *                  lives.  Every activation's gradient is then exactly zero above a first row that follows from the layer
  *                  graph, and the data- and weight-gradient launches skip those rows.  Needs HLA_VGG_BWD_SCALE_INVARIANT;
  *                  ignored (0) otherwise and at level 4. */
 #define HLA_VGG_BWD_SCALE_INVARIANT 1
+#define HLA_VGG_BWD_DENSE 2           /* visit every tile even where the incoming gradient is exactly zero (A/B and tests) */
 int hla_vgg_backward(const float* x, const hla_vgg_params* params, const void* packed_weights_T,
                      const void* fwd_workspace, const float* const feat[4], const double* inv_norm,
                      const float* const d_feat[4], const float* const conf[4], const float* const d_conf[4],

@@ -1298,6 +1298,61 @@ def test_dead_ground_rows_elimination_is_exact(monkeypatch):
         assert dev < 2e-6
 
 
+@pytest.mark.parametrize('precision', ['fp32', 'bf16'])
+def test_backward_dynamic_trimming_is_exact(precision):
+    """hla_vgg_backward finds the bounding box of the non-zero incoming gradient and skips every tile of every dgrad / wgrad
+    launch that it proves zero (vgg_backward.hip, bwd_boxes_kernel).  Against the dense walk (HLA_VGG_BWD_DENSE) the gradients
+    may differ only by the summation order of the weight-gradient partials -- for boxes at odd offsets, one per level, a
+    single texel, per-sample different footprints, and no gradient at all."""
+    from oracle import ref_cpu as O
+    from highlyaccurate_amd.VGG import VGGUnet, vgg_forward_nhwc, vgg_backward_nhwc
+    d = _dev()
+    rs = np.random.RandomState(77)
+    sd = O.synth_vgg_state(rs, bias_scale=0.05)
+    B, H, W = 3, 96, 160                                          # maps 12x20, 24x40, 48x80: several 32-px column tiles
+    x = T(rs.random_sample((B, 3, H, W)).astype(np.float32)).to(d)
+    net = VGGUnet(3, precision=precision)
+    net.load_state_dict(sd)
+    net = net.to(d)
+    feats, _, inv, ctx = vgg_forward_nhwc(net, x, want_conf=False, defer_norm=True, save_for_backward=True)
+    shapes = [(B, H // 8, W // 8, 256), (B, H // 4, W // 4, 128), (B, H // 2, W // 2, 64)]
+
+    def boxes(spec):
+        out = []
+        for (b, h, w, c), per_level in zip(shapes, spec):
+            g = torch.zeros(b, h, w, c)
+            for bi, (y0, y1, x0, x1) in per_level:
+                g[bi, y0:y1, x0:x1] = T(rs.standard_normal((y1 - y0, x1 - x0, c)).astype(np.float32))
+            out.append(g.to(d))
+        return out
+
+    cases = {
+        'right half': [[(0, (1, 11, 11, 19)), (1, (2, 9, 12, 20))], [(0, (3, 22, 23, 39)), (2, (5, 20, 25, 40))],
+                       [(0, (7, 45, 47, 79)), (1, (9, 40, 50, 80))]],
+        'coarse level only': [[(1, (5, 6, 3, 4))], [], []],
+        'fine level only, one texel': [[], [], [(2, (17, 18, 33, 34))]],
+        'disjoint boxes per level': [[(0, (0, 2, 0, 3))], [(1, (20, 24, 36, 40))], [(2, (21, 27, 1, 9))]],
+        'nothing': [[], [], []],
+        'everything': [[(0, (0, 12, 0, 20))], [(1, (0, 24, 0, 40))], [(2, (0, 48, 0, 80))]],
+    }
+    for tag, spec in cases.items():
+        dfe = boxes(spec)
+        g_dense = vgg_backward_nhwc(net, ctx, dfe, scale_invariant=True, dense=True)
+        g_trim = vgg_backward_nhwc(net, ctx, dfe, scale_invariant=True)
+        worst, wk = 0.0, ''
+        for k in g_dense:
+            a, b = g_dense[k].double(), g_trim[k].double()
+            assert torch.isfinite(b).all(), (tag, k)
+            if tag == 'nothing':
+                assert float(b.abs().max()) == 0.0 and float(a.abs().max()) == 0.0, (tag, k)
+                continue
+            e = float((a - b).norm() / max(float(a.norm()), 1e-30))
+            if e > worst:
+                worst, wk = e, k
+        print(f'dynamic trimming {precision} [{tag}]: worst gradient rel-l2 deviation {worst:.2e} ({wk})')
+        assert worst < 2e-5, (tag, wk, worst)
+
+
 @pytest.mark.parametrize('kw', [dict(), dict(using_weight=1, train_damping=1), dict(train_ground_crop=1)])
 def test_backward_row_trimming_is_exact(kw, monkeypatch):
     """The ground branch's gradient lives in rows h_l/2.. of its three maps; hla_vgg_backward(first_row8) skips, layer by
@@ -1311,6 +1366,7 @@ def test_backward_row_trimming_is_exact(kw, monkeypatch):
     res = {}
     for trim in ('0', '1'):
         monkeypatch.setenv('HLA_BWD_TRIM', trim)
+        monkeypatch.setenv('HLA_VGG_BWD_DENSE', '1' if trim == '0' else '0')   # (the data-dependent trimming of both branches too)
         net = LM_S2GP(O.default_args(**kw))
         sd = O.synth_model_state(seed, bias_scale=0.02)
         if kw.get('train_damping'):
