@@ -1141,40 +1141,72 @@ static __global__ void absmax_kernel(const float* __restrict__ w, size_t n, int 
 
 // ---------------------------------------------------------------------------------------------
 // confidence head: sigmoid(-sigmoid(conv3x3(relu(x), C->1)))  VGG.py:62-81,160-163.  `act` is already ReLU'd.
-template <typename T>
+// One block per 8x32 output tile.  Every pixel of the 10x34 halo is read ONCE and gives its nine per-tap dot products
+// td[pixel][tap] = sum_c act[pixel][c] * w[c][tap] to LDS; an output pixel then adds the nine values its neighbours hold for
+// it.  The dot products are a [9 (padded to 32) x C] x [C x 32 pixels] matrix product per wave: the weights sit in registers as
+// MFMA row fragments (hi + lo halves for the 16-bit types: the product is as exact as an fp32 FMA chain on the stored
+// activations) and a pixel's channels go from global memory straight into the column fragment (NHWC: 16 contiguous bytes per
+// lane and K-step).  (History: gathering the nine neighbours per output pixel took 560 us for the three maps of a training
+// step -- nine passes over the activations through the caches; a scalar version of the present scheme was bound by its
+// 9 log2(C/8) cross-lane reduction steps per pixel and no faster.)
+constexpr int CONF_TH = 8, CONF_TW = 32, CONF_HW = CONF_TW + 2, CONF_HPIX = (CONF_TH + 2) * CONF_HW;
+constexpr int CONF_NT = (CONF_HPIX + 31) / 32;             // 32-pixel MFMA tiles per block
+template <typename T, int C>
 __global__ __launch_bounds__(256) void conf_kernel(const T* __restrict__ act, const float* __restrict__ w,
-                                                   float* __restrict__ out, int B, int H, int W, int C) {
-  constexpr int EPL = 16 / sizeof(T);
-  extern __shared__ float ws[];   // [9][C]
-  for (int e = threadIdx.x; e < 9 * C; e += 256) ws[(e % 9) * C + e / 9] = w[e];   // OIHW (O=1): w[c*9+tap]
+                                                   float* __restrict__ out, int B, int H, int W) {
+  constexpr int EPL = 16 / sizeof(T), KS = 2 * EPL, NS = C / KS;      // channels per lane / per K-step, K-steps
+  constexpr bool SPLITW = sizeof(T) == 2;
+  __shared__ float td[CONF_NT * 32 * 9];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, n = lane & 31, g = lane >> 5;
+  const int tiles_x = (W + CONF_TW - 1) / CONF_TW, tiles_y = (H + CONF_TH - 1) / CONF_TH;
+  int bid = blockIdx.x;
+  const int x0 = (bid % tiles_x) * CONF_TW; bid /= tiles_x;
+  const int y0 = (bid % tiles_y) * CONF_TH;
+  const size_t b = bid / tiles_y;
+  // row fragments of the weights: row n = tap (zero for n >= 9), this lane's channels of K-step s: s*KS + g*EPL + [0, EPL)
+  uint4 wh[NS], wl[SPLITW ? NS : 1];
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    T hi[EPL], lo[EPL];
+#pragma unroll
+    for (int k = 0; k < EPL; ++k) {
+      const float v = n < 9 ? w[(s * KS + g * EPL + k) * 9 + n] : 0.f;         // OIHW (O=1): w[c*9+tap]
+      hi[k] = (T)v;
+      lo[k] = (T)(v - to_f32(hi[k]));
+    }
+    __builtin_memcpy(&wh[s], hi, 16);
+    if (SPLITW) __builtin_memcpy(&wl[s], lo, 16);
+  }
+  for (int t = wv; t < CONF_NT; t += 4) {
+    const int hp = t * 32 + n, hy = hp / CONF_HW, hx = hp - hy * CONF_HW, y = y0 - 1 + hy, x = x0 - 1 + hx;
+    const bool ok = hp < CONF_HPIX && y >= 0 && y < H && x >= 0 && x < W;
+    const T* src = act + ((b * H + (ok ? y : 0)) * W + (ok ? x : 0)) * C + g * EPL;
+    uint4 a[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) a[s] = ok ? *(const uint4*)(src + s * KS) : make_uint4(0, 0, 0, 0);
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      mma16<T>(acc, wh[s], a[s]);
+      if (SPLITW) mma16<T>(acc, wl[s], a[s]);
+    }
+    // D[tap][pixel]: lane -> pixel n; register r -> tap (r&3) + 8(r>>2) + 4g
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const int tap = (r & 3) + 8 * (r >> 2) + 4 * g;
+      if (tap < 9) td[hp * 9 + tap] = acc[r];
+    }
+  }
   __syncthreads();
-  const int G = C / EPL;                     // threads per pixel (8 channels bf16 / 4 fp32 each), power of 2 <= 64
-  const int ppb = 256 / G;
-  const size_t npix = (size_t)B * H * W;
-  const int gi = threadIdx.x % G;
-  for (size_t pix = (size_t)blockIdx.x * ppb + threadIdx.x / G; pix < (npix + ppb - 1) / ppb * ppb;
-       pix += (size_t)gridDim.x * ppb) {
+  const int py = threadIdx.x / CONF_TW, px = threadIdx.x % CONF_TW, y = y0 + py, x = x0 + px;   // 256 threads = the 8x32 tile
+  if (y < H && x < W) {
     float s = 0.f;
-    const bool live = pix < npix;
-    if (live) {
-      const int x = (int)(pix % W), y = (int)((pix / W) % H);
-      const size_t b = pix / ((size_t)W * H);
 #pragma unroll
-      for (int tap = 0; tap < 9; ++tap) {
-        const int yy = y + tap / 3 - 1, xx = x + tap % 3 - 1;
-        if (yy < 0 || yy >= H || xx < 0 || xx >= W) continue;
-        const uint4 raw = *(const uint4*)(act + ((b * H + yy) * W + xx) * C + gi * EPL);
-        T e[EPL];
-        __builtin_memcpy(e, &raw, 16);
-#pragma unroll
-        for (int k = 0; k < EPL; ++k) s += to_f32(e[k]) * ws[tap * C + gi * EPL + k];
-      }
-    }
-    for (int o = G >> 1; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-    if (live && gi == 0) {
-      const float sg = 1.f / (1.f + __expf(-s));
-      out[pix] = 1.f / (1.f + __expf(sg));
-    }
+    for (int tap = 0; tap < 9; ++tap) s += td[((py + tap / 3) * CONF_HW + px + tap % 3) * 9 + tap];
+    const float sg = 1.f / (1.f + __expf(-s));
+    out[(b * H + y) * W + x] = 1.f / (1.f + __expf(sg));
   }
 }
 

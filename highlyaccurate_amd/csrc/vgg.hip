@@ -131,13 +131,12 @@ int vgg_forward_t(const float* x, const hla_vgg_params* prm, const char* packed,
     const int Cs[4] = {256, 128, 64, 64}, hs[4] = {H / 8, H / 4, H / 2, H}, wsz[4] = {W / 8, W / 4, W / 2, W};
     for (int l = 0; l < NL; ++l) {
       if (!conf[l]) continue;
-      constexpr int EPL = 16 / sizeof(CT);
-      const int ppb = 256 / (Cs[l] / EPL);
       const size_t npix = (size_t)B * hs[l] * wsz[l];
-      const int grid = (int)((npix + ppb - 1) / ppb < 4096 ? (npix + ppb - 1) / ppb : 4096);
+      const int grid = B * ((hs[l] + CONF_TH - 1) / CONF_TH) * ((wsz[l] + CONF_TW - 1) / CONF_TW);
       hla_prof_begin(K_CONF, 2.0 * 9 * Cs[l] * (double)npix, (double)npix * (Cs[l] * sizeof(CT) + 4), st);
-      hipLaunchKernelGGL((conf_kernel<CT>), dim3(grid), dim3(256), 9 * Cs[l] * sizeof(float), st, acts[l],
-                         prm->w[13 + l], conf[l], B, hs[l], wsz[l], Cs[l]);
+      if (Cs[l] == 256) hipLaunchKernelGGL((conf_kernel<CT, 256>), dim3(grid), dim3(256), 0, st, acts[l], prm->w[13 + l], conf[l], B, hs[l], wsz[l]);
+      else if (Cs[l] == 128) hipLaunchKernelGGL((conf_kernel<CT, 128>), dim3(grid), dim3(256), 0, st, acts[l], prm->w[13 + l], conf[l], B, hs[l], wsz[l]);
+      else hipLaunchKernelGGL((conf_kernel<CT, 64>), dim3(grid), dim3(256), 0, st, acts[l], prm->w[13 + l], conf[l], B, hs[l], wsz[l]);
       hla_prof_end(st);
     }
   }

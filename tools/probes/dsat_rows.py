@@ -24,6 +24,17 @@ def spy(*a, **k):
         per = [(int(rows[b].nonzero().min()), int(rows[b].nonzero().max())) for b in range(B)]
         print(f'level {l} A={A}: rows with gradient over the batch [{int(r_any.min())}, {int(r_any.max())}], cols [{int(c_any.min())}, {int(c_any.max())}]; '
               f'per-sample last row: min {min(p[1] for p in per)} max {max(p[1] for p in per)}; texels touched {float(nz.float().mean()):.3f}')
+        # live 8x32 tiles of this map under three descriptions of the batch-union support, after a 3-px dilation
+        u = nz.any(0).float()[None, None]
+        u = torch.nn.functional.max_pool2d(u, 7, 1, 3)[0, 0] > 0
+        t = u.view(A // 8, 8, A // 32, 32).any(3).any(1)                 # exact tile bitmap [A/8, A/32]
+        ys, xs = u.any(1).nonzero().flatten(), u.any(0).nonzero().flatten()
+        box = ((int(ys.max()) // 8 - int(ys.min()) // 8 + 1) * (int(xs.max()) // 32 - int(xs.min()) // 32 + 1))
+        band = 0
+        for ty in range(A // 8):
+            c = u[ty * 8:ty * 8 + 8].any(0).nonzero().flatten()
+            if len(c): band += int(c.max()) // 32 - int(c.min()) // 32 + 1
+        print(f'   tiles 8x32: all {t.numel()}, box {box}, per-band interval {band}, exact bitmap {int(t.sum())}')
     return out
 net.lm_backward = spy
 r = net(sat, grd, gt[0], gt[1], gt[2], mode='train')
