@@ -340,8 +340,9 @@ def train_leg(net, a, sat, grd, extra, B, world, dist, dev, want_kt):
     if trecs:
         tagg = aggregate(trecs)
         tot = sum(v[1] for v in tagg.values())
-        train['kernels'] = {k: {'launches': v[0], 'avg_us': round(v[1] / v[0] * 1e3, 1), 'share': round(v[1] / tot, 3),
-                                'tflops': round(v[2] / (v[1] * 1e-3) / 1e12, 1) if v[2] else None}
+        # (no TFLOP/s here: the backward skips the tiles whose gradient is exactly zero -- data-dependent, DESIGN.md 6 -- so
+        #  the FLOPs a dgrad / wgrad launch executes are not the dense layer's; per-launch numbers: tools/probes/train_launches.py)
+        train['kernels'] = {k: {'launches': v[0], 'avg_us': round(v[1] / v[0] * 1e3, 1), 'share': round(v[1] / tot, 3)}
                             for k, v in sorted(tagg.items(), key=lambda kv: -kv[1][1])[:8]}
     net.eval()
     return train
