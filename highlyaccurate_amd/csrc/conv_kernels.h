@@ -157,7 +157,8 @@ struct ConvArgs {
   int src_row_lo;     // source rows above this one (in THIS launch's full-resolution row coordinates) read as zero: the
                       // backward's gradient maps are exactly zero -- and unwritten -- above their first row
   int add_row_lo;     // likewise for add_src, in output row coordinates
-  const int* dyn;     // device-side bounds of a data-dependent launch (ConvDyn), or null: see below
+  const int* dyn;     // data-dependent launch (vgg_backward.hip, bwd_fan_kernel): base of the device-side tables, or null
+  int dyn_desc;       //   int offset of this launch's ConvDyn in them
   // --- training / backward extras (all optional) ---
   const unsigned char* unpool_idx;  // src1 is a max-pooled map's gradient at half resolution [B,H/2,W/2,C1] and this is
                                     // the forward argmax (0..3): the loader routes it to full resolution (virtual unpool)
@@ -173,14 +174,15 @@ struct ConvArgs {
   const float* wscale;              // the power-of-two scale baked into wpk (device scalar written by the packer)
 };
 
-// Data-dependent trimming (the backward of a branch whose incoming gradient has a small footprint, vgg_backward.hip): three
-// half-open pixel boxes {y0, y1, x0, x1} in DEVICE memory, written by an earlier kernel on the same stream.  A tile that does
-// not meet `out` exits at once (its output is never read: it lies outside every consumer's `src` box); the sources read as
-// zero outside `src`, add_src outside `add`.
+// Data-dependent trimming (the backward of a branch whose incoming gradient has a small footprint, vgg_backward.hip): tables in
+// DEVICE memory, written by an earlier kernel on the same stream.  Only the `n_live` tiles of the list are computed (the same
+// ones for every sample); a source pixel reads as zero unless its column lies in the interval its producer WROTE for that
+// band of 8 source rows (`src_bands`: {lo, hi} pairs, multiples of 32 in the source's own coordinates), add_src likewise.
 struct ConvDyn {
-  int out[4];         // in this launch's full-resolution coordinates (before a POOL epilogue)
-  int src[4];         // in this launch's full-resolution coordinates (after a virtual 2x upsample / unpool)
-  int add[4];         // in output coordinates
+  int n_live;         // live tiles per sample
+  int list;           // int offset of the list: entry = (tile row << 16) | tile column
+  int src_bands;      // int offset of the source's band table, or -1: the source is dense
+  int add_bands;      // likewise for add_src (output coordinates)
 };
 struct PixBox { int y0, y1, x0, x1; };
 
@@ -629,25 +631,32 @@ __global__ __launch_bounds__(256, (NT == 1 && !PF_UPFRONT && (CONV_VARIANT == 50
   // (readfirstlane: the wave index is uniform, which lets every address that depends on it live in scalar registers)
   const int t = threadIdx.x, lane = t & 63, wv = __builtin_amdgcn_readfirstlane(t >> 6), wm = wv / WN, wn = wv % WN;
   // source / fan-in bounds: the image (and the caller's static first rows), narrowed by the device-side boxes if there are any
-  int sy0 = a.src_row_lo, sy1 = a.H, sx0 = 0, sx1 = a.W;
+  const int sy0 = a.src_row_lo, sy1 = a.H;
   int tx, ty, b;
-  if (a.dyn) {                              // kernel-uniform; the ints are scalar loads
-    // Only the tiles that meet `out` are enumerated, by the FIRST workgroups of the grid; the rest exit.  (Launching every
-    // tile and returning from the dead ones is not enough: workgroup ids go round-robin to the shader engines, so a dead /
-    // live pattern with the period of a tile row -- 2 dead + 2 live columns at H/4 -- leaves whole engines idle: measured
+  // column interval of the source per halo row class: top halo row / the tile's own rows / bottom halo row
+  int slo[3] = {0, 0, 0}, shi[3] = {a.W, a.W, a.W};
+  if (a.dyn) {                              // kernel-uniform; everything below is scalar loads
+    // Only the live tiles are enumerated, by the FIRST workgroups of the grid; the rest exit.  (Launching every tile and
+    // returning from the dead ones is not enough: workgroup ids go round-robin to the shader engines, so a dead / live
+    // pattern with the period of a tile row -- 2 dead + 2 live columns at H/4 -- leaves whole engines idle: measured
     // 160 -> 145 us for half the tiles.)
-    const ConvDyn& d = *(const ConvDyn*)a.dyn;
-    if (d.out[0] >= d.out[1] || d.out[2] >= d.out[3]) return;
-    const int tx_lo = max(d.out[2], 0) / 32, ntx = min((d.out[3] + 31) / 32, a.tiles_x) - tx_lo;
-    const int ty_lo = max(d.out[0] - a.row_begin, 0) / TH, nty = min((d.out[1] - a.row_begin + TH - 1) / TH, a.tiles_y) - ty_lo;
-    if (ntx <= 0 || nty <= 0) return;
-    const int nlive = ntx * nty * a.B;
+    const ConvDyn& d = *(const ConvDyn*)(a.dyn + a.dyn_desc);
+    const int nl = d.n_live, nlive = nl * a.B;
     if ((int)blockIdx.x >= nlive) return;
     int bid = xcd_contiguous(blockIdx.x, nlive);
-    tx = tx_lo + bid % ntx; bid /= ntx;
-    ty = ty_lo + bid % nty;
-    b = bid / nty;
-    sy0 = max(sy0, d.src[0]); sy1 = min(sy1, d.src[1]); sx0 = max(sx0, d.src[2]); sx1 = min(sx1, d.src[3]);
+    b = bid / nl;
+    const int e = a.dyn[d.list + bid % nl];
+    ty = e >> 16; tx = e & 0xffff;
+    if (d.src_bands >= 0) {
+      const int sh = (a.up1 || a.unpool_idx) ? 1 : 0, nb = ((a.H >> sh) + 7) >> 3, yy = a.row_begin + ty * TH;
+      const int rows[3] = {yy - 1, yy, yy + TH};
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const int band = min(max(rows[k], 0) >> sh >> 3, nb - 1);
+        slo[k] = a.dyn[d.src_bands + 2 * band] << sh;
+        shi[k] = min(a.dyn[d.src_bands + 2 * band + 1] << sh, a.W);
+      }
+    }
   } else {
     int bid = xcd_contiguous(blockIdx.x, gridDim.x);
     tx = bid % a.tiles_x; bid /= a.tiles_x;
@@ -679,7 +688,8 @@ __global__ __launch_bounds__(256, (NT == 1 && !PF_UPFRONT && (CONV_VARIANT == 50
       const int hy = pix / HWID, hx = pix - hy * HWID;
       const int y = y0 - 1 + hy, x = x0 - 1 + hx;
       uint4 v = make_uint4(0, 0, 0, 0);
-      if (pix < HPIX && y >= sy0 && y < sy1 && x >= sx0 && x < sx1) {
+      const int xlo = hy == 0 ? slo[0] : (hy == TH + 1 ? slo[2] : slo[1]), xhi = hy == 0 ? shi[0] : (hy == TH + 1 ? shi[2] : shi[1]);
+      if (pix < HPIX && y >= sy0 && y < sy1 && x >= xlo && x < xhi) {
         const size_t e0 = (((size_t)b * Hs + (y >> sh)) * Ws + (x >> sh)) * Cs + coff;
         v = *(const uint4*)(src + e0);
         if (a.unpool_idx) {          // keep only the elements whose forward argmax is this (y&1, x&1) position
@@ -796,8 +806,12 @@ __global__ __launch_bounds__(256, (NT == 1 && !PF_UPFRONT && (CONV_VARIANT == 50
     const int mode = epilogue_mode(a);      // kernel-uniform
     PixBox addb{a.add_row_lo, 1 << 30, 0, 1 << 30};
     if (a.dyn) {
-      const ConvDyn& d = *(const ConvDyn*)a.dyn;
-      addb = PixBox{max(addb.y0, d.add[0]), d.add[1], d.add[2], d.add[3]};
+      const ConvDyn& d = *(const ConvDyn*)(a.dyn + a.dyn_desc);
+      if (d.add_bands >= 0) {               // the tile's output rows lie in ONE band of the fan-in map
+        const int band = (POOL ? y0 >> 1 : y0) >> 3;
+        addb.x0 = a.dyn[d.add_bands + 2 * band];
+        addb.x1 = a.dyn[d.add_bands + 2 * band + 1];
+      }
     }
     // (in the un-pooled 64-channel-wave-tile kernel the raw-copy epilogue WITH bias spills ~30 registers -- 31 k cycles against
     // the generic path's 21 k -- so only its bias-free form is compiled there; that is the one the model uses: dec1.3)

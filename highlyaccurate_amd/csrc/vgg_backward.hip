@@ -58,29 +58,40 @@ struct WgradArgs {
   float* bpart;                        // [KS][Cout] partial bias gradients, or null
   int C1, C2, up1, B, H, W, Cout, Cin, tiles_x, tiles_y, ntile, KS;
   int row_begin;                       // first pixel row that carries gradient (even with g_unpool); rows above are skipped
-  const int* dyn;                      // device-side box {y0, y1, x0, x1} outside which g is zero (and unwritten), in this launch's
-                                       // pixel coordinates, or null: only the tiles that meet it are visited
+  const int* dyn;                      // data-dependent launch (bwd_fan_kernel): base of the device-side tables, or null
+  int dyn_desc;                        //   int offset of {live tiles per sample, list offset, band table of g or -1}: only the
+                                       //   listed tiles are visited, and g reads as zero outside the part its producer wrote
 };
 
-// tile enumeration of the weight-gradient kernels, restricted to the tiles that meet the gradient's box
+// tile enumeration of the weight-gradient kernels
 struct WgTiles {
-  int tx_lo, ntx, ty_lo, nty, ntile, gy0, gy1, gx0, gx1;
-  __device__ __forceinline__ WgTiles(const int* dyn, int H, int W, int row_begin, int tiles_x, int tiles_y, int ntile_all, int B)
-      : tx_lo(0), ntx(tiles_x), ty_lo(0), nty(tiles_y), ntile(ntile_all), gy0(0), gy1(H), gx0(0), gx1(W) {
+  const int* dyn; int nl, list, gb, ntile, tiles_x, tiles_y, row_begin, H, W, gsh;
+  __device__ __forceinline__ WgTiles(const int* dyn_, int desc, int H_, int W_, int row_begin_, int tiles_x_, int tiles_y_,
+                                     int ntile_all, int B, int gsh_)
+      : dyn(dyn_), nl(0), list(0), gb(-1), ntile(ntile_all), tiles_x(tiles_x_), tiles_y(tiles_y_), row_begin(row_begin_),
+        H(H_), W(W_), gsh(gsh_) {
     if (!dyn) return;
-    gy0 = max(dyn[0], 0); gy1 = min(dyn[1], H); gx0 = max(dyn[2], 0); gx1 = min(dyn[3], W);
-    if (gy0 >= gy1 || gx0 >= gx1) { ntile = 0; ntx = nty = 1; return; }
-    tx_lo = gx0 / 32; ntx = (gx1 + 31) / 32 - tx_lo;
-    ty_lo = max(gy0 - row_begin, 0) / WG_TH;
-    nty = min((gy1 - row_begin + WG_TH - 1) / WG_TH, tiles_y) - ty_lo;
-    if (nty <= 0) { ntile = 0; ntx = nty = 1; return; }
-    ntile = B * ntx * nty;
+    nl = dyn[desc]; list = dyn[desc + 1]; gb = dyn[desc + 2];
+    ntile = nl * B;
   }
-  __device__ __forceinline__ void origin(int tile, int row_begin, int& b, int& y0, int& x0) const {
-    int q = tile;
-    x0 = (tx_lo + q % ntx) * 32; q /= ntx;
-    y0 = row_begin + (ty_lo + q % nty) * WG_TH;
-    b = q / nty;
+  // origin of a tile and the column interval [gx0, gx1) of this launch's coordinates in which g may be read
+  __device__ __forceinline__ void origin(int tile, int& b, int& y0, int& x0, int& gx0, int& gx1) const {
+    gx0 = 0; gx1 = W;
+    if (dyn) {
+      b = tile / nl;
+      const int e = dyn[list + tile % nl];
+      y0 = (e >> 16) * WG_TH; x0 = (e & 0xffff) * 32;
+      if (gb >= 0) {
+        const int band = (y0 >> gsh) >> 3;
+        gx0 = dyn[gb + 2 * band] << gsh;
+        gx1 = min(dyn[gb + 2 * band + 1] << gsh, W);
+      }
+    } else {
+      int q = tile;
+      x0 = (q % tiles_x) * 32; q /= tiles_x;
+      y0 = row_begin + (q % tiles_y) * WG_TH;
+      b = q / tiles_y;
+    }
   }
 };
 
@@ -120,8 +131,9 @@ __global__ __launch_bounds__(256, CONV_VARIANT == 73 ? 1 : 2) void wgrad_kernel(
   const int part = t % PPX, pix0 = t / PPX;
   uint4 xr[NX], gr[NG];
   unsigned long long gid[NG];
-  const WgTiles tl(a.dyn, a.H, a.W, a.row_begin, a.tiles_x, a.tiles_y, a.ntile, a.B);
-  auto tile_origin = [&](int tile, int& b, int& y0, int& x0) { tl.origin(tile, a.row_begin, b, y0, x0); };
+  const WgTiles tl(a.dyn, a.dyn_desc, a.H, a.W, a.row_begin, a.tiles_x, a.tiles_y, a.ntile, a.B, a.g_unpool ? 1 : 0);
+  int gx0, gx1;                         // (set by every tile_origin call: the interval of the tile being loaded)
+  auto tile_origin = [&](int tile, int& b, int& y0, int& x0) { tl.origin(tile, b, y0, x0, gx0, gx1); };
   auto load_x = [&](int tile, int lo, int hi) {
     int b, y0, x0;
     tile_origin(tile, b, y0, x0);
@@ -146,7 +158,7 @@ __global__ __launch_bounds__(256, CONV_VARIANT == 73 ? 1 : 2) void wgrad_kernel(
       const int y = y0 + pix / 32, x = x0 + pix % 32;
       uint4 v = make_uint4(0, 0, 0, 0);
       unsigned long long id = 0;
-      if (y >= tl.gy0 && y < tl.gy1 && x >= tl.gx0 && x < tl.gx1) {
+      if (y < a.H && x >= gx0 && x < gx1) {
         const size_t e0 = (((size_t)b * Hg + (y >> gsh)) * Wg + (x >> gsh)) * a.Cout + co0 + part * EPL;
         v = *(const uint4*)((const T*)a.g + e0);
         if (a.g_unpool) __builtin_memcpy(&id, a.g_unpool + e0, EPL);
@@ -252,7 +264,8 @@ struct Wgrad0Args {
   float* bpart;          // [KS][2][64]
   int B, H, W, tiles_x, tiles_y, ntile, KS;
   int row_begin;         // first pixel row that carries gradient
-  const int* dyn;        // as WgradArgs::dyn
+  const int* dyn;        // as WgradArgs::dyn / dyn_desc
+  int dyn_desc;
 };
 
 template <typename T>
@@ -270,10 +283,10 @@ __global__ __launch_bounds__(256) void wgrad0_kernel(Wgrad0Args a) {
   const uint4 ones = frag_ones<T>();
   const int j = lane & 31, g5 = lane >> 5;            // B operand: column j = k index (c, ky, kx)
   const int jc = j < 27 ? j / 9 : 0, jky = (j % 9) / 3, jkx = j % 3;
-  const WgTiles tl(a.dyn, a.H, a.W, a.row_begin, a.tiles_x, a.tiles_y, a.ntile, a.B);
+  const WgTiles tl(a.dyn, a.dyn_desc, a.H, a.W, a.row_begin, a.tiles_x, a.tiles_y, a.ntile, a.B, 0);
   for (int tile = ks; tile < tl.ntile; tile += a.KS) {
-    int b, y0, x0;
-    tl.origin(tile, a.row_begin, b, y0, x0);
+    int b, y0, x0, gx0, gx1;
+    tl.origin(tile, b, y0, x0, gx0, gx1);
     __syncthreads();
     for (int e = t; e < 3 * (WG_TH + 2) * IW; e += 256) {
       const int c = e / ((WG_TH + 2) * IW), r = e % ((WG_TH + 2) * IW), iy = r / IW, ix = r % IW;
@@ -286,7 +299,7 @@ __global__ __launch_bounds__(256) void wgrad0_kernel(Wgrad0Args a) {
       const int pix = e / PPX, part = e % PPX;
       const int y = y0 + pix / 32, x = x0 + pix % 32;
       uint4 v = make_uint4(0, 0, 0, 0);
-      if (y >= tl.gy0 && y < tl.gy1 && x >= tl.gx0 && x < tl.gx1)
+      if (y < a.H && x >= gx0 && x < gx1)
         v = *(const uint4*)((const T*)a.g + (((size_t)b * a.H + y) * a.W + x) * 64 + part * EPL);
       *(uint4*)(Gs + pix * STR + part * 16) = v;
     }
@@ -389,13 +402,13 @@ static __global__ __launch_bounds__(256) void l2bwd_dot_kernel(const float* __re
   if (threadIdx.x == 0) part[(size_t)b * nblk + k] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
 }
 
-// `box` (optional, ORTHO only): the bounding box of the pixels where dy is not exactly zero, over the whole batch, kept as four
-// atomicMax targets {-y0, y1, -x0, x1} (memset to 0x80 bytes = "nothing yet") -- the seed of the data-dependent trimming below.
+// `rowiv` (optional, ORTHO only): per map row the column interval of the pixels where dy is not exactly zero, over the whole
+// batch, kept as atomicMax targets {-lo, hi} (memset to 0x80 bytes = "nothing yet") -- the seed of the data-dependent trimming.
 template <typename T, bool ORTHO>
 __global__ __launch_bounds__(256) void l2bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                           const double* __restrict__ part, const double* __restrict__ inv,
                                                           T* __restrict__ out, size_t per_sample, int nblk,
-                                                          int* __restrict__ box = nullptr, int C = 1, int Wl = 1) {
+                                                          int* __restrict__ rowiv = nullptr, int C = 1, int Wl = 1) {
   const int b = blockIdx.x / nblk, k = blockIdx.x % nblk;
   double dot = 0.0;
   if (!ORTHO)
@@ -405,27 +418,57 @@ __global__ __launch_bounds__(256) void l2bwd_apply_kernel(const float* __restric
   const float4* px = (const float4*)(x + (size_t)b * per_sample);
   const float4* pd = (const float4*)(dy + (size_t)b * per_sample);
   T* po = out + (size_t)b * per_sample;
-  int m[4] = {INT_MIN, INT_MIN, INT_MIN, INT_MIN};
+  if (ORTHO && rowiv) {
+    // Row tracking: the block takes a CONTIGUOUS slice of the sample (a few map rows), collects their intervals in LDS and
+    // touches the global counters once per row at the end.  (History: one filter read + atomic per non-zero vector made the
+    // counters an L2 hot spot -- 0.18 -> 2.6 ms for the three maps; one per wave and iteration still cost +0.45 ms.)
+    constexpr int MAXR = 64;
+    __shared__ int siv[2 * MAXR];
+    const size_t n4 = per_sample / 4, c = (n4 + nblk - 1) / nblk, start = (size_t)k * c, end = start + c < n4 ? start + c : n4;
+    const int r0 = (int)(start * 4 / (unsigned)C) / Wl, r1 = end > start ? (int)((end * 4 - 1) / (unsigned)C) / Wl : r0;
+    const bool local = r1 - r0 < MAXR;                                    // block-uniform
+    for (int e = threadIdx.x; e < 2 * MAXR; e += 256) siv[e] = INT_MIN;
+    __syncthreads();
+    for (size_t i = start + threadIdx.x; i < end; i += 256) {
+      const float4 v = pd[i];
+      store4(po + i * 4, c1 * v.x, c1 * v.y, c1 * v.z, c1 * v.w);
+      const bool nz = v.x != 0.f || v.y != 0.f || v.z != 0.f || v.w != 0.f;
+      const unsigned long long m = __ballot(nz);
+      if (m) {
+        // a wave's 64 vectors are consecutive in memory (1-4 pixels), so they almost always lie in ONE row: reduce the columns
+        // across the wave and let one lane update that row
+        const int pix = (int)(i * 4 / (unsigned)C), py = pix / Wl, pxx = pix - py * Wl;
+        const int first = __ffsll((long long)m) - 1;
+        const int py0 = __shfl(py, first, 64);
+        int nlo = nz ? -pxx : INT_MIN, hi = nz ? pxx + 1 : INT_MIN, row = py;
+        if (__ballot(nz && py != py0) == 0) {
+#pragma unroll
+          for (int o = 32; o > 0; o >>= 1) { nlo = max(nlo, __shfl_xor(nlo, o, 64)); hi = max(hi, __shfl_xor(hi, o, 64)); }
+          if ((int)(threadIdx.x & 63) != first) nlo = hi = INT_MIN;
+          row = py0;
+        }
+        if (nlo != INT_MIN) {
+          if (local) { atomicMax(&siv[2 * (row - r0)], nlo); atomicMax(&siv[2 * (row - r0) + 1], hi); }
+          else { atomicMax(rowiv + 2 * row, nlo); atomicMax(rowiv + 2 * row + 1, hi); }
+        }
+      }
+    }
+    __syncthreads();
+    if (local && (int)threadIdx.x <= r1 - r0 && siv[2 * threadIdx.x + 1] != INT_MIN) {
+      int* r = rowiv + 2 * (r0 + threadIdx.x);
+      // (the plain reads only filter: a stale value costs one redundant atomic, never a missed one)
+      if (siv[2 * threadIdx.x] > __hip_atomic_load(r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(r, siv[2 * threadIdx.x]);
+      if (siv[2 * threadIdx.x + 1] > __hip_atomic_load(r + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(r + 1, siv[2 * threadIdx.x + 1]);
+    }
+    return;
+  }
   for (size_t i = (size_t)k * 256 + threadIdx.x; i < per_sample / 4; i += (size_t)nblk * 256) {
     const float4 v = pd[i];
     if (ORTHO) {       // HLA_VGG_BWD_SCALE_INVARIANT: x . dy = 0 analytically, dx = dy / ||x||; x is not read
       store4(po + i * 4, c1 * v.x, c1 * v.y, c1 * v.z, c1 * v.w);
-      if (box && (v.x != 0.f || v.y != 0.f || v.z != 0.f || v.w != 0.f)) {
-        const int pix = (int)(i * 4 / (unsigned)C), py = pix / Wl, pxx = pix - py * Wl;
-        m[0] = max(m[0], -py); m[1] = max(m[1], py + 1); m[2] = max(m[2], -pxx); m[3] = max(m[3], pxx + 1);
-      }
     } else {
       const float4 u = px[i];
       store4(po + i * 4, c1 * v.x - c3 * u.x, c1 * v.y - c3 * u.y, c1 * v.z - c3 * u.z, c1 * v.w - c3 * u.w);
-    }
-  }
-  if (ORTHO && box) {
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) m[q] = max(m[q], __shfl_xor(m[q], o, 64));
-      // (the plain read only filters: a stale value costs one redundant atomic, never a missed one)
-      if ((threadIdx.x & 63) == 0 && m[q] > __hip_atomic_load(box + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(box + q, m[q]);
     }
   }
 }
@@ -533,80 +576,168 @@ __global__ __launch_bounds__(256) void conf_bwd_kernel(const T* __restrict__ act
 // host
 // ---------------------------------------------------------------------------------------------
 // Data-dependent trimming.  The satellite branch's incoming gradient is what the LM loop's bilinear taps scattered: for KITTI
-// geometry that is ~10 % of the texels, all of them inside less than half of the map's columns (the camera looks along +u).
-// l2bwd_apply records the bounding box of the non-zero gradient of each returned map; the kernel below pushes the three boxes
-// through the layer graph exactly like the static first rows further down (a 3x3 conv widens a box by one pixel, the 2x
-// upsample's sum-pool halves it, an unpool doubles it, a fan-in is a union) and writes one ConvDyn per data-gradient launch
-// and one box per weight-gradient launch.  Nothing is promised by the caller and nothing is approximated: outside its box a
-// gradient map is exactly zero, so skipping those tiles changes no value (only the weight-gradient summation order).
+// geometry ~10 % of the texels, inside the fan the camera sees (apex at the map centre, opening towards +u).  l2bwd_apply
+// records, per ROW of each returned map, the column interval of its non-zero gradient (over the batch); bwd_fan_kernel pushes
+// the three interval sets through the layer graph exactly -- a 3x3 conv: union of the three neighbouring rows, one pixel wider;
+// the 2x upsample's sum-pool: rows pairwise, halved; an unpool: doubled; a fan-in: union -- and derives, for every gradient map,
+// the part its producer WRITES: per band of 8 rows one column interval rounded out to the 32-px tiles (DYN_BANDS).  From those
+// it builds the list of live tiles of every data- and weight-gradient launch.  A launch visits only its live tiles and reads a
+// source as zero outside the part its producer wrote.  Nothing is promised by the caller and nothing is approximated: outside
+// its support a gradient is exactly zero, so no value changes (only the weight-gradient summation order).
 enum { DC_10, DC_9U, DC_9S, DC_8, DC_7U, DC_7S, DC_6, DC_5, DC_4, DC_3, DC_2, DC_1, DC_N };
 enum { DW_10, DW_9, DW_8, DW_7, DW_6, DW_5, DW_4, DW_3, DW_2, DW_1, DW_0, DW_N };
-constexpr int DYN_RAW = 0, DYN_CONV = 16, DYN_WG = DYN_CONV + 12 * DC_N, DYN_INTS = DYN_WG + 4 * DW_N;
-
-struct Bx { int y0, y1, x0, x1; };
-__device__ __forceinline__ bool bx_empty(const Bx& b) { return b.y0 >= b.y1 || b.x0 >= b.x1; }
-__device__ __forceinline__ Bx bx_clip(Bx b, int Hn, int Wn) {
-  b.y0 = max(b.y0, 0); b.y1 = min(b.y1, Hn); b.x0 = max(b.x0, 0); b.x1 = min(b.x1, Wn);
-  return bx_empty(b) ? Bx{0, 0, 0, 0} : b;
-}
-__device__ __forceinline__ Bx bx_grow(const Bx& b, int Hn, int Wn) {
-  return bx_empty(b) ? Bx{0, 0, 0, 0} : bx_clip(Bx{b.y0 - 1, b.y1 + 1, b.x0 - 1, b.x1 + 1}, Hn, Wn);
-}
-__device__ __forceinline__ Bx bx_down2(const Bx& b) { return bx_empty(b) ? Bx{0, 0, 0, 0} : Bx{b.y0 >> 1, (b.y1 + 1) >> 1, b.x0 >> 1, (b.x1 + 1) >> 1}; }
-__device__ __forceinline__ Bx bx_up2(const Bx& b) { return Bx{2 * b.y0, 2 * b.y1, 2 * b.x0, 2 * b.x1}; }
-__device__ __forceinline__ Bx bx_union(const Bx& a, const Bx& b) {
-  if (bx_empty(a)) return b;
-  if (bx_empty(b)) return a;
-  return Bx{min(a.y0, b.y0), max(a.y1, b.y1), min(a.x0, b.x0), max(a.x1, b.x1)};
-}
-
-static __global__ void bwd_boxes_kernel(int* __restrict__ dyn, int H, int W) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  const int H2 = H / 2, W2 = W / 2, H4 = H / 4, W4 = W / 4, H8 = H / 8, W8 = W / 8;
-  Bx lb[3];
-  const int hs[3] = {H8, H4, H2}, ws[3] = {W8, W4, W2};
-  for (int l = 0; l < 3; ++l) {
-    const int* r = dyn + DYN_RAW + 4 * l;        // {-y0, y1, -x0, x1}; untouched = 0x80808080
-    lb[l] = r[1] < 0 ? Bx{0, 0, 0, 0} : bx_clip(Bx{-r[0], r[1], -r[2], r[3]}, hs[l], ws[l]);
+// gradient maps (their resolution divisor): what a dgrad launch writes / a later launch reads
+enum { M_X21, M_D2A, M_X3P, M_X18, M_D1A, M_X8P, M_X15, M_A12, M_A10, M_X8, M_A5, M_X3, M_A0, M_N };
+struct DynLayout {
+  int seed[3];              // per-row {-lo, hi} atomicMax targets of d_feat[l] (memset to 0x80 bytes = "nothing yet")
+  int seed_ints;
+  int bands[M_N];           // per map: [ceil(rows / 8)] x {lo, hi}
+  int conv_desc[DC_N];      // ConvDyn
+  int conv_list[DC_N];
+  int wg_desc[DW_N];        // {n_live, list offset, band offset of g or -1}
+  int wg_list[DW_N];
+  int total;                // ints
+};
+static DynLayout dyn_layout(int H, int W) {
+  DynLayout L{};
+  int o = 0;
+  auto take = [&](int n) { const int r = o; o += (n + 3) & ~3; return r; };
+  const int hs[3] = {H / 8, H / 4, H / 2};
+  for (int l = 0; l < 3; ++l) L.seed[l] = take(2 * hs[l]);
+  L.seed_ints = o;
+  const int mdiv[M_N] = {2, 2, 2, 4, 4, 4, 8, 4, 4, 4, 2, 2, 1};
+  for (int m = 0; m < M_N; ++m) L.bands[m] = take(2 * ((H / mdiv[m] + 7) / 8));
+  const int cdiv[DC_N] = {2, 2, 2, 4, 4, 4, 4, 4, 4, 2, 2, 1};        // resolution divisor of each launch
+  for (int i = 0; i < DC_N; ++i) {
+    L.conv_desc[i] = take(4);
+    L.conv_list[i] = take(((H / cdiv[i] + 7) / 8) * ((W / cdiv[i] + 31) / 32));
   }
-  const Bx none{0, 0, 0, 0};
-  const Bx g_x21 = lb[2];                                          // H/2
-  const Bx g_d2a = bx_grow(g_x21, H2, W2);
-  const Bx c9 = bx_grow(g_d2a, H2, W2);                            // conv_dec2.1^T of g_d2a, still at H/2
-  const Bx g_x18 = bx_union(lb[1], bx_down2(c9));                  // H/4
-  const Bx g_d1a = bx_grow(g_x18, H4, W4);
-  const Bx c7 = bx_grow(g_d1a, H4, W4);
-  const Bx g_x15 = bx_union(lb[0], bx_down2(c7));                  // H/8
-  const Bx u15 = bx_up2(g_x15);                                    // H/4 (virtual unpool)
-  const Bx g_a12 = bx_grow(u15, H4, W4);
-  const Bx g_a10 = bx_grow(g_a12, H4, W4);
-  const Bx g_x8 = bx_union(bx_grow(g_a10, H4, W4), c7);            // + the x8 skip branch (g_x8p = c7)
-  const Bx u8 = bx_up2(g_x8);                                      // H/2
-  const Bx g_a5 = bx_grow(u8, H2, W2);
-  const Bx g_x3 = bx_union(bx_grow(g_a5, H2, W2), c9);             // + the x3 skip branch (g_x3p = c9)
-  const Bx u3 = bx_up2(g_x3);                                      // H
-  const Bx g_a0 = bx_grow(u3, H, W);
-  auto conv = [&](int i, const Bx& out, const Bx& src, const Bx& add) {
-    int* d = dyn + DYN_CONV + 12 * i;
-    d[0] = out.y0; d[1] = out.y1; d[2] = out.x0; d[3] = out.x1;
-    d[4] = src.y0; d[5] = src.y1; d[6] = src.x0; d[7] = src.x1;
-    d[8] = add.y0; d[9] = add.y1; d[10] = add.x0; d[11] = add.x1;
+  const int wdiv[DW_N] = {2, 2, 4, 4, 4, 4, 4, 2, 2, 1, 1};
+  for (int i = 0; i < DW_N; ++i) {
+    L.wg_desc[i] = take(4);
+    L.wg_list[i] = take(((H / wdiv[i] + WG_TH - 1) / WG_TH) * ((W / wdiv[i] + 31) / 32));
+  }
+  L.total = o;
+  return L;
+}
+
+typedef int2 IV;                                    // column interval [x, y); empty = {1 << 29, 0}
+__device__ __forceinline__ IV iv_empty() { return make_int2(1 << 29, 0); }
+__device__ __forceinline__ bool iv_none(const IV& a) { return a.x >= a.y; }
+__device__ __forceinline__ IV iv_union(const IV& a, const IV& b) { return make_int2(min(a.x, b.x), max(a.y, b.y)); }
+
+// one block of 1024 threads, thread = row.  H <= 1024 (the host falls back to the dense walk otherwise).
+static __global__ __launch_bounds__(1024) void bwd_fan_kernel(int* __restrict__ dyn, DynLayout L, int H, int W) {
+  __shared__ IV A[1024], Bv[1024], C9[512], C7[256];
+  const int t = threadIdx.x;
+  const int H2 = H / 2, W2 = W / 2, H4 = H / 4, W4 = W / 4, H8 = H / 8, W8 = W / 8;
+  auto seed = [&](int l, int row, int Wn) {
+    const int* r = dyn + L.seed[l] + 2 * row;
+    if (r[1] < 0) return iv_empty();
+    const IV v = make_int2(max(-r[0], 0), min(r[1], Wn));
+    return iv_none(v) ? iv_empty() : v;
   };
-  auto wg = [&](int i, const Bx& g) { int* d = dyn + DYN_WG + 4 * i; d[0] = g.y0; d[1] = g.y1; d[2] = g.x0; d[3] = g.x1; };
-  conv(DC_10, g_d2a, g_x21, none);
-  conv(DC_9U, bx_up2(g_x18), g_d2a, Bx{0, H4, 0, W4});             // (sum-pooled launch: `out` in H/2 coordinates; l2_18 is dense)
-  conv(DC_9S, c9, g_d2a, none);
-  conv(DC_8, g_d1a, g_x18, none);
-  conv(DC_7U, bx_up2(g_x15), g_d1a, Bx{0, H8, 0, W8});
-  conv(DC_7S, c7, g_d1a, none);
-  conv(DC_6, g_a12, u15, none);
-  conv(DC_5, g_a10, g_a12, none);
-  conv(DC_4, g_x8, g_a10, c7);
-  conv(DC_3, g_a5, u8, none);
-  conv(DC_2, g_x3, g_a5, c9);
-  conv(DC_1, g_a0, u3, none);
-  wg(DW_10, g_x21); wg(DW_9, g_d2a); wg(DW_8, g_x18); wg(DW_7, g_d1a); wg(DW_6, u15); wg(DW_5, g_a12);
-  wg(DW_4, g_a10); wg(DW_3, u8); wg(DW_2, g_a5); wg(DW_1, u3); wg(DW_0, g_a0);
+  auto at = [&](const IV* src, int row, int n) { return (row >= 0 && row < n) ? src[row] : iv_empty(); };
+  auto grow = [&](const IV* src, int row, int n, int Wn) {
+    IV v = iv_union(iv_union(at(src, row - 1, n), at(src, row, n)), at(src, row + 1, n));
+    if (iv_none(v)) return iv_empty();
+    return make_int2(max(v.x - 1, 0), min(v.y + 1, Wn));
+  };
+  auto down2 = [&](const IV* src, int row, int n) {
+    const IV v = iv_union(at(src, 2 * row, n), at(src, 2 * row + 1, n));
+    return iv_none(v) ? iv_empty() : make_int2(v.x >> 1, (v.y + 1) >> 1);
+  };
+  auto up2 = [&](const IV* src, int row, int n) {
+    const IV v = at(src, row >> 1, n);
+    return iv_none(v) ? iv_empty() : make_int2(2 * v.x, 2 * v.y);
+  };
+  // what the producer of map m writes: per band of 8 rows the support rounded out to 32-px tiles
+  auto bands = [&](int m, const IV* src, int n, int Wn) {
+    __syncthreads();
+    if (t < (n + 7) / 8) {
+      IV v = iv_empty();
+      for (int r = 0; r < 8; ++r) v = iv_union(v, at(src, 8 * t + r, n));
+      if (iv_none(v)) v = make_int2(0, 0);
+      else v = make_int2(v.x & ~31, min((v.y + 31) & ~31, Wn));
+      dyn[L.bands[m] + 2 * t] = v.x;
+      dyn[L.bands[m] + 2 * t + 1] = v.y;
+    }
+    __syncthreads();
+  };
+  if (t < H2) A[t] = seed(2, t, W2);                          bands(M_X21, A, H2, W2);
+  if (t < H2) Bv[t] = grow(A, t, H2, W2);                     bands(M_D2A, Bv, H2, W2);
+  if (t < H2) C9[t] = grow(Bv, t, H2, W2);                    bands(M_X3P, C9, H2, W2);     // conv_dec2.1^T of g_d2a, still at H/2
+  if (t < H4) A[t] = iv_union(seed(1, t, W4), down2(C9, t, H2));   bands(M_X18, A, H4, W4);
+  if (t < H4) Bv[t] = grow(A, t, H4, W4);                     bands(M_D1A, Bv, H4, W4);
+  if (t < H4) C7[t] = grow(Bv, t, H4, W4);                    bands(M_X8P, C7, H4, W4);
+  if (t < H8) A[t] = iv_union(seed(0, t, W8), down2(C7, t, H4));   bands(M_X15, A, H8, W8);
+  if (t < H4) Bv[t] = up2(A, t, H8);                          __syncthreads();               // virtual unpool of g_x15
+  if (t < H4) A[t] = grow(Bv, t, H4, W4);                     bands(M_A12, A, H4, W4);
+  if (t < H4) Bv[t] = grow(A, t, H4, W4);                     bands(M_A10, Bv, H4, W4);
+  if (t < H4) A[t] = iv_union(grow(Bv, t, H4, W4), C7[t]);    bands(M_X8, A, H4, W4);        // + the x8 skip branch
+  if (t < H2) Bv[t] = up2(A, t, H4);                          __syncthreads();
+  if (t < H2) A[t] = grow(Bv, t, H2, W2);                     bands(M_A5, A, H2, W2);
+  if (t < H2) Bv[t] = iv_union(grow(A, t, H2, W2), C9[t]);    bands(M_X3, Bv, H2, W2);       // + the x3 skip branch
+  if (t < H) A[t] = up2(Bv, t, H2);                           __syncthreads();
+  if (t < H) Bv[t] = grow(A, t, H, W);                        bands(M_A0, Bv, H, W);
+  __threadfence_block();
+  __syncthreads();
+
+  // ---- live-tile lists: one wave per launch.  entry = (tile row << 16) | tile column
+  const int lane = t & 63, wv = t >> 6;
+  // dgrad launch i: out map, resolution divisor, pooled (the sum-pool launches run at twice the out map's resolution),
+  // source map (-1: dense, written by l2bwd_apply), add map (-1: none / dense)
+  const int c_out[DC_N] = {M_D2A, M_X18, M_X3P, M_D1A, M_X15, M_X8P, M_A12, M_A10, M_X8, M_A5, M_X3, M_A0};
+  const int c_div[DC_N] = {2, 2, 2, 4, 4, 4, 4, 4, 4, 2, 2, 1};
+  const int c_pool[DC_N] = {0, 1, 0, 0, 1, 0, 0, 0, 0, 0, 0, 0};
+  const int c_src[DC_N] = {-1, M_D2A, M_D2A, M_X18, M_D1A, M_D1A, M_X15, M_A12, M_A10, M_X8, M_A5, M_X3};
+  const int c_add[DC_N] = {-1, -1, -1, -1, -1, -1, -1, -1, M_X8P, -1, M_X3P, -1};
+  // wgrad launch i: gradient map, launch resolution divisor, g at half the launch resolution (virtual unpool)
+  const int w_g[DW_N] = {M_X21, M_D2A, M_X18, M_D1A, M_X15, M_A12, M_A10, M_X8, M_A5, M_X3, M_A0};
+  const int w_div[DW_N] = {2, 2, 4, 4, 4, 4, 4, 2, 2, 1, 1};
+  const int w_sh[DW_N] = {0, 0, 0, 0, 1, 0, 0, 1, 0, 1, 0};
+  for (int job = wv; job < DC_N + DW_N; job += 16) {
+    const bool isw = job >= DC_N;
+    const int i = isw ? job - DC_N : job;
+    const int div = isw ? w_div[i] : c_div[i], th = isw ? WG_TH : 8;
+    const int Hl = H / div, Wl = W / div, tiles_y = (Hl + th - 1) / th, tiles_x = (Wl + 31) / 32;
+    const int map = isw ? w_g[i] : c_out[i];
+    const int* bd = dyn + L.bands[map];
+    int* list = dyn + (isw ? L.wg_list[i] : L.conv_list[i]);
+    int base = 0;
+    for (int ty0 = 0; ty0 < tiles_y; ty0 += 64) {
+      const int ty = ty0 + lane;
+      int tx0 = 0, tx1 = 0;
+      if (ty < tiles_y) {
+        // band of the map this tile row belongs to, and the map -> launch column scale
+        const int sh = isw ? w_sh[i] : 0, pool = isw ? 0 : c_pool[i];
+        const int band = pool ? (ty * 8 / 2) >> 3 : ((ty * th) >> sh) >> 3;
+        const int lo = bd[2 * band], hi = bd[2 * band + 1];
+        const int up = pool ? 1 : sh;                        // map columns -> launch columns: << up
+        tx0 = (lo << up) / 32;
+        tx1 = min(((hi << up) + 31) / 32, tiles_x);
+      }
+      const int cnt = max(tx1 - tx0, 0);
+      int inc = cnt;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(inc, o, 64); if (lane >= o) inc += v; }
+      int w = base + inc - cnt;
+      for (int tx = tx0; tx < tx1; ++tx) list[w++] = (ty << 16) | tx;
+      base += __shfl(inc, 63, 64);
+    }
+    if (lane == 0) {
+      int* d = dyn + (isw ? L.wg_desc[i] : L.conv_desc[i]);
+      d[0] = base;
+      d[1] = isw ? L.wg_list[i] : L.conv_list[i];
+      if (isw) {
+        d[2] = map == M_X21 ? -1 : L.bands[map];             // g_x21 is dense (l2bwd_apply writes every element)
+        d[3] = 0;
+      } else {
+        d[2] = c_src[i] < 0 ? -1 : L.bands[c_src[i]];
+        d[3] = c_add[i] < 0 ? -1 : L.bands[c_add[i]];
+      }
+    }
+  }
 }
 
 struct BwdPlan {
@@ -650,7 +781,7 @@ static void bwd_plan(int B, int H, int W, int dtype, BwdPlan* p, bool level4 = f
   p->part = take(maxpart);
   p->bpart = take((size_t)2048 * 256 * 4);
   p->dz = take((level4 ? P : P / 4) * sizeof(float));
-  p->dyn = take(DYN_INTS * sizeof(int));
+  p->dyn = take((size_t)dyn_layout(H, W).total * sizeof(int));
   p->g_x24 = p->g_d3a = p->g_x2p = p->g_c2 = p->l2_21 = 0;
   if (level4) {
     p->g_x24 = take(P * 64 * es); p->g_d3a = take(P * 64 * es); p->g_x2p = take(P * 64 * es); p->g_c2 = take(P * 64 * es);
@@ -692,11 +823,14 @@ int vgg_backward_t(const float* x, const hla_vgg_params* prm, const char* packed
                          (size_t)H * W * 64};
   // at level 4 x21 also feeds conv_dec3, so its L2-norm gradient goes to a side buffer and is merged by that dgrad's epilogue
   void* l2out[4] = {G(bp.l2_15), G(bp.l2_18), level4 ? G(bp.l2_21) : G(bp.g_x21), G(bp.g_x24)};
-  // data-dependent trimming (see bwd_boxes_kernel): needs exact zeros outside the support, i.e. the one-pass L2 backward, and
-  // no confidence-head gradient (which is dense)
-  const bool dynamic = !level4 && (flags & HLA_VGG_BWD_SCALE_INVARIANT) && !(flags & HLA_VGG_BWD_DENSE) && !(conf && d_conf);
+  // data-dependent trimming (see bwd_fan_kernel): needs exact zeros outside the support, i.e. the one-pass L2 backward, and no
+  // confidence-head gradient (which is dense).  Not combined with the caller's static first rows (the ground branch: every
+  // column of its bottom half carries gradient, so there is nothing to gain).
+  const bool dynamic = !level4 && (flags & HLA_VGG_BWD_SCALE_INVARIANT) && !(flags & HLA_VGG_BWD_DENSE) && !(conf && d_conf) &&
+                       first_row8 == 0 && H <= 1024;
+  const DynLayout dl = dyn_layout(H, W);
   int* dynp = (int*)(bw + bp.dyn);
-  if (dynamic) HLA_CHECK_HIP(hipMemsetAsync(dynp + DYN_RAW, 0x80, 12 * sizeof(int), st));
+  if (dynamic) HLA_CHECK_HIP(hipMemsetAsync(dynp, 0x80, (size_t)dl.seed_ints * sizeof(int), st));
   for (int l = 0; l < NL; ++l) {
     int nblk = (int)(per[l] / 4 / 256 / 8);
     nblk = nblk < 1 ? 1 : (nblk > 64 ? 64 : nblk);
@@ -705,7 +839,7 @@ int vgg_backward_t(const float* x, const hla_vgg_params* prm, const char* packed
       hla_prof_begin(K_ELEMWISE, 0, (double)B * per[l] * (4 + sizeof(T)), st);
       const int Cl[4] = {256, 128, 64, 64};
       hipLaunchKernelGGL((l2bwd_apply_kernel<T, true>), dim3(B * nblk), dim3(256), 0, st, feat[l], d_feat[l], part,
-                         inv_norm + (size_t)l * B, (T*)l2out[l], per[l], nblk, dynamic ? dynp + DYN_RAW + 4 * l : (int*)nullptr,
+                         inv_norm + (size_t)l * B, (T*)l2out[l], per[l], nblk, dynamic ? dynp + dl.seed[l] : (int*)nullptr,
                          Cl[l], W >> (3 - l));
     } else {
       hla_prof_begin(K_ELEMWISE, 0, (double)B * per[l] * (16 + sizeof(T)), st);
@@ -716,7 +850,7 @@ int vgg_backward_t(const float* x, const hla_vgg_params* prm, const char* packed
     hla_prof_end(st);
   }
 
-  if (dynamic) hipLaunchKernelGGL(bwd_boxes_kernel, dim3(1), dim3(64), 0, st, dynp, H, W);
+  if (dynamic) hipLaunchKernelGGL(bwd_fan_kernel, dim3(1), dim3(1024), 0, st, dynp, dl, H, W);
 
   // ---- confidence heads (only the ground branch with using_weight=1 ever has d_conf): adds into the raw-map gradients
   if (conf && d_conf) {
@@ -746,7 +880,7 @@ int vgg_backward_t(const float* x, const hla_vgg_params* prm, const char* packed
   auto dgrad = [&](int l, int c0, int n, const void* gsrc, const unsigned char* unpool, int Hout, int Wout, void* out,
                    const void* mask, const void* add, bool pool_sum, int row_begin = 0, int src_lo = 0, int add_lo = 0, int dc = -1) {
     ConvArgs a{};
-    a.dyn = (dynamic && dc >= 0) ? dynp + DYN_CONV + 12 * dc : nullptr;
+    a.dyn = (dynamic && dc >= 0) ? dynp : nullptr; a.dyn_desc = dc >= 0 ? dl.conv_desc[dc] : 0;
     a.src1 = gsrc; a.C1 = kLayers[l].cout; a.unpool_idx = unpool;
     const int nstage = kLayers[l].cout / KC;
     a.wpk = (const uint4*)(packedT + packed_offset(l, dtype)) + (size_t)(c0 / 32) * nstage * 18 * 64;
@@ -758,7 +892,7 @@ int vgg_backward_t(const float* x, const hla_vgg_params* prm, const char* packed
   auto wgrad = [&](int l, const void* x1, int C1, const void* x2, int C2, int up1, const void* g, const unsigned char* unpool,
                    int Hout, int Wout, int row_begin = 0, int dw = -1) {
     WgradArgs a{};
-    a.dyn = (dynamic && dw >= 0) ? dynp + DYN_WG + 4 * dw : nullptr;
+    a.dyn = (dynamic && dw >= 0) ? dynp : nullptr; a.dyn_desc = dw >= 0 ? dl.wg_desc[dw] : 0;
     a.x1 = x1; a.x2 = x2; a.C1 = C1; a.C2 = C2; a.up1 = up1; a.g = g; a.g_unpool = unpool;
     a.B = B; a.H = Hout; a.W = Wout; a.Cout = kLayers[l].cout; a.Cin = kLayers[l].cin;
     a.row_begin = row_begin > 0 ? row_begin : 0;
@@ -859,7 +993,7 @@ int vgg_backward_t(const float* x, const hla_vgg_params* prm, const char* packed
     Wgrad0Args a{};
     a.x = x; a.g = G(bp.g_a0); a.B = B; a.H = H; a.W = W;
     a.row_begin = level4 ? 0 : n_a0;
-    a.dyn = dynamic ? dynp + DYN_WG + 4 * DW_0 : nullptr;
+    a.dyn = dynamic ? dynp : nullptr; a.dyn_desc = dl.wg_desc[DW_0];
     a.tiles_x = (W + 31) / 32; a.tiles_y = (H - a.row_begin + WG_TH - 1) / WG_TH; a.ntile = B * a.tiles_x * a.tiles_y;
     a.KS = a.ntile < 1024 ? a.ntile : 1024;
     a.part = (float*)(bw + bp.part); a.bpart = (float*)(bw + bp.bpart);

@@ -1300,10 +1300,10 @@ def test_dead_ground_rows_elimination_is_exact(monkeypatch):
 
 @pytest.mark.parametrize('precision', ['fp32', 'bf16'])
 def test_backward_dynamic_trimming_is_exact(precision):
-    """hla_vgg_backward finds the bounding box of the non-zero incoming gradient and skips every tile of every dgrad / wgrad
-    launch that it proves zero (vgg_backward.hip, bwd_boxes_kernel).  Against the dense walk (HLA_VGG_BWD_DENSE) the gradients
-    may differ only by the summation order of the weight-gradient partials -- for boxes at odd offsets, one per level, a
-    single texel, per-sample different footprints, and no gradient at all."""
+    """hla_vgg_backward finds, per map row, the column interval of the non-zero incoming gradient and skips every tile of every
+    dgrad / wgrad launch that it proves zero (vgg_backward.hip, bwd_fan_kernel).  Against the dense walk (HLA_VGG_BWD_DENSE) the
+    gradients may differ only by the summation order of the weight-gradient partials -- for boxes at odd offsets, one per level,
+    a single texel, per-sample different footprints, a sparse wedge, and no gradient at all."""
     from oracle import ref_cpu as O
     from highlyaccurate_amd.VGG import VGGUnet, vgg_forward_nhwc, vgg_backward_nhwc
     d = _dev()
@@ -1335,8 +1335,19 @@ def test_backward_dynamic_trimming_is_exact(precision):
         'nothing': [[], [], []],
         'everything': [[(0, (0, 12, 0, 20))], [(1, (0, 24, 0, 40))], [(2, (0, 48, 0, 80))]],
     }
-    for tag, spec in cases.items():
-        dfe = boxes(spec)
+    def fan():          # the shape the LM loop produces: a wedge opening towards +x from the map centre, per sample slightly rotated
+        out = []
+        for (b, h, w, c) in shapes:
+            g = torch.zeros(b, h, w, c)
+            ys, xs = torch.meshgrid(torch.arange(h, dtype=torch.float32), torch.arange(w, dtype=torch.float32), indexing='ij')
+            for bi in range(b):
+                m = ((ys - h / 2 - 0.1 * bi * (xs - w / 2)).abs() < 0.45 * (xs - w / 2 - 1)) & (((xs + 3 * ys).long() % 4) == 0)
+                g[bi][m] = T(rs.standard_normal((int(m.sum()), c)).astype(np.float32))
+            out.append(g.to(d))
+        return out
+
+    for tag, spec in list(cases.items()) + [('fan', None)]:
+        dfe = fan() if spec is None else boxes(spec)
         g_dense = vgg_backward_nhwc(net, ctx, dfe, scale_invariant=True, dense=True)
         g_trim = vgg_backward_nhwc(net, ctx, dfe, scale_invariant=True)
         worst, wk = 0.0, ''
