@@ -1078,10 +1078,11 @@ __global__ __launch_bounds__(256, 2) void conv02_kernel(Conv02Args a0) {
 //   mode 2 (dgrad): the packed conv is the transpose: Cout' = Cin_orig, Cin' = Cout_orig, taps flipped:
 //            v = w_orig[cin'][cout'][8 - tap]  with w_orig laid out [Cout_orig = Cin'][Cin_orig = Cout'][9]
 template <typename T>
-__global__ void pack_weights_kernel(const float* __restrict__ w, T* __restrict__ out, int Cout, int Cin, int first) {
+__device__ __forceinline__ void pack_weights_body(const float* __restrict__ w, T* __restrict__ out, int Cout, int Cin, int first,
+                                                  size_t e0, size_t stride) {
   constexpr int EPL = 16 / sizeof(T), KC = SB / sizeof(T), NFRAG = 32 / (2 * EPL);
   const size_t total = first == 1 ? (size_t)(Cout / 32) * NFRAG * 64 * EPL : (size_t)Cout * Cin * 9;
-  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+  for (size_t e = e0; e < total; e += stride) {
     size_t r = e;
     const int j = r % EPL; r /= EPL;
     const int lane = r % 64; r /= 64;
@@ -1102,6 +1103,22 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, T* __restrict__
     }
     out[e] = (T)v;
   }
+}
+template <typename T>
+__global__ void pack_weights_kernel(const float* __restrict__ w, T* __restrict__ out, int Cout, int Cin, int first) {
+  pack_weights_body<T>(w, out, Cout, Cin, first, (size_t)blockIdx.x * blockDim.x + threadIdx.x, (size_t)gridDim.x * blockDim.x);
+}
+// every layer of a network in ONE launch (blockIdx.y = table row): a training step repacks both directions of both networks,
+// 44 launches of a few microseconds each when done layer by layer
+struct PackTable {
+  const float* w[16]; size_t off[16];      // source weights, byte offset of the packed layer
+  int cout[16], cin[16], first[16];
+};
+template <typename T>
+__global__ void pack_weights_multi_kernel(PackTable tb, char* __restrict__ packed) {
+  const int l = blockIdx.y;
+  pack_weights_body<T>(tb.w[l], (T*)(packed + tb.off[l]), tb.cout[l], tb.cin[l], tb.first[l],
+                       (size_t)blockIdx.x * blockDim.x + threadIdx.x, (size_t)gridDim.x * blockDim.x);
 }
 
 // Split-fp16 packing: the same fragment order with the two k-groups of a stage replaced by (hi, lo) of ONE 16-channel

@@ -13,6 +13,20 @@ void vgg_pack_all(const hla_vgg_params* prm, char* packed, int dtype, hipStream_
   float* tail = (float*)(packed + packed_offset(kAllLayers, dtype));
   unsigned* scratch = (unsigned*)tail + 32;
   if (Prec<T>::SPLIT) (void)hipMemsetAsync(tail, 0, kPackTailBytes, st);
+  if constexpr (!Prec<T>::SPLIT) {
+    PackTable tb{};
+    int n = 0;
+    for (int l = 0; l < kAllLayers; ++l) {
+      if (l >= kPackedLayers && !prm->w[l]) continue;      // conv_dec3.* only when the caller supplies its padded weights
+      tb.w[n] = prm->w[l]; tb.off[n] = packed_offset(l, dtype); tb.cout[n] = kLayers[l].cout; tb.cin[n] = kLayers[l].cin;
+      tb.first[n] = l == 0 ? 1 : 0;
+      ++n;
+    }
+    hla_prof_begin(K_PACK, 0, (double)packed_offset(kAllLayers, dtype) * (1.0 + 4.0 / sizeof(T)), st);
+    hipLaunchKernelGGL((pack_weights_multi_kernel<T>), dim3(256, n), dim3(256), 0, st, tb, packed);
+    hla_prof_end(st);
+    return;
+  }
   for (int l = 0; l < kAllLayers; ++l) {
     if (l >= kPackedLayers && !prm->w[l]) continue;        // conv_dec3.* only when the caller supplies its padded weights
     const size_t n = l == 0 ? (size_t)2 * 32 * 32 : (size_t)kLayers[l].cin * kLayers[l].cout * 9;
@@ -26,9 +40,6 @@ void vgg_pack_all(const hla_vgg_params* prm, char* packed, int dtype, hipStream_
       hipLaunchKernelGGL(pack_weights_split_kernel, dim3(grid), dim3(256), 0, st, prm->w[l],
                          (f16*)(packed + packed_offset(l, dtype)), kLayers[l].cout, kLayers[l].cin, l == 0 ? 1 : 0,
                          (const unsigned*)(scratch + l), tail + l);
-    } else {
-      hipLaunchKernelGGL((pack_weights_kernel<T>), dim3(grid), dim3(256), 0, st, prm->w[l],
-                         (T*)(packed + packed_offset(l, dtype)), kLayers[l].cout, kLayers[l].cin, l == 0 ? 1 : 0);
     }
     hla_prof_end(st);
   }

@@ -792,14 +792,16 @@ static void bwd_plan(int B, int H, int W, int dtype, BwdPlan* p, bool level4 = f
 
 template <typename T>
 void vgg_pack_all_T(const hla_vgg_params* prm, char* packed, int dtype, hipStream_t st) {
+  PackTable tb{};
+  int n = 0;
   for (int l = 1; l < kAllLayers; ++l) {          // conv0 needs no data gradient
     if (l >= kPackedLayers && !prm->w[l]) continue;
-    const size_t n = (size_t)kLayers[l].cin * kLayers[l].cout * 9;
-    const int grid = (int)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024);
     // transposed conv: Cout' = cin, Cin' = cout
-    hipLaunchKernelGGL((pack_weights_kernel<T>), dim3(grid), dim3(256), 0, st, prm->w[l],
-                       (T*)(packed + packed_offset(l, dtype)), kLayers[l].cin, kLayers[l].cout, 2);
+    tb.w[n] = prm->w[l]; tb.off[n] = packed_offset(l, dtype); tb.cout[n] = kLayers[l].cin; tb.cin[n] = kLayers[l].cout;
+    tb.first[n] = 2;
+    ++n;
   }
+  hipLaunchKernelGGL((pack_weights_multi_kernel<T>), dim3(256, n), dim3(256), 0, st, tb, packed);
 }
 
 template <typename T>
