@@ -149,10 +149,11 @@ size_t hla_vgg_bwd_workspace_bytes(int B, int H, int W, int level, int dtype);
  *                  scale (LM_update renormalises both maps, models_kitti.py:982-990), so d_feat[l] is orthogonal to feat[l]
  *                  and the L2_norm Jacobian  dx = a*dy - a^3 (x.dy) x  (a = 1/||x||) reduces to a*dy: the (x.dy) pass and the
  *                  re-read of feat are skipped.  (In the reference that dot product is fp32 rounding noise, ~1e-7 |x||dy|.)
- *                  With this flag (level 3, no d_conf) the call also finds the bounding box of the pixels where each
- *                  d_feat[l] is not exactly zero and skips every tile of every data- and weight-gradient launch whose
- *                  gradient is zero as a consequence (the satellite maps' gradient covers ~10 % of the texels inside
- *                  half of the columns).  Values do not change; HLA_VGG_BWD_DENSE switches it off.
+ *                  With this flag (level 3, no d_conf, first_row8 == 0, H <= 1024) the call also finds, per map row, the
+ *                  column interval in which d_feat[l] is not exactly zero and skips every tile of every data- and
+ *                  weight-gradient launch whose gradient is zero as a consequence (the satellite maps' gradient covers
+ *                  ~10 % of the texels: the fan the camera sees).  Values do not change (weight gradients: the order of
+ *                  the partial sums does); HLA_VGG_BWD_DENSE switches it off.
  * first_row8       0, or f in [4, H/8): a promise that d_feat[0] / d_feat[1] / d_feat[2] (and d_conf) are zero above rows
  *                  f / 2f / 4f -- the LM loop only reads rows h_l/2.. of the ground maps, so that is where its gradient
  *                  lives.  Every activation's gradient is then exactly zero above a first row that follows from the layer
