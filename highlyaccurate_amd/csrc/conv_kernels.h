@@ -1254,6 +1254,19 @@ static __global__ __launch_bounds__(256) void inv_norm_kernel(const double* __re
   __syncthreads();
   if (threadIdx.x == 0) inv[b] = 1.0 / fmax(sqrt((sh[0] + sh[1]) + (sh[2] + sh[3])), 1e-12);
 }
+// all levels of a network in one launch: blockIdx.y = level
+struct InvNormArgs { const double* ss[4]; int np[4]; double* inv; int B; };
+static __global__ __launch_bounds__(256) void inv_norm_multi_kernel(InvNormArgs a) {
+  __shared__ double sh[4];
+  const int b = blockIdx.x, l = blockIdx.y, np = a.np[l];
+  const double* sumsq = a.ss[l];
+  double s = 0.0;
+  for (int i = threadIdx.x; i < np; i += 256) s += sumsq[(size_t)b * np + i];
+  s = wave_sum_f64(s);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) a.inv[(size_t)l * a.B + b] = 1.0 / fmax(sqrt((sh[0] + sh[1]) + (sh[2] + sh[3])), 1e-12);
+}
 // scale_kernel: in-place x *= inv[b] (fp64 multiply, one rounding)
 static __global__ __launch_bounds__(256) void scale_kernel(float* __restrict__ x, const double* __restrict__ inv, size_t per_sample,
                                                     int blocks_per_sample) {

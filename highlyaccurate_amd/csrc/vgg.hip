@@ -156,10 +156,16 @@ int vgg_forward_t(const float* x, const hla_vgg_params* prm, const char* packed,
     const size_t per[4] = {(size_t)(H / 8) * (W / 8) * 256, (size_t)(H / 4) * (W / 4) * 128, (size_t)(H / 2) * (W / 2) * 64,
                            (size_t)H * W * 64};
     double* inv = inv_norm ? inv_norm : (double*)(w + pl.inv);
-    for (int l = 0; l < NL; ++l) {
-      hla_prof_begin(K_L2NORM, 0, (double)B * pl.np[l] * 8, st);
-      hipLaunchKernelGGL(inv_norm_kernel, dim3(B), dim3(256), 0, st, (const double*)(w + pl.ss[l]), np_used[l], inv + (size_t)l * B);
+    {
+      InvNormArgs ia{};
+      double bytes = 0;
+      for (int l = 0; l < NL; ++l) { ia.ss[l] = (const double*)(w + pl.ss[l]); ia.np[l] = np_used[l]; bytes += (double)B * pl.np[l] * 8; }
+      ia.inv = inv; ia.B = B;
+      hla_prof_begin(K_L2NORM, 0, bytes, st);
+      hipLaunchKernelGGL(inv_norm_multi_kernel, dim3(B, NL), dim3(256), 0, st, ia);
       hla_prof_end(st);
+    }
+    for (int l = 0; l < NL; ++l) {
       if (flags & HLA_VGG_DEFER_NORM) continue;
       int bps = (int)(per[l] / 4 / 256 / 4);
       bps = bps < 1 ? 1 : (bps > 64 ? 64 : bps);
