@@ -280,6 +280,53 @@ class S2GPBase(nn.Module):
         _lib.check(rc, 'hla_s2g_lm_solve_bwd')
         return d_sat, d_grd, d_conf, d_lambda
 
+    def _features(self, sat_map, grd_img, want_conf, return_confs):
+        """Both extractors of the inference path: (sat_feats, sat_inv, grd_feats, grd_confs, grd_inv), normalisation deferred."""
+        # Reduced-precision inference modes: the LM loop reads fp16 feature maps (written saturating by the three feature
+        # layers' epilogues; also in bf16 mode: bf16's 8 significand bits moved the worst golden seed's pose 23x, fp16's 11
+        # move it 1.6x).  With the gather loop written on channel PAIRS (lm_solve.hip) the accumulate kernels are VALU-bound on
+        # 16-bit maps and 30 % faster than on fp32 ones: +7 % pairs/s.  args.lm_feat16 = 0 / HLA_LM_FEAT16=0 keeps fp32 maps;
+        # the fp32-class modes and every training path always do.
+        f16 = (self.SatFeatureNet.precision in ('bf16', 'fp16') and self.level == 3
+               and bool(getattr(self.args, 'lm_feat16', 1)) and os.environ.get('HLA_LM_FEAT16', '1') != '0')
+        sat_feats, _, sat_inv = vgg_forward_nhwc(self.SatFeatureNet, sat_map, want_conf=False, defer_norm=True, feat16=f16)
+        grd_in = grd_img
+        # (only LM_update renormalises the ground features; SGD / ADAM see the whole-map L2_norm scale, so they need every row)
+        dead_ok = (not return_confs and self.level == 3 and getattr(self.args, 'Optimizer', 'LM') == 'LM'
+                   and os.environ.get('HLA_GRD_CROP', '1') != '0')
+        skip = dead_ground_rows(grd_img.shape[-2]) if dead_ok else 0
+        if skip:
+            grd_in = grd_img[:, :, skip:, :].contiguous()
+        # ... and inside the extractor every layer only computes the rows the LM loop's rows depend on
+        f8 = ((grd_img.shape[-2] // 8) // 2 - skip // 8) if dead_ok else 0
+        f8 = f8 if (f8 >= 4 and os.environ.get('HLA_GRD_TRIM', '1') != '0') else 0
+        grd_feats, grd_confs, grd_inv = vgg_forward_nhwc(self.GrdFeatureNet, grd_in, want_conf=want_conf, defer_norm=True,
+                                                         first_row8=f8, feat16=f16)
+        return sat_feats, sat_inv, grd_feats, grd_confs, grd_inv
+
+    def _localise_pipelined(self, sat_map, grd_img, level_first):
+        """Experiment (HLA_LM_PIPELINE=1): the batch in two halves, the LM loop of the first half on a side stream underneath the
+        second half's extractors -- the loop is latency-bound (a quarter of the HBM rate, small grids), the extractors compute-bound."""
+        B = sat_map.shape[0]
+        h = B // 2
+        cur = torch.cuda.current_stream()
+        side = self.__dict__.get('_side_stream')
+        if side is None or side.device != sat_map.device:
+            side = self.__dict__['_side_stream'] = torch.cuda.Stream(device=sat_map.device)
+        f0 = self._features(sat_map[:h], grd_img[:h], False, False)
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            t0 = self.lm_solve(f0[0], f0[2], f0[3], grd_img.shape[-2:], None, level_first, None, f0[1], f0[4])
+        for t in list(f0[0]) + list(f0[2]) + [f0[1], f0[4]]:
+            t.record_stream(side)
+        f1 = self._features(sat_map[h:], grd_img[h:], False, False)
+        t1 = self.lm_solve(f1[0], f1[2], f1[3], grd_img.shape[-2:], None, level_first, None, f1[1], f1[4])
+        cur.wait_stream(side)
+        t0.record_stream(cur)
+        trace = torch.cat([t0, t1])
+        self.last_trace = trace.detach()
+        return trace, [None] * self.level
+
     @_lib.on_device(lambda self, sat_map, *a, **k: sat_map)
     def localise(self, sat_map, grd_img, want_conf, extra, level_first, init_pose, return_confs=True):
         """Both feature pyramids (normalisation deferred into the LM sums) + the whole LM loop.
@@ -312,26 +359,12 @@ class S2GPBase(nn.Module):
             for t in list(grd_feats) + [c for c in grd_confs if c is not None] + [grd_inv]:
                 t.record_stream(cur)
         else:
-            # Reduced-precision inference modes: the LM loop reads fp16 feature maps (written saturating by the three feature
-            # layers' epilogues; also in bf16 mode: bf16's 8 significand bits moved the worst golden seed's pose 23x, fp16's 11
-            # move it 1.6x).  With the gather loop written on channel PAIRS (lm_solve.hip) the accumulate kernels are VALU-bound on
-            # 16-bit maps and 30 % faster than on fp32 ones: +7 % pairs/s.  args.lm_feat16 = 0 / HLA_LM_FEAT16=0 keeps fp32 maps;
-            # the fp32-class modes and every training path always do.
-            f16 = (self.SatFeatureNet.precision in ('bf16', 'fp16') and self.level == 3
-                   and bool(getattr(self.args, 'lm_feat16', 1)) and os.environ.get('HLA_LM_FEAT16', '1') != '0')
-            sat_feats, _, sat_inv = vgg_forward_nhwc(self.SatFeatureNet, sat_map, want_conf=False, defer_norm=True, feat16=f16)
-            grd_in = grd_img
-            # (only LM_update renormalises the ground features; SGD / ADAM see the whole-map L2_norm scale, so they need every row)
-            dead_ok = (not return_confs and self.level == 3 and getattr(self.args, 'Optimizer', 'LM') == 'LM'
-                       and os.environ.get('HLA_GRD_CROP', '1') != '0')
-            skip = dead_ground_rows(grd_img.shape[-2]) if dead_ok else 0
-            if skip:
-                grd_in = grd_img[:, :, skip:, :].contiguous()
-            # ... and inside the extractor every layer only computes the rows the LM loop's rows depend on
-            f8 = ((grd_img.shape[-2] // 8) // 2 - skip // 8) if dead_ok else 0
-            f8 = f8 if (f8 >= 4 and os.environ.get('HLA_GRD_TRIM', '1') != '0') else 0
-            grd_feats, grd_confs, grd_inv = vgg_forward_nhwc(self.GrdFeatureNet, grd_in, want_conf=want_conf, defer_norm=True,
-                                                             first_row8=f8, feat16=f16)
+            B = sat_map.shape[0]
+            pipe = (os.environ.get('HLA_LM_PIPELINE', '0') == '1' and B >= 16 and B % 2 == 0 and extra is None and not want_conf
+                    and not return_confs and init_pose is None)
+            if pipe:
+                return self._localise_pipelined(sat_map, grd_img, level_first)
+            sat_feats, sat_inv, grd_feats, grd_confs, grd_inv = self._features(sat_map, grd_img, want_conf, return_confs)
         trace = self.lm_solve(sat_feats, grd_feats, grd_confs, grd_img.shape[-2:], extra, level_first, init_pose,
                               sat_inv, grd_inv)
         return trace, grd_confs
