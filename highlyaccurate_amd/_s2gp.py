@@ -304,29 +304,6 @@ class S2GPBase(nn.Module):
                                                          first_row8=f8, feat16=f16)
         return sat_feats, sat_inv, grd_feats, grd_confs, grd_inv
 
-    def _localise_pipelined(self, sat_map, grd_img, level_first):
-        """Experiment (HLA_LM_PIPELINE=1): the batch in two halves, the LM loop of the first half on a side stream underneath the
-        second half's extractors -- the loop is latency-bound (a quarter of the HBM rate, small grids), the extractors compute-bound."""
-        B = sat_map.shape[0]
-        h = B // 2
-        cur = torch.cuda.current_stream()
-        side = self.__dict__.get('_side_stream')
-        if side is None or side.device != sat_map.device:
-            side = self.__dict__['_side_stream'] = torch.cuda.Stream(device=sat_map.device)
-        f0 = self._features(sat_map[:h], grd_img[:h], False, False)
-        side.wait_stream(cur)
-        with torch.cuda.stream(side):
-            t0 = self.lm_solve(f0[0], f0[2], f0[3], grd_img.shape[-2:], None, level_first, None, f0[1], f0[4])
-        for t in list(f0[0]) + list(f0[2]) + [f0[1], f0[4]]:
-            t.record_stream(side)
-        f1 = self._features(sat_map[h:], grd_img[h:], False, False)
-        t1 = self.lm_solve(f1[0], f1[2], f1[3], grd_img.shape[-2:], None, level_first, None, f1[1], f1[4])
-        cur.wait_stream(side)
-        t0.record_stream(cur)
-        trace = torch.cat([t0, t1])
-        self.last_trace = trace.detach()
-        return trace, [None] * self.level
-
     @_lib.on_device(lambda self, sat_map, *a, **k: sat_map)
     def localise(self, sat_map, grd_img, want_conf, extra, level_first, init_pose, return_confs=True):
         """Both feature pyramids (normalisation deferred into the LM sums) + the whole LM loop.
@@ -359,11 +336,6 @@ class S2GPBase(nn.Module):
             for t in list(grd_feats) + [c for c in grd_confs if c is not None] + [grd_inv]:
                 t.record_stream(cur)
         else:
-            B = sat_map.shape[0]
-            pipe = (os.environ.get('HLA_LM_PIPELINE', '0') == '1' and B >= 16 and B % 2 == 0 and extra is None and not want_conf
-                    and not return_confs and init_pose is None)
-            if pipe:
-                return self._localise_pipelined(sat_map, grd_img, level_first)
             sat_feats, sat_inv, grd_feats, grd_confs, grd_inv = self._features(sat_map, grd_img, want_conf, return_confs)
         trace = self.lm_solve(sat_feats, grd_feats, grd_confs, grd_img.shape[-2:], extra, level_first, init_pose,
                               sat_inv, grd_inv)
