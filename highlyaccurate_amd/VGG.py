@@ -133,7 +133,7 @@ def vgg_forward_nhwc(module: 'VGGUnet', x: torch.Tensor, want_conf: bool = True,
 
 @_lib.on_device(lambda module, ctx, *a, **k: ctx['x'])
 def vgg_backward_nhwc(module: 'VGGUnet', ctx: dict, d_feats, confs=None, d_confs=None, scale_invariant: bool = False,
-                      first_row8: int = 0, flat: bool = False, dense: bool = False):
+                      first_row8: int = 0, flat: bool = False, dense: bool = False, stats: dict = None):
     """Backward of ``vgg_forward_nhwc(..., defer_norm=True, save_for_backward=True)``.
     d_feats[l]: NHWC fp32 gradient w.r.t. the L2-normalised map l.  Returns {parameter name: gradient} for the
     22 tensors that receive one at level 3 (conv0..conv14 weights+biases, conv_dec1/2 weights), plus the conf head weights
@@ -143,7 +143,9 @@ def vgg_backward_nhwc(module: 'VGGUnet', ctx: dict, d_feats, confs=None, d_confs
     wgrad kernels write into directly, and ``(grads, flat_buffer)`` is returned: a data-parallel caller all-reduces that one
     buffer in place (parallel.GradSync) -- no gather copy before and no scatter copy after the collective.
     With ``scale_invariant`` the call skips every tile whose gradient is zero because the d_feats are (include/hla.h,
-    HLA_VGG_BWD_SCALE_INVARIANT); ``dense=True`` (or HLA_VGG_BWD_DENSE=1 in the environment) visits all of them (A/B, tests)."""
+    HLA_VGG_BWD_SCALE_INVARIANT); ``dense=True`` (or HLA_VGG_BWD_DENSE=1 in the environment) visits all of them (A/B, tests).
+    ``stats`` (a dict, diagnostics: costs a device synchronisation) receives 'live_tiles' / 'total_tiles' per sample, summed over
+    the data- and weight-gradient launches; both 0 when the call took the dense walk."""
     lib = _lib.load()
     x, dt = ctx['x'], ctx['dt']
     B, _, H, W = x.shape
@@ -201,6 +203,12 @@ def vgg_backward_nhwc(module: 'VGGUnet', ctx: dict, d_feats, confs=None, d_confs
                               | (_lib.HLA_VGG_BWD_DENSE if dense or os.environ.get('HLA_VGG_BWD_DENSE') == '1' else 0),
                               int(first_row8), _lib.stream_ptr())
     _lib.check(rc, 'hla_vgg_backward')
+    if stats is not None:
+        torch.cuda.current_stream().synchronize()
+        live, total = C.c_longlong(0), C.c_longlong(0)
+        _lib.check(lib.hla_vgg_backward_live_tiles(_lib.ptr(ws), B, H, W, L, dt, C.byref(live), C.byref(total)),
+                   'hla_vgg_backward_live_tiles')
+        stats['live_tiles'], stats['total_tiles'] = live.value, total.value
     for name, g in padded.items():
         co, ci = sd[name].shape[:2]
         grads[name] = g[:co, :ci].contiguous()

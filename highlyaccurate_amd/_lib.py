@@ -17,7 +17,7 @@ HLA_F32, HLA_BF16, HLA_F16, HLA_F16X3 = 0, 1, 2, 3
 HLA_VGG_WANT_CONF, HLA_VGG_DEFER_NORM, HLA_VGG_SAVE_FOR_BACKWARD, HLA_VGG_FEAT16 = 1, 2, 4, 8
 HLA_VGG_BWD_SCALE_INVARIANT = 1
 HLA_VGG_BWD_DENSE = 2
-ABI_VERSION = 15
+ABI_VERSION = 16
 
 
 class HlaError(RuntimeError):
@@ -112,6 +112,8 @@ def load() -> C.CDLL:
     lib.hla_vgg_pack_weights_T.argtypes = [C.POINTER(VggParams), vp, i, vp]
     lib.hla_vgg_bwd_workspace_bytes.restype = sz
     lib.hla_vgg_bwd_workspace_bytes.argtypes = [i, i, i, i, i]
+    lib.hla_vgg_backward_live_tiles.restype = i
+    lib.hla_vgg_backward_live_tiles.argtypes = [vp, i, i, i, i, i, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]
     lib.hla_vgg_backward.restype = i
     lib.hla_vgg_backward.argtypes = [vp, C.POINTER(VggParams), vp, vp, C.POINTER(vp), vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(VggGrads),
                                      vp, sz, i, i, i, i, i, i, i, vp]

@@ -8,6 +8,7 @@
 //     ds_read_b64_tr_b16 straight from the same [pixel][channel] LDS tiles the forward kernel uses
 //     (tools/probes/tr16_probe.hip documents the lane semantics), for fp32 a lane needs one element per MFMA
 //     so plain ds_read_b32 suffices.  Bias gradients ride along as one extra MFMA against an all-ones fragment.
+#include <vector>
 #include "conv_kernels.h"
 #include "vgg_layers.h"
 
@@ -596,6 +597,7 @@ struct DynLayout {
   int conv_list[DC_N];
   int wg_desc[DW_N];        // {n_live, list offset, band offset of g or -1}
   int wg_list[DW_N];
+  int used;
   int total;                // ints
 };
 static DynLayout dyn_layout(int H, int W) {
@@ -617,6 +619,7 @@ static DynLayout dyn_layout(int H, int W) {
     L.wg_desc[i] = take(4);
     L.wg_list[i] = take(((H / wdiv[i] + WG_TH - 1) / WG_TH) * ((W / wdiv[i] + 31) / 32));
   }
+  L.used = take(4);         // [0] = 1 when the last call trimmed
   L.total = o;
   return L;
 }
@@ -833,6 +836,7 @@ int vgg_backward_t(const float* x, const hla_vgg_params* prm, const char* packed
   const DynLayout dl = dyn_layout(H, W);
   int* dynp = (int*)(bw + bp.dyn);
   if (dynamic) HLA_CHECK_HIP(hipMemsetAsync(dynp, 0x80, (size_t)dl.seed_ints * sizeof(int), st));
+  HLA_CHECK_HIP(hipMemsetAsync(dynp + dl.used, dynamic ? 1 : 0, sizeof(int), st));
   for (int l = 0; l < NL; ++l) {
     int nblk = (int)(per[l] / 4 / 256 / 8);
     nblk = nblk < 1 ? 1 : (nblk > 64 ? 64 : nblk);
@@ -1078,5 +1082,27 @@ extern "C" int hla_vgg_backward(const float* x, const hla_vgg_params* params, co
                                d_feat, conf, d_conf, grads, (char*)workspace, bp, B, H, W, flags, first_row8, (hipStream_t)stream);
   return vgg_backward_t<float>(x, params, (const char*)packed_weights_T, dtype, (const char*)fwd_workspace, feat, inv_norm,
                                d_feat, conf, d_conf, grads, (char*)workspace, bp, B, H, W, flags, first_row8, (hipStream_t)stream);
+}
+extern "C" int hla_vgg_backward_live_tiles(const void* workspace, int B, int H, int W, int level, int dtype, long long* live,
+                                           long long* total) {
+  HLA_REQUIRE(workspace && live && total, "hla_vgg_backward_live_tiles: null argument");
+  HLA_REQUIRE(hla_dtype_ok(dtype), "hla_vgg_backward_live_tiles: bad dtype %d", dtype);
+  BwdPlan bp;
+  bwd_plan(B, H, W, bwd_dtype(dtype), &bp, level == 4);
+  const DynLayout L = dyn_layout(H, W);
+  std::vector<int> h(L.total);
+  HLA_CHECK_HIP(hipMemcpy(h.data(), (const char*)workspace + bp.dyn, (size_t)L.total * sizeof(int), hipMemcpyDeviceToHost));
+  *live = *total = 0;
+  if ((h[L.used] & 0xff) != 1) return HLA_OK;
+  const int cdiv[DC_N] = {2, 2, 2, 4, 4, 4, 4, 4, 4, 2, 2, 1}, wdiv[DW_N] = {2, 2, 4, 4, 4, 4, 4, 2, 2, 1, 1};
+  for (int i = 0; i < DC_N; ++i) {
+    *live += h[L.conv_desc[i]];
+    *total += (long long)((H / cdiv[i] + 7) / 8) * ((W / cdiv[i] + 31) / 32);
+  }
+  for (int i = 0; i < DW_N; ++i) {
+    *live += h[L.wg_desc[i]];
+    *total += (long long)((H / wdiv[i] + WG_TH - 1) / WG_TH) * ((W / wdiv[i] + 31) / 32);
+  }
+  return HLA_OK;
 }
 #endif

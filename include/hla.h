@@ -58,7 +58,7 @@ const char* hla_last_error(void);
  * with its own struct sizes (ctypes structs are positional: a mismatch corrupts silently).  highlyaccurate_amd/_lib.py
  * does both at load time, and rebuilds or refuses a binary whose hla_source_hash() is not the hash of the sources
  * next to it (the library is git-ignored but shipped prebuilt). */
-#define HLA_ABI_VERSION 15
+#define HLA_ABI_VERSION 16
 int hla_abi_version(void);
 const char* hla_source_hash(void); /* sha256 (hex) of the csrc sources, this header and the compiler flags at build time */
 typedef enum hla_struct_id {
@@ -166,6 +166,12 @@ int hla_vgg_backward(const float* x, const hla_vgg_params* params, const void* p
                      const float* const d_feat[4], const float* const conf[4], const float* const d_conf[4],
                      const hla_vgg_grads* grads, void* workspace, size_t workspace_bytes, int B, int H, int W, int level,
                      int dtype, int flags, int first_row8, hla_stream_t stream);
+
+/* Diagnostics for the data-dependent trimming of the last hla_vgg_backward call that used `workspace` (its stream must have
+ * completed): live and total tiles per sample of every data- and weight-gradient launch, summed.  Both are 0 when that call
+ * took the dense walk.  Synchronous (one small device-to-host copy). */
+int hla_vgg_backward_live_tiles(const void* workspace, int B, int H, int W, int level, int dtype, long long* live,
+                                long long* total);
 
 /* ------------------------------------------------------------------------- *
  * Dataset-side satellite tile: KITTI_dataset.py:128-157, Ford_dataset.py:185-209

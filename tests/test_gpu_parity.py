@@ -1348,10 +1348,20 @@ def test_backward_dynamic_trimming_is_exact(precision, shape):
 
     if H != 96:
         cases = {'nothing': [[], [], []]}
+    # live-tile fractions as measured, + 0.03: they pin how TIGHT the propagated footprint is (a regression that marks
+    # everything live would still be exact)
+    LIMITS = {('right half', 96): 0.97, ('coarse level only', 96): 0.21, ('fine level only, one texel', 96): 0.47,
+              ('disjoint boxes per level', 96): 0.62, ('fan', 96): 0.90, ('fan', 1024): 0.11}
     for tag, spec in list(cases.items()) + [('fan', None)]:
         dfe = fan() if spec is None else boxes(spec)
-        g_dense = vgg_backward_nhwc(net, ctx, dfe, scale_invariant=True, dense=True)
-        g_trim = vgg_backward_nhwc(net, ctx, dfe, scale_invariant=True)
+        st_d, st_t = {}, {}
+        g_dense = vgg_backward_nhwc(net, ctx, dfe, scale_invariant=True, dense=True, stats=st_d)
+        g_trim = vgg_backward_nhwc(net, ctx, dfe, scale_invariant=True, stats=st_t)
+        # the trimming must actually have happened (and by how much): hla_vgg_backward_live_tiles
+        assert st_d == {'live_tiles': 0, 'total_tiles': 0} and st_t['total_tiles'] > 0, (tag, st_d, st_t)
+        frac = st_t['live_tiles'] / st_t['total_tiles']
+        limit = {'nothing': 0.0, 'everything': 1.0}.get(tag, LIMITS.get((tag, H), 1.0))
+        assert frac <= limit and (tag != 'everything' or frac == 1.0), (tag, frac)
         worst, wk = 0.0, ''
         for k in g_dense:
             a, b = g_dense[k].double(), g_trim[k].double()
@@ -1362,7 +1372,7 @@ def test_backward_dynamic_trimming_is_exact(precision, shape):
             e = float((a - b).norm() / max(float(a.norm()), 1e-30))
             if e > worst:
                 worst, wk = e, k
-        print(f'dynamic trimming {precision} {H}x{W} [{tag}]: worst gradient rel-l2 deviation {worst:.2e} ({wk})')
+        print(f'dynamic trimming {precision} {H}x{W} [{tag}]: live tiles {frac:.2f}, worst gradient rel-l2 deviation {worst:.2e} ({wk})')
         assert worst < 2e-5, (tag, wk, worst)
 
 
