@@ -322,12 +322,21 @@ def train_leg(net, a, sat, grd, extra, B, world, dist, dev, want_kt):
         if want_kt:
             _lib.prof_enable(False)
             trecs = _lib.prof_fetch()
+    live = None
+    if a.model != 'g2sp':       # one more step with the backward's diagnostics on: which share of its tiles the satellite branch visits
+        net.bwd_stats = {}
+        tstep()
+        torch.cuda.synchronize()
+        st, net.bwd_stats = net.bwd_stats, None
+        if st.get('total_tiles'):
+            live = round(st['live_tiles'] / st['total_tiles'], 3)
     if dist:
         dist.barrier()
     train = {'value': round(B * world * a.train_steps / tdt, 3), 'unit': 'pairs/s', 'steps': a.train_steps,
              'ms_per_step': round(tdt / a.train_steps * 1e3, 3), 'loss_finite': bool(torch.isfinite(lossv)),
              'what': "forward(mode='train') + HIP backward (LM loop + both VGGs) + gradient all-reduce + Adam",
-             'allreduce_bytes_per_step': ar_bytes}
+             'allreduce_bytes_per_step': ar_bytes,
+             'sat_backward_live_tiles': live}       # data-dependent trimming; None = dense walk
     if a.model != 'g2sp':
         # secondary number: the same step with args.train_ground_crop=1 (an extension: the ground branch trains on the
         # image rows that can reach the loss; loss and gradients equal to rounding, the RETURNED confidence maps are

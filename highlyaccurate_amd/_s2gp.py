@@ -429,7 +429,9 @@ class _LocaliseFn(torch.autograd.Function):
         # LM_update renormalises both projected maps (models_kitti.py:982-990), so the loss does not depend on the per-sample
         # scale of either extractor's output: d_feat is orthogonal to feat and the L2_norm backward needs no (x . dy) pass
         inv = getattr(model.args, 'Optimizer', 'LM') == 'LM' and os.environ.get('HLA_L2BWD_FULL', '0') != '1'
-        g_sat, flat_sat = vgg_backward_nhwc(model.SatFeatureNet, cs, d_sat, scale_invariant=inv, flat=True)
+        # (model.bwd_stats = {}: diagnostics, filled with the satellite branch's live / total backward tiles; costs a device sync)
+        g_sat, flat_sat = vgg_backward_nhwc(model.SatFeatureNet, cs, d_sat, scale_invariant=inv, flat=True,
+                                            stats=getattr(model, 'bwd_stats', None))
         h1 = sync.start({'SatFeatureNet.' + k: v for k, v in g_sat.items()}, flat_sat) if sync else None
         use_w = model.using_weight and all(c is not None for c in d_conf)
         # the ground maps' gradient lives in rows h_l/2.. (all the LM loop reads): the backward skips the rows above its support
