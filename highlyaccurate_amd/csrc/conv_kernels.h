@@ -272,6 +272,9 @@ enum { EPI_GENERIC = 0,   // everything, decided at run time (backward / trainin
        EPI_DGRAD = 4 };   // backward data gradient: out_act = (mask > 0 ? acc : 0) [+ add], no bias, no ReLU of its own
 __device__ __forceinline__ int epilogue_mode(const ConvArgs& a) {
   if (a.mask_act && a.out_act && !a.relu_act && !a.bias && !a.out_raw && !a.sumsq && !a.idx_out && !a.pool_sum) return EPI_DGRAD;
+  // (a 16-bit raw copy without the activation output: the last decoder layer when nothing consumes relu(x21) -- vgg.hip)
+  if (!a.out_act && a.out_raw && a.raw16 && a.sumsq && !a.bias && !a.mask_act && !a.add_src && !a.idx_out && !a.pool_sum)
+    return EPI_ACT_RAW_NOBIAS;
   if (a.mask_act || a.add_src || a.idx_out || a.pool_sum || !a.out_act || !a.relu_act) return EPI_GENERIC;
   if (!a.out_raw) return a.sumsq ? EPI_GENERIC : EPI_ACT;
   return a.sumsq ? (a.bias ? EPI_ACT_RAW : EPI_ACT_RAW_NOBIAS) : EPI_GENERIC;
@@ -361,13 +364,14 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[MT][NT], const ConvA
             }
             RowStager<RawT, NT>::put(stage, px, j * 32 + q * 8 + g * 4, w0, w1, w2, w3);
             if (lane_ok) ss += w0 * w0 + w1 * w1 + w2 * w2 + w3 * w3;
-            RowStager<T, NT>::put(stage2, px, j * 32 + q * 8 + g * 4, fmaxf(w0, 0.f), fmaxf(w1, 0.f), fmaxf(w2, 0.f), fmaxf(w3, 0.f));
+            if (a.out_act)      // (kernel-uniform)
+              RowStager<T, NT>::put(stage2, px, j * 32 + q * 8 + g * 4, fmaxf(w0, 0.f), fmaxf(w1, 0.f), fmaxf(w2, 0.f), fmaxf(w3, 0.f));
           }
       }
       __builtin_amdgcn_sched_barrier(0);
       if (row_ok) {
         RowStager<RawT, NT>::template flush<true>(stage, (RawT*)a.out_raw + pix0 * a.Cout + cb, NPX, nvalid, a.Cout, lane);
-        RowStager<T, NT>::template flush<true>(stage2, (T*)a.out_act + pix0 * a.Cout + cb, NPX, nvalid, a.Cout, lane);
+        if (a.out_act) RowStager<T, NT>::template flush<true>(stage2, (T*)a.out_act + pix0 * a.Cout + cb, NPX, nvalid, a.Cout, lane);
       }
       __builtin_amdgcn_sched_barrier(0);      // keep the rows apart: hoisting the next rows' arithmetic up here spills
       continue;

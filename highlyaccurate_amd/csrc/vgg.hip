@@ -128,7 +128,10 @@ int vgg_forward_t(const float* x, const hla_vgg_params* prm, const char* packed,
   conv(8, w + pl.d1a, 128, H / 4, W / 4, w + pl.x18r, 1, false, nullptr, 0, 0, feat[1],
        (double*)(w + pl.ss[1]), nullptr, r_d13, 1);                                   // dec1.3 -> x18
   conv(9, w + pl.x18r, 128, H / 2, W / 2, w + pl.d2a, 1, false, w + pl.x3, 64, 1, nullptr, nullptr, nullptr, r_d21);    // dec2.1
-  conv(10, w + pl.d2a, 64, H / 2, W / 2, w + pl.x21r, 1, false, nullptr, 0, 0, feat[2],
+  // relu(x21) feeds conv_dec3 (level 4), the conf2 head and the training backward only: without them the 16-bit feature path
+  // stores just the raw map
+  const bool x21r_dead = !level4 && !wc && !train && (flags & HLA_VGG_FEAT16) && sizeof(T) == 2;
+  conv(10, w + pl.d2a, 64, H / 2, W / 2, x21r_dead ? (char*)nullptr : w + pl.x21r, 1, false, nullptr, 0, 0, feat[2],
        (double*)(w + pl.ss[2]), nullptr, r_d23, 2);                                   // dec2.3 -> x21
   if (level4) {      // VGG.py:153-155: conv_dec3 on cat(up(x21), x2), zero-padded to 64 channels (vgg_layers.h)
     conv(11, w + pl.x21r, 64, H, W, w + pl.d3a, 1, false, w + pl.x2r, 64, 1);          // dec3.1
