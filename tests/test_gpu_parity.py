@@ -36,6 +36,14 @@ def test_library_loaded_and_exports():
         assert hasattr(lib, sym)
 
 
+def test_graft_entry_smoke():
+    """The driver's round-end smoke(): one small forward in all four arithmetic modes against the fp64 oracle."""
+    import os, sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import __graft_entry__
+    __graft_entry__.smoke()
+
+
 def test_cpu_tensor_is_rejected():
     from highlyaccurate_amd import _lib
     from highlyaccurate_amd.VGG import VGGUnet
