@@ -517,7 +517,10 @@ def main():
         if train:
             res['train'] = train
         if not a.no_cpu_baseline:
-            res['cpu_baseline'] = cpu_baseline()
+            try:
+                res['cpu_baseline'] = cpu_baseline()
+            except Exception as ex:     # the headline line must still be printed
+                res['cpu_baseline'] = {'error': repr(ex)[:300]}
         print(json.dumps(res), flush=True)
     if dist:
         dist.barrier()
