@@ -516,7 +516,7 @@ def main():
             res['secondary'] = secondary
         if train:
             res['train'] = train
-        if not a.no_cpu_baseline:
+        if not a.no_cpu_baseline and world == 1:        # rank 0 at N = 1 only (the task's contract)
             try:
                 res['cpu_baseline'] = cpu_baseline()
             except Exception as ex:     # the headline line must still be printed
