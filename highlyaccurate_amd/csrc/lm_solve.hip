@@ -165,9 +165,22 @@ template <> __device__ __forceinline__ lm_f2 lm_pair<_Float16>(const uint4& v, i
 #define LM_OCC 6
 #define LM_UNROLL(F) (sizeof(F) == 4 ? 2 : 1)
 #endif
+// Pixels per block of the forward accumulate kernels (level-dependent only, like lm_pick_tile: a sample's partial-sum grouping
+// must not depend on its batch mates).  Larger than the backward's tiles: a block's fixed cost -- the fp64 pixel set-up, the
+// reductions, the published partials, the ticket -- is what these kernels spend their time on.
+#define FWD_MAX_TP 512
+static inline int lm_pick_tile_fwd(int npix) {
+#if CONV_VARIANT == 150           // the backward's sizes (256 / 128 / 64), which the forward shared until round 2
+  return lm_pick_tile(npix);
+#elif CONV_VARIANT == 154         // (measured: the two coarse levels lose 10-30 % with tiles this large)
+  return npix >= 16384 ? 512 : (npix >= 4096 ? 512 : 256);
+#else                             // measured against 150 on one box: lm_accum<64> 72.3 -> 70.8 us, <128> 45.3 -> 41.7, <256> 30.8 -> 29.5
+  return npix >= 16384 ? 512 : (npix >= 4096 ? 256 : 128);
+#endif
+}
 template <int C, bool USE_W, typename F>
 __global__ __launch_bounds__(256, LM_OCC) void lm_accum(AccumArgs a, SolveArgs sa) {
-  __shared__ PixParam pp[MAX_TP];
+  __shared__ PixParam pp[FWD_MAX_TP];
   __shared__ float red[4][14];
   __shared__ double redd[14];
   int b, tile;
@@ -177,15 +190,15 @@ __global__ __launch_bounds__(256, LM_OCC) void lm_accum(AccumArgs a, SolveArgs s
   const int np = min(a.TP, a.npix - p0);
   const double* cf = a.coef + (size_t)b * COEF_N;
 
-  if (t < np) {
-    const int p = p0 + t;
+  for (int tt = t; tt < np; tt += 256) {
+    const int p = p0 + tt;
     const int r = a.row0 + p / a.w, c = p % a.w;
     const float cw = USE_W ? a.conf[((size_t)b * a.hs + (r - a.rskip)) * a.w + c] : 1.f;
     PixParam P = lm_pixel<C>(cf, a.xyz + ((size_t)r * a.w + c) * 3, a.A, cw);
     if (a.keep && !a.keep[p]) {          // dropped by args.dropout: the pixel leaves every sum (models_kitti.py:968-974)
       P.wx0 = P.wx1 = P.wy0 = P.wy1 = 0.f; P.off = P.dxo = P.dyo = 0; P.j2u = P.j2v = 0.f; P.gm = P.wt = P.m = 0.f;
     }
-    pp[t] = P;
+    pp[tt] = P;
   }
   __syncthreads();
 
@@ -311,7 +324,7 @@ static size_t ws_layout(const hla_s2g_config* cfg, const hla_s2g_level* lv, int 
   int max_nt = 1;
   for (int l = 0; l < cfg->n_levels; ++l) {
     const int npix = (lv[l].h - lv[l].row0) * lv[l].w;
-    const int tp = lm_pick_tile(npix);
+    const int tp = lm_pick_tile_fwd(npix);
     max_nt = max(max_nt, (npix + tp - 1) / tp);
   }
   size_t o = 0;
@@ -433,7 +446,7 @@ extern "C" int hla_s2g_lm_solve(const hla_s2g_config* cfg, const hla_s2g_level* 
     aa.A = v.A; aa.h = v.h; aa.w = v.w; aa.row0 = v.row0; aa.npix = (v.h - v.row0) * v.w;
     aa.hs = v.h - v.grd_row_skip; aa.rskip = v.grd_row_skip;
     aa.keep = cfg->keep ? cfg->keep + (size_t)k * cfg->keep_stride : nullptr;
-    aa.TP = lm_pick_tile(aa.npix); aa.nt = (aa.npix + aa.TP - 1) / aa.TP; aa.B = B;
+    aa.TP = lm_pick_tile_fwd(aa.npix); aa.nt = (aa.npix + aa.TP - 1) / aa.TP; aa.B = B;
     aa.xcd_affine = (B >= 8) ? 1 : 0;
     const int nblk = aa.xcd_affine ? 8 * ((B + 7) / 8) * aa.nt : B * aa.nt;
     aa.ticket = ticket + (size_t)k * B;
