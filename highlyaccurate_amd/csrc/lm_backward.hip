@@ -317,12 +317,26 @@ __global__ __launch_bounds__(64) void lm_bwd_solve(BwdSolveArgs a) {
   lm_coefficients(a.geom, pin[0], pin[1], pin[2], R, T, a.coef + (size_t)b * COEF_N);
 }
 
+// pixels per block of lm_bwd_accum (level-dependent only)
+#ifndef CONV_VARIANT
+#define CONV_VARIANT 0
+#endif
+static inline int lm_pick_tile_bwd(int npix) {
+#if CONV_VARIANT == 155           // the sizes shared with LM_G2SP's kernels (256 / 128 / 64), used here until round 2
+  return lm_pick_tile(npix);
+#elif CONV_VARIANT == 157         // (measured: smaller tiles, 128 / 128 / 64: 227 -> 245 us per launch)
+  return npix >= 16384 ? 128 : (npix >= 4096 ? 128 : 64);
+#else                             // the coarse levels on larger tiles: 227.7 -> 218.3 us per launch on average (same-box A/B, twice)
+  return npix >= 16384 ? 256 : (npix >= 4096 ? 256 : 128);
+#endif
+}
+
 // ---------------------------------------------------------------------------------------------
 static size_t bwd_layout(const hla_s2g_config* cfg, const hla_s2g_level* lv, int B, size_t off[5]) {
   int max_nt = 1;
   for (int l = 0; l < cfg->n_levels; ++l) {
     const int npix = (lv[l].h - lv[l].row0) * lv[l].w;
-    const int tp = lm_pick_tile(npix);
+    const int tp = lm_pick_tile_bwd(npix);
     max_nt = max(max_nt, (npix + tp - 1) / tp);
   }
   size_t o = 0;
@@ -420,7 +434,7 @@ extern "C" int hla_s2g_lm_solve_bwd(const hla_s2g_config* cfg, const hla_s2g_lev
     aa.A = v.A; aa.h = v.h; aa.w = v.w; aa.row0 = v.row0; aa.npix = (v.h - v.row0) * v.w;
     aa.hs = v.h - v.grd_row_skip; aa.rskip = v.grd_row_skip;
     aa.keep = cfg->keep ? cfg->keep + (size_t)k * cfg->keep_stride : nullptr;
-    aa.TP = lm_pick_tile(aa.npix); aa.nt = (aa.npix + aa.TP - 1) / aa.TP; aa.B = B;
+    aa.TP = lm_pick_tile_bwd(aa.npix); aa.nt = (aa.npix + aa.TP - 1) / aa.TP; aa.B = B;
     aa.xcd_affine = (B >= 8) ? 1 : 0;
     const int nblk = aa.xcd_affine ? 8 * ((B + 7) / 8) * aa.nt : B * aa.nt;
     hla_prof_begin(K_LMBWD, 0, (double)B * (5.0 * (double)v.A * v.A + 3.0 * (double)aa.npix) * v.C * 4.0, st);
