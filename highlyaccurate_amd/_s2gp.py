@@ -250,7 +250,7 @@ class S2GPBase(nn.Module):
 
     @_lib.on_device(lambda self, sat_feats, *a, **k: sat_feats[0])
     def lm_backward(self, sat_feats, grd_feats, grd_confs, grd_hw, trace, normal_eq, d_trace, extra=None, level_first=0,
-                    init_pose=None, sat_inv_norm=None, grd_inv_norm=None, keep=None):
+                    init_pose=None, sat_inv_norm=None, grd_inv_norm=None, keep=None, grd_first_row8=0):
         """Backward of ``lm_solve``: d(loss)/d(trace) [B,N,L,3] -> (d_sat[l], d_grd[l], d_conf[l] or None, d_lambda[3]).
         ``keep``: the forward's dropout mask (``self.last_keep``), if args.dropout.
         Map gradients are NHWC fp32 and taken w.r.t. the L2-normalised maps (inv_norm * stored map)."""
@@ -262,7 +262,14 @@ class S2GPBase(nn.Module):
         if keep is not None:
             cfg.keep, cfg.keep_stride = keep.data_ptr(), keep.shape[1]
         d_sat = [torch.zeros_like(t) for t in sat_feats]
-        d_grd = [torch.zeros_like(t) for t in grd_feats]
+        if grd_first_row8:      # the consumer (hla_vgg_backward(first_row8 = f)) never reads d_grd[l] above row f * 2^l - 2, and the loop
+            d_grd = []          # only writes rows h_l/2.. : the top of the maps is left uninitialised instead of zero-filled
+            for l, t in enumerate(grd_feats):
+                d = torch.empty_like(t)
+                d[:, max(0, (grd_first_row8 << l) - 2):].zero_()
+                d_grd.append(d)
+        else:
+            d_grd = [torch.zeros_like(t) for t in grd_feats]
         d_conf = [torch.zeros_like(grd_confs[l]) if (self.using_weight and grd_confs[l] is not None) else None
                   for l in range(L)]
         gr = (_lib.S2GLevelGrad * L)()
@@ -423,20 +430,20 @@ class _LocaliseFn(torch.autograd.Function):
             raise RuntimeError('backward through the same forward twice: the saved activations (GBs at B = 32) are released after '
                                'the first backward; retain_graph is not supported by the HIP backward')
         sat_feats, grd_feats, grd_confs, grd_hw, trace, neq, sat_inv, grd_inv, cs, cg, keep = ctx.state
+        inv = getattr(model.args, 'Optimizer', 'LM') == 'LM' and os.environ.get('HLA_L2BWD_FULL', '0') != '1'
+        # the ground maps' gradient lives in rows h_l/2.. (all the LM loop reads): the backward skips the rows above its support
+        f8 = (grd_hw[0] // 8) // 2 - (grd_hw[0] - grd_feats[2].shape[1] * 2) // 8
+        f8 = f8 if (inv and f8 >= 4 and model.level == 3 and os.environ.get('HLA_BWD_TRIM', '1') != '0') else 0
         d_sat, d_grd, d_conf, d_lam = model.lm_backward(sat_feats, grd_feats, grd_confs, grd_hw, trace, neq, d_trace, ctx.extra,
-                                                   ctx.level_first, ctx.init_pose, sat_inv, grd_inv, keep)
+                                                   ctx.level_first, ctx.init_pose, sat_inv, grd_inv, keep, grd_first_row8=f8)
         sync = getattr(model, 'grad_sync', None)        # optional: overlap the sat-branch all-reduce with the grd backward
         # LM_update renormalises both projected maps (models_kitti.py:982-990), so the loss does not depend on the per-sample
         # scale of either extractor's output: d_feat is orthogonal to feat and the L2_norm backward needs no (x . dy) pass
-        inv = getattr(model.args, 'Optimizer', 'LM') == 'LM' and os.environ.get('HLA_L2BWD_FULL', '0') != '1'
         # (model.bwd_stats = {}: diagnostics, filled with the satellite branch's live / total backward tiles; costs a device sync)
         g_sat, flat_sat = vgg_backward_nhwc(model.SatFeatureNet, cs, d_sat, scale_invariant=inv, flat=True,
                                             stats=getattr(model, 'bwd_stats', None))
         h1 = sync.start({'SatFeatureNet.' + k: v for k, v in g_sat.items()}, flat_sat) if sync else None
         use_w = model.using_weight and all(c is not None for c in d_conf)
-        # the ground maps' gradient lives in rows h_l/2.. (all the LM loop reads): the backward skips the rows above its support
-        f8 = (grd_hw[0] // 8) // 2 - (grd_hw[0] - grd_feats[2].shape[1] * 2) // 8
-        f8 = f8 if (inv and f8 >= 4 and model.level == 3 and os.environ.get('HLA_BWD_TRIM', '1') != '0') else 0
         g_grd, flat_grd = vgg_backward_nhwc(model.GrdFeatureNet, cg, d_grd, grd_confs if use_w else None, d_conf if use_w else None,
                                             scale_invariant=inv, first_row8=f8, flat=True)
         h2 = sync.start({'GrdFeatureNet.' + k: v for k, v in g_grd.items()}, flat_grd) if sync else None

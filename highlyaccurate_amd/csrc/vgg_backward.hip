@@ -409,7 +409,9 @@ template <typename T, bool ORTHO>
 __global__ __launch_bounds__(256) void l2bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                           const double* __restrict__ part, const double* __restrict__ inv,
                                                           T* __restrict__ out, size_t per_sample, int nblk,
-                                                          int* __restrict__ rowiv = nullptr, int C = 1, int Wl = 1) {
+                                                          int* __restrict__ rowiv = nullptr, int C = 1, int Wl = 1,
+                                                          size_t skip = 0) {      // floats at the start of a sample that are neither
+                                                                                 // read nor written (the caller's static first rows)
   const int b = blockIdx.x / nblk, k = blockIdx.x % nblk;
   double dot = 0.0;
   if (!ORTHO)
@@ -463,7 +465,7 @@ __global__ __launch_bounds__(256) void l2bwd_apply_kernel(const float* __restric
     }
     return;
   }
-  for (size_t i = (size_t)k * 256 + threadIdx.x; i < per_sample / 4; i += (size_t)nblk * 256) {
+  for (size_t i = skip / 4 + (size_t)k * 256 + threadIdx.x; i < per_sample / 4; i += (size_t)nblk * 256) {
     const float4 v = pd[i];
     if (ORTHO) {       // HLA_VGG_BWD_SCALE_INVARIANT: x . dy = 0 analytically, dx = dy / ||x||; x is not read
       store4(po + i * 4, c1 * v.x, c1 * v.y, c1 * v.z, c1 * v.w);
@@ -837,16 +839,47 @@ int vgg_backward_t(const float* x, const hla_vgg_params* prm, const char* packed
   int* dynp = (int*)(bw + bp.dyn);
   if (dynamic) HLA_CHECK_HIP(hipMemsetAsync(dynp, 0x80, (size_t)dl.seed_ints * sizeof(int), st));
   HLA_CHECK_HIP(hipMemsetAsync(dynp + dl.used, dynamic ? 1 : 0, sizeof(int), st));
+  // Row ranges.  first_row8 = f > 0 is the caller's promise that d_feat[0..2] are zero above rows f / 2f / 4f (the LM loop
+  // only ever reads rows h_l/2.. of the ground maps, so that is where its gradient lives).  The gradient of every activation
+  // is then exactly zero above a first row that follows from the layer graph -- a 3x3 conv widens the support by one row, a 2x
+  // upsample / 2x2 pool halves / doubles it -- and every launch below starts at that row (ConvArgs::row_begin, even where a
+  // pool is involved), reading its sources as zero above THEIR first row (src_row_lo / add_row_lo: those rows are never
+  // written).  With confidence heads (d_conf) the support of the three raw-map gradients starts one row higher.
+  // n_* : first row of a gradient map in its own resolution; all zero (= no trimming) when f == 0.
+  const int f = (level4 || !(flags & HLA_VGG_BWD_SCALE_INVARIANT)) ? 0 : first_row8;   // (the two-pass L2 backward leaves
+                                                                                       //  rounding noise above the support)
+  const int wc = (conf && d_conf) ? 1 : 0;
+  auto ev = [](int v) { return v < 0 ? 0 : (v & ~1); };
+  auto nn = [](int v) { return v < 0 ? 0 : v; };
+  const int n_x21 = f ? 4 * f - wc : 0;                 // H/2
+  const int n_d2a = nn(n_x21 - 1);                      // H/2
+  const int rb_up18 = ev(n_d2a - 1);                    // H/2 rows of the pool_sum launch that produces g_x18
+  const int n_x18 = rb_up18 / 2;                        // H/4   (<= 2f - wc: covers x18's own L2 / conf gradient)
+  const int n_x3p = nn(n_d2a - 1);                      // H/2
+  const int n_d1a = nn(n_x18 - 1);                      // H/4
+  const int rb_up15 = ev(n_d1a - 1);
+  const int n_x15 = rb_up15 / 2;                        // H/8
+  const int n_x8p = nn(n_d1a - 1);                      // H/4
+  const int n_a12 = nn(2 * n_x15 - 1);                  // H/4
+  const int n_a10 = nn(n_a12 - 1);
+  const int n_x8 = nn(n_a10 - 1);                       // H/4
+  const int n_a5 = nn(2 * n_x8 - 1);                    // H/2
+  const int n_x3 = nn(n_a5 - 1);                        // H/2
+  const int n_a0 = nn(2 * n_x3 - 1);                    // H
+  // ... and the L2-norm backward below starts at n_x15 / n_x18 / n_x21 as well: the rows of d_feat[l] above f * 2^l - 2 are neither
+  // read nor written (the caller need not even zero them)
+  const int l2_row0[4] = {n_x15, n_x18, n_x21, 0};
   for (int l = 0; l < NL; ++l) {
     int nblk = (int)(per[l] / 4 / 256 / 8);
     nblk = nblk < 1 ? 1 : (nblk > 64 ? 64 : nblk);
     double* part = (double*)(bw + bp.dot);
     if (flags & HLA_VGG_BWD_SCALE_INVARIANT) {
-      hla_prof_begin(K_ELEMWISE, 0, (double)B * per[l] * (4 + sizeof(T)), st);
       const int Cl[4] = {256, 128, 64, 64};
+      const size_t skip = (size_t)l2_row0[l] * (W >> (3 - l)) * Cl[l];
+      hla_prof_begin(K_ELEMWISE, 0, (double)B * (per[l] - skip) * (4 + sizeof(T)), st);
       hipLaunchKernelGGL((l2bwd_apply_kernel<T, true>), dim3(B * nblk), dim3(256), 0, st, feat[l], d_feat[l], part,
                          inv_norm + (size_t)l * B, (T*)l2out[l], per[l], nblk, dynamic ? dynp + dl.seed[l] : (int*)nullptr,
-                         Cl[l], W >> (3 - l));
+                         Cl[l], W >> (3 - l), skip);
     } else {
       hla_prof_begin(K_ELEMWISE, 0, (double)B * per[l] * (16 + sizeof(T)), st);
       hipLaunchKernelGGL(l2bwd_dot_kernel, dim3(B * nblk), dim3(256), 0, st, feat[l], d_feat[l], part, per[l], nblk);
@@ -931,35 +964,8 @@ int vgg_backward_t(const float* x, const hla_vgg_params* prm, const char* packed
     dgrad(11, 64, 64, G(bp.g_d3a), nullptr, H, W, G(bp.g_x2p), F(fp.x2r), nullptr, false);         // x2 skip branch
     wgrad(11, F(fp.x21r), 64, F(fp.x2r), 64, 1, G(bp.g_d3a), nullptr, H, W);
   }
-  // Row ranges.  first_row8 = f > 0 is the caller's promise that d_feat[0..2] are zero above rows f / 2f / 4f (the LM loop
-  // only ever reads rows h_l/2.. of the ground maps, so that is where its gradient lives).  The gradient of every activation
-  // is then exactly zero above a first row that follows from the layer graph -- a 3x3 conv widens the support by one row, a 2x
-  // upsample / 2x2 pool halves / doubles it -- and every launch below starts at that row (ConvArgs::row_begin, even where a
-  // pool is involved), reading its sources as zero above THEIR first row (src_row_lo / add_row_lo: those rows are never
-  // written).  With confidence heads (d_conf) the support of the three raw-map gradients starts one row higher.
-  // n_* : first row of a gradient map in its own resolution; all zero (= no trimming) when f == 0.
-  const int f = (level4 || !(flags & HLA_VGG_BWD_SCALE_INVARIANT)) ? 0 : first_row8;   // (the two-pass L2 backward leaves
-                                                                                       //  rounding noise above the support)
-  const int wc = (conf && d_conf) ? 1 : 0;
-  auto ev = [](int v) { return v < 0 ? 0 : (v & ~1); };
-  auto nn = [](int v) { return v < 0 ? 0 : v; };
-  const int n_x21 = f ? 4 * f - wc : 0;                 // H/2
-  const int n_d2a = nn(n_x21 - 1);                      // H/2
-  const int rb_up18 = ev(n_d2a - 1);                    // H/2 rows of the pool_sum launch that produces g_x18
-  const int n_x18 = rb_up18 / 2;                        // H/4   (<= 2f - wc: covers x18's own L2 / conf gradient)
-  const int n_x3p = nn(n_d2a - 1);                      // H/2
-  const int n_d1a = nn(n_x18 - 1);                      // H/4
-  const int rb_up15 = ev(n_d1a - 1);
-  const int n_x15 = rb_up15 / 2;                        // H/8
-  const int n_x8p = nn(n_d1a - 1);                      // H/4
-  const int n_a12 = nn(2 * n_x15 - 1);                  // H/4
-  const int n_a10 = nn(n_a12 - 1);
-  const int n_x8 = nn(n_a10 - 1);                       // H/4
-  const int n_a5 = nn(2 * n_x8 - 1);                    // H/2
-  const int n_x3 = nn(n_a5 - 1);                        // H/2
-  const int n_a0 = nn(2 * n_x3 - 1);                    // H
   // ---- decoder 2 (VGG.py:148-151)
-  dgrad(10, 0, 64, G(bp.g_x21), nullptr, H2, W2, G(bp.g_d2a), F(fp.d2a), nullptr, false, n_d2a, 0, 0, DC_10);
+  dgrad(10, 0, 64, G(bp.g_x21), nullptr, H2, W2, G(bp.g_d2a), F(fp.d2a), nullptr, false, n_d2a, n_x21, 0, DC_10);   // (g_x21 is unwritten above n_x21)
   wgrad(10, F(fp.d2a), 64, nullptr, 0, 0, G(bp.g_x21), nullptr, H2, W2, n_x21, DW_10);
   dgrad(9, 0, 128, G(bp.g_d2a), nullptr, H2, W2, G(bp.g_x18), F(fp.x18r), G(bp.l2_18), true, rb_up18, n_d2a, 0, DC_9U);   // up(x18) branch
   dgrad(9, 128, 64, G(bp.g_d2a), nullptr, H2, W2, G(bp.g_x3p), F(fp.x3), nullptr, false, n_x3p, n_d2a, 0, DC_9S);          // x3 skip branch

@@ -156,7 +156,7 @@ size_t hla_vgg_bwd_workspace_bytes(int B, int H, int W, int level, int dtype);
  *                  the partial sums does); HLA_VGG_BWD_DENSE switches it off.
  * first_row8       0, or f in [4, H/8): a promise that d_feat[0] / d_feat[1] / d_feat[2] (and d_conf) are zero above rows
  *                  f / 2f / 4f -- the LM loop only reads rows h_l/2.. of the ground maps, so that is where its gradient
- *                  lives.  Every activation's gradient is then exactly zero above a first row that follows from the layer
+ *                  lives.  The rows of d_feat[l] above f * 2^l - 2 are then not even read (they may be uninitialised).  Every activation's gradient is then exactly zero above a first row that follows from the layer
  *                  graph, and the data- and weight-gradient launches skip those rows.  Needs HLA_VGG_BWD_SCALE_INVARIANT;
  *                  ignored (0) otherwise and at level 4. */
 #define HLA_VGG_BWD_SCALE_INVARIANT 1
