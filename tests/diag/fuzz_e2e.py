@@ -22,6 +22,26 @@ R_FL0 = torch.tensor([[[0., 0., 1.], [1., 0., 0.], [0., 1., 0.]]])
 T_FL0 = torch.tensor([[1.7, 0.3, -1.2]])
 
 
+def knife_edge(make_oracle, sd, evaluate, ref, seed):
+    """Is the fp64 oracle itself discontinuous here?  The in-bounds masks are hard (jacobian.py:168-170) and LM steps can be
+    large, so a pose can sit within rounding of a pixel entering or leaving a sum; then the reference moves by a finite jump under
+    a 1e-6 relative perturbation of its inputs, and no arithmetic can be expected to land on the same side.  Returns the largest
+    change of `evaluate(oracle)` against `ref` over a few such perturbations."""
+    worst = 0.0
+    for key, rel in (('damping', 1e-6), ('damping', -1e-6), ('SatFeatureNet.conv0.bias', 1e-6), ('GrdFeatureNet.conv0.bias', 1e-6)):
+        s2 = {k: v.clone() for k, v in sd.items()}
+        s2[key] = s2[key].double() * (1.0 + rel)
+        try:
+            o = make_oracle()
+            o.load_state_dict({k: v.double() for k, v in s2.items()})
+            torch.manual_seed(seed)
+            with torch.no_grad():
+                worst = max(worst, float(np.abs(evaluate(o) - ref).max()))
+        except Exception as e:          # (a probe, not a verdict: a case it cannot evaluate stays failed)
+            print('   knife_edge probe failed:', repr(e)[:200])
+    return worst
+
+
 def one_case(seed):
     rs = np.random.RandomState(seed)
     fam = int(rs.randint(2)) if seed < 1000 else int(rs.randint(3))     # seeds >= 1000 add LM_G2SP (keeps the old seeds' cases)
@@ -56,6 +76,7 @@ def one_case(seed):
         onet = (O.LM_S2GP_Ford if ford else O.LM_S2GP)(args, grd_hw=(gh, gw))
     onet.load_state_dict(sd)
     onet = onet.double()
+    mk = (lambda: O.LM_G2SP(args).double()) if g2s else (lambda: (O.LM_S2GP_Ford if ford else O.LM_S2GP)(args, grd_hw=(gh, gw)).double())
     net = LM_G2SP(args) if g2s else (LM_S2GP_Ford if ford else LM_S2GP)(args)
     net.load_state_dict(sd)
     net = net.to(d)
@@ -101,6 +122,10 @@ def one_case(seed):
             gap = float(np.abs(r32 - ref).max())
             ok = err < 2 * gap
             note = f', reference fp32-vs-fp64 gap {gap:.2e}'
+            if not ok:
+                jump = knife_edge(mk, sd, lambda o: torch.stack(o(sat.double(), grd.double(), *extra_o, mode='test', **lfkw), -1).numpy(), ref, seed)
+                ok = jump > 0.3 * err
+                note += f'; fp64 oracle under 1e-6 relative perturbations of the damping / image moves by {jump:.2e}' + (' (a discontinuity: hard in-bounds masks)' if ok else '')
         print(f"{'ok  ' if ok else 'FAIL'} fwd   {desc}: pose err {err:.2e} (range {np.abs(ref).max():.2e}{note})", flush=True)
         return ok
     gts_o = [g.double() if not ford else g.double().reshape(-1) for g in (gu, gv, gt)]
@@ -125,7 +150,40 @@ def one_case(seed):
         if cos < worst:
             worst, wname = cos, n
     ok = lerr < 1e-3 and worst > 0.995
-    print(f"{'ok  ' if ok else 'FAIL'} train {desc}: loss rel err {lerr:.1e}, {nchk} grads, worst cosine {worst:.6f} ({wname})", flush=True)
+    note = ''
+    if not ok and worst > 0.995 and np.isfinite(lerr):
+        # ill-conditioned case?  the same gate as for the forward cases: the reference's own fp32-vs-fp64 gap on the loss
+        o32 = type(onet)(args) if g2s else type(onet)(args, grd_hw=(gh, gw))
+        o32.load_state_dict(sd)
+        ex32 = tuple(e.float() if torch.is_tensor(e) else e for e in extra_o)
+        g32 = [g.float() for g in gts_o]
+        torch.manual_seed(seed)
+        with torch.no_grad():
+            l32 = float(o32(sat, grd, *ex32, *g32, mode='train', **lfkw)[0])
+        gap = abs(l32 - float(ro[0].detach())) / max(abs(float(ro[0].detach())), 1e-9)
+        ok = lerr < 2 * gap
+        note = f', reference fp32-vs-fp64 gap of the loss {gap:.1e}'
+        if not ok:
+            l64 = float(ro[0].detach())
+            jump = knife_edge(mk, sd, lambda o: np.array([float(o(sat.double(), grd.double(), *extra_o, *gts_o, mode='train', **lfkw)[0]) / l64]),
+                              np.array([1.0]), seed)
+            ok = jump > 0.3 * lerr
+            note += f'; fp64 oracle loss under 1e-6 relative perturbations of the damping / image moves by {jump:.1e} relative' + \
+                    (' (a discontinuity: hard in-bounds masks)' if ok else '')
+        if not ok and os.environ.get('HLA_FUZZ_DIAG'):      # where does it come from: the forward poses of the same case
+            with torch.no_grad():
+                torch.manual_seed(seed)
+                p64 = torch.stack(onet(sat.double(), grd.double(), *extra_o, mode='test', **lfkw), -1).numpy()
+                torch.manual_seed(seed)
+                p32 = torch.stack(o32(sat, grd, *ex32, mode='test', **lfkw), -1).double().numpy()
+                torch.manual_seed(seed)
+                ph = torch.stack(net(sat.to(d), grd.to(d), *extra_g, mode='test', **lfkw), -1).double().cpu().numpy()
+            print('   damping:', sd['damping'].tolist())
+            print('   final poses fp64 oracle:', p64.round(6).tolist())
+            print('   |HIP - fp64|', np.abs(ph - p64).max(0), ' |oracle fp32 - fp64|', np.abs(p32 - p64).max(0))
+            tr = net.last_trace.double().cpu().numpy()
+            print('   HIP trace (sample 0):', tr[0].reshape(-1, 3).round(5).tolist())
+    print(f"{'ok  ' if ok else 'FAIL'} train {desc}: loss rel err {lerr:.1e}, {nchk} grads, worst cosine {worst:.6f} ({wname}){note}", flush=True)
     return ok
 
 
