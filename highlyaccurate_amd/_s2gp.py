@@ -332,9 +332,7 @@ class S2GPBase(nn.Module):
             # experiment (measured 2 % SLOWER on MI355X, so off by default): ground branch on a side stream so that each branch's
             # kernel tails (the last, partially filled wave of workgroups) overlap with the other branch's work
             cur = torch.cuda.current_stream()
-            side = self.__dict__.get('_side_stream')
-            if side is None or side.device != sat_map.device:
-                side = self.__dict__['_side_stream'] = torch.cuda.Stream(device=sat_map.device)
+            side = _side_stream(sat_map.device)
             side.wait_stream(cur)
             with torch.cuda.stream(side):
                 grd_feats, grd_confs, grd_inv = vgg_forward_nhwc(self.GrdFeatureNet, grd_img, want_conf=want_conf, defer_norm=True)
@@ -379,6 +377,18 @@ def raise_like_reference(trace, in_view, level_first, gn_norm2=None):
     if k_s < steps:
         raise RuntimeError(f'linalg.inv: the normal matrix of LM step {k_s} is singular '
                            '(use_hessian / zero damping / Gauss-Newton with no Jacobian support in one pose component)')
+
+
+_SIDE_STREAMS = {}
+
+
+def _side_stream(device) -> 'torch.cuda.Stream':
+    """One extra stream per device, kept OUTSIDE the modules (a Stream inside a module's __dict__ would break pickling / deepcopy)."""
+    key = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
+    st = _SIDE_STREAMS.get(key)
+    if st is None:
+        st = _SIDE_STREAMS[key] = torch.cuda.Stream(device=key)
+    return st
 
 
 def dead_ground_rows(H: int) -> int:
@@ -448,9 +458,7 @@ class _LocaliseFn(torch.autograd.Function):
         two = os.environ.get('HLA_BWD_TWO_STREAMS', '1') != '0' and sync is None
         if two:
             cur = torch.cuda.current_stream()
-            side = model.__dict__.get('_side_stream')
-            if side is None or side.device != d_sat[0].device:
-                side = model.__dict__['_side_stream'] = torch.cuda.Stream(device=d_sat[0].device)
+            side = _side_stream(d_sat[0].device)
             side.wait_stream(cur)
             with torch.cuda.stream(side):
                 g_sat, flat_sat = vgg_backward_nhwc(model.SatFeatureNet, cs, d_sat, scale_invariant=inv, flat=True,
