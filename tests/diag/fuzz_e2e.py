@@ -101,6 +101,20 @@ def one_case(seed):
             os.environ.pop('HLA_STRICT_ERRORS', None)
         print(f'FAIL raise {desc}: the oracle raised {type(oe).__name__}, the HIP path did not', flush=True)
         return False
+    except RuntimeError as oe:
+        if 'out of bounds' not in str(oe):
+            raise
+        # the pose went NaN / Inf in the reference (a diverging update), whose sampler then indexes with int(NaN): it crashes.
+        # The HIP path must not pretend to have an answer: it has to raise, or return a non-finite pose
+        try:
+            with torch.no_grad():
+                res = torch.stack(net(sat.to(d), grd.to(d), *extra_g, mode='test', **lfkw), -1)
+            bad = not bool(torch.isfinite(res).all())
+        except (RuntimeError, AssertionError):
+            bad = True
+        print(f"{'ok  ' if bad else 'FAIL'} diverged (the reference's sampler raises on a non-finite pose; HIP path "
+              f"{'raises / returns a non-finite pose' if bad else 'returned finite numbers'}) {desc}", flush=True)
+        return bad
     if not train:
         torch.manual_seed(seed)
         with torch.no_grad():
