@@ -269,22 +269,21 @@ def workload_name(model, sat_a, grd_hw, n_iters):
             f"{n_iters} LM iters x 3 levels, 3-DoF, random-init weights")
 
 
-def train_leg(net, a, sat, grd, extra, B, world, dist, dev, want_kt):
+def train_leg(net, a, sat, grd, extra, B, world, rank, dist, dev, want_kt):
     from highlyaccurate_amd import _lib
     from highlyaccurate_amd.parallel import GradSync
     net.train()
-    if dist:
-        net.grad_sync = GradSync()
     opt = torch.optim.Adam(net.parameters(), lr=1e-4)
     gt = [torch.rand(B, 1, device=dev) * 2 - 1 for _ in range(3)]
     if a.model == 'ford':      # Ford_dataset.py:211 collates python floats: [B] float64
         gt = [g[:, 0].double() for g in gt]
 
-    def tstep():
-        opt.zero_grad(set_to_none=True)
+    def tstep(o=None):
+        o = o or opt
+        o.zero_grad(set_to_none=True)
         r = net(sat, grd, *extra, gt[0], gt[1], gt[2], mode='train')
         r[0].backward()
-        opt.step()
+        o.step()
         return r[0]
 
     def timed(nsteps):
@@ -309,6 +308,23 @@ def train_leg(net, a, sat, grd, extra, B, world, dist, dev, want_kt):
             tdt = float(tt.item())
         return tdt, lossv
 
+    # N > 1: rank 0 first times the SAME step alone (no gradient exchange, the other ranks wait at a barrier), so that the line
+    # can state what the all-reduce costs: train.scaling_eff = train.value / (N x that single-rank rate), both measured here
+    single = None
+    if dist:
+        if rank == 0:
+            opt0 = torch.optim.Adam(net.parameters(), lr=0.0)    # the same work, but the replica stays identical to the others'
+            for _ in range(2):
+                tstep(opt0)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(a.train_steps):
+                tstep(opt0)
+            torch.cuda.synchronize()
+            single = B * a.train_steps / (time.perf_counter() - t1)
+            del opt0
+        dist.barrier()
+        net.grad_sync = GradSync()
     ar0 = net.grad_sync.bytes_reduced if dist else 0
     tdt, lossv = timed(a.train_steps)
     ar_bytes = ((net.grad_sync.bytes_reduced - ar0) // (a.train_steps + 2)) if dist else 0
@@ -337,6 +353,9 @@ def train_leg(net, a, sat, grd, extra, B, world, dist, dev, want_kt):
              'what': "forward(mode='train') + HIP backward (LM loop + both VGGs) + gradient all-reduce + Adam",
              'allreduce_bytes_per_step': ar_bytes,
              'sat_backward_live_tiles': live}       # data-dependent trimming; None = dense walk
+    if dist:
+        train['single_rank_value'] = round(single, 3) if single else None      # rank 0 alone, same step, no all-reduce
+        train['scaling_eff'] = round(train['value'] / (world * single), 4) if single else None
     if a.model != 'g2sp':
         # secondary number: the same step with args.train_ground_crop=1 (an extension: the ground branch trains on the
         # image rows that can reach the loss; loss and gradients equal to rounding, the RETURNED confidence maps are
@@ -357,7 +376,45 @@ def train_leg(net, a, sat, grd, extra, B, world, dist, dev, want_kt):
     return train
 
 
-def main():
+def _free_port():
+    import socket
+    with socket.socket() as so:
+        so.bind(('127.0.0.1', 0))
+        return so.getsockname()[1]
+
+
+def launcher_command(n_ranks, argv, port):
+    """The command `python bench.py --gpus N` re-executes itself under when it was started WITHOUT a launcher: one process
+    per GPU, rendezvous on 127.0.0.1 (the container hostname may not resolve) -- the same line the driver uses."""
+    return [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={n_ranks}',
+            '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__), *argv]
+
+
+def self_launch(n_ranks, argv):
+    import subprocess
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')     # dmabuf IPC: RCCL needs it on this driver
+    env.setdefault('OMP_NUM_THREADS', '8')
+    env['HLA_BENCH_SELF_LAUNCHED'] = '1'
+    return subprocess.run(launcher_command(n_ranks, argv, _free_port()), env=env).returncode
+
+
+def resolve_world(gpus, environ):
+    """(world, rank, local_rank) of THIS process, or None when the process still has to spawn its ranks.  `--gpus N` is the
+    contract: it must equal the launcher's WORLD_SIZE; a plain `python bench.py --gpus N` (no launcher) spawns N ranks."""
+    if 'WORLD_SIZE' not in environ:
+        if gpus > 1:
+            return None
+        return 1, 0, 0
+    world = int(environ['WORLD_SIZE'])
+    if world != gpus:
+        raise SystemExit(f'bench.py: --gpus {gpus} but the launcher started WORLD_SIZE={world} ranks; they must agree '
+                         f'(n_gpus in the JSON line is the number of ranks that really ran)')
+    return world, int(environ.get('RANK', '0')), int(environ.get('LOCAL_RANK', '0'))
+
+
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=50)
@@ -373,19 +430,25 @@ def main():
     ap.add_argument('--no-kernel-timing', action='store_true')
     ap.add_argument('--no-extra-legs', action='store_true', help='skip by_precision and the secondary configs (N=1 extras)')
     ap.add_argument('--train-steps', type=int, default=6, help='extra: time this many training steps (0 = skip)')
-    a = ap.parse_args()
+    a = ap.parse_args(argv)
     if a.n_iters is None:
         a.n_iters = 10 if a.model == 'ford' else 5
 
-    world = int(os.environ.get('WORLD_SIZE', '1'))
-    rank = int(os.environ.get('RANK', '0'))
-    local = int(os.environ.get('LOCAL_RANK', '0'))
+    wr = resolve_world(a.gpus, os.environ)
+    if wr is None:                       # `python bench.py --gpus N` with no launcher: be the launcher
+        sys.exit(self_launch(a.gpus, argv))
+    world, rank, local = wr
     assert torch.cuda.is_available(), 'bench.py needs an MI355X'
-    # HLA_BENCH_REHEARSE=1: run the N>1 control flow on a box with fewer GPUs than ranks (ranks share devices, the
-    # collectives go over gloo instead of RCCL).  For checking the multi-rank logic only; the numbers mean nothing.
-    rehearse = bool(os.environ.get('HLA_BENCH_REHEARSE'))
+    # Fewer GPUs than ranks (HLA_BENCH_REHEARSE=1, or detected): REHEARSAL -- the ranks share devices and the collectives go over
+    # gloo instead of RCCL.  It checks the multi-rank control flow only; the line says "rehearsal": true and its numbers are not
+    # a scaling measurement.
+    ndev = torch.cuda.device_count()
+    rehearse = bool(os.environ.get('HLA_BENCH_REHEARSE')) or world > ndev
     if rehearse:
-        local %= torch.cuda.device_count()
+        if rank == 0:
+            print(f'bench.py: REHEARSAL -- {world} ranks on {ndev} GPU(s), gloo instead of RCCL; not a scaling measurement',
+                  file=sys.stderr, flush=True)
+        local %= ndev
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
     dist = None
@@ -430,7 +493,7 @@ def main():
     train = None
     if a.train_steps > 0:
         try:
-            train = train_leg(net, a, sat, grd, extra, B, world, dist, dev, want_kt)
+            train = train_leg(net, a, sat, grd, extra, B, world, rank, dist, dev, want_kt)
         except Exception as e:      # the headline line must still be printed
             train = {'error': repr(e)[:300]}
 
@@ -494,6 +557,12 @@ def main():
         if world > 1:
             res['collective_ranks_seen'] = ranks_seen      # all-reduced count over the process group (RCCL unless rehearsing)
             res['collective_backend'] = 'gloo (rehearsal)' if rehearse else 'nccl (RCCL)'
+            res['rehearsal'] = rehearse                     # true: the ranks SHARE GPUs -- control-flow check, not a measurement
+            res['n_gpus_physical'] = min(world, ndev)
+            res['self_launched'] = bool(os.environ.get('HLA_BENCH_SELF_LAUNCHED'))
+            res['scale_reads'] = ('value = inference pairs/s, batch sharded over the ranks, no data-path collective (weak scaling, '
+                                  f'{B} pairs per GPU); train.value = data-parallel training pairs/s INCLUDING the gradient '
+                                  'all-reduce over RCCL (train.allreduce_bytes_per_step, train.scaling_eff)')
         if recs:
             agg = aggregate(recs)
             # whole-forward conv rate on the FLOPs that were actually EXECUTED (dead rows / dead layers excluded; the

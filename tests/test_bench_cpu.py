@@ -1,0 +1,38 @@
+"""bench.py's launcher contract (no GPU needed): `--gpus N` is what decides the number of ranks."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_gpus_flag_decides_the_world_size():
+    import bench
+    # no launcher: N = 1 runs in-process, N > 1 must spawn (None = "be the launcher")
+    assert bench.resolve_world(1, {}) == (1, 0, 0)
+    assert bench.resolve_world(2, {}) is None and bench.resolve_world(8, {}) is None
+    # under a launcher the flag and WORLD_SIZE must agree ...
+    assert bench.resolve_world(4, {'WORLD_SIZE': '4', 'RANK': '3', 'LOCAL_RANK': '3'}) == (4, 3, 3)
+    assert bench.resolve_world(1, {'WORLD_SIZE': '1', 'RANK': '0', 'LOCAL_RANK': '0'}) == (1, 0, 0)
+    # ... a mismatch is refused instead of reporting a 1-GPU number under "--gpus 8"
+    with pytest.raises(SystemExit):
+        bench.resolve_world(8, {'WORLD_SIZE': '1'})
+    with pytest.raises(SystemExit):
+        bench.resolve_world(2, {'WORLD_SIZE': '4'})
+
+
+def test_self_launch_command_is_the_drivers_line():
+    import bench
+    cmd = bench.launcher_command(8, ['--gpus', '8', '--steps', '5', '--warmup', '2'], 29511)
+    assert cmd[1:4] == ['-m', 'torch.distributed.run', '--nnodes=1']
+    assert '--nproc-per-node=8' in cmd and cmd[cmd.index('--master-addr') + 1] == '127.0.0.1'
+    assert cmd[cmd.index('--master-port') + 1] == '29511'
+    assert cmd[-7] == os.path.join(ROOT, 'bench.py') and cmd[-6:] == ['--gpus', '8', '--steps', '5', '--warmup', '2']
+
+
+def test_world_size_mismatch_exits_before_touching_the_gpu():
+    env = dict(os.environ, WORLD_SIZE='1', RANK='0', LOCAL_RANK='0')
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '8'], env=env, capture_output=True, text=True)
+    assert r.returncode != 0 and 'WORLD_SIZE=1' in r.stderr

@@ -1755,3 +1755,30 @@ def test_training_steps_do_not_accumulate_memory():
             assert used[-1] <= used[1] + (1 << 20), (cls.__name__, used)
     finally:
         gc.enable()
+
+
+def test_bench_gpus_flag_spawns_its_ranks_and_reports_them():
+    """`python bench.py --gpus 2` with NO launcher and no WORLD_SIZE must spawn two ranks itself and say so in its one JSON line
+    (round 2's bench parsed --gpus and ignored it).  On this one-GPU box the two ranks share the device (rehearsal: gloo instead
+    of RCCL, flagged in the line), which exercises everything but the transport: rank spawn, rendezvous on 127.0.0.1, the
+    collective census, barriers + MAX-over-ranks timing, the batch-sharded inference leg, the data-parallel training leg with
+    the in-place all-reduce of the two flat gradient buffers (19.78 MB of live fp32 gradients, SURVEY B-8), rank-0-only output."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT',
+                                                            'HLA_BENCH_REHEARSE')}
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1',
+                        '--train-steps', '2', '--batch', '8', '--no-cpu-baseline'], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, r.stdout[-2000:]                      # ONE line, from rank 0
+    j = json.loads(lines[0])
+    assert j['n_gpus'] == 2 and j['collective_ranks_seen'] == 2 and j['self_launched'] is True
+    assert j['rehearsal'] == (torch.cuda.device_count() < 2) and j['n_gpus_physical'] == min(2, torch.cuda.device_count())
+    assert j['collective_backend'].startswith('gloo' if j['rehearsal'] else 'nccl')
+    assert j['config']['global_batch'] == 16 and j['config']['pairs_per_gpu'] == 8 and j['value'] > 0 and j['scaling'] == 'weak'
+    t = j['train']
+    assert 'error' not in t, t
+    assert abs(t['allreduce_bytes_per_step'] - 19.78e6) < 0.02e6, t['allreduce_bytes_per_step']     # 4 945 536 fp32, once per step
+    assert t['loss_finite'] and t['value'] > 0 and t['single_rank_value'] > 0 and 0 < t['scaling_eff'] < 1.5
+    assert 'roofline' in j and 'scale_reads' in j
