@@ -11,7 +11,6 @@ Differences a caller can observe:
 from __future__ import annotations
 
 import ctypes as C
-import os
 
 import torch
 import torch.nn as nn
@@ -78,6 +77,19 @@ def _packed_weights(module: 'VGGUnet', prm, versions, dt: int, device):
     return cache['buf']
 
 
+def _image_window(x: torch.Tensor):
+    """(x, x_plane) for the C side: an fp32 NCHW image whose rows are W apart and whose samples are 3 planes apart is passed as
+    it lies in memory -- in particular ``img[:, :, r0:, :]``, a window of rows of a taller image (x_plane = the full plane), is
+    NOT copied (mode='test' crops the ground image that way on every call: 66 MB per step at B = 32).  Anything else is made dense."""
+    x = x.float()
+    B, _, H, W = x.shape
+    sb, sc, sh, sw = x.stride()
+    if not (sw == 1 and sh == W and sc >= H * W and sb == 3 * sc):
+        x = x.contiguous()
+        sc = H * W
+    return x, sc
+
+
 @_lib.on_device(lambda module, x, *a, **k: x)
 def vgg_forward_nhwc(module: 'VGGUnet', x: torch.Tensor, want_conf: bool = True, defer_norm: bool = False,
                      save_for_backward: bool = False, first_row8: int = 0, feat16: bool = False):
@@ -93,7 +105,7 @@ def vgg_forward_nhwc(module: 'VGGUnet', x: torch.Tensor, want_conf: bool = True,
     if x.dim() != 4 or x.shape[1] != 3:
         raise ValueError(f'expected [B,3,H,W], got {tuple(x.shape)}')
     lib = _lib.load()
-    x = x.contiguous().float()
+    x, x_plane = _image_window(x)
     B, _, H, W = x.shape
     _lib.same_device(('input', x), ('parameters', module.conv0.weight))
     dt = _dtype_code(module.precision)
@@ -121,13 +133,13 @@ def vgg_forward_nhwc(module: 'VGGUnet', x: torch.Tensor, want_conf: bool = True,
         if not defer_norm:
             raise ValueError('save_for_backward needs defer_norm=True (the backward works on the raw maps)')
         flags |= _lib.HLA_VGG_SAVE_FOR_BACKWARD
-    rc = lib.hla_vgg_forward(_lib.ptr(x), C.byref(prm), _lib.ptr(packed), fp, cp, _lib.ptr(inv_norm), _lib.ptr(ws), nbytes,
+    rc = lib.hla_vgg_forward(_lib.ptr(x), x_plane, C.byref(prm), _lib.ptr(packed), fp, cp, _lib.ptr(inv_norm), _lib.ptr(ws), nbytes,
                              B, H, W, L, dt, flags, int(first_row8), _lib.stream_ptr())
     _lib.check(rc, 'hla_vgg_forward')
     # ws is only used by work already enqueued on this stream; the caching allocator keeps the block
     # stream-ordered, so dropping the Python reference here is safe.
     if save_for_backward:
-        return feats, confs, inv_norm, dict(x=x, ws=ws, feats=feats, inv_norm=inv_norm, dt=dt, L=L)
+        return feats, confs, inv_norm, dict(x=x, x_plane=x_plane, ws=ws, feats=feats, inv_norm=inv_norm, dt=dt, L=L)
     return feats, confs, inv_norm
 
 
@@ -143,7 +155,7 @@ def vgg_backward_nhwc(module: 'VGGUnet', ctx: dict, d_feats, confs=None, d_confs
     wgrad kernels write into directly, and ``(grads, flat_buffer)`` is returned: a data-parallel caller all-reduces that one
     buffer in place (parallel.GradSync) -- no gather copy before and no scatter copy after the collective.
     With ``scale_invariant`` the call skips every tile whose gradient is zero because the d_feats are (include/hla.h,
-    HLA_VGG_BWD_SCALE_INVARIANT); ``dense=True`` (or HLA_VGG_BWD_DENSE=1 in the environment) visits all of them (A/B, tests).
+    HLA_VGG_BWD_SCALE_INVARIANT); ``dense=True`` (``args.bwd_trim = 0`` on the models) visits all of them (A/B, tests).
     ``stats`` (a dict, diagnostics: costs a device synchronisation) receives 'live_tiles' / 'total_tiles' per sample, summed over
     the data- and weight-gradient launches; both 0 when the call took the dense walk."""
     lib = _lib.load()
@@ -197,10 +209,10 @@ def vgg_backward_nhwc(module: 'VGGUnet', ctx: dict, d_feats, confs=None, d_confs
     dp = (C.c_void_p * 4)(*([d.data_ptr() for d in dfs] + [0] * (4 - L)))
     nbytes = lib.hla_vgg_bwd_workspace_bytes(B, H, W, L, dt)
     ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
-    rc = lib.hla_vgg_backward(_lib.ptr(x), C.byref(prm), _lib.ptr(cache['buf']), _lib.ptr(ctx['ws']), fp, _lib.ptr(ctx['inv_norm']),
+    rc = lib.hla_vgg_backward(_lib.ptr(x), ctx.get('x_plane', 0), C.byref(prm), _lib.ptr(cache['buf']), _lib.ptr(ctx['ws']), fp, _lib.ptr(ctx['inv_norm']),
                               dp, cp, dcp, C.byref(gs), _lib.ptr(ws), nbytes, B, H, W, L, dt,
                               (_lib.HLA_VGG_BWD_SCALE_INVARIANT if scale_invariant else 0)
-                              | (_lib.HLA_VGG_BWD_DENSE if dense or os.environ.get('HLA_VGG_BWD_DENSE') == '1' else 0),
+                              | (_lib.HLA_VGG_BWD_DENSE if dense else 0),
                               int(first_row8), _lib.stream_ptr())
     _lib.check(rc, 'hla_vgg_backward')
     if stats is not None:
@@ -266,16 +278,21 @@ class _VggFn(torch.autograd.Function):
         B = x.shape[0]
         # the un-deferred path scales in-kernel with one fp64 multiply per element (scale_kernel): the same arithmetic here
         normed = [(f.double() * inv[l].view(B, 1, 1, 1)).float() for l, f in enumerate(feats)]
-        ctx.module, ctx.names, ctx.saved, ctx.confs = module, names, c, confs
-        return tuple(normed) + tuple(confs)
+        ctx.module, ctx.names, ctx.saved, ctx.n_levels = module, names, c, len(confs)
+        confs = tuple(confs)
+        # the confidence maps are OUTPUTS: kept through save_for_backward (which knows how to hold an output without the
+        # output -> grad_fn -> ctx -> output cycle a plain attribute would make), not as ctx.confs
+        ctx.save_for_backward(*confs)
+        return tuple(normed) + confs
 
     @staticmethod
     def backward(ctx, *grads):
-        c, confs = ctx.saved, ctx.confs
+        c = ctx.saved
         if c is None:
             raise RuntimeError('VGGUnet: backward through the same forward twice (the saved activations were released after the '
                                'first backward; retain_graph is not supported by the HIP backward)')
-        L = len(confs)
+        confs = list(ctx.saved_tensors)
+        L = ctx.n_levels
         d_feats = [g if g is not None else torch.zeros_like(c['feats'][l]) for l, g in enumerate(grads[:L])]
         d_confs = [g if g is not None else torch.zeros_like(confs[l]) for l, g in enumerate(grads[L:])]
         g = vgg_backward_nhwc(ctx.module, c, d_feats, confs, d_confs, scale_invariant=False)

@@ -6,7 +6,6 @@ inside one ``torch.autograd.Function`` whose backward is ``hla_g2s_lm_solve_bwd`
 from __future__ import annotations
 
 import ctypes as C
-import os
 
 import torch
 from torch import nn
@@ -77,7 +76,7 @@ class LM_G2SP(nn.Module):
         B, L = sat_feats[0].shape[0], len(sat_feats)
         cfg, lv, K = self._structs(sat_feats, grd_feats, grd_confs, camera_k, sat_inv_norm, grd_inv_norm)
         trace = torch.empty(B, self.N_iters, L, 3, device=dev, dtype=torch.float32)
-        strict = bool(getattr(self.args, 'strict_errors', 0)) or os.environ.get('HLA_STRICT_ERRORS', '0') == '1'
+        strict = bool(getattr(self.args, 'strict_errors', 0))
         want_neq = strict or (self.keep_normal_eq if keep_normal_eq is None else keep_normal_eq)
         neq = torch.empty(L * self.N_iters, B, 16, device=dev, dtype=torch.float64) if want_neq else None
         nbytes = lib.hla_g2s_workspace_bytes(C.byref(cfg), lv, B)

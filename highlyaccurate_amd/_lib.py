@@ -17,7 +17,7 @@ HLA_F32, HLA_BF16, HLA_F16, HLA_F16X3 = 0, 1, 2, 3
 HLA_VGG_WANT_CONF, HLA_VGG_DEFER_NORM, HLA_VGG_SAVE_FOR_BACKWARD, HLA_VGG_FEAT16 = 1, 2, 4, 8
 HLA_VGG_BWD_SCALE_INVARIANT = 1
 HLA_VGG_BWD_DENSE = 2
-ABI_VERSION = 16
+ABI_VERSION = 17
 
 
 class HlaError(RuntimeError):
@@ -84,14 +84,22 @@ def load() -> C.CDLL:
     if _lib is not None:
         return _lib
     from . import build as _b
-    if _b.lib_hash(LIB_PATH) != _b.source_hash() and not (os.environ.get('HLA_LIB') and os.environ.get('HLA_ALLOW_STALE') == '1'):
-        # (HLA_LIB + HLA_ALLOW_STALE=1: A/B timing of an older experiment build against the current one, tools/variants.py)
+    try:
+        want = _b.source_hash()
+    except _b.SourcesMissing as e:
+        # a prebuilt library deployed without its sources: nothing to compare its content with (and nothing to rebuild from);
+        # the ABI-version and struct-size checks below still apply
+        if not os.path.exists(LIB_PATH):
+            raise HlaError(f'{LIB_PATH} is missing and so are its sources: {e}') from None
+        want = _b.lib_hash(LIB_PATH)
+    if _b.lib_hash(LIB_PATH) != want and not (os.environ.get('HLA_LIB') and os.environ.get('HLA_ALLOW_STALE') == '1'):
+        # (HLA_LIB + HLA_ALLOW_STALE=1: A/B timing of an older experiment build against the current one, tools/ab_libs.py)
         if os.environ.get('HLA_LIB'):
-            raise HlaError(f'{LIB_PATH} (HLA_LIB) was not built from the sources in {_b.CSRC}; rebuild the variant')
+            raise HlaError(f'{LIB_PATH} (HLA_LIB) was not built from the sources in {_b.CSRC}; rebuild it')
         if not _b.have_compiler():
             what = 'is missing' if not os.path.exists(LIB_PATH) else 'is stale (built from different sources)'
             raise HlaError(f'{LIB_PATH} {what} and there is no hipcc to rebuild it; highlyaccurate_amd has no fallback path')
-        _b.build(force=True)
+        _b.build()          # takes a file lock and re-checks: concurrent ranks build once
     lib = C.CDLL(LIB_PATH)
     _check_binary(lib, LIB_PATH)
     vp, i, sz = C.c_void_p, C.c_int, C.c_size_t
@@ -100,7 +108,7 @@ def load() -> C.CDLL:
     lib.hla_vgg_workspace_bytes.restype = sz
     lib.hla_vgg_workspace_bytes.argtypes = [i, i, i, i, i]
     lib.hla_vgg_forward.restype = i
-    lib.hla_vgg_forward.argtypes = [vp, C.POINTER(VggParams), vp, C.POINTER(vp), C.POINTER(vp), vp, vp, sz,
+    lib.hla_vgg_forward.argtypes = [vp, sz, C.POINTER(VggParams), vp, C.POINTER(vp), C.POINTER(vp), vp, vp, sz,
                                     i, i, i, i, i, i, i, vp]
     lib.hla_vgg_packed_weight_bytes.restype = sz
     lib.hla_vgg_packed_weight_bytes.argtypes = [i]
@@ -115,7 +123,7 @@ def load() -> C.CDLL:
     lib.hla_vgg_backward_live_tiles.restype = i
     lib.hla_vgg_backward_live_tiles.argtypes = [vp, i, i, i, i, i, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]
     lib.hla_vgg_backward.restype = i
-    lib.hla_vgg_backward.argtypes = [vp, C.POINTER(VggParams), vp, vp, C.POINTER(vp), vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(VggGrads),
+    lib.hla_vgg_backward.argtypes = [vp, sz, C.POINTER(VggParams), vp, vp, C.POINTER(vp), vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(VggGrads),
                                      vp, sz, i, i, i, i, i, i, i, vp]
     lib.hla_resize_bilinear.restype = i
     lib.hla_resize_bilinear.argtypes = [vp, vp, vp, i, vp, vp, i, vp, vp, i, i, i, i, i, vp]

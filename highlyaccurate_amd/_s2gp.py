@@ -7,7 +7,6 @@ H2D copies (the reference does ~60 syncs and ~100 small uploads per forward, SUR
 from __future__ import annotations
 
 import ctypes as C
-import os
 
 import numpy as np
 import torch
@@ -70,6 +69,15 @@ def loss_func(loss_method, ref_feat_list, pred_feat_dict, gt_feat_dict, shift_la
 class S2GPBase(nn.Module):
     ford = False
 
+    # Fields of ``args`` beyond the reference's argparse namespace (all optional; a reference Namespace works unchanged):
+    #   precision          'fp32' (default, exact-fp32 MFMA) | 'fp16x3' | 'bf16' | 'fp16'                       DESIGN.md 3.8
+    #   lm_feat16          1: bf16 / fp16 inference hands the LM loop fp16 feature maps; 0: fp32 maps           DESIGN.md 3.3
+    #   ground_crop        1: mode='test' skips the ground-image rows (and, layer by layer, the feature rows) that cannot
+    #                      reach the rows the LM loop reads; 0: whole image.  Computed rows are bit-identical  DESIGN.md 3.5
+    #   train_ground_crop  0; 1: the same for training (changes the returned confidence maps above the crop)   DESIGN.md 3.5
+    #   bwd_trim           1: the backward skips rows / tiles whose gradient is exactly zero; 0: dense walk     DESIGN.md 6
+    #   bwd_two_streams    1: the two extractors' backward passes run on two streams (single-GPU training)       DESIGN.md 6
+    #   strict_errors      0; 1: reproduce jacobian.py:172's AssertionError (costs a host sync per forward)     DESIGN.md 1
     def __init__(self, args):
         super().__init__()
         self.args = args
@@ -154,12 +162,7 @@ class S2GPBase(nn.Module):
     def _draw_reinit(self, n_steps: int, B: int, device):
         """Reproduce the reference's global-RNG consumption: two Uniform(-1,1).sample([B,1]) draws per
         LM step (models_kitti.py:1028-1029), in step order, from torch's CPU generator."""
-        draws = []
-        for _ in range(n_steps):
-            ru = torch.distributions.uniform.Uniform(-1, 1).sample([B, 1])
-            rv = torch.distributions.uniform.Uniform(-1, 1).sample([B, 1])
-            draws.append(torch.stack([ru[:, 0], rv[:, 0]], 0))
-        return torch.stack(draws, 0).to(device)
+        return draw_reinit(n_steps, B, device)
 
     def _draw_dropout(self, lv, level_first, device):
         """args.dropout > 0 (models_kitti.py:968-974, models_ford.py:406-412): every LM step keeps a random half of the
@@ -225,7 +228,7 @@ class S2GPBase(nn.Module):
         if self.last_keep is not None:
             cfg.keep, cfg.keep_stride = self.last_keep.data_ptr(), self.last_keep.shape[1]
         trace = torch.empty(B, self.N_iters, L, 3, device=dev, dtype=torch.float32)
-        strict = bool(getattr(self.args, 'strict_errors', 0)) or os.environ.get('HLA_STRICT_ERRORS', '0') == '1'
+        strict = bool(getattr(self.args, 'strict_errors', 0))
         want_neq = strict or cfg.optimizer == 3 or (self.keep_normal_eq if keep_normal_eq is None else keep_normal_eq)
         cfg.count_in_view = 1 if strict else 0
         neq = torch.empty(steps, B, 16, device=dev, dtype=torch.float64) if want_neq else None
@@ -237,7 +240,7 @@ class S2GPBase(nn.Module):
         _lib.check(rc, 'hla_s2g_lm_solve')
         # Error behaviour of the reference, which costs a host sync and is therefore only reproduced (a) under the ablation
         # flags that can make H + damping*D exactly singular (use_hessian / zero damping) and (b) when strict error checking
-        # is asked for (HLA_STRICT_ERRORS=1 or args.strict_errors).  With the default flags the forward has no host sync;
+        # is asked for (args.strict_errors).  With the default flags the forward has no host sync;
         # a step whose pixels all fall outside the satellite map then leaves the pose unchanged (J = 0, r = -g).
         risky = cfg.optimizer == 3 or (cfg.optimizer == 0 and (cfg.use_hessian or min(cfg.damping[i] for i in range(3)) <= 0.0))
         if risky or strict:
@@ -292,21 +295,20 @@ class S2GPBase(nn.Module):
         # Reduced-precision inference modes: the LM loop reads fp16 feature maps (written saturating by the three feature
         # layers' epilogues; also in bf16 mode: bf16's 8 significand bits moved the worst golden seed's pose 23x, fp16's 11
         # move it 1.6x).  With the gather loop written on channel PAIRS (lm_solve.hip) the accumulate kernels are VALU-bound on
-        # 16-bit maps and 30 % faster than on fp32 ones: +7 % pairs/s.  args.lm_feat16 = 0 / HLA_LM_FEAT16=0 keeps fp32 maps;
-        # the fp32-class modes and every training path always do.
-        f16 = (self.SatFeatureNet.precision in ('bf16', 'fp16') and self.level == 3
-               and bool(getattr(self.args, 'lm_feat16', 1)) and os.environ.get('HLA_LM_FEAT16', '1') != '0')
+        # 16-bit maps and 30 % faster than on fp32 ones: +7 % pairs/s.  args.lm_feat16 = 0 keeps fp32 maps; the fp32-class modes
+        # and every training path always do.
+        f16 = (self.SatFeatureNet.precision in ('bf16', 'fp16') and self.level == 3 and bool(getattr(self.args, 'lm_feat16', 1)))
         sat_feats, _, sat_inv = vgg_forward_nhwc(self.SatFeatureNet, sat_map, want_conf=False, defer_norm=True, feat16=f16)
         grd_in = grd_img
         # (only LM_update renormalises the ground features; SGD / ADAM see the whole-map L2_norm scale, so they need every row)
         dead_ok = (not return_confs and self.level == 3 and getattr(self.args, 'Optimizer', 'LM') == 'LM'
-                   and os.environ.get('HLA_GRD_CROP', '1') != '0')
+                   and bool(getattr(self.args, 'ground_crop', 1)))
         skip = dead_ground_rows(grd_img.shape[-2]) if dead_ok else 0
         if skip:
-            grd_in = grd_img[:, :, skip:, :].contiguous()
+            grd_in = grd_img[:, :, skip:, :]         # a row window, passed as it lies in memory (hla_vgg_forward's x_plane): no copy
         # ... and inside the extractor every layer only computes the rows the LM loop's rows depend on
         f8 = ((grd_img.shape[-2] // 8) // 2 - skip // 8) if dead_ok else 0
-        f8 = f8 if (f8 >= 4 and os.environ.get('HLA_GRD_TRIM', '1') != '0') else 0
+        f8 = f8 if f8 >= 4 else 0
         grd_feats, grd_confs, grd_inv = vgg_forward_nhwc(self.GrdFeatureNet, grd_in, want_conf=want_conf, defer_norm=True,
                                                          first_row8=f8, feat16=f16)
         return sat_feats, sat_inv, grd_feats, grd_confs, grd_inv
@@ -328,23 +330,23 @@ class S2GPBase(nn.Module):
             params = [p for _, p in self.named_parameters()]
             out = _LocaliseFn.apply(self, names, sat_map, grd_img, want_conf, extra, level_first, init_pose, *params)
             return out[0], list(out[1:]) if want_conf else [None] * self.level
-        if os.environ.get('HLA_TWO_STREAMS', '0') == '1':
-            # experiment (measured 2 % SLOWER on MI355X, so off by default): ground branch on a side stream so that each branch's
-            # kernel tails (the last, partially filled wave of workgroups) overlap with the other branch's work
-            cur = torch.cuda.current_stream()
-            side = _side_stream(sat_map.device)
-            side.wait_stream(cur)
-            with torch.cuda.stream(side):
-                grd_feats, grd_confs, grd_inv = vgg_forward_nhwc(self.GrdFeatureNet, grd_img, want_conf=want_conf, defer_norm=True)
-            sat_feats, _, sat_inv = vgg_forward_nhwc(self.SatFeatureNet, sat_map, want_conf=False, defer_norm=True)
-            cur.wait_stream(side)
-            for t in list(grd_feats) + [c for c in grd_confs if c is not None] + [grd_inv]:
-                t.record_stream(cur)
-        else:
-            sat_feats, sat_inv, grd_feats, grd_confs, grd_inv = self._features(sat_map, grd_img, want_conf, return_confs)
+        # (the two dense extractor passes on two streams measured 2 % slower than back to back: DESIGN.md 3.1)
+        sat_feats, sat_inv, grd_feats, grd_confs, grd_inv = self._features(sat_map, grd_img, want_conf, return_confs)
         trace = self.lm_solve(sat_feats, grd_feats, grd_confs, grd_img.shape[-2:], extra, level_first, init_pose,
                               sat_inv, grd_inv)
         return trace, grd_confs
+
+
+def draw_reinit(n_steps: int, B: int, device):
+    """[n_steps, 2, B] = the (rand_u, rand_v) of every LM step, VALUE FOR VALUE what the reference's 2 * n_steps calls
+    ``Uniform(-1, 1).sample([B, 1])`` (models_kitti.py:1028-1029) draw from torch's global CPU generator, which is left in the
+    same state: ``Uniform.sample`` is ``low + torch.rand(shape) * (high - low)`` and the CPU generator fills a tensor serially,
+    so one ``torch.rand`` of all of them is the same stream (``tests/test_host_logic_cpu.py`` pins both).  One call, one pinned
+    staging buffer from the caching host allocator and one asynchronous copy, instead of 30 draws + a blocking upload per forward."""
+    r = torch.rand(n_steps, 2, B).mul_(2.0).add_(-1.0)         # -1 + rand * 2, the same two fp32 roundings
+    if torch.device(device).type == 'cuda':
+        return r.pin_memory().to(device, non_blocking=True)
+    return r.to(device)
 
 
 def raise_like_reference(trace, in_view, level_first, gn_norm2=None):
@@ -417,7 +419,7 @@ class _LocaliseFn(torch.autograd.Function):
         skip = 0
         if getattr(model.args, 'train_ground_crop', 0) and model.level == 3 and getattr(model.args, 'Optimizer', 'LM') == 'LM':
             skip = dead_ground_rows(grd_img.shape[-2])
-        grd_in = grd_img[:, :, skip:, :].contiguous() if skip else grd_img
+        grd_in = grd_img[:, :, skip:, :] if skip else grd_img      # (a view: the extractor takes the window's plane stride)
         grd_feats, grd_confs, grd_inv, cg = vgg_forward_nhwc(model.GrdFeatureNet, grd_in, want_conf=want_conf,
                                                              defer_norm=True, save_for_backward=True)
         trace = model.lm_solve(sat_feats, grd_feats, grd_confs, grd_img.shape[-2:], extra, level_first, init_pose,
@@ -440,10 +442,12 @@ class _LocaliseFn(torch.autograd.Function):
             raise RuntimeError('backward through the same forward twice: the saved activations (GBs at B = 32) are released after '
                                'the first backward; retain_graph is not supported by the HIP backward')
         sat_feats, grd_feats, grd_confs, grd_hw, trace, neq, sat_inv, grd_inv, cs, cg, keep = ctx.state
-        inv = getattr(model.args, 'Optimizer', 'LM') == 'LM' and os.environ.get('HLA_L2BWD_FULL', '0') != '1'
+        # LM_update renormalises both maps, so d_feat is orthogonal to feat: HLA_VGG_BWD_SCALE_INVARIANT (include/hla.h)
+        inv = getattr(model.args, 'Optimizer', 'LM') == 'LM'
+        trim = bool(getattr(model.args, 'bwd_trim', 1))
         # the ground maps' gradient lives in rows h_l/2.. (all the LM loop reads): the backward skips the rows above its support
         f8 = (grd_hw[0] // 8) // 2 - (grd_hw[0] - grd_feats[2].shape[1] * 2) // 8
-        f8 = f8 if (inv and f8 >= 4 and model.level == 3 and os.environ.get('HLA_BWD_TRIM', '1') != '0') else 0
+        f8 = f8 if (inv and f8 >= 4 and model.level == 3 and trim) else 0
         d_sat, d_grd, d_conf, d_lam = model.lm_backward(sat_feats, grd_feats, grd_confs, grd_hw, trace, neq, d_trace, ctx.extra,
                                                    ctx.level_first, ctx.init_pose, sat_inv, grd_inv, keep, grd_first_row8=f8)
         sync = getattr(model, 'grad_sync', None)        # optional: overlap the sat-branch all-reduce with the grd backward
@@ -454,28 +458,32 @@ class _LocaliseFn(torch.autograd.Function):
         # are sparse (0.42 of the tiles: many of them fill the chip for a round or two only), so it runs on a side stream next to
         # the ground branch's: 24.78 -> 24.43 ms per step (same-box A/B, four alternating pairs, the faster one every time).  (The
         # same split of the two FORWARD passes, both dense, measured 2 % slower.)  Not with a gradient all-reduce installed: there
-        # the satellite bucket is already in flight under the ground branch's backward.  HLA_BWD_TWO_STREAMS=0 switches it off.
-        two = os.environ.get('HLA_BWD_TWO_STREAMS', '1') != '0' and sync is None
+        # the satellite bucket is already in flight under the ground branch's backward.  args.bwd_two_streams = 0 switches it off.
+        # Memory: the satellite branch's backward workspace and gradient buffer then come from the side stream's pool of the
+        # caching allocator, so the freed block cannot be reused for the ground branch's workspace on the main stream: peak
+        # training memory is one backward workspace higher (GB-class at B = 32 in fp32) for that 1.4 %.
+        two = bool(getattr(model.args, 'bwd_two_streams', 1)) and sync is None
         if two:
             cur = torch.cuda.current_stream()
             side = _side_stream(d_sat[0].device)
             side.wait_stream(cur)
             with torch.cuda.stream(side):
-                g_sat, flat_sat = vgg_backward_nhwc(model.SatFeatureNet, cs, d_sat, scale_invariant=inv, flat=True,
+                g_sat, flat_sat = vgg_backward_nhwc(model.SatFeatureNet, cs, d_sat, scale_invariant=inv, flat=True, dense=not trim,
                                                     stats=getattr(model, 'bwd_stats', None))
             for t in d_sat:
                 t.record_stream(side)
         else:
-            g_sat, flat_sat = vgg_backward_nhwc(model.SatFeatureNet, cs, d_sat, scale_invariant=inv, flat=True,
+            g_sat, flat_sat = vgg_backward_nhwc(model.SatFeatureNet, cs, d_sat, scale_invariant=inv, flat=True, dense=not trim,
                                                 stats=getattr(model, 'bwd_stats', None))
         h1 = sync.start({'SatFeatureNet.' + k: v for k, v in g_sat.items()}, flat_sat) if sync else None
         use_w = model.using_weight and all(c is not None for c in d_conf)
         g_grd, flat_grd = vgg_backward_nhwc(model.GrdFeatureNet, cg, d_grd, grd_confs if use_w else None, d_conf if use_w else None,
-                                            scale_invariant=inv, first_row8=f8, flat=True)
+                                            scale_invariant=inv, first_row8=f8, flat=True, dense=not trim)
         h2 = sync.start({'GrdFeatureNet.' + k: v for k, v in g_grd.items()}, flat_grd) if sync else None
         if two:
             torch.cuda.current_stream().wait_stream(side)
-            flat_sat.record_stream(torch.cuda.current_stream())
+            for t in [flat_sat] + list(g_sat.values()):       # allocated on the side stream, consumed (optimizer) on this one
+                t.record_stream(torch.cuda.current_stream())
         if sync:
             sync.finish(h1)
             sync.finish(h2)

@@ -1,4 +1,4 @@
-"""Build libhla.so (gfx950) in-tree with hipcc.  `python -m highlyaccurate_amd.build [--force] [--verbose]`"""
+"""Build libhla.so (gfx950) in-tree with hipcc.  `python -m highlyaccurate_amd.build [--force] [--verbose] [--out=NAME.so] [-DX=1]`"""
 from __future__ import annotations
 
 import os
@@ -18,16 +18,24 @@ FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=f
 HASH_MARK = b'HLA_SOURCE_HASH='
 
 
+class SourcesMissing(RuntimeError):
+    pass
+
+
 def source_hash() -> str:
     """sha256 over everything the library is built from (csrc/*, include/hla.h, the compiler flags).  The build bakes it
     into the binary (``hla_source_hash()``), so a stale libhla.so is detected by CONTENT: file times do not survive the
     copy to the GPU box, and *.so is git-ignored but shipped prebuilt."""
     import hashlib
     h = hashlib.sha256(' '.join(FLAGS).encode())
-    deps = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(('.hip', '.h')))
-    for d in deps + [os.path.join(HERE, '..', 'include', 'hla.h')]:
-        h.update(os.path.basename(d).encode() + b'\0')
-        h.update(open(d, 'rb').read())
+    try:
+        deps = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(('.hip', '.h')))
+        for d in deps + [os.path.join(HERE, '..', 'include', 'hla.h')]:
+            h.update(os.path.basename(d).encode() + b'\0')
+            h.update(open(d, 'rb').read())
+    except OSError as e:        # a prebuilt library shipped without csrc/ or the repo-root include/: there is nothing to compare with
+        raise SourcesMissing(f'cannot hash the library sources ({e.filename}: {e.strerror}); the tree needs '
+                             f'highlyaccurate_amd/csrc/*.hip,*.h and include/hla.h next to the package') from None
     return h.hexdigest()
 
 
@@ -80,23 +88,37 @@ def _resource_table(text: str) -> None:
               f"lds {r.get('LDS','?')}")
 
 
-def build(force: bool = False, verbose: bool = False, variant: int = 0) -> str:
-    """variant != 0 builds an experiment library libhla_v<variant>.so with -DCONV_VARIANT=<variant>
-    (select it at run time with HLA_LIB=<path>)."""
+def build(force: bool = False, verbose: bool = False, out: str = None, defines=()) -> str:
+    """Build highlyaccurate_amd/libhla.so.  ``out`` = another file name (an A/B build kept next to the product library and
+    selected at run time with HLA_LIB=<path>, e.g. the previous commit's kernels for a same-box comparison: tools/ab_libs.py);
+    ``defines`` = extra -D flags for such a build."""
     global LIB
-    if variant:
-        LIB = os.path.join(HERE, f'libhla_v{variant}.so')
+    if out:
+        LIB = out if os.path.isabs(out) else os.path.join(HERE, out)
         force = True
     if not force and not _stale():
         return LIB
+    os.makedirs(os.path.join(HERE, 'build'), exist_ok=True)
+    # One builder at a time: under torchrun every rank reaches a stale library at once, and all of them would write the same
+    # build/*.o (only the final link is atomic) -- a rank could link another rank's half-written object.  Whoever gets the lock
+    # second finds the library fresh and returns.
+    import fcntl
+    with open(os.path.join(HERE, 'build', '.lock'), 'w') as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        if not force and not _stale():
+            return LIB
+        return _build_locked(verbose, tuple(defines))
+
+
+def _build_locked(verbose: bool, defines: tuple) -> str:
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
     srchash = source_hash()
     objs = []
     procs = []
     os.makedirs(os.path.join(HERE, 'build'), exist_ok=True)
     for s, tu in SOURCES:
-        o = os.path.join(HERE, 'build', s.replace('.hip', f'.v{variant}.t{tu + 1}.o'))
-        cmd = [hipcc, *FLAGS, f'-DCONV_VARIANT={variant}', f'-DHLA_TU_DTYPE={tu}', '-c', os.path.join(CSRC, s), '-o', o]
+        o = os.path.join(HERE, 'build', s.replace('.hip', f'.{os.path.basename(LIB)}.t{tu + 1}.o'))
+        cmd = [hipcc, *FLAGS, *[f'-D{d}' for d in defines], f'-DHLA_TU_DTYPE={tu}', '-c', os.path.join(CSRC, s), '-o', o]
         if s == 'capi.hip':
             cmd.insert(-4, f'-DHLA_SOURCE_HASH_HEX="{srchash}"')
         if verbose:
@@ -121,5 +143,6 @@ def build(force: bool = False, verbose: bool = False, variant: int = 0) -> str:
 
 
 if __name__ == '__main__':
-    _v = [int(a.split('=')[1]) for a in sys.argv if a.startswith('--variant=')]
-    print(build(force='--force' in sys.argv, verbose='--verbose' in sys.argv, variant=_v[0] if _v else 0))
+    _o = [a.split('=', 1)[1] for a in sys.argv if a.startswith('--out=')]
+    _d = [a[2:] for a in sys.argv if a.startswith('-D')]
+    print(build(force='--force' in sys.argv, verbose='--verbose' in sys.argv, out=_o[0] if _o else None, defines=_d))

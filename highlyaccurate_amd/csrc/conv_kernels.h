@@ -131,12 +131,8 @@ __device__ __forceinline__ float wave_max_f32(float v) {
 // a CONTIGUOUS run of tiles: vertically adjacent tiles, which share two halo rows, then hit the same L2.  Bijective for
 // any grid size (cdna_hip_programming.md "XCD swizzle must be bijective").  Measured: +1 % in one A/B, within noise in the next.
 __device__ __forceinline__ int xcd_contiguous(int bid, int nb) {
-#if CONV_VARIANT == 111
-  return bid;
-#else
   const int q = nb >> 3, r = nb & 7, xcd = bid & 7;
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-#endif
 }
 
 struct ConvArgs {
@@ -166,7 +162,6 @@ struct ConvArgs {
   const void* add_src;              // NHWC T, output shape: out += add                (gradient fan-in)
   unsigned char* idx_out;           // POOL (max): argmax position 2*row+col of every pooled element (forward, training)
   int pool_sum;                     // POOL epilogue sums the 2x2 block instead of max (backward of nearest upsample)
-  unsigned long long* dbg;          // CONV_VARIANT 40 only: per-wave cycle accounting
   // --- split-fp16 mode (T = split32) ---
   const unsigned* amax1;            // [B] fp32 bit pattern of max |src1| per sample (written by the producer's epilogue)
   const unsigned* amax2;            // likewise for src2, or null; the two sources share one scale
@@ -190,16 +185,6 @@ constexpr int HWID = 34;   // halo tile width in pixels
 constexpr int SB = 64;     // bytes of channels per pixel per pipeline stage
 constexpr int PSTR = 80;   // LDS bytes per halo pixel (64 B of channels + 16 B pad: conflict-free ds_read_b128)
 constexpr int HALO_TAP = 3;  // tap at which the next stage's halo loads are issued
-#ifndef CONV_VARIANT
-#define CONV_VARIANT 0
-#endif
-// timing ablations for tools/variants.py (results are wrong on purpose): 10 no weight loads, 11 no LDS reads,
-// 12 no halo staging, 13 = all three, 14 = 13 + no barrier
-constexpr bool ABL_ALL = (CONV_VARIANT == 13 || CONV_VARIANT == 14);
-constexpr bool ABL_NO_W = (CONV_VARIANT == 10 || ABL_ALL);
-constexpr bool ABL_NO_LDS = (CONV_VARIANT == 11 || ABL_ALL);
-constexpr bool ABL_NO_HALO = (CONV_VARIANT == 12 || ABL_ALL);
-constexpr bool ABL_NO_BAR = (CONV_VARIANT == 14);
 
 // ---------------------------------------------------------------------------------------------
 // shared epilogue: acc[i][j] holds, for lane (x = lane&31, g = lane>>5), output channels
@@ -228,11 +213,7 @@ template <typename E, int NT> struct RowStager {
       if (c0 < chunks && c < chunks) {
         const int px = c / CPP, part = c % CPP;
         if (px < npx_valid) {
-#if CONV_VARIANT == 42 || CONV_VARIANT == 43
-          uint4 v = make_uint4(px, part, lane, c0);                        // timing ablation: no LDS read-back
-#else
           uint4 v = *(const uint4*)(stage + px * PITCH + part * 16);
-#endif
           const unsigned off = (unsigned)px * (unsigned)Cout * (unsigned)sizeof(E) + part * 16;   // < 2^20: one row segment
           if (!PLAIN && (mask || add)) {
             E e[EPV], m[EPV], ad[EPV];
@@ -249,11 +230,7 @@ template <typename E, int NT> struct RowStager {
             }
             __builtin_memcpy(&v, e, 16);
           }
-#if CONV_VARIANT == 41 || CONV_VARIANT == 42
-          asm volatile("" :: "v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w));     // timing ablation: no global store
-#else
           *(uint4*)((char*)dst + off) = v;
-#endif
         }
       }
     }
@@ -263,7 +240,7 @@ template <typename E, int NT> struct RowStager {
 // dsc (split mode): accumulators hold (s_x s_w) * result; 1 otherwise.  red: 8 floats of LDS.
 // EPI selects what is COMPILED IN.  The generic epilogue evaluates every optional output at run time (raw copy, ReLU mask,
 // gradient fan-in, pool argmax, sum-pool): 3200 instructions and 120 exec-mask branches per wave, 8.5 k cycles even with every
-// store removed (CONV_VARIANT 40-45 accounting) -- as long as two pipeline stages of MFMAs.  The forward pass only ever needs
+// store removed (per-wave cycle accounting) -- as long as two pipeline stages of MFMAs.  The forward pass only ever needs
 // two shapes of it, so those are compiled separately and picked by one kernel-uniform branch (epilogue_mode):
 enum { EPI_GENERIC = 0,   // everything, decided at run time (backward / training forward)
        EPI_ACT = 1,       // out_act = relu(acc + bias) only
@@ -307,7 +284,7 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[MT][NT], const ConvA
 #pragma unroll
     for (int q = 0; q < 4; ++q)
       bias[j][q] = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (!NOBIAS && a.bias && CONV_VARIANT != 45) {          // (45: timing ablation without the bias loads)
+  if (!NOBIAS && a.bias) {
 #pragma unroll
     for (int j = 0; j < NT; ++j)
 #pragma unroll
@@ -496,123 +473,50 @@ struct WeightRing {
 // hardware wave slot a higher static priority lets it run ahead, which staggers the two streams: one computes
 // while the other waits.  HW_REG_HW_ID (id 4) bits [3:0] = wave slot within the SIMD.
 __device__ __forceinline__ void stagger_priority() {
-#if CONV_VARIANT != 31
   const unsigned slot = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4);
-  if (slot & 1) __builtin_amdgcn_s_setprio(CONV_VARIANT == 32 ? 3 : 1);
-#endif
-#if CONV_VARIANT >= 60 && CONV_VARIANT <= 62
-  // experiment: phase-shift the first generation of workgroups in the odd wave slots by about half a stage so that
-  // the two co-resident workgroups of a CU never run their prologue / epilogue at the same time
-  if ((slot & 1) && blockIdx.x + blockIdx.y * gridDim.x < 512) {
-    constexpr int N = CONV_VARIANT == 60 ? 1 : (CONV_VARIANT == 61 ? 2 : 4);
-#pragma unroll
-    for (int k = 0; k < N; ++k) __builtin_amdgcn_s_sleep(80);
-  }
-#endif
+  if (slot & 1) __builtin_amdgcn_s_setprio(1);
 }
 
-template <typename T, int MT, int NT, int WD, bool PF_UPFRONT, typename Mid>
+template <typename T, int MT, int NT, int WD, typename Mid>
 __device__ __forceinline__ void stage_mma(f32x16 (&acc)[MT][NT], const char* cur, WeightRing<T, MT, NT, WD>& ring,
                                           Mid&& mid) {
   constexpr int RS = WD + 1;
 #pragma unroll
   for (int tap = 0; tap < 9; ++tap) {
-    const int ky = tap / 3, kx = tap % 3;
-    if (CONV_VARIANT == 98 || CONV_VARIANT == 99) __syncthreads();   // experiment: one workgroup barrier per tap
 #pragma unroll
     for (int kg = 0; kg < 2; ++kg)
 #pragma unroll
-      for (int j = 0; j < NT; ++j)
-        if (!ABL_NO_W) {
-          if (CONV_VARIANT >= 97 && CONV_VARIANT <= 99)     // experiment: what if the weight fragments came from LDS instead of L1?  (garbage data)
-            ring.wb[(tap + WD) % RS][kg][j] = *(const uint4*)(cur + (((tap * 2 + kg) * NT + j) % 8) * 1024);
-          else
-            ring.wb[(tap + WD) % RS][kg][j] = ring.wq[j][((tap + WD) * 2 + kg) * 64];
-        }
+      for (int j = 0; j < NT; ++j) ring.wb[(tap + WD) % RS][kg][j] = ring.wq[j][((tap + WD) * 2 + kg) * 64];
     mid(tap);
-    const char* ap = cur + (ky * HWID + kx) * PSTR;
-    if (PF_UPFRONT) {
-      // all pixel fragments of the tap are requested up front; the MFMAs then wait on counted lgkmcnt
-      uint4 pf[2][MT];
+    // pixel fragments software-pipelined DEPTH reads ahead of the MFMAs that consume them, through tap boundaries.  (The
+    // straightforward "read the fragments of a row, multiply" order leaves every ds_read_b128 one LDS latency -- about 100
+    // cycles -- ahead of its first MFMA with only 64 cycles of matrix work queued behind it: the pipe idled ~4 x 50 cycles per
+    // tap.  Requesting all fragments of a tap up front measured 906 against 960 TF on the 32-channel wave tile.)
+    constexpr int FPT = MT * 2, DEPTH = WeightRing<T, MT, NT, WD>::PFD;   // fragments per tap: (row i, k-group kg), kg fastest
+    auto frag_ptr = [&](int f) {                          // f counts fragments within THIS tap; f >= FPT spills into the next tap
+      const int tp = tap + f / FPT, r = f % FPT;
+      return cur + (((tp / 3) * HWID + tp % 3) + (r >> 1) * HWID) * PSTR + (r & 1) * 32;
+    };
+    if (tap == 0) {
 #pragma unroll
-      for (int kg = 0; kg < 2; ++kg)
+      for (int f = 0; f < DEPTH; ++f) ring.pf[f] = *(const uint4*)frag_ptr(f);
+    }
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int i = 0; i < MT; ++i) {
-          if (!ABL_NO_LDS) pf[kg][i] = *(const uint4*)(ap + i * HWID * PSTR + kg * 32);
-          else pf[kg][i] = ring.wb[0][kg][0];
-        }
-      __builtin_amdgcn_sched_barrier(0);
+    for (int f = 0; f < FPT; ++f) {
+      const int slot = (tap * FPT + f) % (DEPTH + 1), nslot = (tap * FPT + f + DEPTH) % (DEPTH + 1);
+      if (tap * FPT + f + DEPTH < 9 * FPT) ring.pf[nslot] = *(const uint4*)frag_ptr(f + DEPTH);
+      const int i = f >> 1, kg = f & 1;
       if constexpr (Prec<T>::SPLIT) {
-        // fragment 0 = hi, fragment 1 = lo of both operands: hi hi + lo_w hi + hi lo_x (lo lo is 2^-24 relative: dropped)
+        // fragment 0 = hi, fragment 1 = lo of both operands: hi hi + lo_w hi + hi lo_x (lo lo is 2^-24 relative: dropped).
+        // kg 0: the hi pixel fragment against the hi and the lo weights; kg 1: the lo pixel fragment against the hi weights
 #pragma unroll
-        for (int c = 0; c < 3; ++c)
+        for (int c = 0; c < (kg == 0 ? 2 : 1); ++c)
 #pragma unroll
-          for (int i = 0; i < MT; ++i)
-#pragma unroll
-            for (int j = 0; j < NT; ++j) mma16<T>(acc[i][j], ring.wb[tap % RS][c == 1][j], pf[c == 2][i]);
+          for (int j = 0; j < NT; ++j) mma16<T>(acc[i][j], ring.wb[tap % RS][c][j], ring.pf[slot]);
       } else {
 #pragma unroll
-      for (int kg = 0; kg < 2; ++kg)
-#pragma unroll
-        for (int i = 0; i < MT; ++i)
-#pragma unroll
-          for (int j = 0; j < NT; ++j) mma16<T>(acc[i][j], ring.wb[tap % RS][kg][j], pf[kg][i]);
-      }
-    } else if constexpr (CONV_VARIANT != 130) {
-      // pixel fragments software-pipelined three reads ahead of the MFMAs that consume them.  (The straightforward "read the
-      // fragments of a row, multiply" order leaves every ds_read_b128 one LDS latency -- about 100 cycles -- ahead of its
-      // first MFMA with only 64 cycles of matrix work queued behind it: the pipe idled ~4 x 50 cycles per tap.)
-      constexpr int FPT = MT * 2, DEPTH = WeightRing<T, MT, NT, WD>::PFD;   // fragments per tap: (row i, k-group kg), kg fastest
-      auto frag_ptr = [&](int f) {                          // f counts fragments within THIS tap; f >= FPT spills into the next tap
-        const int tp = tap + f / FPT, r = f % FPT;
-        return cur + (((tp / 3) * HWID + tp % 3) + (r >> 1) * HWID) * PSTR + (r & 1) * 32;
-      };
-      if (tap == 0) {
-#pragma unroll
-        for (int f = 0; f < DEPTH; ++f) ring.pf[f] = ABL_NO_LDS ? ring.wb[0][0][0] : *(const uint4*)frag_ptr(f);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int f = 0; f < FPT; ++f) {
-        const int slot = (tap * FPT + f) % (DEPTH + 1), nslot = (tap * FPT + f + DEPTH) % (DEPTH + 1);
-        if (tap * FPT + f + DEPTH < 9 * FPT) ring.pf[nslot] = ABL_NO_LDS ? ring.wb[0][0][0] : *(const uint4*)frag_ptr(f + DEPTH);
-        const int i = f >> 1, kg = f & 1;
-        if constexpr (Prec<T>::SPLIT) {
-          // kg 0: the hi pixel fragment against the hi and the lo weights; kg 1: the lo pixel fragment against the hi weights
-#pragma unroll
-          for (int c = 0; c < (kg == 0 ? 2 : 1); ++c)
-#pragma unroll
-            for (int j = 0; j < NT; ++j) mma16<T>(acc[i][j], ring.wb[tap % RS][c][j], ring.pf[slot]);
-        } else {
-#pragma unroll
-          for (int j = 0; j < NT; ++j) mma16<T>(acc[i][j], ring.wb[tap % RS][kg][j], ring.pf[slot]);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    } else {
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int kg = 0; kg < 2; ++kg) {
-        uint4 pf[MT];
-#pragma unroll
-        for (int i = 0; i < MT; ++i) {
-          if (!ABL_NO_LDS) pf[i] = *(const uint4*)(ap + i * HWID * PSTR + kg * 32);
-          else pf[i] = ring.wb[0][kg][0];
-        }
-        if constexpr (Prec<T>::SPLIT) {
-          // kg 0: the hi pixel fragments against the hi and the lo weights; kg 1: the lo pixel fragments against the hi weights
-#pragma unroll
-          for (int c = 0; c < (kg == 0 ? 2 : 1); ++c)
-#pragma unroll
-            for (int i = 0; i < MT; ++i)
-#pragma unroll
-              for (int j = 0; j < NT; ++j) mma16<T>(acc[i][j], ring.wb[tap % RS][c][j], pf[i]);
-        } else {
-#pragma unroll
-        for (int i = 0; i < MT; ++i)
-#pragma unroll
-          for (int j = 0; j < NT; ++j) mma16<T>(acc[i][j], ring.wb[tap % RS][kg][j], pf[i]);
-        }
+        for (int j = 0; j < NT; ++j) mma16<T>(acc[i][j], ring.wb[tap % RS][kg][j], ring.pf[slot]);
       }
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -620,8 +524,8 @@ __device__ __forceinline__ void stage_mma(f32x16 (&acc)[MT][NT], const char* cur
   ring.next_stage();
 }
 
-template <typename T, int MT, int NT, int WM, int WN, bool POOL, int WD, bool PF_UPFRONT>
-__global__ __launch_bounds__(256, (NT == 1 && !PF_UPFRONT && (CONV_VARIANT == 50 || CONV_VARIANT == 51 || CONV_VARIANT == 132)) ? 3 : 2) void conv3x3_kernel(ConvArgs a) {
+template <typename T, int MT, int NT, int WM, int WN, bool POOL, int WD>
+__global__ __launch_bounds__(256, 2) void conv3x3_kernel(ConvArgs a) {
   static_assert(WM * WN == 4, "4 waves per block");
   constexpr int EPL = 16 / sizeof(T), KC = SB / sizeof(T);     // channels per stage: 32 (bf16) / 16 (fp32)
   constexpr int TH = WM * MT, HPIX = (TH + 2) * HWID, BUF = HPIX * PSTR;
@@ -629,9 +533,6 @@ __global__ __launch_bounds__(256, (NT == 1 && !PF_UPFRONT && (CONV_VARIANT == 50
   __shared__ __attribute__((aligned(16))) char lds[2 * BUF];
   __shared__ float red[8];
 
-#if CONV_VARIANT >= 40 && CONV_VARIANT <= 47
-  const unsigned long long t_begin = __builtin_readcyclecounter();
-#endif
   // (readfirstlane: the wave index is uniform, which lets every address that depends on it live in scalar registers)
   const int t = threadIdx.x, lane = t & 63, wv = __builtin_amdgcn_readfirstlane(t >> 6), wm = wv / WN, wn = wv % WN;
   // source / fan-in bounds: the image (and the caller's static first rows), narrowed by the device-side boxes if there are any
@@ -755,22 +656,6 @@ __global__ __launch_bounds__(256, (NT == 1 && !PF_UPFRONT && (CONV_VARIANT == 50
 #pragma unroll
   for (int j = 0; j < NT; ++j) ring.wq[j] = a.wpk + (size_t)(ntg0 + j) * nstage * 18 * 64 + lane;
 
-#if CONV_VARIANT >= 120 && CONV_VARIANT <= 123
-  // experiment: de-phase the CUs.  All workgroups of a generation start together, run for the same time and therefore hit their
-  // store-bound epilogues together, chip-wide (an HBM write burst while every matrix pipe idles).  Delay the workgroups of the
-  // FIRST generation by a pseudo-random fraction of a workgroup's lifetime; later generations inherit the spread.
-  {
-    const unsigned lin = blockIdx.x + blockIdx.y * gridDim.x;
-    if (gridDim.x * gridDim.y > 1024 && lin < 512) {
-      constexpr int DIV = CONV_VARIANT == 120 ? 1 : (CONV_VARIANT == 121 ? 2 : (CONV_VARIANT == 122 ? 4 : 1));
-      const unsigned key = CONV_VARIANT == 123 ? (lin >> 1) : lin;            // 123: pairs of consecutive ids share a delay
-      const unsigned h = (key * 2654435761u) >> 16;
-      const int nslot = (2 + nstage + nstage / 4) / DIV;                     // ~ a lifetime in units of 8 k cycles
-      const int n = nslot > 0 ? (int)(h % (unsigned)(nslot + 1)) : 0;
-      for (int k = 0; k < n; ++k) __builtin_amdgcn_s_sleep(127);
-    }
-  }
-#endif
   uint4 st[NPIECE];
   ring.prime();              // the first weight fragments do not depend on the halo tile: request them ahead of it
   load_stage(0, st);
@@ -778,33 +663,16 @@ __global__ __launch_bounds__(256, (NT == 1 && !PF_UPFRONT && (CONV_VARIANT == 50
   __syncthreads();
   stagger_priority();
 
-#if CONV_VARIANT >= 40 && CONV_VARIANT <= 47   // cycle accounting per wave: [prologue, mma, halo write, barrier wait, epilogue]
-  unsigned long long tc[5] = {0, 0, 0, 0, 0};
-  unsigned long long t_prev = __builtin_readcyclecounter();
-  tc[0] = t_prev - t_begin;
-#define TICK(k) { const unsigned long long _n = __builtin_readcyclecounter(); tc[k] += _n - t_prev; t_prev = _n; }
-#else
-#define TICK(k)
-#endif
   for (int sg = 0; sg < nstage; ++sg) {
     const bool more = sg + 1 < nstage;
-    stage_mma<T, MT, NT, WD, PF_UPFRONT>(acc, lds + (sg & 1) * BUF + aoff, ring, [&](int tap) {
-      if (tap == HALO_TAP && more && !ABL_NO_HALO) load_stage(sg + 1, st);
+    stage_mma<T, MT, NT, WD>(acc, lds + (sg & 1) * BUF + aoff, ring, [&](int tap) {
+      if (tap == HALO_TAP && more) load_stage(sg + 1, st);
     });
-    TICK(1)
-    if (more && !ABL_NO_HALO) write_stage(lds + ((sg + 1) & 1) * BUF, st);
-    TICK(2)
-    if (!ABL_NO_BAR) __syncthreads();
-    TICK(3)
+    if (more) write_stage(lds + ((sg + 1) & 1) * BUF, st);
+    __syncthreads();
   }
   // the loop's last barrier guarantees nobody still reads the halo buffers: reuse them as 4 wave-private stagers
   static_assert(2 * BUF / 4 >= 32 * (NT * 32 * 4 + 16) && (2 * BUF / 4) % 16 == 0, "stager does not fit");
-#if CONV_VARIANT == 44      // timing ablation: no epilogue at all
-#pragma unroll
-  for (int i = 0; i < MT; ++i)
-#pragma unroll
-    for (int j = 0; j < NT; ++j) asm volatile("" :: "v"(acc[i][j]));
-#else
   {
     char* stager = lds + wv * (2 * BUF / 4);
     const int mode = epilogue_mode(a);      // kernel-uniform
@@ -835,25 +703,13 @@ __global__ __launch_bounds__(256, (NT == 1 && !PF_UPFRONT && (CONV_VARIANT == 50
       conv_epilogue<T, MT, NT, POOL, (RAW_SPECIAL || sizeof(T) == 2) ? EPI_ACT_RAW_NOBIAS : EPI_GENERIC>(acc, a, b, y0 + wm * MT, x0, ntg0 * 32, red, stager, dsc, addb);
     else conv_epilogue<T, MT, NT, POOL, EPI_GENERIC>(acc, a, b, y0 + wm * MT, x0, ntg0 * 32, red, stager, dsc, addb);
   }
-#endif
-#if CONV_VARIANT >= 40 && CONV_VARIANT <= 47
-  TICK(4)
-  if (a.dbg && lane == 0) {
-    unsigned long long* d = a.dbg + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 4 + wv) * 5;
-    for (int k = 0; k < 5; ++k) d[k] = tc[k];
-  }
-#endif
-#undef TICK
 }
-
-#if CONV_VARIANT >= 100 && CONV_VARIANT <= 109
-#include "conv_lw_experiment.h"   // weights through an LDS ring: correct, not faster
-#endif
 
 // ---------------------------------------------------------------------------------------------
 // conv0 + ReLU + conv2 + bias + 2x2 max-pool + ReLU in one kernel (VGG.py:123-128).
 struct Conv02Args {
-  const float* x;      // [B,3,H,W] NCHW fp32
+  const float* x;      // [B,3,H,W] NCHW fp32; channel planes x_plane elements apart (>= H*W: the image may be a row window
+  size_t x_plane;      //   of a taller one), rows W apart
   const uint4* w0;     // conv0 fragments [2 ntiles][NFRAG][64 lanes], k = cin*9 + tap (27 padded to 32)
   const float* b0;     // [64]
   const uint4* w2;     // conv2 fragments, generic layout
@@ -874,12 +730,12 @@ struct Conv02Args {
 // two workgroups fit a CU; with 4-byte ones (exact fp32, split fp16) they would be four 16-channel stages = 109 KB, one
 // workgroup per CU with nothing to overlap its phases -- so those types produce and consume them in TWO ROUNDS of 32 channels
 // through the same two buffers (conv0 is computed per 32-channel half anyway: the same MFMA work, one more barrier).
-template <typename T> constexpr int conv02_rounds() { return (CONV_VARIANT != 160 && sizeof(T) == 4) ? 2 : 1; }
+template <typename T> constexpr int conv02_rounds() { return sizeof(T) == 4 ? 2 : 1; }
 template <typename T> constexpr int conv02_lds_bytes() {
   return (64 * (int)sizeof(T) / SB) / conv02_rounds<T>() * (10 * HWID * PSTR) + 3 * 12 * 36 * 4;
 }
 
-template <typename T, int WD, bool PF_UPFRONT>
+template <typename T, int WD>
 __global__ __launch_bounds__(256, 2) void conv02_kernel(Conv02Args a0) {
   constexpr bool SPLIT = Prec<T>::SPLIT;
   constexpr int EPL = Prec<T>::CEPL, KC = SB / sizeof(T), NSG = 64 / KC, NFRAG = 32 / (2 * EPL), NH = SPLIT ? 2 : 1;
@@ -909,7 +765,7 @@ __global__ __launch_bounds__(256, 2) void conv02_kernel(Conv02Args a0) {
     const int c = e / (IH * IW), r = e % (IH * IW), iy = r / IW, ix = r % IW;
     const int y = y0 - 2 + iy, xx = x0 - 2 + ix;
     float v = 0.f;
-    if (y >= 0 && y < a0.H && xx >= 0 && xx < a0.W) v = a0.x[(((size_t)b * 3 + c) * a0.H + y) * a0.W + xx];
+    if (y >= 0 && y < a0.H && xx >= 0 && xx < a0.W) v = a0.x[((size_t)b * 3 + c) * a0.x_plane + (size_t)y * a0.W + xx];
     in[e] = v;
     if (SPLIT) amx = fmaxf(amx, fabsf(v));
   }
@@ -961,7 +817,7 @@ __global__ __launch_bounds__(256, 2) void conv02_kernel(Conv02Args a0) {
   for (int rd = 0; rd < ROUNDS; ++rd) {
   const int j0 = rd * JPR;                           // first 32-channel half of conv0's output this round produces
   if (rd > 0) __syncthreads();                       // the previous round's MFMAs are done with the buffers
-  for (int m = wv; m * 32 < (CONV_VARIANT == 95 ? 0 : HPIX); m += 4) {   // (ablation 95: no conv0 phase)
+  for (int m = wv; m * 32 < HPIX; m += 4) {
     const int p = m * 32 + x, pc = p < HPIX ? p : HPIX - 1;
     const int hy = pc / HWID, hx = pc - hy * HWID;
     const float* ib = in + hy * IW + hx;
@@ -1055,8 +911,8 @@ __global__ __launch_bounds__(256, 2) void conv02_kernel(Conv02Args a0) {
   // phase C: conv2 over this round's resident stages (no further loads, no barriers)
   if (rd == 0) stagger_priority();
 #pragma unroll 1
-  for (int sg = 0; sg < (CONV_VARIANT == 96 ? 0 : SPR); ++sg)   // (ablation 96: no conv2 MFMA loop)
-    stage_mma<T, MT, NT, WD, PF_UPFRONT>(acc, lds + sg * BUF + aoff, ring, [](int) {});
+  for (int sg = 0; sg < SPR; ++sg)
+    stage_mma<T, MT, NT, WD>(acc, lds + sg * BUF + aoff, ring, [](int) {});
   }     // rounds
 
   ConvArgs a{};
@@ -1293,81 +1149,20 @@ template <typename T>
 static void launch_conv(hipStream_t st, ConvArgs a, bool pool) {
   a.tiles_x = (a.W + 31) / 32;
   a.tiles_y = (a.H - a.row_begin + 7) / 8;
-#if CONV_VARIANT == 51 || CONV_VARIANT == 52    // experiment: every layer on the 64-channel block (3 blocks per CU)
-  const bool big = false;
-  const dim3 grid(a.tiles_x * a.tiles_y * a.B, a.Cout / 64);
-#else
   const bool big = a.Cout >= 128;
   const dim3 grid(a.tiles_x * a.tiles_y * a.B, big ? a.Cout / 128 : 1);
-#endif
   const size_t es = sizeof(T), P = (size_t)a.B * (a.H - a.row_begin) * a.W, Po = pool ? P / 4 : P;
   const double flops = 2.0 * 9.0 * (a.C1 + a.C2) * a.Cout * (double)P;
   const double bytes = (double)P * ((a.up1 ? a.C1 / 4.0 : a.C1) + a.C2) * es + (double)Po * a.Cout * ((a.out_act ? es : 0) + (a.out_raw ? 4 : 0));
-#if (CONV_VARIANT >= 40 && CONV_VARIANT <= 47) || CONV_VARIANT == 104
-  static unsigned long long* dbg = nullptr;
-  static int n_reported = 0;
-  if (!dbg) (void)hipMallocManaged((void**)&dbg, (size_t)1 << 26);
-  a.dbg = dbg;
-#endif
   hla_prof_begin(a.Cout >= 128 ? (pool ? K_CONV_NT2_POOL : K_CONV_NT2) : (pool ? K_CONV_NT1_POOL : K_CONV_NT1), flops, bytes, st);
   // Cout >= 128: block = 8x32 pixels x 128 channels, waves 2(M) x 2(N), wave tile 128 px x 64 ch, weights 1 tap ahead
   // Cout == 64 : block = 8x32 pixels x  64 channels, waves 2 x 2,       wave tile 128 px x 32 ch, weights 2 taps ahead
-#if CONV_VARIANT == 50 || CONV_VARIANT == 51
-#define SMALL_OPT 1, false     // 154 VGPRs -> 3 waves/SIMD, 3 blocks/CU (LDS 3 x 54,416 B fits the 160 KiB)
-#elif CONV_VARIANT == 133
-#define SMALL_OPT 2, true      // the former default: all fragments of a tap requested up front (960 -> 906 TF)
-#else
-#define SMALL_OPT 2, false     // the pipelined fragment loop, six ds_reads ahead (132: the same at 3 waves/SIMD -- spills, 690 TF)
-#endif
-#if CONV_VARIANT >= 100 && CONV_VARIANT <= 109   // experiment (negative result): weights through LDS
-  if (big && !a.unpool_idx) {
-#if CONV_VARIANT == 104
-    a.dbg = dbg;
-#endif            // experiment: weights through LDS (conv3x3_lw_kernel)
-    constexpr int lb = conv_lw_lds_bytes<T, 4, 2, 2, 2>();
-    static bool attr_set = false;
-    if (!attr_set) {
-      (void)hipFuncSetAttribute((const void*)conv3x3_lw_kernel<T, 4, 2, 2, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lb);
-      (void)hipFuncSetAttribute((const void*)conv3x3_lw_kernel<T, 4, 2, 2, 2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lb);
-      attr_set = true;
-    }
-    if (pool) hipLaunchKernelGGL((conv3x3_lw_kernel<T, 4, 2, 2, 2, true>), grid, dim3(256), lb, st, a);
-    else hipLaunchKernelGGL((conv3x3_lw_kernel<T, 4, 2, 2, 2, false>), grid, dim3(256), lb, st, a);
-  } else
-#endif
   if (big) {
-    if (pool) hipLaunchKernelGGL((conv3x3_kernel<T, 4, 2, 2, 2, true, 1, false>), grid, dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((conv3x3_kernel<T, 4, 2, 2, 2, false, 1, false>), grid, dim3(256), 0, st, a);
+    if (pool) hipLaunchKernelGGL((conv3x3_kernel<T, 4, 2, 2, 2, true, 1>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((conv3x3_kernel<T, 4, 2, 2, 2, false, 1>), grid, dim3(256), 0, st, a);
   } else {
-    if (pool) hipLaunchKernelGGL((conv3x3_kernel<T, 4, 1, 2, 2, true, SMALL_OPT>), grid, dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((conv3x3_kernel<T, 4, 1, 2, 2, false, SMALL_OPT>), grid, dim3(256), 0, st, a);
+    if (pool) hipLaunchKernelGGL((conv3x3_kernel<T, 4, 1, 2, 2, true, 2>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((conv3x3_kernel<T, 4, 1, 2, 2, false, 2>), grid, dim3(256), 0, st, a);
   }
   hla_prof_end(st);
-#if CONV_VARIANT == 104
-  if (big && !a.unpool_idx && n_reported++ < 12) {
-    (void)hipStreamSynchronize(st);
-    const size_t nw = (size_t)grid.x * grid.y * 4;
-    double m[6] = {0, 0, 0, 0, 0, 0};
-    for (size_t i = 0; i < nw; ++i) for (int k = 0; k < 6; ++k) m[k] += (double)dbg[i * 6 + k];
-    const int nstage = (a.C1 + a.C2) / (int)(SB / sizeof(T));
-    fprintf(stderr, "[lw] Cin %d Cout %d H %d pool %d stages %d | per wave cycles: prologue %.0f | per tap: wait+barrier %.0f issue %.0f read+mma %.0f | "
-            "halo write/stage %.0f | epilogue %.0f | total %.0f\n", a.C1 + a.C2, a.Cout, a.H, (int)pool, nstage, m[0] / nw,
-            m[1] / nw / nstage / 9, m[2] / nw / nstage / 9, m[3] / nw / nstage / 9, m[4] / nw / nstage, m[5] / nw,
-            (m[0] + m[1] + m[2] + m[3] + m[4] + m[5]) / nw);
-  }
-#endif
-#if CONV_VARIANT >= 40 && CONV_VARIANT <= 47
-  if (n_reported++ < 40) {
-    (void)hipStreamSynchronize(st);
-    const size_t nw = (size_t)grid.x * grid.y * 4;
-    double m[5] = {0, 0, 0, 0, 0};
-    for (size_t i = 0; i < nw; ++i) for (int k = 0; k < 5; ++k) m[k] += (double)dbg[i * 5 + k];
-    const int nstage = (a.C1 + a.C2) / (int)(SB / sizeof(T));
-    fprintf(stderr, "[dbg] Cin %d Cout %d H %d pool %d stages %d | per wave cycles: prologue %.0f, mma/stage %.0f (ideal 4608 alone), "
-            "write/stage %.0f, barrier/stage %.0f, epilogue %.0f, total %.0f\n", a.C1 + a.C2, a.Cout, a.H, (int)pool, nstage,
-            m[0] / nw, m[1] / nw / nstage, m[2] / nw / nstage, m[3] / nw / nstage, m[4] / nw,
-            (m[0] + m[1] + m[2] + m[3] + m[4]) / nw);
-  }
-#endif
 }
-

@@ -76,7 +76,7 @@ __global__ __launch_bounds__(256) void lm_bwd_accum(BwdAccumArgs a) {
   int cur_off = -1, cur_dxo = 0, cur_dyo = 0;
   float c00[4] = {0, 0, 0, 0}, c01[4] = {0, 0, 0, 0}, c10[4] = {0, 0, 0, 0}, c11[4] = {0, 0, 0, 0};
   auto flush_cell = [&]() {
-    if (cur_off >= 0 && CONV_VARIANT != 80) {          // (ablation 80: no d_sat atomics)
+    if (cur_off >= 0) {
       float* dp = a.d_sat + sat_base + cur_off;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
@@ -318,18 +318,9 @@ __global__ __launch_bounds__(64) void lm_bwd_solve(BwdSolveArgs a) {
 }
 
 // pixels per block of lm_bwd_accum (level-dependent only)
-#ifndef CONV_VARIANT
-#define CONV_VARIANT 0
-#endif
-static inline int lm_pick_tile_bwd(int npix) {
-#if CONV_VARIANT == 155           // the sizes shared with LM_G2SP's kernels (256 / 128 / 64), used here until round 2
-  return lm_pick_tile(npix);
-#elif CONV_VARIANT == 157         // (measured: smaller tiles, 128 / 128 / 64: 227 -> 245 us per launch)
-  return npix >= 16384 ? 128 : (npix >= 4096 ? 128 : 64);
-#else                             // the coarse levels on larger tiles: 227.7 -> 218.3 us per launch on average (same-box A/B, twice)
-  return npix >= 16384 ? 256 : (npix >= 4096 ? 256 : 128);
-#endif
-}
+// (measured, same-box A/B twice: 256 / 128 / 64 -- the sizes LM_G2SP's kernels use -- 227.7 us per launch on average against
+// 218.3 for these; 128 / 128 / 64: 245)
+static inline int lm_pick_tile_bwd(int npix) { return npix >= 4096 ? 256 : 128; }
 
 // ---------------------------------------------------------------------------------------------
 static size_t bwd_layout(const hla_s2g_config* cfg, const hla_s2g_level* lv, int B, size_t off[5]) {

@@ -149,35 +149,16 @@ template <> __device__ __forceinline__ lm_f2 lm_pair<_Float16>(const uint4& v, i
 // Guideline 16: 8-byte agent-scope (sc1) stores of the partials -> s_waitcnt vmcnt(0) -> relaxed agent-scope ticket; the
 // last arriver reads with agent-scope loads.  Which tile arrives last never changes a bit of the result.
 // (6 waves per SIMD = 80 registers: what the gather loop needs; the closing solve, one wave per sample, may spill a little)
-#ifndef CONV_VARIANT
-#define CONV_VARIANT 0
-#endif
-#if CONV_VARIANT == 140      // experiments: more loads in flight per wave, fewer waves
-#define LM_OCC 4
-#define LM_UNROLL(F) (sizeof(F) == 4 ? 4 : 2)
-#elif CONV_VARIANT == 141
-#define LM_OCC 8
-#define LM_UNROLL(F) 1
-#elif CONV_VARIANT == 142
-#define LM_OCC 3
-#define LM_UNROLL(F) (sizeof(F) == 4 ? 4 : 4)
-#else
+// (measured: 3, 4 or 8 waves per SIMD with 1-4 pixels in flight per lane change nothing -- the kernel waits on its dependent taps)
 #define LM_OCC 6
 #define LM_UNROLL(F) (sizeof(F) == 4 ? 2 : 1)
-#endif
 // Pixels per block of the forward accumulate kernels (level-dependent only, like lm_pick_tile: a sample's partial-sum grouping
 // must not depend on its batch mates).  Larger than the backward's tiles: a block's fixed cost -- the fp64 pixel set-up, the
 // reductions, the published partials, the ticket -- is what these kernels spend their time on.
 #define FWD_MAX_TP 512
-static inline int lm_pick_tile_fwd(int npix) {
-#if CONV_VARIANT == 150           // the backward's sizes (256 / 128 / 64), which the forward shared until round 2
-  return lm_pick_tile(npix);
-#elif CONV_VARIANT == 154         // (measured: the two coarse levels lose 10-30 % with tiles this large)
-  return npix >= 16384 ? 512 : (npix >= 4096 ? 512 : 256);
-#else                             // measured against 150 on one box: lm_accum<64> 72.3 -> 70.8 us, <128> 45.3 -> 41.7, <256> 30.8 -> 29.5
-  return npix >= 16384 ? 512 : (npix >= 4096 ? 256 : 128);
-#endif
-}
+// (measured on one box against 256 / 128 / 64: lm_accum<64> 72.3 -> 70.8 us, <128> 45.3 -> 41.7, <256> 30.8 -> 29.5; with 512 / 512 / 256
+// the two coarse levels lose 10-30 %)
+static inline int lm_pick_tile_fwd(int npix) { return npix >= 16384 ? 512 : (npix >= 4096 ? 256 : 128); }
 template <int C, bool USE_W, typename F>
 __global__ __launch_bounds__(256, LM_OCC) void lm_accum(AccumArgs a, SolveArgs sa) {
   __shared__ PixParam pp[FWD_MAX_TP];

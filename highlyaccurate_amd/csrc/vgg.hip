@@ -2,9 +2,6 @@
 #include "conv_kernels.h"
 #include "vgg_layers.h"
 #include <type_traits>
-#ifndef CONV02_UPFRONT
-#define CONV02_UPFRONT (CONV_VARIANT == 134)    // false: the pipelined fragment loop (621 -> 594 us); 134 = the former default
-#endif
 
 template <typename T>
 void vgg_pack_all(const hla_vgg_params* prm, char* packed, int dtype, hipStream_t st) {
@@ -46,7 +43,7 @@ void vgg_pack_all(const hla_vgg_params* prm, char* packed, int dtype, hipStream_
 }
 
 template <typename T>
-int vgg_forward_t(const float* x, const hla_vgg_params* prm, const char* packed, int dtype, void* const feat[4],
+int vgg_forward_t(const float* x, size_t x_plane, const hla_vgg_params* prm, const char* packed, int dtype, void* const feat[4],
                          float* const conf[4], double* inv_norm, char* ws, const VggPlan& pl, int B, int H, int W,
                          int flags, int first_row8, hipStream_t st) {
   const bool level4 = pl.x2r != 0;
@@ -61,7 +58,7 @@ int vgg_forward_t(const float* x, const hla_vgg_params* prm, const char* packed,
   // conv0 + conv2 + pool fused (VGG.py:123-128): relu(x3)
   {
     Conv02Args a{};
-    a.x = x; a.w0 = W_(0); a.b0 = prm->b[0]; a.w2 = W_(1); a.b2 = prm->b[1]; a.out_act = w + pl.x3;
+    a.x = x; a.x_plane = x_plane ? x_plane : (size_t)H * W; a.w0 = W_(0); a.b0 = prm->b[0]; a.w2 = W_(1); a.b2 = prm->b[1]; a.out_act = w + pl.x3;
     if (flags & HLA_VGG_SAVE_FOR_BACKWARD) { a.a0_out = w + pl.a0; a.idx_out = (unsigned char*)(w + pl.idx3); }
     if (level4) a.a2_out = w + pl.x2r;
     a.wtail = wtail; a.amax_out = AM(AM_X3); a.amax_a2_out = level4 ? AM(AM_X2) : nullptr;
@@ -73,10 +70,10 @@ int vgg_forward_t(const float* x, const hla_vgg_params* prm, const char* packed,
     constexpr int lds_bytes = conv02_lds_bytes<T>();
     static HlaPerDeviceOnce attr_once;
     HLA_CHECK_HIP(attr_once.run([] {
-      return hipFuncSetAttribute((const void*)conv02_kernel<T, 2, CONV02_UPFRONT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+      return hipFuncSetAttribute((const void*)conv02_kernel<T, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
     }));
     hla_prof_begin(K_CONV02, 2.0 * 9 * (3 + 64) * 64 * P, P * (3 * 4 + 16 * sizeof(T)), st);
-    hipLaunchKernelGGL((conv02_kernel<T, 2, CONV02_UPFRONT>), dim3(a.tiles_x * a.tiles_y * B), dim3(256), lds_bytes, st, a);
+    hipLaunchKernelGGL((conv02_kernel<T, 2>), dim3(a.tiles_x * a.tiles_y * B), dim3(256), lds_bytes, st, a);
     hla_prof_end(st);
   }
   const bool train = flags & HLA_VGG_SAVE_FOR_BACKWARD;
@@ -183,13 +180,13 @@ int vgg_forward_t(const float* x, const hla_vgg_params* prm, const char* packed,
 
 #if HLA_TU_DTYPE >= 0
 template void vgg_pack_all<TuT>(const hla_vgg_params* prm, char* packed, int dtype, hipStream_t st);
-template int vgg_forward_t<TuT>(const float* x, const hla_vgg_params* prm, const char* packed, int dtype, void* const feat[4],
+template int vgg_forward_t<TuT>(const float* x, size_t x_plane, const hla_vgg_params* prm, const char* packed, int dtype, void* const feat[4],
                               float* const conf[4], double* inv_norm, char* ws, const VggPlan& pl, int B, int H, int W,
                               int flags, int first_row8, hipStream_t st);
 #else
 #define HLA_EXTERN_T(T) \
   extern template void vgg_pack_all<T>(const hla_vgg_params* prm, char* packed, int dtype, hipStream_t st); \
-  extern template int vgg_forward_t<T>(const float* x, const hla_vgg_params* prm, const char* packed, int dtype, void* const feat[4],                               float* const conf[4], double* inv_norm, char* ws, const VggPlan& pl, int B, int H, int W,                               int flags, int first_row8, hipStream_t st);
+  extern template int vgg_forward_t<T>(const float* x, size_t x_plane, const hla_vgg_params* prm, const char* packed, int dtype, void* const feat[4],                               float* const conf[4], double* inv_norm, char* ws, const VggPlan& pl, int B, int H, int W,                               int flags, int first_row8, hipStream_t st);
 HLA_EXTERN_T(float) HLA_EXTERN_T(bf16) HLA_EXTERN_T(f16) HLA_EXTERN_T(split32)
 
 extern "C" size_t hla_vgg_packed_weight_bytes(int dtype) {
@@ -213,13 +210,14 @@ extern "C" size_t hla_vgg_workspace_bytes(int B, int H, int W, int level, int dt
   return p.total;
 }
 
-extern "C" int hla_vgg_forward(const float* x, const hla_vgg_params* params, const void* packed_weights,
+extern "C" int hla_vgg_forward(const float* x, size_t x_plane, const hla_vgg_params* params, const void* packed_weights,
                                void* const feat[4], float* const conf[4], double* inv_norm, void* workspace,
                                size_t workspace_bytes, int B, int H, int W, int level, int dtype, int flags,
                                int first_row8, hla_stream_t stream) {
   HLA_REQUIRE(x && params && packed_weights && feat && workspace, "hla_vgg_forward: null argument");
   HLA_REQUIRE(hla_dtype_ok(dtype), "hla_vgg_forward: dtype must be HLA_F32, HLA_BF16, HLA_F16 or HLA_F16X3 (got %d)", dtype);
   HLA_REQUIRE(B > 0 && H >= 8 && W >= 8 && H % 8 == 0 && W % 8 == 0, "hla_vgg_forward: H and W must be multiples of 8");
+  HLA_REQUIRE(x_plane == 0 || x_plane >= (size_t)H * W, "hla_vgg_forward: x_plane (%zu) must be 0 or >= H*W", x_plane);
   HLA_REQUIRE(level == 3 || level == 4, "hla_vgg_forward: level must be 3 (x15,x18,x21) or 4 (+x24), got %d", level);
   HLA_REQUIRE(feat[0] && feat[1] && feat[2], "hla_vgg_forward: feat[0..2] are required");
   HLA_REQUIRE(level == 3 || (feat[3] && params->w[11] && params->w[12]),
@@ -237,15 +235,15 @@ extern "C" int hla_vgg_forward(const float* x, const hla_vgg_params* params, con
     return HLA_ERR_WORKSPACE;
   }
   if (dtype == HLA_BF16)
-    return vgg_forward_t<bf16>(x, params, (const char*)packed_weights, dtype, feat, conf, inv_norm, (char*)workspace, pl,
+    return vgg_forward_t<bf16>(x, x_plane, params, (const char*)packed_weights, dtype, feat, conf, inv_norm, (char*)workspace, pl,
                                B, H, W, flags, first_row8, (hipStream_t)stream);
   if (dtype == HLA_F16)
-    return vgg_forward_t<f16>(x, params, (const char*)packed_weights, dtype, feat, conf, inv_norm, (char*)workspace, pl,
+    return vgg_forward_t<f16>(x, x_plane, params, (const char*)packed_weights, dtype, feat, conf, inv_norm, (char*)workspace, pl,
                               B, H, W, flags, first_row8, (hipStream_t)stream);
   if (dtype == HLA_F16X3)
-    return vgg_forward_t<split32>(x, params, (const char*)packed_weights, dtype, feat, conf, inv_norm, (char*)workspace, pl,
+    return vgg_forward_t<split32>(x, x_plane, params, (const char*)packed_weights, dtype, feat, conf, inv_norm, (char*)workspace, pl,
                                   B, H, W, flags, first_row8, (hipStream_t)stream);
-  return vgg_forward_t<float>(x, params, (const char*)packed_weights, dtype, feat, conf, inv_norm, (char*)workspace, pl,
+  return vgg_forward_t<float>(x, x_plane, params, (const char*)packed_weights, dtype, feat, conf, inv_norm, (char*)workspace, pl,
                               B, H, W, flags, first_row8, (hipStream_t)stream);
 }
 #endif

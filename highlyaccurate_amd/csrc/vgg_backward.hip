@@ -100,7 +100,7 @@ template <typename T> constexpr int wg_stride() { return 64 * (int)sizeof(T) + 1
 template <typename T> constexpr int wg_lds_bytes() { return ((WG_TH + 2) * HWID + WG_TH * 32) * wg_stride<T>(); }
 
 template <typename T>
-__global__ __launch_bounds__(256, CONV_VARIANT == 73 ? 1 : 2) void wgrad_kernel(WgradArgs a) {
+__global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
   constexpr int EPL = 16 / sizeof(T), STR = wg_stride<T>(), PPX = 64 * (int)sizeof(T) / 16;   // 16-B pieces per pixel
   constexpr int XPIX = (WG_TH + 2) * HWID, GPIX = WG_TH * 32, KPX = KStep<T>::PX;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -124,11 +124,10 @@ __global__ __launch_bounds__(256, CONV_VARIANT == 73 ? 1 : 2) void wgrad_kernel(
   for (int r = 0; r < 16; ++r) accb[r] = 0.f;
   const uint4 ones = frag_ones<T>();
 
-  // Register-staged tile loads: all of a tile's 16-B pieces are requested back to back (memory-level parallelism), and
-  // for the 16-bit types the NEXT tile's requests are issued before the current tile's MFMA phase so that they are in
-  // flight behind it (fp32 would need 84 staging registers: it loads inside the load phase instead).
+  // Register-staged tile loads: all of a tile's 16-B pieces are requested back to back (memory-level parallelism).  (Issuing
+  // the NEXT tile's requests before the current tile's MFMA phase needs the staging registers live across it: one workgroup
+  // per CU, measured slower.)
   constexpr int NX = (XPIX * PPX + 255) / 256, NG = GPIX * PPX / 256, PSTEP = 256 / PPX;
-  constexpr bool PREFETCH = sizeof(T) == 2 && CONV_VARIANT == 73;
   const int part = t % PPX, pix0 = t / PPX;
   uint4 xr[NX], gr[NG];
   unsigned long long gid[NG];
@@ -197,28 +196,25 @@ __global__ __launch_bounds__(256, CONV_VARIANT == 73 ? 1 : 2) void wgrad_kernel(
     }
   };
 
-  if (PREFETCH && ks < tl.ntile) { load_x(ks, 0, NX); load_g(ks, 0, NG); }
   for (int tile = ks; tile < tl.ntile; tile += a.KS) {
-    const bool ld = !PREFETCH && !(CONV_VARIANT == 70 && tile != ks);        // (ablation 70: loads for the first tile only)
     if (sizeof(T) == 2) {
-      if (ld) { load_x(tile, 0, NX); load_g(tile, 0, NG); }
+      load_x(tile, 0, NX); load_g(tile, 0, NG);
       __syncthreads();                                 // previous tile fully consumed
       store_x(0, NX);
       store_g(tile, 0, NG);
     } else {                                           // fp32 (parity mode): batches of 4 pieces = 16 staging registers
       __syncthreads();
 #pragma unroll
-      for (int lo = 0; lo < NX; lo += 4) { if (ld) load_x(tile, lo, lo + 4); store_x(lo, lo + 4); }
+      for (int lo = 0; lo < NX; lo += 4) { load_x(tile, lo, lo + 4); store_x(lo, lo + 4); }
 #pragma unroll
-      for (int lo = 0; lo < NG; lo += 4) { if (ld) load_g(tile, lo, lo + 4); store_g(tile, lo, lo + 4); }
+      for (int lo = 0; lo < NG; lo += 4) { load_g(tile, lo, lo + 4); store_g(tile, lo, lo + 4); }
     }
     __syncthreads();
-    if (PREFETCH && tile + a.KS < tl.ntile) { load_x(tile + a.KS, 0, NX); load_g(tile + a.KS, 0, NG); }
     // G fragments of the whole tile stay in registers; every X fragment (halo row rho, column shift kx, K-step kk) is
     // fetched ONCE and feeds the up to three taps ky with r = rho - ky inside the tile  (halves the LDS reads per MFMA)
     // (K-steps are taken two at a time so that the resident G fragments cost 32 VGPRs for every dtype)
 #pragma unroll 1
-    for (int kk0 = 0; kk0 < (CONV_VARIANT == 71 ? 0 : 32 / KPX); kk0 += 2) {   // (ablation 71: no MFMA phase)
+    for (int kk0 = 0; kk0 < 32 / KPX; kk0 += 2) {
       uint4 Af[WG_TH][2];
 #pragma unroll
       for (int r = 0; r < WG_TH; ++r)
@@ -233,8 +229,7 @@ __global__ __launch_bounds__(256, CONV_VARIANT == 73 ? 1 : 2) void wgrad_kernel(
         for (int kx = 0; kx < 3; ++kx)
 #pragma unroll
           for (int kk = 0; kk < 2; ++kk) {
-            const uint4 Bf = CONV_VARIANT == 72 ? Af[rho % WG_TH][kk]      // (ablation 72: no X-fragment LDS reads)
-                                                : frag_kmajor<T>(Xs, STR, rho * HWID + kx + (kk0 + kk) * KPX, it * 32, lane);
+            const uint4 Bf = frag_kmajor<T>(Xs, STR, rho * HWID + kx + (kk0 + kk) * KPX, it * 32, lane);
 #pragma unroll
             for (int ky = 0; ky < 3; ++ky) {
               const int r = rho - ky;
@@ -259,7 +254,8 @@ __global__ __launch_bounds__(256, CONV_VARIANT == 73 ? 1 : 2) void wgrad_kernel(
 
 // conv0: dW0[co][k = c*9+tap] over the NCHW fp32 input (k padded to 32 as one "ci tile").
 struct Wgrad0Args {
-  const float* x;        // [B,3,H,W]
+  const float* x;        // [B,3,H,W], channel planes x_plane elements apart
+  size_t x_plane;
   const void* g;         // d(loss)/d(conv0 pre-activation) NHWC T [B,H,W,64]
   float* part;           // [KS][2 row-halves][64][32]
   float* bpart;          // [KS][2][64]
@@ -293,7 +289,7 @@ __global__ __launch_bounds__(256) void wgrad0_kernel(Wgrad0Args a) {
       const int c = e / ((WG_TH + 2) * IW), r = e % ((WG_TH + 2) * IW), iy = r / IW, ix = r % IW;
       const int y = y0 - 1 + iy, x = x0 - 1 + ix;
       float v = 0.f;
-      if (ix < HWID && y >= 0 && y < a.H && x >= 0 && x < a.W) v = a.x[(((size_t)b * 3 + c) * a.H + y) * a.W + x];
+      if (ix < HWID && y >= 0 && y < a.H && x >= 0 && x < a.W) v = a.x[((size_t)b * 3 + c) * a.x_plane + (size_t)y * a.W + x];
       in[e] = v;
     }
     for (int e = t; e < WG_TH * 32 * PPX; e += 256) {
@@ -810,7 +806,7 @@ void vgg_pack_all_T(const hla_vgg_params* prm, char* packed, int dtype, hipStrea
 }
 
 template <typename T>
-int vgg_backward_t(const float* x, const hla_vgg_params* prm, const char* packedT, int dtype, const char* fw,
+int vgg_backward_t(const float* x, size_t x_plane, const hla_vgg_params* prm, const char* packedT, int dtype, const char* fw,
                           const float* const feat[4], const double* inv_norm, const float* const d_feat[4],
                           const float* const conf[4], const float* const d_conf[4], const hla_vgg_grads* gr, char* bw, const BwdPlan& bp, int B, int H, int W, int flags, int first_row8, hipStream_t st) {
   const bool level4 = bp.g_x24 != 0;
@@ -1003,7 +999,7 @@ int vgg_backward_t(const float* x, const hla_vgg_params* prm, const char* packed
   }
   {
     Wgrad0Args a{};
-    a.x = x; a.g = G(bp.g_a0); a.B = B; a.H = H; a.W = W;
+    a.x = x; a.x_plane = x_plane ? x_plane : (size_t)H * W; a.g = G(bp.g_a0); a.B = B; a.H = H; a.W = W;
     a.row_begin = level4 ? 0 : n_a0;
     a.dyn = dynamic ? dynp : nullptr; a.dyn_desc = dl.wg_desc[DW_0];
     a.tiles_x = (W + 31) / 32; a.tiles_y = (H - a.row_begin + WG_TH - 1) / WG_TH; a.ntile = B * a.tiles_x * a.tiles_y;
@@ -1023,11 +1019,11 @@ int vgg_backward_t(const float* x, const hla_vgg_params* prm, const char* packed
 
 #if HLA_TU_DTYPE >= 0
 template void vgg_pack_all_T<TuT>(const hla_vgg_params* prm, char* packed, int dtype, hipStream_t st);
-template int vgg_backward_t<TuT>(const float* x, const hla_vgg_params* prm, const char* packedT, int dtype, const char* fw, const float* const feat[3], const double* inv_norm, const float* const d_feat[3], const float* const conf[3], const float* const d_conf[3], const hla_vgg_grads* gr, char* bw, const BwdPlan& bp, int B, int H, int W, int flags, int first_row8, hipStream_t st);
+template int vgg_backward_t<TuT>(const float* x, size_t x_plane, const hla_vgg_params* prm, const char* packedT, int dtype, const char* fw, const float* const feat[3], const double* inv_norm, const float* const d_feat[3], const float* const conf[3], const float* const d_conf[3], const hla_vgg_grads* gr, char* bw, const BwdPlan& bp, int B, int H, int W, int flags, int first_row8, hipStream_t st);
 #else
 #define HLA_EXTERN_T(T) \
   extern template void vgg_pack_all_T<T>(const hla_vgg_params* prm, char* packed, int dtype, hipStream_t st); \
-  extern template int vgg_backward_t<T>(const float* x, const hla_vgg_params* prm, const char* packedT, int dtype, const char* fw, const float* const feat[3], const double* inv_norm, const float* const d_feat[3], const float* const conf[3], const float* const d_conf[3], const hla_vgg_grads* gr, char* bw, const BwdPlan& bp, int B, int H, int W, int flags, int first_row8, hipStream_t st);
+  extern template int vgg_backward_t<T>(const float* x, size_t x_plane, const hla_vgg_params* prm, const char* packedT, int dtype, const char* fw, const float* const feat[3], const double* inv_norm, const float* const d_feat[3], const float* const conf[3], const float* const d_conf[3], const hla_vgg_grads* gr, char* bw, const BwdPlan& bp, int B, int H, int W, int flags, int first_row8, hipStream_t st);
 HLA_EXTERN_T(float) HLA_EXTERN_T(bf16) HLA_EXTERN_T(f16)
 
 extern "C" size_t hla_vgg_bwd_workspace_bytes(int B, int H, int W, int level, int dtype) {
@@ -1053,7 +1049,7 @@ extern "C" int hla_vgg_pack_weights_T(const hla_vgg_params* params, void* packed
   return HLA_OK;
 }
 
-extern "C" int hla_vgg_backward(const float* x, const hla_vgg_params* params, const void* packed_weights_T,
+extern "C" int hla_vgg_backward(const float* x, size_t x_plane, const hla_vgg_params* params, const void* packed_weights_T,
                                 const void* fwd_workspace, const float* const feat[4], const double* inv_norm,
                                 const float* const d_feat[4], const float* const conf[4], const float* const d_conf[4],
                                 const hla_vgg_grads* grads, void* workspace, size_t workspace_bytes, int B, int H, int W,
@@ -1081,12 +1077,12 @@ extern "C" int hla_vgg_backward(const float* x, const hla_vgg_params* params, co
     return HLA_ERR_WORKSPACE;
   }
   if (dtype == HLA_BF16)
-    return vgg_backward_t<bf16>(x, params, (const char*)packed_weights_T, dtype, (const char*)fwd_workspace, feat, inv_norm,
+    return vgg_backward_t<bf16>(x, x_plane, params, (const char*)packed_weights_T, dtype, (const char*)fwd_workspace, feat, inv_norm,
                                 d_feat, conf, d_conf, grads, (char*)workspace, bp, B, H, W, flags, first_row8, (hipStream_t)stream);
   if (dtype == HLA_F16)
-    return vgg_backward_t<f16>(x, params, (const char*)packed_weights_T, dtype, (const char*)fwd_workspace, feat, inv_norm,
+    return vgg_backward_t<f16>(x, x_plane, params, (const char*)packed_weights_T, dtype, (const char*)fwd_workspace, feat, inv_norm,
                                d_feat, conf, d_conf, grads, (char*)workspace, bp, B, H, W, flags, first_row8, (hipStream_t)stream);
-  return vgg_backward_t<float>(x, params, (const char*)packed_weights_T, dtype, (const char*)fwd_workspace, feat, inv_norm,
+  return vgg_backward_t<float>(x, x_plane, params, (const char*)packed_weights_T, dtype, (const char*)fwd_workspace, feat, inv_norm,
                                d_feat, conf, d_conf, grads, (char*)workspace, bp, B, H, W, flags, first_row8, (hipStream_t)stream);
 }
 extern "C" int hla_vgg_backward_live_tiles(const void* workspace, int B, int H, int W, int level, int dtype, long long* live,

@@ -51,10 +51,10 @@ def localisation_metrics(pred_shifts, pred_headings, gt_shifts, gt_headings, shi
         i = np.sum((init_angle[:, 0] < a) & (np.abs(gs[:, 0]) < m)) / n * 100
         stats[f'lat@{m}&angle@{a}'] = (p, i)
         lines.append(f'lat within {m} & angle within {a} (pred, init): {p} {i}')
-    if reference_compat:
-        result = float(np.sum((distance < METRICS[0]) & (angle_diff < ANGLES[0])) / n * 100)      # [N] & [N,1] -> [N,N]
-    else:
-        result = float(np.sum((distance < METRICS[0]) & (angle_diff[:, 0] < ANGLES[0])) / n * 100)
+    # both scores are always reported, so that checkpoint selection can be compared with an existing run either way
+    stats['result_reference'] = float(np.sum((distance < METRICS[0]) & (angle_diff < ANGLES[0])) / n * 100)   # [N] & [N,1] -> [N,N]
+    stats['result_per_sample'] = float(np.sum((distance < METRICS[0]) & (angle_diff[:, 0] < ANGLES[0])) / n * 100)
+    result = stats['result_reference'] if reference_compat else stats['result_per_sample']
     return result, stats, lines
 
 

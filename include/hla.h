@@ -58,7 +58,7 @@ const char* hla_last_error(void);
  * with its own struct sizes (ctypes structs are positional: a mismatch corrupts silently).  highlyaccurate_amd/_lib.py
  * does both at load time, and rebuilds or refuses a binary whose hla_source_hash() is not the hash of the sources
  * next to it (the library is git-ignored but shipped prebuilt). */
-#define HLA_ABI_VERSION 16
+#define HLA_ABI_VERSION 17
 int hla_abi_version(void);
 const char* hla_source_hash(void); /* sha256 (hex) of the csrc sources, this header and the compiler flags at build time */
 typedef enum hla_struct_id {
@@ -102,6 +102,9 @@ int hla_vgg_pack_weights(const hla_vgg_params* params, void* packed, int dtype, 
 size_t hla_vgg_workspace_bytes(int B, int H, int W, int level, int dtype);
 
 /* x        [B,3,H,W] NCHW fp32 (what the reference's DataLoader hands over)
+ * x_plane  elements between consecutive channel planes of x: 0 = H*W (a dense tensor); larger when x is a window of H rows
+ *          inside a taller image (rows stay W apart, samples 3*x_plane apart) -- mode='test' runs the ground extractor on the
+ *          image rows that can reach the LM loop without first copying them out
  * params   biases b[0..6] and the confidence-head weights w[13..15] are read from here
  * packed_weights  output of hla_vgg_pack_weights for the same dtype
  * feat[l]  [B,H/2^(3-l),W/2^(3-l),C_l] NHWC fp32, C = 256,128,64 for l = 0..2 (x15,x18,x21):
@@ -117,7 +120,7 @@ size_t hla_vgg_workspace_bytes(int B, int H, int W, int level, int dtype);
  *          those depend on; rows above are left unwritten, and inv_norm covers the computed rows only (usable only where
  *          the per-sample scale cancels, as in LM_update).  conf[l], if requested, is likewise only valid from rows
  *          f / 2f / 4f on.  Ignored (treated as 0) at level 4 and with HLA_VGG_SAVE_FOR_BACKWARD.                */
-int hla_vgg_forward(const float* x, const hla_vgg_params* params, const void* packed_weights, void* const feat[4],
+int hla_vgg_forward(const float* x, size_t x_plane, const hla_vgg_params* params, const void* packed_weights, void* const feat[4],
                     float* const conf[4], double* inv_norm, void* workspace, size_t workspace_bytes, int B, int H,
                     int W, int level, int dtype, int flags, int first_row8, hla_stream_t stream);
 
@@ -161,7 +164,7 @@ size_t hla_vgg_bwd_workspace_bytes(int B, int H, int W, int level, int dtype);
  *                  ignored (0) otherwise and at level 4. */
 #define HLA_VGG_BWD_SCALE_INVARIANT 1
 #define HLA_VGG_BWD_DENSE 2           /* visit every tile even where the incoming gradient is exactly zero (A/B and tests) */
-int hla_vgg_backward(const float* x, const hla_vgg_params* params, const void* packed_weights_T,
+int hla_vgg_backward(const float* x, size_t x_plane, const hla_vgg_params* params, const void* packed_weights_T,
                      const void* fwd_workspace, const float* const feat[4], const double* inv_norm,
                      const float* const d_feat[4], const float* const conf[4], const float* const d_conf[4],
                      const hla_vgg_grads* grads, void* workspace, size_t workspace_bytes, int B, int H, int W, int level,
@@ -222,9 +225,12 @@ typedef struct hla_s2g_level {
                             receptive field reaches it and nothing above -- see DESIGN.md "dead rows"; 0 = full map */
   double meter_per_pixel;/* metres per satellite-feature pixel at this level */
   double centre;         /* A/2 (KITTI, float) or A//2 (Ford, integer) */
-  int feat_dtype;        /* element type of sat_feat / grd_feat: HLA_F32 (always for the backward and for hla_g2s_*), or HLA_BF16 /
-                            HLA_F16: the 16-bit maps hla_vgg_forward writes with HLA_VGG_FEAT16 (inference in the reduced-precision
-                            modes: half the bytes through the HBM-bound LM loop; all LM arithmetic stays fp32 / fp64) */
+  int feat_dtype;        /* element type of sat_feat / grd_feat: HLA_F32 (always for the backward and for hla_g2s_*), HLA_F16 or
+                            HLA_BF16.  The 16-bit maps hla_vgg_forward writes with HLA_VGG_FEAT16 are ALWAYS fp16 -- also when
+                            the convolutions ran with dtype HLA_BF16 -- so they must be passed as HLA_F16 (HLA_BF16 here would
+                            reinterpret fp16 bits; it is only for bf16 maps a caller made itself).  Inference in the
+                            reduced-precision modes: half the bytes through the HBM-bound LM loop; all LM arithmetic stays
+                            fp32 / fp64 */
 } hla_s2g_level;
 
 typedef struct hla_s2g_config {

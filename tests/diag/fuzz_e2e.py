@@ -89,7 +89,7 @@ def one_case(seed):
     except (torch.linalg.LinAlgError, AssertionError) as oe:
         # LinAlgError: singular normal matrix (torch.inverse); AssertionError: no pixel of the batch in view (jacobian.py:172),
         # which the HIP path reproduces in strict mode only (it costs a host sync)
-        os.environ['HLA_STRICT_ERRORS'] = '1'
+        net.args.strict_errors = 1
         try:
             with torch.no_grad():
                 net(sat.to(d), grd.to(d), *extra_g, mode='test', **lfkw)
@@ -98,7 +98,7 @@ def one_case(seed):
             print(f"{'ok  ' if same else 'FAIL'} raise ({type(oe).__name__} / {type(e).__name__}) {desc}", flush=True)
             return same
         finally:
-            os.environ.pop('HLA_STRICT_ERRORS', None)
+            net.args.strict_errors = 0
         print(f'FAIL raise {desc}: the oracle raised {type(oe).__name__}, the HIP path did not', flush=True)
         return False
     except RuntimeError as oe:

@@ -100,13 +100,37 @@ def test_stale_binary_is_refused_or_rebuilt(monkeypatch, tmp_path):
     monkeypatch.setattr(B, 'have_compiler', lambda: True)
     monkeypatch.setattr(B, 'build', lambda force=False, **kw: called.append(force) or shutil.copy(good, str(stale)))
     _lib.load()
-    assert called == [True]
+    assert called == [False]       # build() itself re-checks staleness under its file lock: concurrent ranks build once
     # a missing library without a compiler: loud, no fallback
     _lib = _fresh_loader(monkeypatch)
     monkeypatch.setattr(_lib, 'LIB_PATH', str(tmp_path / 'nothing.so'))
     monkeypatch.setattr(B, 'have_compiler', lambda: False)
     with pytest.raises(_lib.HlaError, match='missing'):
         _lib.load()
+
+
+def test_prebuilt_library_without_sources_loads_and_missing_everything_is_loud(monkeypatch, tmp_path):
+    """A deployment that ships libhla.so without csrc/ or the repo-root include/ has nothing to hash: the library is taken as it
+    is (ABI version and struct sizes are still checked); with neither sources nor library the error says so."""
+    from highlyaccurate_amd import build as B
+    good = B.build()
+
+    def no_sources():
+        raise B.SourcesMissing('cannot hash the library sources (include/hla.h: No such file or directory)')
+    _lib = _fresh_loader(monkeypatch)
+    monkeypatch.setattr(B, 'source_hash', no_sources)
+    monkeypatch.setattr(B, 'have_compiler', lambda: False)
+    assert _lib.load().hla_abi_version() == _lib.ABI_VERSION
+    _lib = _fresh_loader(monkeypatch)
+    monkeypatch.setattr(_lib, 'LIB_PATH', str(tmp_path / 'nothing.so'))
+    with pytest.raises(_lib.HlaError, match='missing and so are its sources'):
+        _lib.load()
+    # and source_hash() itself reports a missing file as SourcesMissing, not a bare FileNotFoundError
+    monkeypatch.undo()
+    monkeypatch.setattr(B, 'CSRC', str(tmp_path / 'no_csrc'))
+    with pytest.raises(B.SourcesMissing):
+        B.source_hash()
+    assert good
 
 
 def test_abi_version_and_struct_sizes_are_enforced_at_load(monkeypatch):

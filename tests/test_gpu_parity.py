@@ -1262,7 +1262,7 @@ def test_ford_train_step_vs_oracle_autograd_small(level):
         assert e < (2e-4 if 'dec2' in k else 2e-2)
 
 
-def test_dead_ground_rows_elimination_is_exact(monkeypatch):
+def test_dead_ground_rows_elimination_is_exact():
     """mode='test' extracts ground features only for image rows >= dead_ground_rows(H) (88 at H=256): every row of the
     three maps that the LM loop reads (h_l/2..) must be BIT-identical to the full-image run, and the pose trace equal up
     to the rounding of the (mathematically cancelling) per-sample L2_norm scale."""
@@ -1277,7 +1277,9 @@ def test_dead_ground_rows_elimination_is_exact(monkeypatch):
         net = net.to(d)
         x = torch.rand(2, 3, 256, 1024, device=d)
         full, cfull, _ = vgg_forward_nhwc(net, x, want_conf=True, defer_norm=True)
-        crop, ccrop, _ = vgg_forward_nhwc(net, x[:, :, 88:].contiguous(), want_conf=True, defer_norm=True)
+        crop, ccrop, _ = vgg_forward_nhwc(net, x[:, :, 88:], want_conf=True, defer_norm=True)       # a row window: no copy (x_plane)
+        dense, cdense, _ = vgg_forward_nhwc(net, x[:, :, 88:].contiguous(), want_conf=True, defer_norm=True)
+        assert all(torch.equal(a, b) for a, b in zip(crop + ccrop, dense + cdense)), precision
         for l in range(3):
             h = full[l].shape[1]
             skip = 88 >> (3 - l)
@@ -1288,7 +1290,7 @@ def test_dead_ground_rows_elimination_is_exact(monkeypatch):
         # are still bit-identical, whatever lies above them
         f8 = 16 - 11
         for wc in (False, True):
-            trim, ctrim, _ = vgg_forward_nhwc(net, x[:, :, 88:].contiguous(), want_conf=wc, defer_norm=True, first_row8=f8)
+            trim, ctrim, _ = vgg_forward_nhwc(net, x[:, :, 88:], want_conf=wc, defer_norm=True, first_row8=f8)
             for l in range(3):
                 r = f8 << l
                 assert torch.equal(trim[l][:, r:], crop[l][:, r:]), (precision, l, wc)
@@ -1297,10 +1299,8 @@ def test_dead_ground_rows_elimination_is_exact(monkeypatch):
     g = load_golden('e2e_kitti.npz')
     seed, B = int(g['seeds'][0]), int(g['B'])
     for kw in (dict(), dict(using_weight=1)):
-        monkeypatch.setenv('HLA_GRD_CROP', '0')
-        net0, _ = _run_kitti(seed, B, **kw)
-        monkeypatch.setenv('HLA_GRD_CROP', '1')
-        net1, _ = _run_kitti(seed, B, **kw)
+        net0, _ = _run_kitti(seed, B, ground_crop=0, **kw)
+        net1, _ = _run_kitti(seed, B, **kw)              # args.ground_crop defaults to 1
         dev = (net0.last_trace - net1.last_trace).abs().max().item()
         print(f'dead-row elimination {kw}: max pose deviation {dev:.2e}')
         assert dev < 2e-6
@@ -1385,7 +1385,7 @@ def test_backward_dynamic_trimming_is_exact(precision, shape):
 
 
 @pytest.mark.parametrize('kw', [dict(), dict(using_weight=1, train_damping=1), dict(train_ground_crop=1)])
-def test_backward_row_trimming_is_exact(kw, monkeypatch):
+def test_backward_row_trimming_is_exact(kw):
     """The ground branch's gradient lives in rows h_l/2.. of its three maps; hla_vgg_backward(first_row8) skips, layer by
     layer, the rows above the support of every activation gradient (exact zeros).  Gradients must equal the untrimmed
     backward up to the summation order of the weight-gradient partials."""
@@ -1396,9 +1396,7 @@ def test_backward_row_trimming_is_exact(kw, monkeypatch):
     sat, grd, gu, gv, gh = O.synth_images(seed + 100, B)
     res = {}
     for trim in ('0', '1'):
-        monkeypatch.setenv('HLA_BWD_TRIM', trim)
-        monkeypatch.setenv('HLA_VGG_BWD_DENSE', '1' if trim == '0' else '0')   # (the data-dependent trimming of both branches too)
-        net = LM_S2GP(O.default_args(**kw))
+        net = LM_S2GP(O.default_args(bwd_trim=int(trim), **kw))     # (0: no row trimming and no data-dependent trimming either)
         sd = O.synth_model_state(seed, bias_scale=0.02)
         if kw.get('train_damping'):
             sd['damping'] = torch.tensor([[0.1, -0.2, 0.15]])
@@ -1484,11 +1482,11 @@ def test_e2e_ragged_shapes_vs_oracle(B, grd_hw, sat_a):
     assert np.isfinite(res).all() and err < 2e-4
 
 
-def test_error_behaviour_matches_the_reference(monkeypatch):
+def test_error_behaviour_matches_the_reference():
     """(1) use_hessian=1 with a pose component that has no Jacobian support: H + damping*diag(H) is singular and the
     reference raises from torch.inverse (models_ford.py:446); the HIP path must raise too, not return a NaN pose.
     (2) No pixel of the batch projecting inside the satellite map: the reference asserts (jacobian.py:172); the HIP path
-    reproduces that under HLA_STRICT_ERRORS=1 (it costs a host sync) and otherwise leaves the pose unchanged."""
+    reproduces that under args.strict_errors = 1 (it costs a host sync) and otherwise leaves the pose unchanged."""
     from oracle import ref_cpu as O
     from highlyaccurate_amd.models_ford import LM_S2GP_Ford
     d = _dev()
@@ -1520,7 +1518,7 @@ def test_error_behaviour_matches_the_reference(monkeypatch):
     with torch.no_grad():
         out = net(sat.to(d), grd.to(d), 1e-3, R_FL.to(d), T_FL.to(d), mode='test')
     assert all(float(o.abs().max()) == 0.0 for o in out)          # J = 0: the pose stays at its initial value
-    monkeypatch.setenv('HLA_STRICT_ERRORS', '1')
+    net.args.strict_errors = 1
     with pytest.raises(AssertionError, match='jacobian.py:172'), torch.no_grad():
         net(sat.to(d), grd.to(d), 1e-3, R_FL.to(d), T_FL.to(d), mode='test')
 

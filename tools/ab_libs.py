@@ -1,4 +1,6 @@
-"""Run bench.py against several experiment builds of libhla (HLA_LIB=...) and print the conv kernel numbers."""
+"""Same-box A/B: run bench.py's headline leg against several builds of libhla kept next to the product library (HLA_LIB=...,
+e.g. `python -m highlyaccurate_amd.build --out=libhla_base.so` in a checkout of the previous commit) and print the kernel numbers.
+    gpurun -- 'python tools/ab_libs.py libhla_base.so libhla.so libhla_base.so libhla.so'"""
 import json, os, subprocess, sys
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 libs = sys.argv[1:] or ['libhla.so']
