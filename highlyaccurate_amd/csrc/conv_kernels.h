@@ -79,7 +79,7 @@ typedef bf16 TuT;
 #elif HLA_TU_DTYPE == 2
 typedef f16 TuT;
 #elif HLA_TU_DTYPE == 3
-typedef split32 TuT;     // forward only (the backward of a split-mode forward runs on the fp32 kernels: same storage)
+typedef split32 TuT;
 #endif
 
 template <typename T> __device__ __forceinline__ void mma16(f32x16& acc, const uint4& w, const uint4& p);
@@ -183,8 +183,30 @@ struct PixBox { int y0, y1, x0, x1; };
 
 constexpr int HWID = 34;   // halo tile width in pixels
 constexpr int SB = 64;     // bytes of channels per pixel per pipeline stage
-constexpr int PSTR = 80;   // LDS bytes per halo pixel (64 B of channels + 16 B pad: conflict-free ds_read_b128)
-constexpr int HALO_TAP = 3;  // tap at which the next stage's halo loads are issued
+constexpr int PSTR = 64;   // LDS bytes per halo pixel: its 64 B of channels and no pad.  ds_read_b128 is conflict-free through an XOR
+                           // swizzle: 16-B slot s of the pixel in halo column hx is stored at slot s ^ halo_key(hx).  A lane group of a
+                           // b128 read covers 16 pixels of one halo row with x mod 16 all distinct (MI355X_MICROARCH.md, LDS table)
+                           // and one slot s: (pixel mod 4 = which quarter of the 256-B bank row, swizzled slot) is then distinct for
+                           // all 16.  (Round 2 padded the pixel to 80 B instead: 25 % more LDS, which capped the 64-channel kernels
+                           // at two workgroups per CU.)
+__device__ __forceinline__ int halo_key(int hx) { return (hx >> 2) & 3; }
+// byte offset of 16-B slot `slot` of halo pixel `pix` (= hy * HWID + hx) inside a stage buffer
+__device__ __forceinline__ int halo_off(int pix, int hx, int slot) { return pix * PSTR + ((slot ^ halo_key(hx)) << 4); }
+// The next stage's halo tile is fetched in two halves through the SAME staging registers: half 0 is requested at tap HALO_TAP0,
+// written to the idle buffer at tap HALO_TAP1, where half 1 is requested; half 1 is written after the stage's last MFMA.
+constexpr int HALO_TAP0 = 1, HALO_TAP1 = 5;
+// per-lane byte offsets of a wave's pixel fragments: [kx][kg] -> (x + kx) * PSTR + swizzled slot of (lane half g, k-group kg),
+// relative to the wave's first halo row
+struct FragOff { int o[3][2]; };
+__device__ __forceinline__ FragOff frag_offsets(int lane, int row0) {
+  const int x = lane & 31, g = lane >> 5;
+  FragOff f;
+#pragma unroll
+  for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+    for (int kg = 0; kg < 2; ++kg) f.o[kx][kg] = halo_off(row0 * HWID + x + kx, x + kx, g | (kg << 1));
+  return f;
+}
 
 // ---------------------------------------------------------------------------------------------
 // shared epilogue: acc[i][j] holds, for lane (x = lane&31, g = lane>>5), output channels
@@ -201,10 +223,13 @@ template <typename E, int NT> struct RowStager {
   }
   // cooperative flush of `npx` pixels: dst points at channel cb of the first pixel; pixel stride = Cout elements
   // `mask` / `add` (optional) are indexed exactly like dst: v = (mask > 0 ? v : 0) + add, applied on the 16-B vectors
+  // returns (not PLAIN, with a mask or an add) the max |v| of what was stored, i.e. AFTER mask and add: in split mode the scale
+  // the consumer of this map will use
   template <bool PLAIN = false>
-  static __device__ __forceinline__ void flush(const char* stage, E* dst, int npx, int npx_valid, int Cout, int lane,
-                                               const E* mask = nullptr, const E* add = nullptr,
-                                               int add_px_lo = 0, int add_px_hi = 1 << 30) {
+  static __device__ __forceinline__ float flush(const char* stage, E* dst, int npx, int npx_valid, int Cout, int lane,
+                                                const E* mask = nullptr, const E* add = nullptr,
+                                                int add_px_lo = 0, int add_px_hi = 1 << 30) {
+    float vmax = 0.f;
     const int chunks = npx * CPP;
     constexpr int EPV = 16 / (int)sizeof(E);
 #pragma unroll
@@ -227,6 +252,7 @@ template <typename E, int NT> struct RowStager {
               if (mask && !((float)m[k] > 0.f)) f = 0.f;
               if (addp) f += (float)ad[k];
               e[k] = (E)f;
+              vmax = fmaxf(vmax, fabsf(f));
             }
             __builtin_memcpy(&v, e, 16);
           }
@@ -234,6 +260,7 @@ template <typename E, int NT> struct RowStager {
         }
       }
     }
+    return vmax;
   }
 };
 
@@ -373,16 +400,21 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[MT][NT], const ConvA
           for (int q = 0; q < 4; ++q) {
             float w0 = v[j][q][0], w1 = v[j][q][1], w2 = v[j][q][2], w3 = v[j][q][3];
             if (relu) { w0 = fmaxf(w0, 0.f); w1 = fmaxf(w1, 0.f); w2 = fmaxf(w2, 0.f); w3 = fmaxf(w3, 0.f); }
-            if (Prec<T>::SPLIT && lane_ok) mx = fmaxf(fmaxf(mx, fmaxf(fabsf(w0), fabsf(w1))), fmaxf(fabsf(w2), fabsf(w3)));
+            // (with a mask or a fan-in the stored values are formed in the flush: the maximum is taken there)
+            if (Prec<T>::SPLIT && lane_ok && !((GEN || DG) && (a.mask_act || a.add_src)))
+              mx = fmaxf(fmaxf(mx, fmaxf(fabsf(w0), fabsf(w1))), fmaxf(fabsf(w2), fabsf(w3)));
             RowStager<T, NT>::put(stage, px, j * 32 + q * 8 + g * 4, w0, w1, w2, w3);
           }
       }
       const size_t o = pix0 * a.Cout + cb;
       if (GEN || DG) {
-        if (row_ok) RowStager<T, NT>::flush(stage, (T*)a.out_act + o, NPX, nvalid, a.Cout, lane,
-                                            a.mask_act ? (const T*)a.mask_act + o : nullptr,
-                                            (a.add_src && yo >= max(a.add_row_lo, addb.y0) && yo < addb.y1) ? (const T*)a.add_src + o : nullptr,
-                                            addb.x0 - xo0, addb.x1 - xo0);
+        if (row_ok) {
+          const float fm = RowStager<T, NT>::flush(stage, (T*)a.out_act + o, NPX, nvalid, a.Cout, lane,
+                                                   a.mask_act ? (const T*)a.mask_act + o : nullptr,
+                                                   (a.add_src && yo >= max(a.add_row_lo, addb.y0) && yo < addb.y1) ? (const T*)a.add_src + o : nullptr,
+                                                   addb.x0 - xo0, addb.x1 - xo0);
+          if (Prec<T>::SPLIT) mx = fmaxf(mx, fm);
+        }
       } else {
         if (row_ok) RowStager<T, NT>::template flush<true>(stage, (T*)a.out_act + o, NPX, nvalid, a.Cout, lane);
       }
@@ -425,15 +457,17 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[MT][NT], const ConvA
 }
 
 // ---------------------------------------------------------------------------------------------
-// One pipeline stage of MFMAs: 9 taps x 2 k-groups against the halo tile at `cur` (already offset to this
-// wave's first row / this lane's pixel + k-half).  Weight fragments come from global memory through a ring of
+// One pipeline stage of MFMAs: 9 taps x 2 k-groups against the halo tile at `cur` (the stage buffer; `fo` holds this lane's
+// offsets into it: the wave's first row, the lane's pixel and the swizzled slot of its k-half).  Weight fragments come from global memory through a ring of
 // WD+1 register sets filled WD taps ahead; `mid(tap)` runs right after the weight loads of each tap (used to
 // issue the next stage's halo loads BEHIND them: VM loads of a wave retire in order).
 template <typename T, int MT, int NT, int WD>
 struct WeightRing {
   static constexpr int RS = WD + 1;
   uint4 wb[RS][2][NT];
-  static constexpr int PFD = NT == 1 ? 6 : 3;   // pixel fragments in flight ahead of the MFMAs (one MFMA per fragment at NT = 1)
+  // pixel fragments in flight ahead of the MFMAs (one MFMA per fragment at NT = 1: four reads = 128 matrix-pipe cycles of cover;
+  // six, round 2's choice at two workgroups per CU, cost the three-workgroup kernel 27 spilled registers: 804 against 1100 TF)
+  static constexpr int PFD = NT == 1 ? 4 : 3;
   uint4 pf[PFD + 1];     // pixel-fragment pipeline of the non-upfront MFMA loop (lives across taps)
   const uint4* wq[NT];   // per-lane pointer to this stage's fragments of output tile j: [tap][kg][lane]
 
@@ -478,8 +512,8 @@ __device__ __forceinline__ void stagger_priority() {
 }
 
 template <typename T, int MT, int NT, int WD, typename Mid>
-__device__ __forceinline__ void stage_mma(f32x16 (&acc)[MT][NT], const char* cur, WeightRing<T, MT, NT, WD>& ring,
-                                          Mid&& mid) {
+__device__ __forceinline__ void stage_mma(f32x16 (&acc)[MT][NT], const char* cur, const FragOff& fo,
+                                          WeightRing<T, MT, NT, WD>& ring, Mid&& mid) {
   constexpr int RS = WD + 1;
 #pragma unroll
   for (int tap = 0; tap < 9; ++tap) {
@@ -495,7 +529,7 @@ __device__ __forceinline__ void stage_mma(f32x16 (&acc)[MT][NT], const char* cur
     constexpr int FPT = MT * 2, DEPTH = WeightRing<T, MT, NT, WD>::PFD;   // fragments per tap: (row i, k-group kg), kg fastest
     auto frag_ptr = [&](int f) {                          // f counts fragments within THIS tap; f >= FPT spills into the next tap
       const int tp = tap + f / FPT, r = f % FPT;
-      return cur + (((tp / 3) * HWID + tp % 3) + (r >> 1) * HWID) * PSTR + (r & 1) * 32;
+      return cur + fo.o[tp % 3][r & 1] + (tp / 3 + (r >> 1)) * HWID * PSTR;
     };
     if (tap == 0) {
 #pragma unroll
@@ -524,13 +558,21 @@ __device__ __forceinline__ void stage_mma(f32x16 (&acc)[MT][NT], const char* cur
   ring.next_stage();
 }
 
+// Occupancy: the 64-channel wave tile (NT = 2) holds 128 accumulator registers: two workgroups per CU.  The 32-channel one
+// (NT = 1, the Cout = 64 layers) fits three -- 43.5 KB of LDS each since the halo pixels lost their pad, <= 168 registers since
+// the halo staging went through half as many -- which is what hides its per-tile prologue and epilogue.
 template <typename T, int MT, int NT, int WM, int WN, bool POOL, int WD>
-__global__ __launch_bounds__(256, 2) void conv3x3_kernel(ConvArgs a) {
+__global__ __launch_bounds__(256, NT == 1 ? 3 : 2) void conv3x3_kernel(ConvArgs a) {
   static_assert(WM * WN == 4, "4 waves per block");
   constexpr int EPL = 16 / sizeof(T), KC = SB / sizeof(T);     // channels per stage: 32 (bf16) / 16 (fp32)
   constexpr int TH = WM * MT, HPIX = (TH + 2) * HWID, BUF = HPIX * PSTR;
-  constexpr int NPIECE = (HPIX * 4 + 255) / 256;               // 16-B pieces per thread per stage
-  __shared__ __attribute__((aligned(16))) char lds[2 * BUF];
+  constexpr int NPIECE = (HPIX * 4 + 255) / 256;               // 16-B pieces per thread per stage ...
+  constexpr int NHALF = (NPIECE + 1) / 2;                      // ... fetched in two halves through NHALF staging registers
+  // the epilogue reuses the halo buffers as four wave-private row stagers; the widest form stages a raw fp32 row and a 16-bit
+  // activation row side by side (EPI_ACT_RAW on 16-bit types), everything else one row of at most NT*32 fp32
+  constexpr int STG = 32 * (RowStager<float, NT>::PITCH + (sizeof(T) == 2 ? RowStager<T, NT>::PITCH : 0));
+  constexpr int LDSB = 2 * BUF > 4 * STG ? 2 * BUF : 4 * STG;
+  __shared__ __attribute__((aligned(16))) char lds[LDSB];
   __shared__ float red[8];
 
   // (readfirstlane: the wave index is uniform, which lets every address that depends on it live in scalar registers)
@@ -539,7 +581,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(ConvArgs a) {
   const int sy0 = a.src_row_lo, sy1 = a.H;
   int tx, ty, b;
   // column interval of the source per halo row class: top halo row / the tile's own rows / bottom halo row
-  int slo[3] = {0, 0, 0}, shi[3] = {a.W, a.W, a.W};
+  // (six scalars, not arrays: once the halo row of a piece is a run-time value the compiler turns a select over array elements
+  // into an indexed load from a stack copy of the array)
+  struct { int lo0, lo1, lo2, hi0, hi1, hi2; } sb = {0, 0, 0, a.W, a.W, a.W};
   if (a.dyn) {                              // kernel-uniform; everything below is scalar loads
     // Only the live tiles are enumerated, by the FIRST workgroups of the grid; the rest exit.  (Launching every tile and
     // returning from the dead ones is not enough: workgroup ids go round-robin to the shader engines, so a dead / live
@@ -554,13 +598,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(ConvArgs a) {
     ty = e >> 16; tx = e & 0xffff;
     if (d.src_bands >= 0) {
       const int sh = (a.up1 || a.unpool_idx) ? 1 : 0, nb = ((a.H >> sh) + 7) >> 3, yy = a.row_begin + ty * TH;
-      const int rows[3] = {yy - 1, yy, yy + TH};
-#pragma unroll
-      for (int k = 0; k < 3; ++k) {
-        const int band = min(max(rows[k], 0) >> sh >> 3, nb - 1);
-        slo[k] = a.dyn[d.src_bands + 2 * band] << sh;
-        shi[k] = min(a.dyn[d.src_bands + 2 * band + 1] << sh, a.W);
-      }
+      const int b0 = min(max(yy - 1, 0) >> sh >> 3, nb - 1), b1 = min(yy >> sh >> 3, nb - 1), b2 = min((yy + TH) >> sh >> 3, nb - 1);
+      sb.lo0 = a.dyn[d.src_bands + 2 * b0] << sh; sb.hi0 = min(a.dyn[d.src_bands + 2 * b0 + 1] << sh, a.W);
+      sb.lo1 = a.dyn[d.src_bands + 2 * b1] << sh; sb.hi1 = min(a.dyn[d.src_bands + 2 * b1 + 1] << sh, a.W);
+      sb.lo2 = a.dyn[d.src_bands + 2 * b2] << sh; sb.hi2 = min(a.dyn[d.src_bands + 2 * b2 + 1] << sh, a.W);
     }
   } else {
     int bid = xcd_contiguous(blockIdx.x, gridDim.x);
@@ -579,30 +620,56 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(ConvArgs a) {
     dsc = 1.f / (sx * *a.wscale);
   }
 
-  auto load_stage = [&](int sg, uint4 (&st)[NPIECE]) {
-    const int c0 = sg * KC;
-    const bool first = c0 < a.C1;       // wave-uniform
-    const T* src = first ? (const T*)a.src1 : (const T*)a.src2;
-    const int Cs = first ? a.C1 : a.C2;
-    const int coff = (first ? c0 : c0 - a.C1) + part * EPL;
-    const int sh = (first && (a.up1 || a.unpool_idx)) ? 1 : 0;
-    const int Hs = a.H >> sh, Ws = a.W >> sh;
+  // Everything about a thread's halo pieces except the channel stage is fixed for the workgroup's life, and is kept in the most
+  // compact form that makes a stage's loads cheap to issue: per piece ONE signed 32-bit byte offset into the sample per source
+  // (< 0: the pixel reads as zero -- outside the image, above the source's first row, outside the columns its producer wrote;
+  // bits 0-1: the pixel's (y&1, x&1) position for the virtual unpool) and one LDS offset.  A stage then costs, per piece, a
+  // compare, a mask and one saddr + 32-bit-offset load.  (Round 2 left this to the compiler, which hoisted ~20 registers of
+  // 64-bit addresses and coordinates out of the stage loop; recomputing them per stage instead costs ~6 VALU per MFMA.)
+  constexpr int ES = (int)sizeof(T);
+  const int sh1 = (a.up1 || a.unpool_idx) ? 1 : 0, Hs1 = a.H >> sh1, Ws1 = a.W >> sh1;
+  const char* s1b = (const char*)a.src1 + (size_t)b * Hs1 * Ws1 * a.C1 * ES;
+  const char* s2b = (const char*)a.src2 + (size_t)b * a.H * a.W * a.C2 * ES;
+  const unsigned char* idxb = a.unpool_idx ? a.unpool_idx + (size_t)b * Hs1 * Ws1 * a.C1 : nullptr;
+  int off1[NPIECE], off2[NPIECE], wo[NPIECE];
+  {
+    // (the six bounds as uniform scalars: left as loads from the struct, the select over them below is rewritten into ONE load
+    // from a selected address, which pins the struct in scratch memory)
+    const int lo0 = __builtin_amdgcn_readfirstlane(sb.lo0), lo1 = __builtin_amdgcn_readfirstlane(sb.lo1),
+              lo2 = __builtin_amdgcn_readfirstlane(sb.lo2), hi0 = __builtin_amdgcn_readfirstlane(sb.hi0),
+              hi1 = __builtin_amdgcn_readfirstlane(sb.hi1), hi2 = __builtin_amdgcn_readfirstlane(sb.hi2);
 #pragma unroll
     for (int i = 0; i < NPIECE; ++i) {
       const int pix = pbase + 64 * i;
       const int hy = pix / HWID, hx = pix - hy * HWID;
       const int y = y0 - 1 + hy, x = x0 - 1 + hx;
+      const int xlo = hy == 0 ? lo0 : (hy == TH + 1 ? lo2 : lo1), xhi = hy == 0 ? hi0 : (hy == TH + 1 ? hi2 : hi1);
+      const bool ok = pix < HPIX && y >= sy0 && y < sy1 && x >= xlo && x < xhi;
+      off1[i] = ok ? ((((y >> sh1) * Ws1 + (x >> sh1)) * a.C1 * ES + part * 16) | ((y & 1) << 1) | (x & 1)) : -1;
+      off2[i] = ok ? ((y * a.W + x) * a.C2 * ES + part * 16) : -1;
+      // split mode: this thread's 4 channels are 8 B of slot part>>1 (hi); the lo half sits 2 slots further = offset ^ 32
+      wo[i] = pix >= HPIX ? -1 : (Prec<T>::SPLIT ? halo_off(pix, hx, part >> 1) + (part & 1) * 8 : halo_off(pix, hx, part));
+    }
+  }
+  auto load_stage = [&](int sg, int half, uint4 (&st)[NHALF]) __attribute__((always_inline)) {
+    const int c0 = sg * KC;
+    const bool first = c0 < a.C1;       // wave-uniform
+    const char* base = first ? s1b + (size_t)c0 * ES : s2b + (size_t)(c0 - a.C1) * ES;
+#pragma unroll
+    for (int ii = 0; ii < NHALF; ++ii) {
+      const int i = half * NHALF + ii;
       uint4 v = make_uint4(0, 0, 0, 0);
-      const int xlo = hy == 0 ? slo[0] : (hy == TH + 1 ? slo[2] : slo[1]), xhi = hy == 0 ? shi[0] : (hy == TH + 1 ? shi[2] : shi[1]);
-      if (pix < HPIX && y >= sy0 && y < sy1 && x >= xlo && x < xhi) {
-        const size_t e0 = (((size_t)b * Hs + (y >> sh)) * Ws + (x >> sh)) * Cs + coff;
-        v = *(const uint4*)(src + e0);
+      const int o = i < NPIECE ? (first ? off1[i] : off2[i]) : -1;
+      if (o >= 0) {
+        const unsigned ob = (unsigned)o & ~15u;
+        v = *(const uint4*)(base + ob);
         if (a.unpool_idx) {          // keep only the elements whose forward argmax is this (y&1, x&1) position
-          const unsigned pos = ((y & 1) << 1) | (x & 1);
+          const unsigned pos = (unsigned)o & 3u;
+          const unsigned char* idp = idxb + ob / ES + c0;      // one argmax byte per element
           if constexpr (sizeof(T) == 2) {
             // 8 argmax bytes -> eight 16-bit keep masks with packed 16-bit math: (id ^ pos) - 1 is negative only for a match
             typedef short s16x2 __attribute__((ext_vector_type(2)));
-            const uint2 id = *(const uint2*)(a.unpool_idx + e0);
+            const uint2 id = *(const uint2*)idp;
             const unsigned m0 = id.x ^ (pos * 0x01010101u), m1 = id.y ^ (pos * 0x01010101u);
             auto keep = [](unsigned m, unsigned sel) {
               s16x2 w = __builtin_bit_cast(s16x2, __builtin_amdgcn_perm(0u, m, sel));   // two id bytes, zero-extended
@@ -615,27 +682,28 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(ConvArgs a) {
             T e[EPL];
             unsigned char id[EPL];
             __builtin_memcpy(e, &v, 16);
-            __builtin_memcpy(id, a.unpool_idx + e0, EPL);
+            __builtin_memcpy(id, idp, EPL);
 #pragma unroll
             for (int k = 0; k < EPL; ++k) if (id[k] != pos) e[k] = (T)0.f;
             __builtin_memcpy(&v, e, 16);
           }
         }
       }
-      st[i] = v;
+      st[ii] = v;
     }
   };
-  auto write_stage = [&](char* buf, const uint4 (&st)[NPIECE]) {
+  auto write_stage = [&](char* buf, int half, const uint4 (&st)[NHALF]) __attribute__((always_inline)) {
 #pragma unroll
-    for (int i = 0; i < NPIECE; ++i) {
-      const int pix = pbase + 64 * i;
+    for (int ii = 0; ii < NHALF; ++ii) {
+      const int i = half * NHALF + ii;
+      const int w = i < NPIECE ? wo[i] : -1;
       if constexpr (Prec<T>::SPLIT) {
         // a stage = 16 channels: [pixel][hi: 16 x fp16 | lo: 16 x fp16]; lane half g of the MFMA reads channels 8g..8g+7
         uint2 hi, lo;
-        split4(__uint_as_float(st[i].x), __uint_as_float(st[i].y), __uint_as_float(st[i].z), __uint_as_float(st[i].w), sx, hi, lo);
-        if (pix < HPIX) { *(uint2*)(buf + pix * PSTR + part * 8) = hi; *(uint2*)(buf + pix * PSTR + 32 + part * 8) = lo; }
+        split4(__uint_as_float(st[ii].x), __uint_as_float(st[ii].y), __uint_as_float(st[ii].z), __uint_as_float(st[ii].w), sx, hi, lo);
+        if (w >= 0) { *(uint2*)(buf + w) = hi; *(uint2*)(buf + (w ^ 32)) = lo; }
       } else {
-        if (pix < HPIX) *(uint4*)(buf + pix * PSTR + part * 16) = st[i];
+        if (w >= 0) *(uint4*)(buf + w) = st[ii];
       }
     }
   };
@@ -648,33 +716,39 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(ConvArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  const int x = lane & 31, g = lane >> 5;
-  const int aoff = ((wm * MT) * HWID + x) * PSTR + g * 16;
+  const FragOff fo = frag_offsets(lane, wm * MT);
   const int ntg0 = (blockIdx.y * WN + wn) * NT;     // first global 32-channel output tile of this wave
   // packed weights: [ntile][stage][tap][kg(2)][lane] 16-B fragments
   WeightRing<T, MT, NT, WD> ring;
 #pragma unroll
   for (int j = 0; j < NT; ++j) ring.wq[j] = a.wpk + (size_t)(ntg0 + j) * nstage * 18 * 64 + lane;
 
-  uint4 st[NPIECE];
+  uint4 st[NHALF];
   ring.prime();              // the first weight fragments do not depend on the halo tile: request them ahead of it
-  load_stage(0, st);
-  write_stage(lds, st);
+  {
+    uint4 st1[NHALF];        // the prologue has registers to spare: both halves are requested back to back
+    load_stage(0, 0, st);
+    load_stage(0, 1, st1);
+    write_stage(lds, 0, st);
+    write_stage(lds, 1, st1);
+  }
   __syncthreads();
   stagger_priority();
 
   for (int sg = 0; sg < nstage; ++sg) {
     const bool more = sg + 1 < nstage;
-    stage_mma<T, MT, NT, WD>(acc, lds + (sg & 1) * BUF + aoff, ring, [&](int tap) {
-      if (tap == HALO_TAP && more) load_stage(sg + 1, st);
+    char* nxt = lds + ((sg + 1) & 1) * BUF;
+    stage_mma<T, MT, NT, WD>(acc, lds + (sg & 1) * BUF, fo, ring, [&](int tap) __attribute__((always_inline)) {
+      if (tap == HALO_TAP0 && more) load_stage(sg + 1, 0, st);
+      if (tap == HALO_TAP1 && more) { write_stage(nxt, 0, st); load_stage(sg + 1, 1, st); }
     });
-    if (more) write_stage(lds + ((sg + 1) & 1) * BUF, st);
+    if (more) write_stage(nxt, 1, st);
     __syncthreads();
   }
   // the loop's last barrier guarantees nobody still reads the halo buffers: reuse them as 4 wave-private stagers
-  static_assert(2 * BUF / 4 >= 32 * (NT * 32 * 4 + 16) && (2 * BUF / 4) % 16 == 0, "stager does not fit");
+  static_assert((LDSB / 4) % 16 == 0, "stager alignment");
   {
-    char* stager = lds + wv * (2 * BUF / 4);
+    char* stager = lds + wv * (LDSB / 4);
     const int mode = epilogue_mode(a);      // kernel-uniform
     PixBox addb{a.add_row_lo, 1 << 30, 0, 1 << 30};
     if (a.dyn) {
@@ -724,6 +798,7 @@ struct Conv02Args {
   const float* wtail;      // the packer's tail: [l] = power-of-two scale of layer l's packed weights, [16] = max_cout sum_k |w0|
   unsigned* amax_out;      // [B] atomicMax target: max of out_act per sample
   unsigned* amax_a2_out;   // likewise for a2_out (level 4), or null
+  unsigned* amax_a0_out;   // likewise for a0_out (training: the split-mode weight gradient of conv2 scales its input by it), or null
 };
 
 // conv0's 64 output channels are conv2's K.  With 2-byte activations they are two 32-channel stages = 54 KB of halo tile and
@@ -736,7 +811,7 @@ template <typename T> constexpr int conv02_lds_bytes() {
 }
 
 template <typename T, int WD>
-__global__ __launch_bounds__(256, 2) void conv02_kernel(Conv02Args a0) {
+__global__ __launch_bounds__(256, sizeof(T) == 2 ? 3 : 2) void conv02_kernel(Conv02Args a0) {
   constexpr bool SPLIT = Prec<T>::SPLIT;
   constexpr int EPL = Prec<T>::CEPL, KC = SB / sizeof(T), NSG = 64 / KC, NFRAG = 32 / (2 * EPL), NH = SPLIT ? 2 : 1;
   constexpr int MT = 4, NT = 1, WN = 2, TH = 8, HPIX = (TH + 2) * HWID, BUF = HPIX * PSTR, IW = 36, IH = 12;
@@ -812,7 +887,7 @@ __global__ __launch_bounds__(256, 2) void conv02_kernel(Conv02Args a0) {
   for (int i = 0; i < MT; ++i)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[i][0][r] = 0.f;
-  const int aoff = ((wm * MT) * HWID + x) * PSTR + g * 16;
+  const FragOff fo = frag_offsets(lane, wm * MT);
 #pragma unroll
   for (int rd = 0; rd < ROUNDS; ++rd) {
   const int j0 = rd * JPR;                           // first 32-channel half of conv0's output this round produces
@@ -869,6 +944,7 @@ __global__ __launch_bounds__(256, 2) void conv02_kernel(Conv02Args a0) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const int co = j * 32 + q * 8 + g * 4, sl = co / KC - rd * SPR;      // channel, its stage buffer within this round
+          const int byte = (co % KC) * (SPLIT ? 2 : (int)sizeof(T));           // where the 4 channels start inside the pixel's stage
           const float4 bb = bias0[j][q];
           float v0 = fmaxf(c0[j][q * 4 + 0] * d0 + bb.x, 0.f), v1 = fmaxf(c0[j][q * 4 + 1] * d0 + bb.y, 0.f);
           float v2 = fmaxf(c0[j][q * 4 + 2] * d0 + bb.z, 0.f), v3 = fmaxf(c0[j][q * 4 + 3] * d0 + bb.w, 0.f);
@@ -876,11 +952,10 @@ __global__ __launch_bounds__(256, 2) void conv02_kernel(Conv02Args a0) {
           if constexpr (SPLIT) {
             uint2 hi, lo;
             split4(v0, v1, v2, v3, s_a0, hi, lo);
-            char* px = lds + sl * BUF + p * PSTR + (co % KC) * 2;
-            *(uint2*)px = hi;
-            *(uint2*)(px + 32) = lo;
+            *(uint2*)(lds + sl * BUF + halo_off(p, hx, byte >> 4) + (byte & 15)) = hi;
+            *(uint2*)(lds + sl * BUF + halo_off(p, hx, 2 + (byte >> 4)) + (byte & 15)) = lo;
           } else {
-            store4((T*)(lds + sl * BUF + p * PSTR) + (co % KC), v0, v1, v2, v3);
+            store4((T*)(lds + sl * BUF + halo_off(p, hx, byte >> 4) + (byte & 15)), v0, v1, v2, v3);
           }
         }
     }
@@ -889,22 +964,30 @@ __global__ __launch_bounds__(256, 2) void conv02_kernel(Conv02Args a0) {
 
   if (a0.a0_out) {     // training: the backward pass needs relu(conv0) (conv2's wgrad input and ReLU mask)
     constexpr int PPP = 64 * (int)sizeof(T) / 16 / ROUNDS;          // 16-B pieces per pixel over this round's stages
+    float a0mx = 0.f;
     for (int e = t; e < TH * 32 * PPP; e += 256) {
       const int pxl = e / PPP, piece = e % PPP, sgi = piece / 4, part = piece % 4;
       const int r = pxl / 32, c = pxl % 32, yy = y0 + r, xx = x0 + c;
       if (yy < a0.H && xx < a0.W) {
         char* dst = (char*)a0.a0_out + (((size_t)b * a0.H + yy) * a0.W + xx) * 64 * sizeof(T) + (rd * PPP + piece) * 16;
-        const char* px = lds + sgi * BUF + ((r + 1) * HWID + c + 1) * PSTR;
+        const char* sb = lds + sgi * BUF;
+        const int hpix = (r + 1) * HWID + c + 1;
         if constexpr (SPLIT) {      // what conv2 actually consumes: (hi + lo) / s, 23 of relu(conv0)'s 24 significand bits
-          const f16x4 h = __builtin_bit_cast(f16x4, *(const uint2*)(px + part * 8));
-          const f16x4 l = __builtin_bit_cast(f16x4, *(const uint2*)(px + 32 + part * 8));
+          const f16x4 h = __builtin_bit_cast(f16x4, *(const uint2*)(sb + halo_off(hpix, c + 1, part >> 1) + (part & 1) * 8));
+          const f16x4 l = __builtin_bit_cast(f16x4, *(const uint2*)(sb + halo_off(hpix, c + 1, 2 + (part >> 1)) + (part & 1) * 8));
           const float is = 1.f / s_a0;
-          *(float4*)dst = make_float4(((float)h[0] + (float)l[0]) * is, ((float)h[1] + (float)l[1]) * is,
-                                      ((float)h[2] + (float)l[2]) * is, ((float)h[3] + (float)l[3]) * is);
+          const float4 o4 = make_float4(((float)h[0] + (float)l[0]) * is, ((float)h[1] + (float)l[1]) * is,
+                                        ((float)h[2] + (float)l[2]) * is, ((float)h[3] + (float)l[3]) * is);
+          *(float4*)dst = o4;
+          a0mx = fmaxf(fmaxf(a0mx, fmaxf(o4.x, o4.y)), fmaxf(o4.z, o4.w));        // (post-ReLU: non-negative)
         } else {
-          *(uint4*)dst = *(const uint4*)(px + part * 16);
+          *(uint4*)dst = *(const uint4*)(sb + halo_off(hpix, c + 1, part));
         }
       }
+    }
+    if (SPLIT && a0.amax_a0_out) {       // kernel-uniform
+      a0mx = wave_max_f32(a0mx);
+      if (lane == 0) atomicMax(a0.amax_a0_out + b, __float_as_uint(a0mx));
     }
   }
 
@@ -912,7 +995,7 @@ __global__ __launch_bounds__(256, 2) void conv02_kernel(Conv02Args a0) {
   if (rd == 0) stagger_priority();
 #pragma unroll 1
   for (int sg = 0; sg < SPR; ++sg)
-    stage_mma<T, MT, NT, WD>(acc, lds + sg * BUF + aoff, ring, [](int) {});
+    stage_mma<T, MT, NT, WD>(acc, lds + sg * BUF, fo, ring, [](int) {});
   }     // rounds
 
   ConvArgs a{};
@@ -1008,7 +1091,8 @@ static __global__ void pack_weights_split_kernel(const float* __restrict__ w, f1
       const int sg = r % nsg; r /= nsg;
       const int nt = (int)r;
       const int cout = nt * 32 + (lane & 31), cin = sg * 16 + (lane >> 5) * 8 + j;
-      v = w[((size_t)cout * Cin + cin) * 9 + tap];
+      // first == 2 (data gradient): the transposed, tap-flipped convolution, as pack_weights_body's mode 2
+      v = first == 2 ? w[((size_t)cin * Cout + cout) * 9 + (8 - tap)] : w[((size_t)cout * Cin + cin) * 9 + tap];
     }
     v *= sw;
     const f16 h = (f16)v;

@@ -62,6 +62,7 @@ int vgg_forward_t(const float* x, size_t x_plane, const hla_vgg_params* prm, con
     if (flags & HLA_VGG_SAVE_FOR_BACKWARD) { a.a0_out = w + pl.a0; a.idx_out = (unsigned char*)(w + pl.idx3); }
     if (level4) a.a2_out = w + pl.x2r;
     a.wtail = wtail; a.amax_out = AM(AM_X3); a.amax_a2_out = level4 ? AM(AM_X2) : nullptr;
+    a.amax_a0_out = (flags & HLA_VGG_SAVE_FOR_BACKWARD) ? AM(AM_A0) : nullptr;
     // (first_row8, see below: x3 is needed from row 4f-16 on = conv2 row 8f-32)
     const int f0 = (level4 || (flags & HLA_VGG_SAVE_FOR_BACKWARD)) ? 0 : first_row8;
     a.row_begin = f0 ? 8 * f0 - 32 : 0;
@@ -218,6 +219,8 @@ extern "C" int hla_vgg_forward(const float* x, size_t x_plane, const hla_vgg_par
   HLA_REQUIRE(hla_dtype_ok(dtype), "hla_vgg_forward: dtype must be HLA_F32, HLA_BF16, HLA_F16 or HLA_F16X3 (got %d)", dtype);
   HLA_REQUIRE(B > 0 && H >= 8 && W >= 8 && H % 8 == 0 && W % 8 == 0, "hla_vgg_forward: H and W must be multiples of 8");
   HLA_REQUIRE(x_plane == 0 || x_plane >= (size_t)H * W, "hla_vgg_forward: x_plane (%zu) must be 0 or >= H*W", x_plane);
+  // the conv kernels address a sample's activation map with signed 32-bit byte offsets (largest map: H x W x 64 fp32)
+  HLA_REQUIRE((size_t)H * W * 64 * 4 < ((size_t)1 << 31), "hla_vgg_forward: image too large (H*W must be below 2^23 pixels)");
   HLA_REQUIRE(level == 3 || level == 4, "hla_vgg_forward: level must be 3 (x15,x18,x21) or 4 (+x24), got %d", level);
   HLA_REQUIRE(feat[0] && feat[1] && feat[2], "hla_vgg_forward: feat[0..2] are required");
   HLA_REQUIRE(level == 3 || (feat[3] && params->w[11] && params->w[12]),

@@ -252,6 +252,174 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Split-fp16 weight gradient (precision 'fp16x3'): the same contraction over pixels with both operands fed to the matrix cores
+// as hi + lo = fp16(s v) + fp16(s v - hi): G X ~= Ghi Xhi + Glo Xhi + Ghi Xlo, three v_mfma_f32_32x32x16_f16 per product, fp32
+// accumulate -- fp32-class gradients at a third of the fp16 MFMA rate instead of the exact-fp32 kernels' sixteenth.
+// Storage stays fp32 (the maps a split-mode forward / backward keep); a tile's 16-B pieces are split where they enter LDS, into
+// an fp16 hi plane and an fp16 lo plane per operand, each laid out like the f16 kernel's tile, so the k-major fragments come
+// from the same transpose reads.  Scales: ONE power of two per operand for the whole launch, from the maximum over the batch
+// of the per-sample maxima their producers recorded (the gradient is a sum over the batch, so a batch-wide scale costs no
+// accuracy where it matters: elements below 2^-17 of the batch maximum keep an absolute error of 2^-39 of it); exact to undo.
+struct WgradSplitExtra {
+  const unsigned* amax_x1; const unsigned* amax_x2; const unsigned* amax_g;   // [B] fp32 bit patterns of max |.| per sample
+};
+constexpr int WGS_STR = 64 * 2 + 16;                       // fp16 plane row stride (as wg_stride<f16>)
+constexpr int wgs_lds_bytes() { return 2 * ((WG_TH + 2) * HWID + WG_TH * 32) * WGS_STR; }
+
+static __global__ __launch_bounds__(256, 1) void wgrad_split_kernel(WgradArgs a, WgradSplitExtra sx) {
+  typedef f16 H;
+  constexpr int STR = WGS_STR, PPX = 16;                   // 16-B fp32 pieces per pixel (64 channels)
+  constexpr int XPIX = (WG_TH + 2) * HWID, GPIX = WG_TH * 32, KPX = 16;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* Xh = smem;
+  char* Xl = Xh + XPIX * STR;
+  char* Gh = Xl + XPIX * STR;
+  char* Gl = Gh + GPIX * STR;
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6, ct = wv >> 1, it = wv & 1;
+  const int ks = blockIdx.x, ci0 = blockIdx.y * 64, co0 = blockIdx.z * 64;
+  const bool first = ci0 < a.C1;
+  const float* xsrc = first ? (const float*)a.x1 : (const float*)a.x2;
+  const int Cs = first ? a.C1 : a.C2, coff = first ? ci0 : ci0 - a.C1, sh = (first && a.up1) ? 1 : 0;
+  const int Hs = a.H >> sh, Ws = a.W >> sh;
+  const int gsh = a.g_unpool ? 1 : 0, Hg = a.H >> gsh, Wg = a.W >> gsh;
+  const bool want_bias = a.bpart && blockIdx.y == 0 && it == 0;
+  // launch-wide scales (uniform)
+  unsigned mx = 0, mg = 0;
+  const unsigned* ax = first ? sx.amax_x1 : sx.amax_x2;
+  for (int b = 0; b < a.B; ++b) { mx = max(mx, ax[b]); mg = max(mg, sx.amax_g[b]); }
+  const float s_x = split_scale(mx), s_g = split_scale(mg);
+
+  f32x16 acc[9], accb;
+#pragma unroll
+  for (int k = 0; k < 9; ++k)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[k][r] = 0.f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) accb[r] = 0.f;
+  const uint4 ones = frag_ones<f16>();
+
+  constexpr int NX = (XPIX * PPX + 255) / 256, NG = GPIX * PPX / 256, PSTEP = 256 / PPX;
+  const int part = t % PPX, pix0 = t / PPX;
+  const WgTiles tl(a.dyn, a.dyn_desc, a.H, a.W, a.row_begin, a.tiles_x, a.tiles_y, a.ntile, a.B, a.g_unpool ? 1 : 0);
+  for (int tile = ks; tile < tl.ntile; tile += a.KS) {
+    int b, y0, x0, gx0, gx1;
+    tl.origin(tile, b, y0, x0, gx0, gx1);
+    __syncthreads();                                   // previous tile fully consumed
+    // input halo tile (zero outside the image) and output-gradient tile, in batches of 4 pieces = 16 staging registers
+#pragma unroll
+    for (int lo = 0; lo < NX; lo += 4) {
+      uint4 xr[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int pix = pix0 + (lo + k) * PSTEP;
+        const int hy = pix / HWID, hx = pix - hy * HWID, y = y0 - 1 + hy, x = x0 - 1 + hx;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (lo + k < NX && pix < XPIX && y >= 0 && y < a.H && x >= 0 && x < a.W)
+          v = *(const uint4*)(xsrc + (((size_t)b * Hs + (y >> sh)) * Ws + (x >> sh)) * Cs + coff + part * 4);
+        xr[k] = v;
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int pix = pix0 + (lo + k) * PSTEP;
+        uint2 hi, lw;
+        split4(__uint_as_float(xr[k].x), __uint_as_float(xr[k].y), __uint_as_float(xr[k].z), __uint_as_float(xr[k].w), s_x, hi, lw);
+        if (lo + k < NX && pix < XPIX) { *(uint2*)(Xh + pix * STR + part * 8) = hi; *(uint2*)(Xl + pix * STR + part * 8) = lw; }
+      }
+    }
+#pragma unroll
+    for (int lo = 0; lo < NG; lo += 4) {
+      uint4 gr[4];
+      unsigned gid[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int pix = pix0 + (lo + k) * PSTEP;
+        const int y = y0 + pix / 32, x = x0 + pix % 32;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        unsigned id = 0;
+        if (y < a.H && x >= gx0 && x < gx1) {
+          const size_t e0 = (((size_t)b * Hg + (y >> gsh)) * Wg + (x >> gsh)) * a.Cout + co0 + part * 4;
+          v = *(const uint4*)((const float*)a.g + e0);
+          if (a.g_unpool) id = *(const unsigned*)(a.g_unpool + e0);
+        }
+        gr[k] = v; gid[k] = id;
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int pix = pix0 + (lo + k) * PSTEP;
+        float e0 = __uint_as_float(gr[k].x), e1 = __uint_as_float(gr[k].y), e2 = __uint_as_float(gr[k].z), e3 = __uint_as_float(gr[k].w);
+        if (a.g_unpool) {                              // keep the elements whose forward argmax is this (y&1, x&1)
+          const unsigned pos = (((y0 + pix / 32) & 1) << 1) | ((x0 + pix % 32) & 1);
+          if ((gid[k] & 0xff) != pos) e0 = 0.f;
+          if (((gid[k] >> 8) & 0xff) != pos) e1 = 0.f;
+          if (((gid[k] >> 16) & 0xff) != pos) e2 = 0.f;
+          if ((gid[k] >> 24) != pos) e3 = 0.f;
+        }
+        uint2 hi, lw;
+        split4(e0, e1, e2, e3, s_g, hi, lw);
+        *(uint2*)(Gh + pix * STR + part * 8) = hi; *(uint2*)(Gl + pix * STR + part * 8) = lw;
+      }
+    }
+    __syncthreads();
+    // one K-step (16 pixels) at a time: the G fragments of the tile's four rows (hi and lo: 32 registers) stay resident while
+    // every X fragment (halo row rho, column shift kx) is fetched once and feeds the up to three taps ky that use it
+#pragma unroll 1
+    for (int kk = 0; kk < 32 / KPX; ++kk) {
+      uint4 Ah[WG_TH], Al[WG_TH];
+#pragma unroll
+      for (int r = 0; r < WG_TH; ++r) {
+        Ah[r] = frag_kmajor<H>(Gh, STR, r * 32 + kk * KPX, ct * 32, lane);
+        Al[r] = frag_kmajor<H>(Gl, STR, r * 32 + kk * KPX, ct * 32, lane);
+        if (want_bias) { mma16<H>(accb, Ah[r], ones); mma16<H>(accb, Al[r], ones); }
+      }
+#pragma unroll
+      for (int rho = 0; rho < WG_TH + 2; ++rho) {
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+          const uint4 Bh = frag_kmajor<H>(Xh, STR, rho * HWID + kx + kk * KPX, it * 32, lane);
+          const uint4 Bl = frag_kmajor<H>(Xl, STR, rho * HWID + kx + kk * KPX, it * 32, lane);
+#pragma unroll
+          for (int ky = 0; ky < 3; ++ky) {
+            const int r = rho - ky;
+            if (r >= 0 && r < WG_TH) {
+              mma16<H>(acc[ky * 3 + kx], Ah[r], Bh);
+              mma16<H>(acc[ky * 3 + kx], Al[r], Bh);
+              mma16<H>(acc[ky * 3 + kx], Ah[r], Bl);
+            }
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  }
+  // D[i = co][j = ci]: lane -> ci = ci0 + it*32 + (lane&31); reg r -> co = co0 + ct*32 + (r&3) + 8(r>>2) + 4(lane>>5)
+  const float inv = 1.f / (s_x * s_g), invg = 1.f / s_g;
+  const int ci = ci0 + it * 32 + (lane & 31), g5 = lane >> 5;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int co = co0 + ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * g5;
+    float* o = a.part + (((size_t)ks * a.Cout + co) * a.Cin + ci) * 9;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) o[tap] = acc[tap][r] * inv;
+    if (want_bias && (lane & 31) == 0) a.bpart[(size_t)ks * a.Cout + co] = accb[r] * invg;
+  }
+}
+
+// per-sample max |x| of an fp32 map (fp32 bit pattern, atomicMax into a zeroed word): the scale of a gradient map that no
+// convolution epilogue produced (the L2-norm backward's outputs, with the confidence heads' contribution added)
+static __global__ __launch_bounds__(256) void absmax_map_kernel(const float* __restrict__ x, size_t per_sample, size_t skip, int nblk,
+                                                                unsigned* __restrict__ amax) {
+  const int b = blockIdx.x / nblk, k = blockIdx.x % nblk;
+  const float4* p = (const float4*)(x + (size_t)b * per_sample);
+  float m = 0.f;
+  for (size_t i = skip / 4 + (size_t)k * 256 + threadIdx.x; i < per_sample / 4; i += (size_t)nblk * 256) {
+    const float4 v = p[i];
+    m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+  }
+  m = wave_max_f32(m);
+  if ((threadIdx.x & 63) == 0) atomicMax(amax + b, __float_as_uint(m));
+}
+
 // conv0: dW0[co][k = c*9+tap] over the NCHW fp32 input (k padded to 32 as one "ci tile").
 struct Wgrad0Args {
   const float* x;        // [B,3,H,W], channel planes x_plane elements apart
@@ -744,9 +912,14 @@ static __global__ __launch_bounds__(1024) void bwd_fan_kernel(int* __restrict__ 
 struct BwdPlan {
   size_t g_x21, g_d2a, g_x18, l2_18, g_d1a, g_x15, l2_15, g_a12, g_a10, g_x8, g_x8p, g_a5, g_x3, g_x3p, g_a0;
   size_t dot, part, bpart, dz, dyn;
+  size_t gamax;                                 // split mode: [kGradAmaxSlots][B] per-sample max |gradient map| (fp32 bits)
   size_t g_x24, g_d3a, g_x2p, g_c2, l2_21;      // level 4 only
   size_t total;
 };
+
+// split mode: one per-sample maximum per gradient map that a data- or weight-gradient launch reads
+enum { GA_X21 = 0, GA_D2A, GA_X18, GA_X3P, GA_D1A, GA_X15, GA_X8P, GA_A12, GA_A10, GA_X8, GA_A5, GA_X3, GA_A0, GA_X24, GA_D3A,
+       GA_X2P, GA_C2, kGradAmaxSlots = 24 };
 
 static int wgrad_ksplit(int Cout, int Cin, int ntile) {
   const int pairs = (Cout / 64) * (Cin / 64);
@@ -783,6 +956,7 @@ static void bwd_plan(int B, int H, int W, int dtype, BwdPlan* p, bool level4 = f
   p->bpart = take((size_t)2048 * 256 * 4);
   p->dz = take((level4 ? P : P / 4) * sizeof(float));
   p->dyn = take((size_t)dyn_layout(H, W).total * sizeof(int));
+  p->gamax = take((size_t)kGradAmaxSlots * B * sizeof(unsigned));
   p->g_x24 = p->g_d3a = p->g_x2p = p->g_c2 = p->l2_21 = 0;
   if (level4) {
     p->g_x24 = take(P * 64 * es); p->g_d3a = take(P * 64 * es); p->g_x2p = take(P * 64 * es); p->g_c2 = take(P * 64 * es);
@@ -793,16 +967,32 @@ static void bwd_plan(int B, int H, int W, int dtype, BwdPlan* p, bool level4 = f
 
 template <typename T>
 void vgg_pack_all_T(const hla_vgg_params* prm, char* packed, int dtype, hipStream_t st) {
-  PackTable tb{};
-  int n = 0;
-  for (int l = 1; l < kAllLayers; ++l) {          // conv0 needs no data gradient
-    if (l >= kPackedLayers && !prm->w[l]) continue;
-    // transposed conv: Cout' = cin, Cin' = cout
-    tb.w[n] = prm->w[l]; tb.off[n] = packed_offset(l, dtype); tb.cout[n] = kLayers[l].cin; tb.cin[n] = kLayers[l].cout;
-    tb.first[n] = 2;
-    ++n;
+  if constexpr (Prec<T>::SPLIT) {
+    // split mode: (hi, lo) fp16 fragments of s_w * w, transposed; the tail behind the last layer holds the per-layer scales
+    // (float[16]) and 32 scratch words for the |w| maxima, as in the forward packing (vgg.hip)
+    float* tail = (float*)(packed + packed_offset(kAllLayers, dtype));
+    unsigned* scratch = (unsigned*)tail + 32;
+    (void)hipMemsetAsync(tail, 0, kPackTailBytes, st);
+    for (int l = 1; l < kAllLayers; ++l) {
+      if (l >= kPackedLayers && !prm->w[l]) continue;
+      const size_t nw = (size_t)kLayers[l].cin * kLayers[l].cout * 9;
+      const int g1 = (int)((nw + 255) / 256 < 256 ? (nw + 255) / 256 : 256), g2 = (int)((nw + 255) / 256 < 1024 ? (nw + 255) / 256 : 1024);
+      hipLaunchKernelGGL(absmax_kernel, dim3(g1), dim3(256), 0, st, prm->w[l], nw, 27, scratch + l, (unsigned*)nullptr);
+      hipLaunchKernelGGL(pack_weights_split_kernel, dim3(g2), dim3(256), 0, st, prm->w[l], (f16*)(packed + packed_offset(l, dtype)),
+                         kLayers[l].cin, kLayers[l].cout, 2, (const unsigned*)(scratch + l), tail + l);
+    }
+  } else {
+    PackTable tb{};
+    int n = 0;
+    for (int l = 1; l < kAllLayers; ++l) {          // conv0 needs no data gradient
+      if (l >= kPackedLayers && !prm->w[l]) continue;
+      // transposed conv: Cout' = cin, Cin' = cout
+      tb.w[n] = prm->w[l]; tb.off[n] = packed_offset(l, dtype); tb.cout[n] = kLayers[l].cin; tb.cin[n] = kLayers[l].cout;
+      tb.first[n] = 2;
+      ++n;
+    }
+    hipLaunchKernelGGL((pack_weights_multi_kernel<T>), dim3(256, n), dim3(256), 0, st, tb, packed);
   }
-  hipLaunchKernelGGL((pack_weights_multi_kernel<T>), dim3(256, n), dim3(256), 0, st, tb, packed);
 }
 
 template <typename T>
@@ -814,12 +1004,26 @@ int vgg_backward_t(const float* x, size_t x_plane, const hla_vgg_params* prm, co
   VggPlan fp;
   vgg_plan(B, H, W, dtype, true, &fp, level4);
   constexpr int KC = SB / (int)sizeof(T);
+  constexpr bool SPLIT = Prec<T>::SPLIT;
+  using ET = std::conditional_t<SPLIT, float, T>;      // element type of the stored maps (split mode: fp32): the elementwise kernels
   static HlaPerDeviceOnce attr_once;
   HLA_CHECK_HIP(attr_once.run([] {
-    return hipFuncSetAttribute((const void*)wgrad_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, wg_lds_bytes<T>());
+    if constexpr (SPLIT)
+      return hipFuncSetAttribute((const void*)wgrad_split_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, wgs_lds_bytes());
+    else
+      return hipFuncSetAttribute((const void*)wgrad_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, wg_lds_bytes<T>());
   }));
   auto F = [&](size_t off) { return (const void*)(fw + off); };
   auto G = [&](size_t off) { return (void*)(bw + off); };
+  // split mode: per-sample maxima of the forward's activations (recorded by its epilogues) and of this pass's gradient maps
+  // (recorded by the data-gradient epilogues, or by absmax_map_kernel for the maps no convolution produced); the transposed
+  // packing's per-layer weight scales sit behind the last packed layer
+  const unsigned* fam = (const unsigned*)(fw + fp.amax);
+  unsigned* gam = (unsigned*)(bw + bp.gamax);
+  auto FA = [&](int slot) { return (SPLIT && slot >= 0) ? fam + (size_t)slot * B : (const unsigned*)nullptr; };
+  auto GA = [&](int slot) { return (SPLIT && slot >= 0) ? gam + (size_t)slot * B : (unsigned*)nullptr; };
+  const float* wtailT = (const float*)(packedT + packed_offset(kAllLayers, dtype));
+  if (SPLIT) HLA_CHECK_HIP(hipMemsetAsync(gam, 0, (size_t)kGradAmaxSlots * B * sizeof(unsigned), st));
 
   // ---- L2_norm backward of the three returned maps
   const size_t per[4] = {(size_t)(H / 8) * (W / 8) * 256, (size_t)(H / 4) * (W / 4) * 128, (size_t)(H / 2) * (W / 2) * 64,
@@ -873,14 +1077,14 @@ int vgg_backward_t(const float* x, size_t x_plane, const hla_vgg_params* prm, co
       const int Cl[4] = {256, 128, 64, 64};
       const size_t skip = (size_t)l2_row0[l] * (W >> (3 - l)) * Cl[l];
       hla_prof_begin(K_ELEMWISE, 0, (double)B * (per[l] - skip) * (4 + sizeof(T)), st);
-      hipLaunchKernelGGL((l2bwd_apply_kernel<T, true>), dim3(B * nblk), dim3(256), 0, st, feat[l], d_feat[l], part,
-                         inv_norm + (size_t)l * B, (T*)l2out[l], per[l], nblk, dynamic ? dynp + dl.seed[l] : (int*)nullptr,
+      hipLaunchKernelGGL((l2bwd_apply_kernel<ET, true>), dim3(B * nblk), dim3(256), 0, st, feat[l], d_feat[l], part,
+                         inv_norm + (size_t)l * B, (ET*)l2out[l], per[l], nblk, dynamic ? dynp + dl.seed[l] : (int*)nullptr,
                          Cl[l], W >> (3 - l), skip);
     } else {
       hla_prof_begin(K_ELEMWISE, 0, (double)B * per[l] * (16 + sizeof(T)), st);
       hipLaunchKernelGGL(l2bwd_dot_kernel, dim3(B * nblk), dim3(256), 0, st, feat[l], d_feat[l], part, per[l], nblk);
-      hipLaunchKernelGGL((l2bwd_apply_kernel<T, false>), dim3(B * nblk), dim3(256), 0, st, feat[l], d_feat[l], part,
-                         inv_norm + (size_t)l * B, (T*)l2out[l], per[l], nblk);
+      hipLaunchKernelGGL((l2bwd_apply_kernel<ET, false>), dim3(B * nblk), dim3(256), 0, st, feat[l], d_feat[l], part,
+                         inv_norm + (size_t)l * B, (ET*)l2out[l], per[l], nblk);
     }
     hla_prof_end(st);
   }
@@ -889,20 +1093,20 @@ int vgg_backward_t(const float* x, size_t x_plane, const hla_vgg_params* prm, co
 
   // ---- confidence heads (only the ground branch with using_weight=1 ever has d_conf): adds into the raw-map gradients
   if (conf && d_conf) {
-    const T* acts[4] = {(const T*)(fw + fp.x15r), (const T*)(fw + fp.x18r), (const T*)(fw + fp.x21r), (const T*)(fw + fp.x24r)};
+    const ET* acts[4] = {(const ET*)(fw + fp.x15r), (const ET*)(fw + fp.x18r), (const ET*)(fw + fp.x21r), (const ET*)(fw + fp.x24r)};
     const int Cs[4] = {256, 128, 64, 64}, hs[4] = {H / 8, H / 4, H / 2, H}, wsz[4] = {W / 8, W / 4, W / 2, W};
     for (int l = 0; l < NL; ++l) {
       if (!d_conf[l]) continue;
-      constexpr int EPL = 16 / (int)sizeof(T);
+      constexpr int EPL = 16 / (int)sizeof(ET);
       const int ppb = 256 / (Cs[l] / EPL);
       const size_t npix = (size_t)B * hs[l] * wsz[l];
       const int grid = (int)((npix + ppb - 1) / ppb < 1024 ? (npix + ppb - 1) / ppb : 1024);
       float* dz = (float*)(bw + bp.dz);
-      hla_prof_begin(K_ELEMWISE, 4.0 * 9 * Cs[l] * (double)npix, (double)npix * (3 * Cs[l] * sizeof(T) + 12), st);
+      hla_prof_begin(K_ELEMWISE, 4.0 * 9 * Cs[l] * (double)npix, (double)npix * (3 * Cs[l] * sizeof(ET) + 12), st);
       hipLaunchKernelGGL(conf_dz_kernel, dim3((unsigned)((npix + 255) / 256 < 2048 ? (npix + 255) / 256 : 2048)), dim3(256), 0, st,
                          conf[l], d_conf[l], dz, npix);
-      hipLaunchKernelGGL((conf_bwd_kernel<T>), dim3(grid), dim3(256), 4 * 9 * Cs[l] * sizeof(float), st, acts[l],
-                         prm->w[13 + l], (const float*)dz, (T*)l2out[l], (float*)(bw + bp.part), B, hs[l], wsz[l], Cs[l]);
+      hipLaunchKernelGGL((conf_bwd_kernel<ET>), dim3(grid), dim3(256), 4 * 9 * Cs[l] * sizeof(float), st, acts[l],
+                         prm->w[13 + l], (const float*)dz, (ET*)l2out[l], (float*)(bw + bp.part), B, hs[l], wsz[l], Cs[l]);
       const size_t n = (size_t)9 * Cs[l];
       hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((n + 15) / 16)), dim3(256), 0, st, (const float*)(bw + bp.part),
                          gr->dw[13 + l], n, grid, (int)n, 1, 1);
@@ -910,11 +1114,28 @@ int vgg_backward_t(const float* x, size_t x_plane, const hla_vgg_params* prm, co
     }
   }
 
+  // split mode: the scale of the two gradient maps that convolutions READ but no convolution wrote (at level 3: g_x21; l2_18 /
+  // l2_15 are only ever added in an epilogue, in fp32)
+  auto absmax_map = [&](const void* map, size_t per_sample, size_t skip, int slot) {
+    int nblk = (int)(per_sample / 4 / 256 / 8);
+    nblk = nblk < 1 ? 1 : (nblk > 64 ? 64 : nblk);
+    hla_prof_begin(K_ELEMWISE, 0, (double)B * (per_sample - skip) * 4, st);
+    hipLaunchKernelGGL(absmax_map_kernel, dim3(B * nblk), dim3(256), 0, st, (const float*)map, per_sample, skip, nblk, GA(slot));
+    hla_prof_end(st);
+  };
+  if (SPLIT) {
+    if (level4) absmax_map(G(bp.g_x24), per[3], 0, GA_X24);
+    else absmax_map(G(bp.g_x21), per[2], (size_t)l2_row0[2] * (W / 2) * 64, GA_X21);
+  }
+
   // ---- helpers
   // data gradient of layer l restricted to its input channels [c0, c0+n): a forward conv on the transposed weights
+  // (ga_src / ga_out, split mode: the amax slots of the gradient map it reads and of the one it writes)
   auto dgrad = [&](int l, int c0, int n, const void* gsrc, const unsigned char* unpool, int Hout, int Wout, void* out,
-                   const void* mask, const void* add, bool pool_sum, int row_begin = 0, int src_lo = 0, int add_lo = 0, int dc = -1) {
+                   const void* mask, const void* add, bool pool_sum, int row_begin = 0, int src_lo = 0, int add_lo = 0, int dc = -1,
+                   int ga_src = -1, int ga_out = -1) {
     ConvArgs a{};
+    a.amax1 = GA(ga_src); a.amax_out = GA(ga_out); a.wscale = SPLIT ? wtailT + l : nullptr;
     a.dyn = (dynamic && dc >= 0) ? dynp : nullptr; a.dyn_desc = dc >= 0 ? dl.conv_desc[dc] : 0;
     a.src1 = gsrc; a.C1 = kLayers[l].cout; a.unpool_idx = unpool;
     const int nstage = kLayers[l].cout / KC;
@@ -924,8 +1145,9 @@ int vgg_backward_t(const float* x, size_t x_plane, const hla_vgg_params* prm, co
     a.row_begin = row_begin > 0 ? row_begin : 0; a.src_row_lo = src_lo > 0 ? src_lo : 0; a.add_row_lo = add_lo > 0 ? add_lo : 0;
     launch_conv<T>(st, a, pool_sum);
   };
+  // (fa1 / fa2 / ga, split mode: the amax slots of its input activation(s) and of the gradient map)
   auto wgrad = [&](int l, const void* x1, int C1, const void* x2, int C2, int up1, const void* g, const unsigned char* unpool,
-                   int Hout, int Wout, int row_begin = 0, int dw = -1) {
+                   int Hout, int Wout, int row_begin = 0, int dw = -1, int fa1 = -1, int fa2 = -1, int ga = -1) {
     WgradArgs a{};
     a.dyn = (dynamic && dw >= 0) ? dynp : nullptr; a.dyn_desc = dw >= 0 ? dl.wg_desc[dw] : 0;
     a.x1 = x1; a.x2 = x2; a.C1 = C1; a.C2 = C2; a.up1 = up1; a.g = g; a.g_unpool = unpool;
@@ -937,7 +1159,12 @@ int vgg_backward_t(const float* x, size_t x_plane, const hla_vgg_params* prm, co
     a.bpart = (kLayers[l].has_bias && gr->db[l]) ? (float*)(bw + bp.bpart) : nullptr;
     const double P = (double)B * (Hout - a.row_begin) * Wout;
     hla_prof_begin(K_WGRAD, 2.0 * 9 * a.Cin * a.Cout * P, P * (a.Cin + a.Cout) * sizeof(T), st);
-    hipLaunchKernelGGL((wgrad_kernel<T>), dim3(a.KS, a.Cin / 64, a.Cout / 64), dim3(256), wg_lds_bytes<T>(), st, a);
+    if constexpr (SPLIT) {
+      WgradSplitExtra ex{FA(fa1), FA(fa2), GA(ga)};
+      hipLaunchKernelGGL(wgrad_split_kernel, dim3(a.KS, a.Cin / 64, a.Cout / 64), dim3(256), wgs_lds_bytes(), st, a, ex);
+    } else {
+      hipLaunchKernelGGL((wgrad_kernel<T>), dim3(a.KS, a.Cin / 64, a.Cout / 64), dim3(256), wg_lds_bytes<T>(), st, a);
+    }
     hla_prof_end(st);
     const size_t n = (size_t)a.Cout * a.Cin * 9;
     hla_prof_begin(K_ELEMWISE, 0, (double)n * 4 * (a.KS + 1), st);
@@ -954,48 +1181,49 @@ int vgg_backward_t(const float* x, size_t x_plane, const hla_vgg_params* prm, co
 
   // ---- decoder 3 (VGG.py:153-155, level 4 only; zero-padded to 64 channels, the host slices the weight gradients)
   if (level4) {
-    dgrad(12, 0, 64, G(bp.g_x24), nullptr, H, W, G(bp.g_d3a), F(fp.d3a), nullptr, false);
-    wgrad(12, F(fp.d3a), 64, nullptr, 0, 0, G(bp.g_x24), nullptr, H, W);
-    dgrad(11, 0, 64, G(bp.g_d3a), nullptr, H, W, G(bp.g_x21), F(fp.x21r), G(bp.l2_21), true);     // up(x21) branch
-    dgrad(11, 64, 64, G(bp.g_d3a), nullptr, H, W, G(bp.g_x2p), F(fp.x2r), nullptr, false);         // x2 skip branch
-    wgrad(11, F(fp.x21r), 64, F(fp.x2r), 64, 1, G(bp.g_d3a), nullptr, H, W);
+    dgrad(12, 0, 64, G(bp.g_x24), nullptr, H, W, G(bp.g_d3a), F(fp.d3a), nullptr, false, 0, 0, 0, -1, GA_X24, GA_D3A);
+    wgrad(12, F(fp.d3a), 64, nullptr, 0, 0, G(bp.g_x24), nullptr, H, W, 0, -1, AM_D3A, -1, GA_X24);
+    dgrad(11, 0, 64, G(bp.g_d3a), nullptr, H, W, G(bp.g_x21), F(fp.x21r), G(bp.l2_21), true, 0, 0, 0, -1, GA_D3A, GA_X21);     // up(x21) branch
+    dgrad(11, 64, 64, G(bp.g_d3a), nullptr, H, W, G(bp.g_x2p), F(fp.x2r), nullptr, false, 0, 0, 0, -1, GA_D3A, GA_X2P);         // x2 skip branch
+    wgrad(11, F(fp.x21r), 64, F(fp.x2r), 64, 1, G(bp.g_d3a), nullptr, H, W, 0, -1, AM_X21, AM_X2, GA_D3A);
   }
   // ---- decoder 2 (VGG.py:148-151)
-  dgrad(10, 0, 64, G(bp.g_x21), nullptr, H2, W2, G(bp.g_d2a), F(fp.d2a), nullptr, false, n_d2a, n_x21, 0, DC_10);   // (g_x21 is unwritten above n_x21)
-  wgrad(10, F(fp.d2a), 64, nullptr, 0, 0, G(bp.g_x21), nullptr, H2, W2, n_x21, DW_10);
-  dgrad(9, 0, 128, G(bp.g_d2a), nullptr, H2, W2, G(bp.g_x18), F(fp.x18r), G(bp.l2_18), true, rb_up18, n_d2a, 0, DC_9U);   // up(x18) branch
-  dgrad(9, 128, 64, G(bp.g_d2a), nullptr, H2, W2, G(bp.g_x3p), F(fp.x3), nullptr, false, n_x3p, n_d2a, 0, DC_9S);          // x3 skip branch
-  wgrad(9, F(fp.x18r), 128, F(fp.x3), 64, 1, G(bp.g_d2a), nullptr, H2, W2, n_d2a, DW_9);
+  dgrad(10, 0, 64, G(bp.g_x21), nullptr, H2, W2, G(bp.g_d2a), F(fp.d2a), nullptr, false, n_d2a, n_x21, 0, DC_10, GA_X21, GA_D2A);   // (g_x21 is unwritten above n_x21)
+  wgrad(10, F(fp.d2a), 64, nullptr, 0, 0, G(bp.g_x21), nullptr, H2, W2, n_x21, DW_10, AM_D2A, -1, GA_X21);
+  dgrad(9, 0, 128, G(bp.g_d2a), nullptr, H2, W2, G(bp.g_x18), F(fp.x18r), G(bp.l2_18), true, rb_up18, n_d2a, 0, DC_9U, GA_D2A, GA_X18);   // up(x18) branch
+  dgrad(9, 128, 64, G(bp.g_d2a), nullptr, H2, W2, G(bp.g_x3p), F(fp.x3), nullptr, false, n_x3p, n_d2a, 0, DC_9S, GA_D2A, GA_X3P);          // x3 skip branch
+  wgrad(9, F(fp.x18r), 128, F(fp.x3), 64, 1, G(bp.g_d2a), nullptr, H2, W2, n_d2a, DW_9, AM_X18, AM_X3, GA_D2A);
   // ---- decoder 1 (VGG.py:144-146)
-  dgrad(8, 0, 128, G(bp.g_x18), nullptr, H4, W4, G(bp.g_d1a), F(fp.d1a), nullptr, false, n_d1a, n_x18, 0, DC_8);
-  wgrad(8, F(fp.d1a), 128, nullptr, 0, 0, G(bp.g_x18), nullptr, H4, W4, n_x18, DW_8);
-  dgrad(7, 0, 256, G(bp.g_d1a), nullptr, H4, W4, G(bp.g_x15), F(fp.x15r), G(bp.l2_15), true, rb_up15, n_d1a, 0, DC_7U);   // up(x15) branch
-  dgrad(7, 256, 128, G(bp.g_d1a), nullptr, H4, W4, G(bp.g_x8p), F(fp.x8), nullptr, false, n_x8p, n_d1a, 0, DC_7S);        // x8 skip branch
-  wgrad(7, F(fp.x15r), 256, F(fp.x8), 128, 1, G(bp.g_d1a), nullptr, H4, W4, n_d1a, DW_7);
+  dgrad(8, 0, 128, G(bp.g_x18), nullptr, H4, W4, G(bp.g_d1a), F(fp.d1a), nullptr, false, n_d1a, n_x18, 0, DC_8, GA_X18, GA_D1A);
+  wgrad(8, F(fp.d1a), 128, nullptr, 0, 0, G(bp.g_x18), nullptr, H4, W4, n_x18, DW_8, AM_D1A, -1, GA_X18);
+  dgrad(7, 0, 256, G(bp.g_d1a), nullptr, H4, W4, G(bp.g_x15), F(fp.x15r), G(bp.l2_15), true, rb_up15, n_d1a, 0, DC_7U, GA_D1A, GA_X15);   // up(x15) branch
+  dgrad(7, 256, 128, G(bp.g_d1a), nullptr, H4, W4, G(bp.g_x8p), F(fp.x8), nullptr, false, n_x8p, n_d1a, 0, DC_7S, GA_D1A, GA_X8P);        // x8 skip branch
+  wgrad(7, F(fp.x15r), 256, F(fp.x8), 128, 1, G(bp.g_d1a), nullptr, H4, W4, n_d1a, DW_7, AM_X15, AM_X8, GA_D1A);
   // ---- encoder block 2 (VGG.py:136-141); conv14 is followed by the pool (no ReLU in between)
-  dgrad(6, 0, 256, G(bp.g_x15), idx15, H4, W4, G(bp.g_a12), F(fp.a12), nullptr, false, n_a12, 2 * n_x15, 0, DC_6);
-  wgrad(6, F(fp.a12), 256, nullptr, 0, 0, G(bp.g_x15), idx15, H4, W4, 2 * n_x15, DW_6);
-  dgrad(5, 0, 256, G(bp.g_a12), nullptr, H4, W4, G(bp.g_a10), F(fp.a10), nullptr, false, n_a10, n_a12, 0, DC_5);
-  wgrad(5, F(fp.a10), 256, nullptr, 0, 0, G(bp.g_a12), nullptr, H4, W4, n_a12, DW_5);
-  dgrad(4, 0, 128, G(bp.g_a10), nullptr, H4, W4, G(bp.g_x8), F(fp.x8), G(bp.g_x8p), false, n_x8, n_a10, n_x8p, DC_4);
-  wgrad(4, F(fp.x8), 128, nullptr, 0, 0, G(bp.g_a10), nullptr, H4, W4, n_a10, DW_4);
+  dgrad(6, 0, 256, G(bp.g_x15), idx15, H4, W4, G(bp.g_a12), F(fp.a12), nullptr, false, n_a12, 2 * n_x15, 0, DC_6, GA_X15, GA_A12);
+  wgrad(6, F(fp.a12), 256, nullptr, 0, 0, G(bp.g_x15), idx15, H4, W4, 2 * n_x15, DW_6, AM_A12, -1, GA_X15);
+  dgrad(5, 0, 256, G(bp.g_a12), nullptr, H4, W4, G(bp.g_a10), F(fp.a10), nullptr, false, n_a10, n_a12, 0, DC_5, GA_A12, GA_A10);
+  wgrad(5, F(fp.a10), 256, nullptr, 0, 0, G(bp.g_a12), nullptr, H4, W4, n_a12, DW_5, AM_A10, -1, GA_A12);
+  dgrad(4, 0, 128, G(bp.g_a10), nullptr, H4, W4, G(bp.g_x8), F(fp.x8), G(bp.g_x8p), false, n_x8, n_a10, n_x8p, DC_4, GA_A10, GA_X8);
+  wgrad(4, F(fp.x8), 128, nullptr, 0, 0, G(bp.g_a10), nullptr, H4, W4, n_a10, DW_4, AM_X8, -1, GA_A10);
   // ---- encoder block 1
-  dgrad(3, 0, 128, G(bp.g_x8), idx8, H2, W2, G(bp.g_a5), F(fp.a5), nullptr, false, n_a5, 2 * n_x8, 0, DC_3);
-  wgrad(3, F(fp.a5), 128, nullptr, 0, 0, G(bp.g_x8), idx8, H2, W2, 2 * n_x8, DW_3);
-  dgrad(2, 0, 64, G(bp.g_a5), nullptr, H2, W2, G(bp.g_x3), F(fp.x3), G(bp.g_x3p), false, n_x3, n_a5, n_x3p, DC_2);
-  wgrad(2, F(fp.x3), 64, nullptr, 0, 0, G(bp.g_a5), nullptr, H2, W2, n_a5, DW_2);
+  dgrad(3, 0, 128, G(bp.g_x8), idx8, H2, W2, G(bp.g_a5), F(fp.a5), nullptr, false, n_a5, 2 * n_x8, 0, DC_3, GA_X8, GA_A5);
+  wgrad(3, F(fp.a5), 128, nullptr, 0, 0, G(bp.g_x8), idx8, H2, W2, 2 * n_x8, DW_3, AM_A5, -1, GA_X8);
+  dgrad(2, 0, 64, G(bp.g_a5), nullptr, H2, W2, G(bp.g_x3), F(fp.x3), G(bp.g_x3p), false, n_x3, n_a5, n_x3p, DC_2, GA_A5, GA_X3);
+  wgrad(2, F(fp.x3), 64, nullptr, 0, 0, G(bp.g_a5), nullptr, H2, W2, n_a5, DW_2, AM_X3, -1, GA_A5);
   // ---- encoder block 0
   if (level4) {      // the conv2 output also fed conv_dec3: materialise unpool(g_x3) + skip gradient once
-    const size_t n = (size_t)B * H * W * (64 * sizeof(T) / 16);
-    hla_prof_begin(K_ELEMWISE, 0, (double)B * H * W * 64 * sizeof(T) * 2.25, st);
-    hipLaunchKernelGGL((unpool_add_kernel<T>), dim3((unsigned)((n + 255) / 256 < 65535 ? (n + 255) / 256 : 65535)), dim3(256), 0, st,
-                       (const T*)G(bp.g_x3), idx3, (const T*)G(bp.g_x2p), (T*)G(bp.g_c2), B, H, W);
+    const size_t n = (size_t)B * H * W * (64 * sizeof(ET) / 16);
+    hla_prof_begin(K_ELEMWISE, 0, (double)B * H * W * 64 * sizeof(ET) * 2.25, st);
+    hipLaunchKernelGGL((unpool_add_kernel<ET>), dim3((unsigned)((n + 255) / 256 < 65535 ? (n + 255) / 256 : 65535)), dim3(256), 0, st,
+                       (const ET*)G(bp.g_x3), idx3, (const ET*)G(bp.g_x2p), (ET*)G(bp.g_c2), B, H, W);
     hla_prof_end(st);
-    dgrad(1, 0, 64, G(bp.g_c2), nullptr, H, W, G(bp.g_a0), F(fp.a0), nullptr, false);
-    wgrad(1, F(fp.a0), 64, nullptr, 0, 0, G(bp.g_c2), nullptr, H, W);
+    if (SPLIT) absmax_map(G(bp.g_c2), (size_t)H * W * 64, 0, GA_C2);
+    dgrad(1, 0, 64, G(bp.g_c2), nullptr, H, W, G(bp.g_a0), F(fp.a0), nullptr, false, 0, 0, 0, -1, GA_C2, GA_A0);
+    wgrad(1, F(fp.a0), 64, nullptr, 0, 0, G(bp.g_c2), nullptr, H, W, 0, -1, AM_A0, -1, GA_C2);
   } else {
-    dgrad(1, 0, 64, G(bp.g_x3), idx3, H, W, G(bp.g_a0), F(fp.a0), nullptr, false, n_a0, 2 * n_x3, 0, DC_1);
-    wgrad(1, F(fp.a0), 64, nullptr, 0, 0, G(bp.g_x3), idx3, H, W, 2 * n_x3, DW_1);
+    dgrad(1, 0, 64, G(bp.g_x3), idx3, H, W, G(bp.g_a0), F(fp.a0), nullptr, false, n_a0, 2 * n_x3, 0, DC_1, GA_X3, GA_A0);
+    wgrad(1, F(fp.a0), 64, nullptr, 0, 0, G(bp.g_x3), idx3, H, W, 2 * n_x3, DW_1, AM_A0, -1, GA_X3);
   }
   {
     Wgrad0Args a{};
@@ -1005,10 +1233,11 @@ int vgg_backward_t(const float* x, size_t x_plane, const hla_vgg_params* prm, co
     a.tiles_x = (W + 31) / 32; a.tiles_y = (H - a.row_begin + WG_TH - 1) / WG_TH; a.ntile = B * a.tiles_x * a.tiles_y;
     a.KS = a.ntile < 1024 ? a.ntile : 1024;
     a.part = (float*)(bw + bp.part); a.bpart = (float*)(bw + bp.bpart);
-    const int lds = WG_TH * 32 * wg_stride<T>() + 3 * (WG_TH + 2) * 48 * 4;
+    // (split mode: conv0's weight gradient -- K = pixels, N = 27 -- runs on the exact-fp32 kernel: 34 GFLOP, 0.2 ms at B = 32)
+    const int lds = WG_TH * 32 * wg_stride<ET>() + 3 * (WG_TH + 2) * 48 * 4;
     const double P = (double)B * (H - a.row_begin) * W;
-    hla_prof_begin(K_WGRAD, 2.0 * 27 * 64 * P, P * (12 + 64 * sizeof(T)), st);
-    hipLaunchKernelGGL((wgrad0_kernel<T>), dim3(a.KS), dim3(256), lds, st, a);
+    hla_prof_begin(K_WGRAD, 2.0 * 27 * 64 * P, P * (12 + 64 * sizeof(ET)), st);
+    hipLaunchKernelGGL((wgrad0_kernel<ET>), dim3(a.KS), dim3(256), lds, st, a);
     hla_prof_end(st);
     hipLaunchKernelGGL(reduce_partials_kernel, dim3((64 * 27 + 15) / 16), dim3(256), 0, st, a.part, gr->dw[0], (size_t)64 * 27, a.KS * 2, 64 * 32, 27, 32);
     if (gr->db[0]) hipLaunchKernelGGL(reduce_partials_kernel, dim3(4), dim3(256), 0, st, a.bpart, gr->db[0], (size_t)64, a.KS * 2, 64, 1, 1);
@@ -1024,7 +1253,7 @@ template int vgg_backward_t<TuT>(const float* x, size_t x_plane, const hla_vgg_p
 #define HLA_EXTERN_T(T) \
   extern template void vgg_pack_all_T<T>(const hla_vgg_params* prm, char* packed, int dtype, hipStream_t st); \
   extern template int vgg_backward_t<T>(const float* x, size_t x_plane, const hla_vgg_params* prm, const char* packedT, int dtype, const char* fw, const float* const feat[3], const double* inv_norm, const float* const d_feat[3], const float* const conf[3], const float* const d_conf[3], const hla_vgg_grads* gr, char* bw, const BwdPlan& bp, int B, int H, int W, int flags, int first_row8, hipStream_t st);
-HLA_EXTERN_T(float) HLA_EXTERN_T(bf16) HLA_EXTERN_T(f16)
+HLA_EXTERN_T(float) HLA_EXTERN_T(bf16) HLA_EXTERN_T(f16) HLA_EXTERN_T(split32)
 
 extern "C" size_t hla_vgg_bwd_workspace_bytes(int B, int H, int W, int level, int dtype) {
   BwdPlan p;
@@ -1032,11 +1261,13 @@ extern "C" size_t hla_vgg_bwd_workspace_bytes(int B, int H, int W, int level, in
   return p.total;
 }
 
-// HLA_F16X3 has no backward kernels of its own: its forward stores fp32 activations in the HLA_F32 layout, so the backward of
-// a split-mode forward IS the HLA_F32 backward (exact-fp32 MFMA) on those activations.
-static inline int bwd_dtype(int dtype) { return dtype == HLA_F16X3 ? HLA_F32 : dtype; }
+// (HLA_F16X3: fp32 storage in the HLA_F32 workspace layout; data and weight gradients on split-fp16 kernels, conv0's weight
+// gradient and the elementwise passes on the fp32 ones)
+static inline int bwd_dtype(int dtype) { return dtype; }
 
-extern "C" size_t hla_vgg_packed_weight_T_bytes(int dtype) { return packed_offset(kAllLayers, bwd_dtype(dtype)); }
+extern "C" size_t hla_vgg_packed_weight_T_bytes(int dtype) {
+  return packed_offset(kAllLayers, dtype) + (dtype == HLA_F16X3 ? kPackTailBytes : 0);
+}
 
 extern "C" int hla_vgg_pack_weights_T(const hla_vgg_params* params, void* packed, int dtype, hla_stream_t stream) {
   HLA_REQUIRE(params && packed, "hla_vgg_pack_weights_T: null argument");
@@ -1044,6 +1275,7 @@ extern "C" int hla_vgg_pack_weights_T(const hla_vgg_params* params, void* packed
   dtype = bwd_dtype(dtype);
   if (dtype == HLA_BF16) vgg_pack_all_T<bf16>(params, (char*)packed, dtype, (hipStream_t)stream);
   else if (dtype == HLA_F16) vgg_pack_all_T<f16>(params, (char*)packed, dtype, (hipStream_t)stream);
+  else if (dtype == HLA_F16X3) vgg_pack_all_T<split32>(params, (char*)packed, dtype, (hipStream_t)stream);
   else vgg_pack_all_T<float>(params, (char*)packed, dtype, (hipStream_t)stream);
   HLA_CHECK_HIP(hipGetLastError());
   return HLA_OK;
@@ -1059,6 +1291,7 @@ extern "C" int hla_vgg_backward(const float* x, size_t x_plane, const hla_vgg_pa
   HLA_REQUIRE(hla_dtype_ok(dtype), "hla_vgg_backward: bad dtype %d", dtype);
   dtype = bwd_dtype(dtype);
   HLA_REQUIRE(level == 3 || level == 4, "hla_vgg_backward: level must be 3 or 4");
+  HLA_REQUIRE((size_t)H * W * 64 * 4 < ((size_t)1 << 31), "hla_vgg_backward: image too large (H*W must be below 2^23 pixels)");
   HLA_REQUIRE(first_row8 == 0 || (first_row8 >= 4 && first_row8 < H / 8), "hla_vgg_backward: first_row8 must be 0 or in [4, H/8)");
   const int NLc = level == 4 ? 4 : 3;
   HLA_REQUIRE(B > 0 && H % 8 == 0 && W % 8 == 0, "hla_vgg_backward: H and W must be multiples of 8");
@@ -1082,6 +1315,9 @@ extern "C" int hla_vgg_backward(const float* x, size_t x_plane, const hla_vgg_pa
   if (dtype == HLA_F16)
     return vgg_backward_t<f16>(x, x_plane, params, (const char*)packed_weights_T, dtype, (const char*)fwd_workspace, feat, inv_norm,
                                d_feat, conf, d_conf, grads, (char*)workspace, bp, B, H, W, flags, first_row8, (hipStream_t)stream);
+  if (dtype == HLA_F16X3)
+    return vgg_backward_t<split32>(x, x_plane, params, (const char*)packed_weights_T, dtype, (const char*)fwd_workspace, feat, inv_norm,
+                                   d_feat, conf, d_conf, grads, (char*)workspace, bp, B, H, W, flags, first_row8, (hipStream_t)stream);
   return vgg_backward_t<float>(x, x_plane, params, (const char*)packed_weights_T, dtype, (const char*)fwd_workspace, feat, inv_norm,
                                d_feat, conf, d_conf, grads, (char*)workspace, bp, B, H, W, flags, first_row8, (hipStream_t)stream);
 }

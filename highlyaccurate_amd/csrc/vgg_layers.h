@@ -30,7 +30,7 @@ static inline size_t packed_offset(int l, int dtype) {
 
 // Forward workspace: every activation a later layer (or the backward pass) reads.  All maps NHWC, T elements.
 // split mode: one per-sample maximum per activation map that a convolution reads
-enum { AM_X3 = 0, AM_A5, AM_X8, AM_A10, AM_A12, AM_X15, AM_D1A, AM_X18, AM_D2A, AM_X21, AM_X2, AM_D3A, AM_X24, kAmaxSlots = 16 };
+enum { AM_X3 = 0, AM_A5, AM_X8, AM_A10, AM_A12, AM_X15, AM_D1A, AM_X18, AM_D2A, AM_X21, AM_X2, AM_D3A, AM_X24, AM_A0, kAmaxSlots = 16 };
 
 struct VggPlan {
   size_t x3, a5, x8, a10, a12, x15r, d1a, x18r, d2a, x21r;   // post-ReLU activations

@@ -1544,7 +1544,7 @@ def test_bad_arguments_raise():
         with torch.no_grad():
             m(torch.zeros(2, 3, 128, 128, device=d), torch.zeros(1, 3, 64, 256, device=d), mode='test')
     lib = _lib.load()
-    assert lib.hla_vgg_forward(None, None, None, None, None, None, None, 0, 1, 8, 8, 3, 0, 0, 0, None) != 0
+    assert lib.hla_vgg_forward(None, 0, None, None, None, None, None, None, 0, 1, 8, 8, 3, 0, 0, 0, None) != 0
     assert b'null' in lib.hla_last_error()
 
 
