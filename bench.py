@@ -20,7 +20,8 @@ Besides the headline (`value`, the precision BASELINE configs[1] names) the line
                  final-pose deviation from the reference's fp64 run on the committed golden inputs (tests/golden/), in
                  metres / radians, next to the north-star tolerance (1e-4 m / 1e-4 rad)
   secondary      short legs for BASELINE configs[3] (Ford, 10 LM iterations) and configs[4] (1024^2 / 512x2048, fp16)
-  train          forward(train) + HIP backward + gradient all-reduce + Adam
+  train          forward(train) + HIP backward + gradient all-reduce + Adam; train.by_precision: the same step in fp32 / fp16x3 / bf16
+                 with the worst per-tensor relative L2 error and cosine of its gradients against the reference autograd
   cpu_baseline   the CPU oracle on this host's cores (bounded sample)
 """
 import argparse
@@ -306,6 +307,36 @@ def pose_deviation(precision, dev):
             'inputs': 'tests/golden/e2e_kitti.npz: 4 seeds x 2 pairs, full KITTI shapes, 15 LM steps'}
 
 
+def gradient_fidelity(precision, dev):
+    """One training step on the committed golden input (tests/golden/train_kitti.npz: full KITTI shape, B = 1; gradient samples
+    recorded from the REAL reference's autograd in fp64 and fp32) in this arithmetic mode: per tensor the relative L2 error and
+    the cosine of our gradient against the reference's fp64 gradient on the recorded sample positions (64 per tensor, 7 tensors
+    from both branches, encoder to decoder), worst over the tensors, next to the reference's own fp32-vs-fp64 figures."""
+    g = np.load(os.path.join(ROOT, 'tests', 'golden', 'train_kitti.npz'), allow_pickle=False)
+    seed, B = int(g['seed']), int(g['B'])
+    net = build_net('kitti', precision, 5, dev, state=synthetic.model_state(seed)).train()
+    sat, grd, gu, gv, gh = synthetic.images(seed + 100, B)
+    torch.manual_seed(seed)
+    r = net(sat.to(dev), grd.to(dev), gu.to(dev), gv.to(dev), gh.to(dev), mode='train')
+    r[0].backward()
+    named = dict(net.named_parameters())
+    worst_l2, worst_cos, ref_l2, worst_key = 0.0, 1.0, 0.0, ''
+    for k in [k[len('grad64_'):] for k in g.files if k.startswith('grad64_')]:
+        ref, r32 = g['grad64_' + k][2:], g['grad32_' + k][2:]
+        gr = named[k].grad.double().reshape(-1).cpu().numpy()
+        got = gr[synthetic.fixture_sample_idx(gr.size, 77)]
+        l2 = float(np.linalg.norm(got - ref) / max(np.linalg.norm(ref), 1e-300))
+        cos = float(np.dot(got, ref) / max(np.linalg.norm(got) * np.linalg.norm(ref), 1e-300))
+        ref_l2 = max(ref_l2, float(np.linalg.norm(r32 - ref) / max(np.linalg.norm(ref), 1e-300)))
+        if l2 > worst_l2:
+            worst_l2, worst_key = l2, k
+        worst_cos = min(worst_cos, cos)
+    loss_rel = abs(float(r[0].detach()) - float(g['tuple64'][0][0])) / abs(float(g['tuple64'][0][0]))
+    return {'worst_rel_l2': float(f'{worst_l2:.3e}'), 'worst_tensor': worst_key, 'worst_cosine': round(worst_cos, 9),
+            'reference_fp32_vs_fp64_worst_rel_l2': float(f'{ref_l2:.3e}'), 'loss_rel_err': float(f'{loss_rel:.3e}'),
+            'inputs': 'tests/golden/train_kitti.npz: 7 tensors x 64 sampled gradient elements of the reference autograd (fp64), full KITTI shape, B = 1'}
+
+
 def workload_name(model, sat_a, grd_hw, n_iters):
     base = {'kitti': ("BASELINE configs[1]: LM_S2GP" if (sat_a, tuple(grd_hw)) == (512, (256, 1024)) else "BASELINE configs[4] sizes: LM_S2GP"),
             'ford': "BASELINE configs[3] shapes: LM_S2GP_Ford", 'g2sp': "SURVEY 8(f).2: LM_G2SP"}[model]
@@ -313,7 +344,7 @@ def workload_name(model, sat_a, grd_hw, n_iters):
             f"{n_iters} LM iters x 3 levels, 3-DoF, random-init weights")
 
 
-def train_leg(net, a, sat, grd, extra, B, world, rank, dist, dev, want_kt):
+def train_leg(net, a, sat, grd, extra, B, world, rank, dist, dev, want_kt, extras=True):
     from highlyaccurate_amd import _lib
     from highlyaccurate_amd.parallel import GradSync
     net.train()
@@ -383,7 +414,7 @@ def train_leg(net, a, sat, grd, extra, B, world, rank, dist, dev, want_kt):
             _lib.prof_enable(False)
             trecs = _lib.prof_fetch()
     live = None
-    if a.model != 'g2sp':       # one more step with the backward's diagnostics on: which share of its tiles the satellite branch visits
+    if a.model != 'g2sp' and extras:       # one more step with the backward's diagnostics on: which share of its tiles the satellite branch visits
         net.bwd_stats = {}
         tstep()
         torch.cuda.synchronize()
@@ -400,7 +431,7 @@ def train_leg(net, a, sat, grd, extra, B, world, rank, dist, dev, want_kt):
     if dist:
         train['single_rank_value'] = round(single, 3) if single else None      # rank 0 alone, same step, no all-reduce
         train['scaling_eff'] = round(train['value'] / (world * single), 4) if single else None
-    if a.model != 'g2sp':
+    if a.model != 'g2sp' and extras:
         # secondary number: the same step with args.train_ground_crop=1 (an extension: the ground branch trains on the
         # image rows that can reach the loss; loss and gradients equal to rounding, the RETURNED confidence maps are
         # only computed from the crop on -- DESIGN.md 3.5).  Not the default, so it is not `train.value`.
@@ -540,6 +571,32 @@ def main(argv=None):
             train = train_leg(net, a, sat, grd, extra, B, world, rank, dist, dev, want_kt)
         except Exception as e:      # the headline line must still be printed
             train = {'error': repr(e)[:300]}
+
+    # ---- N=1: the training step in every arithmetic mode -- pairs/s and the fidelity of its gradients against the reference's
+    # autograd (the reference trains in fp32: 'fp16x3' is the mode that matches it, on split-fp16 dgrad / wgrad kernels)
+    if train and 'error' not in train and world == 1 and headline_cfg and not a.no_extra_legs:
+        tbp = {}
+        for p in ('fp32', 'fp16x3', 'bf16'):
+            try:
+                if p == a.precision:
+                    e = {'value': train['value'], 'ms_per_step': train['ms_per_step'], 'steps': train['steps']}
+                else:
+                    net = None
+                    torch.cuda.empty_cache()
+                    net = build_net('kitti', p, 5, dev)
+                    sub = argparse.Namespace(**vars(a))
+                    sub.train_steps, sub.no_kernel_timing = (3 if p == 'fp32' else 4), True
+                    t2 = train_leg(net, sub, sat, grd, extra, B, 1, 0, None, dev, False, extras=False)
+                    e = {'value': t2['value'], 'ms_per_step': t2['ms_per_step'], 'steps': t2['steps']}
+                e['unit'] = 'pairs/s'
+                e['gradients'] = gradient_fidelity(p, dev)
+                tbp[p] = e
+            except Exception as ex:
+                tbp[p] = {'error': repr(ex)[:300]}
+        train['by_precision'] = tbp
+        net = None
+        torch.cuda.empty_cache()
+        net = build_net(a.model, a.precision, a.n_iters, dev)
 
     # ---- N=1 extras: the other arithmetic modes on the same workload, and BASELINE configs[3] / [4]
     by_precision, secondary = None, None

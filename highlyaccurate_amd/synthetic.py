@@ -63,3 +63,8 @@ def images(seed: int, B: int, grd_hw=(256, 1024), sat_a=512):
     grd = torch.from_numpy(rs.random_sample((B, 3, grd_hw[0], grd_hw[1])).astype(np.float32))
     gt = torch.from_numpy(rs.uniform(-1, 1, size=(3, B, 1)).astype(np.float32))
     return sat, grd, gt[0], gt[1], gt[2]
+
+
+def fixture_sample_idx(numel: int, salt: int, n: int = 64):
+    """The deterministic sample positions of the committed feature / gradient fixtures (tests/make_idx.py, oracle/make_golden.py)."""
+    return np.random.RandomState(1000 + salt).randint(0, numel, size=n)

@@ -47,8 +47,10 @@ typedef enum hla_dtype {
                    hi + lo = fp16(s x) + fp16(s x - hi) (power-of-two scale s per tensor and sample), one product =
                    three fp16 MFMAs (hi hi + hi lo + lo hi), fp32 accumulate.  fp32-class results (meets the fp32
                    parity gates) at 1/3 of the fp16 MFMA rate instead of the 1/16 of HLA_F32: the matched-accuracy
-                   throughput mode.  Workspaces and packed weights have the HLA_F32 sizes; hla_vgg_backward with this
-                   dtype runs the HLA_F32 kernels on the activations the split forward saved. */
+                   throughput mode, for training too: hla_vgg_backward with this dtype runs split-fp16 data- and
+                   weight-gradient kernels on the fp32 activations the split forward saved (gradient maps stay fp32; a
+                   per-sample maximum of every gradient map is recorded by the kernel that writes it, as the forward does
+                   for activations).  Workspaces have the HLA_F32 layout; packed weights the HLA_F32 size + 256 B of scales. */
 } hla_dtype;
 
 const char* hla_last_error(void);

@@ -16,6 +16,7 @@ from conftest import load_golden
 pytestmark = pytest.mark.gpu
 
 TOL_SHIFT, TOL_YAW = 5e-6, 5.7e-4
+FORD_BF16_LIMITS = (1.2e-2, 2.1e-2)     # 3x the deviation measured on MI355X: shift 3.94e-3, yaw 6.82e-3 (normalised; 30 LM steps, 2 seeds)
 
 
 def _dev():
@@ -224,8 +225,11 @@ def test_lm_solve_ford_small_vs_oracle():
     assert err < 2e-5 * max(1.0, np.abs(ref).max())
 
 
-# reduced-precision pose deviation limits (shift, yaw; normalised units) = 3x the deviation measured on MI355X on golden seed 0
-REDUCED_LIMITS = {'bf16': (2.2e-3, 1.1e-2), 'fp16': (1.2e-3, 2.0e-3)}
+# reduced-precision pose deviation limits (shift, yaw; normalised units) = 3x the deviation measured on MI355X: on golden seed 0
+# of e2e_kitti.npz ('bf16', 'fp16'), on the B = 32 bench batch of seed 2 (worst of the four checked samples: 5.26e-4 / 3.20e-3), on
+# BASELINE configs[4] in its own dtype (1.98e-5 / 2.37e-4) and on configs[3] (Ford, 30 steps) in ITS secondary dtype
+REDUCED_LIMITS = {'bf16': (2.2e-3, 1.1e-2), 'fp16': (1.2e-3, 2.0e-3), 'bf16 B32': (1.6e-3, 9.6e-3), 'fp16 hires': (6.0e-5, 7.2e-4),
+                  'bf16 ford': FORD_BF16_LIMITS}
 
 
 def _pose_gate(got, g64, g32, what):
@@ -339,6 +343,32 @@ def test_e2e_ford_full_shape_vs_golden(precision):
         trace = _exec_order(net.last_trace, 0).cpu().numpy().astype(np.float64)
         _pose_gate(trace, g[f'trace64_{seed}'], g[f'trace32_{seed}'], f'ford {precision} seed {seed}')
         np.testing.assert_array_equal(torch.stack(res, -1).cpu().numpy(), trace[:, -1].astype(np.float32))
+
+
+def test_e2e_ford_bf16_pose_deviation_bounded():
+    """BASELINE configs[3] (Ford shapes, 10 LM iterations = 30 steps) in the dtype bench.py's `secondary` leg runs it in."""
+    from oracle import ref_cpu as O
+    from highlyaccurate_amd.models_ford import LM_S2GP_Ford
+    g = load_golden('e2e_ford.npz')
+    B, d = int(g['B']), _dev()
+    worst_s = worst_y = 0.0
+    for seed in (int(s) for s in g['seeds']):
+        net = LM_S2GP_Ford(O.default_args(N_iters=10, precision='bf16'))
+        net.load_state_dict(O.synth_model_state(seed))
+        net = net.to(d)
+        sat, grd, *_ = O.synth_images(seed + 100, B)
+        R_FL = torch.tensor([[[0., 0., 1.], [1., 0., 0.], [0., 1., 0.]]]).repeat(B, 1, 1)
+        T_FL = torch.tensor([[1.7, 0.3, -1.2]]).repeat(B, 1)
+        torch.manual_seed(seed)
+        with torch.no_grad():
+            net(sat.to(d), grd.to(d), 112.64, R_FL.to(d), T_FL.to(d), mode='test')
+        trace = _exec_order(net.last_trace, 0).cpu().numpy().astype(np.float64)
+        err = np.abs(trace - g[f'trace64_{seed}'])
+        assert np.isfinite(trace).all()
+        worst_s, worst_y = max(worst_s, err[..., :2].max()), max(worst_y, err[..., 2].max())
+    print(f'ford bf16 pose deviation vs fp64 reference (30 steps, 2 seeds): shift {worst_s:.3e} yaw {worst_y:.3e} (normalised)')
+    lim_s, lim_y = REDUCED_LIMITS['bf16 ford']
+    assert worst_s < lim_s and worst_y < lim_y, (worst_s, worst_y)
 
 
 @pytest.mark.parametrize('tag,kw,lf', [('levelfirst', {}, 1), ('weight', dict(using_weight=1), 0), ('dropout', dict(dropout=1), 0),
@@ -528,7 +558,9 @@ def test_e2e_hires_config5_vs_golden():
     t16 = _exec_order(net16.last_trace, 0).cpu().numpy().astype(np.float64)
     err = np.abs(t16 - g['trace64'])
     print(f'hires fp16 pose deviation vs fp64 reference: shift {err[..., :2].max():.3e} yaw {err[..., 2].max():.3e}')
-    assert np.isfinite(t16).all() and err.max() < 0.05
+    # configs[4]'s own dtype, bounded at 3x what it measures on MI355X (shift 1.98e-5, yaw 2.37e-4 normalised = 4e-4 m / 4e-5 rad)
+    lim_s, lim_y = REDUCED_LIMITS['fp16 hires']
+    assert np.isfinite(t16).all() and err[..., :2].max() < lim_s and err[..., 2].max() < lim_y
 
 
 def test_determinism_and_batch_independence():
@@ -583,8 +615,8 @@ def test_train_mode_forward_values_vs_golden():
 def test_train_step_gradients_vs_reference_golden(precision):
     """mode='train' under autograd: loss.backward() runs the HIP backward (LM loop + both VGGs).  Gradients are checked
     against samples recorded from the REAL reference's autograd (fp64 run), full KITTI shape, B=1.  fp16x3: the split-fp16
-    forward saves fp32 activations and the backward is the exact-fp32 one on them -- training in the matched-accuracy mode
-    must meet the same gradient gates."""
+    forward saves fp32 activations and the backward runs split-fp16 data- and weight-gradient kernels on them (three fp16 MFMAs
+    per product) -- training in the matched-accuracy mode must meet the same gradient gates as the exact-fp32 mode."""
     from oracle import ref_cpu as O
     from highlyaccurate_amd.models_kitti import LM_S2GP
     from make_idx import sample_idx
@@ -711,8 +743,8 @@ def test_bench_batch_per_sample_vs_oracle(precision):
         else:
             err = np.abs(trace[k] - t64)
             print(f'B=32 {precision} sample {k}: shift {err[..., :2].max():.3e} yaw {err[..., 2].max():.3e}')
-            lim_s, lim_y = REDUCED_LIMITS[precision]
-            assert err[..., :2].max() < 2 * lim_s and err[..., 2].max() < 2 * lim_y      # other seed than the limits' own: 2x slack
+            lim_s, lim_y = REDUCED_LIMITS[precision + ' B32']        # recorded for this very batch: no extra slack
+            assert err[..., :2].max() < lim_s and err[..., 2].max() < lim_y
 
 
 def test_split_fp16_scaling_is_robust_and_sample_local():
@@ -1780,3 +1812,43 @@ def test_bench_gpus_flag_spawns_its_ranks_and_reports_them():
     assert abs(t['allreduce_bytes_per_step'] - 19.78e6) < 0.02e6, t['allreduce_bytes_per_step']     # 4 945 536 fp32, once per step
     assert t['loss_finite'] and t['value'] > 0 and t['single_rank_value'] > 0 and 0 < t['scaling_eff'] < 1.5
     assert 'roofline' in j and 'scale_reads' in j
+
+
+# A fixed slice of the randomised harness (tests/diag/fuzz_e2e.py: random batch / image sizes -- mostly not multiples of the conv
+# and LM tiles --, model family, level, flags, iteration counts; forward poses on even seeds, training loss + every parameter
+# gradient on odd ones, against the fp64 oracle): LM updater only, including the reference's two run-time errors (three cases
+# where no pixel of the batch is in view -> AssertionError, jacobian.py:172; two singular normal matrices -> LinAlgError) and the
+# largest displacements the harness has produced (2090: |shift| 2.8, past the re-initialisation threshold; 2462: 1.9).
+_FUZZ_SLICE = [2050, 2085, 2090, 2096, 2110, 2120, 2452, 2453, 2454, 2456, 2457, 2459, 2460, 2461, 2462, 2463, 2464, 2465, 2466,
+               2467, 2468, 2469, 2470, 2471, 2473, 2474, 2475, 2477, 2478, 2302]
+
+
+@pytest.mark.parametrize('chunk', [0, 1, 2])
+def test_fuzz_slice_vs_oracle(chunk):
+    import importlib.util, os
+    p = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'diag', 'fuzz_e2e.py')
+    spec = importlib.util.spec_from_file_location('fuzz_e2e', p)
+    fz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fz)
+    bad = [s for s in _FUZZ_SLICE[chunk::3] if not fz.one_case(s)]
+    assert not bad, f'fuzz seeds beyond their bound: {bad}'
+
+
+@pytest.mark.parametrize('precision', ['fp32', 'fp16x3', 'bf16'])
+def test_train_step_gradient_fidelity_by_precision(precision):
+    """The number bench.py reports as train.by_precision.<mode>.gradients, gated: worst per-tensor relative L2 error and cosine
+    of the full-shape training-step gradients against the REAL reference's autograd (tests/golden/train_kitti.npz, fp64 run).
+    fp32 / fp16x3 (the matched-accuracy training mode: split-fp16 dgrad + wgrad kernels): within 3x the reference's OWN
+    fp32-vs-fp64 gap (max-pool flip noise, see test_train_step_gradients_vs_reference_golden).  bf16, the throughput mode the
+    training leg of bench.py runs in: 3x its measured deviation (0.237 / cosine 0.9726 on MI355X), so that a regression of a
+    factor of three fails instead of hiding behind a 0.3 bound on a 32x64 image."""
+    import os, sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    r = bench.gradient_fidelity(precision, _dev())
+    print(f'gradient fidelity [{precision}]: {r}')
+    if precision == 'bf16':
+        assert r['worst_rel_l2'] < 3 * 0.237 and r['worst_cosine'] > 1 - 3 * (1 - 0.9726) and r['loss_rel_err'] < 3 * 3.2e-4
+    else:
+        assert r['worst_rel_l2'] < 3 * r['reference_fp32_vs_fp64_worst_rel_l2'] and r['worst_cosine'] > 0.99998
+        assert r['loss_rel_err'] < 1e-6
