@@ -265,12 +265,16 @@ struct WgradSplitExtra {
   const unsigned* amax_x1; const unsigned* amax_x2; const unsigned* amax_g;   // [B] fp32 bit patterns of max |.| per sample
 };
 constexpr int WGS_STR = 64 * 2 + 16;                       // fp16 plane row stride (as wg_stride<f16>)
-constexpr int wgs_lds_bytes() { return 2 * ((WG_TH + 2) * HWID + WG_TH * 32) * WGS_STR; }
+// A tile of the (shared) tile lists is WG_TH = 4 rows x 32 pixels; with two fp16 planes per operand that is 96 KB of LDS and one
+// workgroup per CU, whose load and MFMA phases then run strictly one after the other (measured: 1.9 ms per launch, 6x the bf16
+// kernel for 3x its MFMAs).  The tile is therefore walked as two HALVES of WGS_TH = 2 rows: 58 KB, two workgroups per CU.
+constexpr int WGS_TH = 2;
+constexpr int wgs_lds_bytes() { return 2 * ((WGS_TH + 2) * HWID + WGS_TH * 32) * WGS_STR; }
 
-static __global__ __launch_bounds__(256, 1) void wgrad_split_kernel(WgradArgs a, WgradSplitExtra sx) {
+static __global__ __launch_bounds__(256, 2) void wgrad_split_kernel(WgradArgs a, WgradSplitExtra sx) {
   typedef f16 H;
   constexpr int STR = WGS_STR, PPX = 16;                   // 16-B fp32 pieces per pixel (64 channels)
-  constexpr int XPIX = (WG_TH + 2) * HWID, GPIX = WG_TH * 32, KPX = 16;
+  constexpr int XPIX = (WGS_TH + 2) * HWID, GPIX = WGS_TH * 32, KPX = 16;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* Xh = smem;
   char* Xl = Xh + XPIX * STR;
@@ -302,10 +306,12 @@ static __global__ __launch_bounds__(256, 1) void wgrad_split_kernel(WgradArgs a,
   constexpr int NX = (XPIX * PPX + 255) / 256, NG = GPIX * PPX / 256, PSTEP = 256 / PPX;
   const int part = t % PPX, pix0 = t / PPX;
   const WgTiles tl(a.dyn, a.dyn_desc, a.H, a.W, a.row_begin, a.tiles_x, a.tiles_y, a.ntile, a.B, a.g_unpool ? 1 : 0);
-  for (int tile = ks; tile < tl.ntile; tile += a.KS) {
+  for (int tile2 = 2 * ks; tile2 < 2 * tl.ntile; tile2 += (tile2 & 1) ? 2 * a.KS - 1 : 1) {      // (tile, half 0), (tile, half 1), next tile
     int b, y0, x0, gx0, gx1;
-    tl.origin(tile, b, y0, x0, gx0, gx1);
-    __syncthreads();                                   // previous tile fully consumed
+    tl.origin(tile2 >> 1, b, y0, x0, gx0, gx1);
+    y0 += (tile2 & 1) * WGS_TH;
+    if (y0 >= a.H) continue;                           // (uniform: the lower half of a tile at the image's last rows)
+    __syncthreads();                                   // previous half tile fully consumed
     // input halo tile (zero outside the image) and output-gradient tile, in batches of 4 pieces = 16 staging registers
 #pragma unroll
     for (int lo = 0; lo < NX; lo += 4) {
@@ -365,15 +371,15 @@ static __global__ __launch_bounds__(256, 1) void wgrad_split_kernel(WgradArgs a,
     // every X fragment (halo row rho, column shift kx) is fetched once and feeds the up to three taps ky that use it
 #pragma unroll 1
     for (int kk = 0; kk < 32 / KPX; ++kk) {
-      uint4 Ah[WG_TH], Al[WG_TH];
+      uint4 Ah[WGS_TH], Al[WGS_TH];
 #pragma unroll
-      for (int r = 0; r < WG_TH; ++r) {
+      for (int r = 0; r < WGS_TH; ++r) {
         Ah[r] = frag_kmajor<H>(Gh, STR, r * 32 + kk * KPX, ct * 32, lane);
         Al[r] = frag_kmajor<H>(Gl, STR, r * 32 + kk * KPX, ct * 32, lane);
         if (want_bias) { mma16<H>(accb, Ah[r], ones); mma16<H>(accb, Al[r], ones); }
       }
 #pragma unroll
-      for (int rho = 0; rho < WG_TH + 2; ++rho) {
+      for (int rho = 0; rho < WGS_TH + 2; ++rho) {
 #pragma unroll
         for (int kx = 0; kx < 3; ++kx) {
           const uint4 Bh = frag_kmajor<H>(Xh, STR, rho * HWID + kx + kk * KPX, it * 32, lane);
@@ -381,7 +387,7 @@ static __global__ __launch_bounds__(256, 1) void wgrad_split_kernel(WgradArgs a,
 #pragma unroll
           for (int ky = 0; ky < 3; ++ky) {
             const int r = rho - ky;
-            if (r >= 0 && r < WG_TH) {
+            if (r >= 0 && r < WGS_TH) {
               mma16<H>(acc[ky * 3 + kx], Ah[r], Bh);
               mma16<H>(acc[ky * 3 + kx], Al[r], Bh);
               mma16<H>(acc[ky * 3 + kx], Ah[r], Bl);
