@@ -203,6 +203,8 @@ __global__ __launch_bounds__(256, LM_OCC) void lm_accum(AccumArgs a, SolveArgs s
 
   constexpr int UNR = LM_UNROLL(F);
 #pragma unroll UNR
+  // (measured with the gather loop compiled out: a launch's FIXED cost -- the fp64 pixel set-up, the reductions, the published
+  // partials, the ticket round trip, the closing solve -- is 31 / 20 / 13 us of the 73 / 43 / 30 us at C = 64 / 128 / 256)
   for (int i = wave * PPW + sub; i < np; i += 4 * PPW) {
     const PixParam P = pp[i];
     const uint4 t00 = *(const uint4*)(satb + P.off);
