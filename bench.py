@@ -234,9 +234,12 @@ def conv_roofline(agg, precision, pmc, pmc_src, headline_cfg):
         for kname, v in pmc.items():
             if isinstance(v, dict) and sym in kname and ('DF16b' in kname) == (precision == 'bf16'):
                 traffic, tsrc = v['hbm_bytes_corrected'], pmc_src
+    # (traffic: PMC passes need rocprofv3 around the process, so it comes from the committed file measured on the same kernel sources
+    #  -- hash-checked --, and the line says so: traffic_measured_in_run)
     return {'kernel': dom, 'bound': 'mfma', 'achieved': round(ach, 2), 'peak': round(PEAK_TFLOPS[precision], 1),
             'unit': 'TFLOP/s', 'frac': round(ach / PEAK_TFLOPS[precision], 4), 'traffic': traffic,
-            'traffic_unit': 'bytes/launch', 'traffic_source': tsrc, 'launches': n, 'avg_launch_us': round(ms / n * 1e3, 2),
+            'traffic_unit': 'bytes/launch', 'traffic_source': tsrc,
+            'traffic_measured_in_run': False, 'launches': n, 'avg_launch_us': round(ms / n * 1e3, 2),
             'flops_per_launch': round(fl / n / 1e9, 3), 'flops_unit': 'GFLOP (algorithmic: 2*9*Cin*Cout*pixels)'}
 
 
@@ -270,7 +273,7 @@ def lm_roofline(agg, pmc, pmc_src):
     if cb:
         ach = cb / (ms * 1e-3) / 1e9
         out.update({'achieved': round(ach, 1), 'frac': round(ach / PEAK_HBM_GBS, 4), 'traffic': round(cb / n),
-                    'traffic_unit': 'bytes/launch (counter)', 'traffic_source': pmc_src,
+                    'traffic_unit': 'bytes/launch (counter)', 'traffic_source': pmc_src, 'traffic_measured_in_run': False,
                     'traffic_over_algorithmic': round(cb / alg, 3)})
     else:
         out.update({'achieved': None, 'frac': None, 'traffic': None})
