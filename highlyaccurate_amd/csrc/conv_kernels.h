@@ -811,7 +811,9 @@ template <typename T> constexpr int conv02_lds_bytes() {
 }
 
 template <typename T, int WD>
-__global__ __launch_bounds__(256, sizeof(T) == 2 ? 3 : 2) void conv02_kernel(Conv02Args a0) {
+// (three workgroups per CU, except in split mode: there the kernel is matrix-bound already -- three MFMAs per product -- and
+// the 168-register cap costs it 31 spills: 1430 us per launch either way, same-box A/B)
+__global__ __launch_bounds__(256, Prec<T>::SPLIT ? 2 : 3) void conv02_kernel(Conv02Args a0) {
   constexpr bool SPLIT = Prec<T>::SPLIT;
   constexpr int EPL = Prec<T>::CEPL, KC = SB / sizeof(T), NSG = 64 / KC, NFRAG = 32 / (2 * EPL), NH = SPLIT ? 2 : 1;
   constexpr int MT = 4, NT = 1, WN = 2, TH = 8, HPIX = (TH + 2) * HWID, BUF = HPIX * PSTR, IW = 36, IH = 12;
@@ -844,13 +846,19 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 3 : 2) void conv02_kernel(Con
     in[e] = v;
     if (SPLIT) amx = fmaxf(amx, fabsf(v));
   }
-  uint4 wf0[2][NFRAG][NH];          // split mode: [..][0] = hi, [..][1] = lo
+  // conv0's weight fragments and biases of the 32-channel halves ONE round produces ([..][0] = hi, [..][1] = lo in split mode).
+  // With two rounds (4-byte activation types) they are fetched per round: holding both halves' cost 32 registers, which kept
+  // the exact-fp32 kernel (176) above the 168 of three workgroups per CU (3983 -> 3884 us per launch).
+  uint4 wf0[JPR][NFRAG][NH];
+  auto load_w0 = [&](int j0) __attribute__((always_inline)) {
 #pragma unroll
-  for (int j = 0; j < 2; ++j)
+    for (int jj = 0; jj < JPR; ++jj)
 #pragma unroll
-    for (int f = 0; f < NFRAG; ++f)
+      for (int f = 0; f < NFRAG; ++f)
 #pragma unroll
-      for (int h = 0; h < NH; ++h) wf0[j][f][h] = a0.w0[((j * NFRAG + f) * NH + h) * 64 + lane];
+        for (int h = 0; h < NH; ++h) wf0[jj][f][h] = a0.w0[(((j0 + jj) * NFRAG + f) * NH + h) * 64 + lane];
+  };
+  load_w0(0);
   if (SPLIT) {
     amx = wave_max_f32(amx);
     if (lane == 0) red[4 + wv] = amx;
@@ -858,23 +866,20 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 3 : 2) void conv02_kernel(Con
   __syncthreads();
 
   // phase B: conv0 on the 10x34 halo pixels, 32 pixels per MFMA tile, straight into the conv2 halo buffers
-  float4 bias0[2][4];
+  float4 bias0[JPR][4];
+  auto load_b0 = [&](int j0) __attribute__((always_inline)) {
 #pragma unroll
-  for (int j = 0; j < 2; ++j)
+    for (int jj = 0; jj < JPR; ++jj)
 #pragma unroll
-    for (int q = 0; q < 4; ++q) bias0[j][q] = *(const float4*)(a0.b0 + j * 32 + q * 8 + g * 4);
+      for (int q = 0; q < 4; ++q) bias0[jj][q] = *(const float4*)(a0.b0 + (j0 + jj) * 32 + q * 8 + g * 4);
+  };
   // split mode: every scale is local to this block (a power-of-two scale never changes a result).  Input patch: from its own
   // maximum.  relu(conv0): from the bound  max_co sum_k |w0[co][k]| * max |x| + max |b0|  (it is split into hi / lo while it is
   // produced, before its true maximum could be known; the bound is a few binades loose, the window is 17 binades wide).
   float s_in = 1.f, s_a0 = 1.f, d0 = 1.f, dsc2 = 1.f;
   if constexpr (SPLIT) {
     const float m = fmaxf(fmaxf(red[4], red[5]), fmaxf(red[6], red[7]));
-    float bm = 0.f;
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int q = 0; q < 4; ++q)
-        bm = fmaxf(fmaxf(bm, fmaxf(fabsf(bias0[j][q].x), fabsf(bias0[j][q].y))), fmaxf(fabsf(bias0[j][q].z), fabsf(bias0[j][q].w)));
+    float bm = fabsf(a0.b0[lane]);                   // max |b0| over its 64 channels
     bm = wave_max_f32(bm);
     s_in = split_scale(__float_as_uint(m));
     s_a0 = split_scale(__float_as_uint(a0.wtail[16] * m + bm));
@@ -891,6 +896,8 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 3 : 2) void conv02_kernel(Con
 #pragma unroll
   for (int rd = 0; rd < ROUNDS; ++rd) {
   const int j0 = rd * JPR;                           // first 32-channel half of conv0's output this round produces
+  if (rd > 0) load_w0(j0);
+  load_b0(j0);
   if (rd > 0) __syncthreads();                       // the previous round's MFMAs are done with the buffers
   for (int m = wv; m * 32 < HPIX; m += 4) {
     const int p = m * 32 + x, pc = p < HPIX ? p : HPIX - 1;
@@ -922,9 +929,9 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 3 : 2) void conv02_kernel(Con
         const uint4 phi = make_uint4(h0.x, h0.y, h1.x, h1.y), plo = make_uint4(l0.x, l0.y, l1.x, l1.y);
 #pragma unroll
         for (int j = j0; j < j0 + JPR; ++j) {
-          mma16<T>(c0[j], wf0[j][f][0], phi);
-          mma16<T>(c0[j], wf0[j][f][NH - 1], phi);
-          mma16<T>(c0[j], wf0[j][f][0], plo);
+          mma16<T>(c0[j], wf0[j - j0][f][0], phi);
+          mma16<T>(c0[j], wf0[j - j0][f][NH - 1], phi);
+          mma16<T>(c0[j], wf0[j - j0][f][0], plo);
         }
       } else {
         T e[EPL];
@@ -932,7 +939,7 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 3 : 2) void conv02_kernel(Con
         for (int jj = 0; jj < EPL; ++jj) e[jj] = (T)ev[jj];
         const uint4 pf = __builtin_bit_cast(uint4, e);
 #pragma unroll
-        for (int j = j0; j < j0 + JPR; ++j) mma16<T>(c0[j], wf0[j][f][0], pf);
+        for (int j = j0; j < j0 + JPR; ++j) mma16<T>(c0[j], wf0[j - j0][f][0], pf);
       }
     }
     // conv2 zero-pads conv0's OUTPUT map: halo pixels outside the image are 0, not conv0 of padded input
@@ -945,7 +952,7 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 3 : 2) void conv02_kernel(Con
         for (int q = 0; q < 4; ++q) {
           const int co = j * 32 + q * 8 + g * 4, sl = co / KC - rd * SPR;      // channel, its stage buffer within this round
           const int byte = (co % KC) * (SPLIT ? 2 : (int)sizeof(T));           // where the 4 channels start inside the pixel's stage
-          const float4 bb = bias0[j][q];
+          const float4 bb = bias0[j - j0][q];
           float v0 = fmaxf(c0[j][q * 4 + 0] * d0 + bb.x, 0.f), v1 = fmaxf(c0[j][q * 4 + 1] * d0 + bb.y, 0.f);
           float v2 = fmaxf(c0[j][q * 4 + 2] * d0 + bb.z, 0.f), v3 = fmaxf(c0[j][q * 4 + 3] * d0 + bb.w, 0.f);
           if (!inside) v0 = v1 = v2 = v3 = 0.f;
