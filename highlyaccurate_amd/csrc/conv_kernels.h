@@ -194,7 +194,9 @@ __device__ __forceinline__ int halo_key(int hx) { return (hx >> 2) & 3; }
 __device__ __forceinline__ int halo_off(int pix, int hx, int slot) { return pix * PSTR + ((slot ^ halo_key(hx)) << 4); }
 // The next stage's halo tile is fetched in two halves through the SAME staging registers: half 0 is requested at tap HALO_TAP0,
 // written to the idle buffer at tap HALO_TAP1, where half 1 is requested; half 1 is written after the stage's last MFMA.
-constexpr int HALO_TAP0 = 1, HALO_TAP1 = 5;
+// (measured, same-box A/B of (TAP0, TAP1): (2, 6) beats (1, 5) by 3 % on the pooled 64-channel-wave-tile kernel and by 1 % on the
+// un-pooled one; (0, 4) the same; (3, 7) and (1, 6) lose 1-4 %; (3, 6) costs the 32-channel wave tile 20 %)
+constexpr int HALO_TAP0 = 2, HALO_TAP1 = 6;
 // per-lane byte offsets of a wave's pixel fragments: [kx][kg] -> (x + kx) * PSTR + swizzled slot of (lane half g, k-group kg),
 // relative to the wave's first halo row
 struct FragOff { int o[3][2]; };
@@ -467,7 +469,7 @@ struct WeightRing {
   uint4 wb[RS][2][NT];
   // pixel fragments in flight ahead of the MFMAs (one MFMA per fragment at NT = 1: four reads = 128 matrix-pipe cycles of cover;
   // six, round 2's choice at two workgroups per CU, cost the three-workgroup kernel 27 spilled registers: 804 against 1100 TF)
-  static constexpr int PFD = NT == 1 ? 4 : 3;
+  static constexpr int PFD = NT == 1 ? 4 : 3;     // (NT = 2: 2 and 4 measure the same as 3)
   uint4 pf[PFD + 1];     // pixel-fragment pipeline of the non-upfront MFMA loop (lives across taps)
   const uint4* wq[NT];   // per-lane pointer to this stage's fragments of output tile j: [tap][kg][lane]
 
@@ -1250,6 +1252,7 @@ static void launch_conv(hipStream_t st, ConvArgs a, bool pool) {
   // Cout >= 128: block = 8x32 pixels x 128 channels, waves 2(M) x 2(N), wave tile 128 px x 64 ch, weights 1 tap ahead
   // Cout == 64 : block = 8x32 pixels x  64 channels, waves 2 x 2,       wave tile 128 px x 32 ch, weights 2 taps ahead
   if (big) {
+    // (weights two taps ahead for this tile as well: spills, -1 %)
     if (pool) hipLaunchKernelGGL((conv3x3_kernel<T, 4, 2, 2, 2, true, 1>), grid, dim3(256), 0, st, a);
     else hipLaunchKernelGGL((conv3x3_kernel<T, 4, 2, 2, 2, false, 1>), grid, dim3(256), 0, st, a);
   } else {
