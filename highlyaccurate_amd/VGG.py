@@ -84,7 +84,7 @@ def _image_window(x: torch.Tensor):
     x = x.float()
     B, _, H, W = x.shape
     sb, sc, sh, sw = x.stride()
-    if not (sw == 1 and sh == W and sc >= H * W and sb == 3 * sc):
+    if not (sw == 1 and sh == W and sc >= H * W and (B == 1 or sb == 3 * sc)):      # (a size-1 batch dimension may carry any stride)
         x = x.contiguous()
         sc = H * W
     return x, sc

@@ -1298,6 +1298,7 @@ extern "C" int hla_vgg_backward(const float* x, size_t x_plane, const hla_vgg_pa
   dtype = bwd_dtype(dtype);
   HLA_REQUIRE(level == 3 || level == 4, "hla_vgg_backward: level must be 3 or 4");
   HLA_REQUIRE((size_t)H * W * 64 * 4 < ((size_t)1 << 31), "hla_vgg_backward: image too large (H*W must be below 2^23 pixels)");
+  HLA_REQUIRE(x_plane == 0 || x_plane >= (size_t)H * W, "hla_vgg_backward: x_plane (%zu) must be 0 or >= H*W", x_plane);
   HLA_REQUIRE(first_row8 == 0 || (first_row8 >= 4 && first_row8 < H / 8), "hla_vgg_backward: first_row8 must be 0 or in [4, H/8)");
   const int NLc = level == 4 ? 4 : 3;
   HLA_REQUIRE(B > 0 && H % 8 == 0 && W % 8 == 0, "hla_vgg_backward: H and W must be multiples of 8");

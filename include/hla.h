@@ -143,8 +143,9 @@ size_t hla_vgg_packed_weight_T_bytes(int dtype);
 int hla_vgg_pack_weights_T(const hla_vgg_params* params, void* packed_T, int dtype, hla_stream_t stream);
 size_t hla_vgg_bwd_workspace_bytes(int B, int H, int W, int level, int dtype);
 
-/* x, params        as in the forward call
- * fwd_workspace    the workspace of the forward call made with HLA_VGG_SAVE_FOR_BACKWARD | HLA_VGG_DEFER_NORM
+/* x, x_plane, params  as in the forward call
+ * fwd_workspace    the workspace of the forward call made with HLA_VGG_SAVE_FOR_BACKWARD | HLA_VGG_DEFER_NORM and the SAME dtype
+ *                  (HLA_F16X3: it also holds the per-sample activation maxima the split weight-gradient kernels scale by)
  * feat[l], inv_norm  its outputs (raw maps + 1/norm)
  * d_feat[l]        d(loss)/d(L2-normalised map l), NHWC fp32 (what hla_s2g_lm_solve_bwd produces)
  * conf[l], d_conf[l]  the forward's confidence maps and d(loss)/d(conf map l) [B,h_l,w_l] fp32 (what
