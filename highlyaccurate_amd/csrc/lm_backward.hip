@@ -32,7 +32,7 @@ struct BwdAccumArgs {
 template <int C, bool USE_W>
 __global__ __launch_bounds__(256) void lm_bwd_accum(BwdAccumArgs a) {
   __shared__ PixParam pp[MAX_TP];
-  __shared__ float pixacc[MAX_TP][9];     // a_ix a_iy a_j0u a_j0v a_j1u a_j1v a_j2u a_j2v a_w
+  __shared__ float pxyz[MAX_TP][3];       // the pixel's ground-plane point (the coefficient adjoints weight by it)
   __shared__ double red[4][12];
   int b, tile;
   if (!lm_block_map(a.xcd_affine, a.nt, a.B, b, tile)) return;
@@ -45,11 +45,13 @@ __global__ __launch_bounds__(256) void lm_bwd_accum(BwdAccumArgs a) {
     const int p = p0 + t;
     const int r = a.row0 + p / a.w, c = p % a.w;
     const float cw = USE_W ? a.conf[((size_t)b * a.hs + (r - a.rskip)) * a.w + c] : 1.f;
-    PixParam P = lm_pixel<C>(cf, a.xyz + ((size_t)r * a.w + c) * 3, a.A, cw);
+    const float* qx = a.xyz + ((size_t)r * a.w + c) * 3;
+    PixParam P = lm_pixel<C>(cf, qx, a.A, cw);
     if (a.keep && !a.keep[p]) {          // dropped by args.dropout: the pixel leaves every sum (models_kitti.py:968-974)
       P.wx0 = P.wx1 = P.wy0 = P.wy1 = 0.f; P.off = P.dxo = P.dyo = 0; P.j2u = P.j2v = 0.f; P.gm = P.wt = P.m = 0.f;
     }
     pp[t] = P;
+    pxyz[t][0] = qx[0]; pxyz[t][1] = qx[1]; pxyz[t][2] = qx[2];
   }
   __syncthreads();
 
@@ -87,6 +89,10 @@ __global__ __launch_bounds__(256) void lm_bwd_accum(BwdAccumArgs a) {
       }
     }
   };
+  double c12[12];
+#pragma unroll
+  for (int k = 0; k < 12; ++k) c12[k] = 0.0;
+  const double kk = cf[12];
   for (int jr = 0; jr < RUN; ++jr) {
     const int i = grp * RUN + jr;
     const bool live = i < np;
@@ -144,36 +150,31 @@ __global__ __launch_bounds__(256) void lm_bwd_accum(BwdAccumArgs a) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) gp[e * LPP] += dg[e];
     }
-    // reduce the per-pixel adjoints over the LPP lanes that share the pixel
-#pragma unroll
-    for (int k = 0; k < (USE_W ? 9 : 8); ++k) {
-#pragma unroll
-      for (int o = LPP >> 1; o > 0; o >>= 1) q[k] += __shfl_xor(q[k], o, 64);
+    // pixel adjoints -> adjoints of the 12 projection coefficients.  The map is linear, so every lane applies it to its own
+    // partial sums (its 4 channels of the pixel) and accumulates in fp64 across its run of pixels; ONE cross-lane reduction at
+    // the end replaces round 2's per-pixel butterfly of eight values over the LPP lanes that share a pixel (72 of the loop's
+    // ~400 instructions) and the pass over an LDS copy of the per-pixel sums.
+    if (live) {
+      const double X = pxyz[i][0], Y = pxyz[i][1], Z = pxyz[i][2];
+      const double gu = (double)q[0] - kk * (double)q[7];     // j2v = -k (u - ctr)
+      const double gv = (double)q[1] + kk * (double)q[6];     // j2u =  k (v - ctr)
+      c12[0] += gu * X; c12[1] += gu * Y; c12[2] += gu * Z; c12[3] += gu;
+      c12[4] += gv * X; c12[5] += gv * Y; c12[6] += gv * Z; c12[7] += gv;
+      c12[8] += (double)q[2]; c12[9] += (double)q[3]; c12[10] += (double)q[4]; c12[11] += (double)q[5];
     }
-    if (live && (lane % LPP) == 0) {
+    if (USE_W) {       // d(loss)/d(confidence) is per pixel: that one value is still reduced over the pixel's lanes
+      float qw = q[8];
 #pragma unroll
-      for (int k = 0; k < 9; ++k) pixacc[i][k] = q[k];
+      for (int o = LPP >> 1; o > 0; o >>= 1) qw += __shfl_xor(qw, o, 64);
+      if (live && (lane % LPP) == 0 && a.d_conf) {
+        const int p = p0 + i;
+        const int r = a.row0 + p / a.w, c = p % a.w;
+        a.d_conf[((size_t)b * a.hs + (r - a.rskip)) * a.w + c] += qw * pp[i].gm;
+      }
     }
   }
   flush_cell();
   __syncthreads();
-
-  // pixel adjoints -> adjoints of the 12 projection coefficients (+ d/d(conf))
-  double c12[12];
-#pragma unroll
-  for (int k = 0; k < 12; ++k) c12[k] = 0.0;
-  if (t < np) {
-    const int p = p0 + t;
-    const int r = a.row0 + p / a.w, c = p % a.w;
-    const float* qx = a.xyz + ((size_t)r * a.w + c) * 3;
-    const double kk = cf[12];
-    const double gu = (double)pixacc[t][0] - kk * (double)pixacc[t][7];     // j2v = -k (u - ctr)
-    const double gv = (double)pixacc[t][1] + kk * (double)pixacc[t][6];     // j2u =  k (v - ctr)
-    c12[0] = gu * qx[0]; c12[1] = gu * qx[1]; c12[2] = gu * qx[2]; c12[3] = gu;
-    c12[4] = gv * qx[0]; c12[5] = gv * qx[1]; c12[6] = gv * qx[2]; c12[7] = gv;
-    c12[8] = pixacc[t][2]; c12[9] = pixacc[t][3]; c12[10] = pixacc[t][4]; c12[11] = pixacc[t][5];
-    if (USE_W && a.d_conf) a.d_conf[((size_t)b * a.hs + (r - a.rskip)) * a.w + c] += pixacc[t][8] * pp[t].gm;
-  }
 #pragma unroll
   for (int k = 0; k < 12; ++k) c12[k] = wave_sum_f64(c12[k]);
   if (lane == 0) {
