@@ -402,7 +402,7 @@ def train_leg(net, a, sat, grd, extra, B, world, rank, dist, dev, want_kt, extra
             single = B * a.train_steps / (time.perf_counter() - t1)
             del opt0
         dist.barrier()
-        net.grad_sync = GradSync()
+        net.grad_sync = GradSync(force=True)       # (force: also in HLA_BENCH_FORCE_DIST's one-rank group)
     ar0 = net.grad_sync.bytes_reduced if dist else 0
     tdt, lossv = timed(a.train_steps)
     ar_bytes = ((net.grad_sync.bytes_reduced - ar0) // (a.train_steps + 2)) if dist else 0
@@ -531,9 +531,15 @@ def main(argv=None):
     dev = torch.device('cuda', local)
     dist = None
     ranks_seen = 1
-    if world > 1:
+    # HLA_BENCH_FORCE_DIST=1 (test hook): run the N = 1 job through the process group too -- RCCL with one rank -- so that every
+    # collective call of the N > 1 path (barriers, MAX over ranks, the gradient all-reduce inside the backward) executes on RCCL on
+    # a 1-GPU box; tests/test_gpu_parity.py::test_bench_single_rank_through_rccl
+    force_dist = bool(os.environ.get('HLA_BENCH_FORCE_DIST')) and world == 1
+    if world > 1 or force_dist:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        if force_dist:
+            os.environ.setdefault('MASTER_PORT', str(_free_port()))
         if rehearse:
             dist.init_process_group('gloo', rank=rank, world_size=world)
         else:
@@ -658,7 +664,7 @@ def main(argv=None):
                                             'rows the LM loop reads) and, layer by layer, the feature rows those rows do not '
                                             'depend on; computed rows are bit-identical, DESIGN.md 3.5)'},
         }
-        if world > 1:
+        if dist:
             res['collective_ranks_seen'] = ranks_seen      # all-reduced count over the process group (RCCL unless rehearsing)
             res['collective_backend'] = 'gloo (rehearsal)' if rehearse else 'nccl (RCCL)'
             res['rehearsal'] = rehearse                     # true: the ranks SHARE GPUs -- control-flow check, not a measurement

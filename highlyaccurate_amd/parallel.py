@@ -50,9 +50,11 @@ class GradSync:
     bucket.  ``finish(handle)`` waits and divides by the world size.  Used by the model's backward (``model.grad_sync``) so
     that the satellite branch's 9.9 MB bucket is in flight on the xGMI links while the ground branch's backward kernels run."""
 
-    def __init__(self, group=None):
+    def __init__(self, group=None, force=False):
+        """``force``: issue the collectives even in a one-rank group (how a 1-GPU box exercises the RCCL path)."""
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.force = bool(force) and dist.is_initialized()
         self.bytes_reduced = 0
         self.collectives = 0
 
@@ -62,7 +64,7 @@ class GradSync:
                 and flat.data_ptr() <= t.data_ptr() and t.data_ptr() + t.numel() * 4 <= flat.data_ptr() + flat.numel() * 4)
 
     def start(self, grads: dict, flat: torch.Tensor | None = None):
-        if self.world == 1 or not grads:
+        if (self.world == 1 and not self.force) or not grads:
             return None
         works = []
         rest = grads

@@ -1814,6 +1814,81 @@ def test_bench_gpus_flag_spawns_its_ranks_and_reports_them():
     assert 'roofline' in j and 'scale_reads' in j
 
 
+def test_bench_single_rank_through_rccl():
+    """The N > 1 code path on the REAL transport, as far as a one-GPU box can take it: HLA_BENCH_FORCE_DIST=1 runs the N = 1 job
+    through a one-rank RCCL process group, so every collective call of the multi-GPU path -- the census all-reduce, the barriers,
+    MAX over ranks on a device tensor, the asynchronous in-place all-reduce of the two flat gradient buffers from inside the
+    backward, wait + divide -- executes on RCCL (the two-rank test above has to fall back to gloo when the ranks share a GPU:
+    RCCL refuses two ranks on one device).  A CPU tensor in a collective, a wait on the wrong stream or a buffer the backend
+    cannot take would fail here and not there."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT',
+                                                            'HLA_BENCH_REHEARSE')}
+    env['HLA_BENCH_FORCE_DIST'] = '1'
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '1', '--steps', '3', '--warmup', '1',
+                        '--train-steps', '2', '--batch', '8', '--no-cpu-baseline', '--no-extra-legs'],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, r.stdout[-2000:]
+    j = json.loads(lines[0])
+    assert j['n_gpus'] == 1 and j['collective_ranks_seen'] == 1 and j['collective_backend'].startswith('nccl') and not j['rehearsal']
+    t = j['train']
+    assert 'error' not in t, t
+    assert abs(t['allreduce_bytes_per_step'] - 19.78e6) < 0.02e6, t['allreduce_bytes_per_step']
+    assert t['loss_finite'] and t['value'] > 0
+
+
+def test_grad_sync_over_rccl_leaves_one_rank_gradients_unchanged():
+    """GradSync on RCCL (one-rank group, force=True) inside the model's own backward: the flat buffers go through
+    ncclAllReduce in place and come back divided by 1 -- every parameter gradient must equal the run without a process group
+    (the all-reduce of one rank is the identity; 1e-5 relative covers the LM backward's fp32 atomics, whose order differs from
+    run to run, and the single-stream instead of two-stream backward), and the grad-less parameters stay grad-less.  The exchange is asynchronous on RCCL's own stream: a missing wait or a wait on the wrong stream shows up as a
+    stale or half-divided buffer here."""
+    import torch.distributed as dist
+    from highlyaccurate_amd.parallel import GradSync
+    import socket
+    from oracle import ref_cpu as O
+    from highlyaccurate_amd.models_kitti import LM_S2GP
+    dev = _dev()
+    net = LM_S2GP(O.default_args(precision='fp32'))
+    net.load_state_dict(O.synth_model_state(3))
+    net = net.to(dev)
+    rs = np.random.RandomState(5)
+    B = 2
+    sat = torch.from_numpy(rs.random_sample((B, 3, 512, 512)).astype(np.float32)).to(dev)
+    grd = torch.from_numpy(rs.random_sample((B, 3, 256, 1024)).astype(np.float32)).to(dev)
+    gt = [torch.from_numpy(rs.uniform(-1, 1, (B, 1)).astype(np.float32)).to(dev) for _ in range(3)]
+
+    def grads():
+        net.zero_grad(set_to_none=True)
+        torch.manual_seed(0)
+        r = net(sat, grd, gt[0], gt[1], gt[2], mode='train')
+        r[0].backward()
+        torch.cuda.synchronize()
+        return {n: (None if p.grad is None else p.grad.clone()) for n, p in net.named_parameters()}
+
+    base = grads()
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    dist.init_process_group('nccl', init_method=f'tcp://127.0.0.1:{port}', rank=0, world_size=1, device_id=dev)
+    try:
+        net.grad_sync = GradSync(force=True)
+        got = grads()
+        assert net.grad_sync.collectives >= 2 and abs(net.grad_sync.bytes_reduced - 19.78e6) < 0.02e6
+    finally:
+        net.grad_sync = None
+        dist.destroy_process_group()
+    for n, g in base.items():
+        assert (g is None) == (got[n] is None), n
+        if g is not None:
+            rel = float((g - got[n]).double().norm() / g.double().norm().clamp_min(1e-30))
+            assert rel < 1e-5, (n, rel)
+
+
 # A fixed slice of the randomised harness (tests/diag/fuzz_e2e.py: random batch / image sizes -- mostly not multiples of the conv
 # and LM tiles --, model family, level, flags, iteration counts; forward poses on even seeds, training loss + every parameter
 # gradient on odd ones, against the fp64 oracle): LM updater only, including the reference's two run-time errors (three cases
