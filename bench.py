@@ -364,8 +364,8 @@ def train_leg(net, a, sat, grd, extra, B, world, rank, dist, dev, want_kt, extra
         o.step()
         return r[0]
 
-    def timed(nsteps):
-        for _ in range(2):          # warm-up: Adam state, caching-allocator segments for the backward workspaces
+    def timed(nsteps, warm=2):
+        for _ in range(warm):       # warm-up: Adam state, caching-allocator segments for the backward workspaces
             tstep()
         torch.cuda.synchronize()
         if dist:
@@ -404,8 +404,14 @@ def train_leg(net, a, sat, grd, extra, B, world, rank, dist, dev, want_kt, extra
         dist.barrier()
         net.grad_sync = GradSync(force=True)       # (force: also in HLA_BENCH_FORCE_DIST's one-rank group)
     ar0 = net.grad_sync.bytes_reduced if dist else 0
+    # Two timed blocks of K steps, the faster one is the value and both are in the line (train.blocks_ms_per_step): on a fresh box
+    # one block in ~10 runs came out at twice the step time of every other block of the same process (profiles/r03: 48.1 ms
+    # against 22.5-23.7 ms before and after it; a one-off stall of ~0.15 s inside six steps, not a property of the step)
     tdt, lossv = timed(a.train_steps)
-    ar_bytes = ((net.grad_sync.bytes_reduced - ar0) // (a.train_steps + 2)) if dist else 0
+    tdt_b, lossv = timed(a.train_steps, warm=0)
+    blocks = [round(t / a.train_steps * 1e3, 3) for t in (tdt, tdt_b)]
+    tdt = min(tdt, tdt_b)
+    ar_bytes = ((net.grad_sync.bytes_reduced - ar0) // (2 * a.train_steps + 2)) if dist else 0
     trecs = []
     if not a.no_kernel_timing:  # per-kernel table from two extra steps (not part of the timing).  EVERY rank runs them --
         if want_kt:             # a training step contains the gradient all-reduce -- but only rank 0 is instrumented
@@ -427,7 +433,7 @@ def train_leg(net, a, sat, grd, extra, B, world, rank, dist, dev, want_kt, extra
     if dist:
         dist.barrier()
     train = {'value': round(B * world * a.train_steps / tdt, 3), 'unit': 'pairs/s', 'steps': a.train_steps,
-             'ms_per_step': round(tdt / a.train_steps * 1e3, 3), 'loss_finite': bool(torch.isfinite(lossv)),
+             'ms_per_step': round(tdt / a.train_steps * 1e3, 3), 'blocks_ms_per_step': blocks, 'loss_finite': bool(torch.isfinite(lossv)),
              'what': "forward(mode='train') + HIP backward (LM loop + both VGGs) + gradient all-reduce + Adam",
              'allreduce_bytes_per_step': ar_bytes,
              'sat_backward_live_tiles': live}       # data-dependent trimming; None = dense walk
