@@ -573,7 +573,7 @@ def main(argv=None):
         recs, dt_ev = kernel_pass(net, sat, grd, extra, n_ev)
     if dist:
         dist.barrier()
-    if not os.environ.get('HLA_BENCH_NOCHECK'):     # timing-ablation builds (tools/variants.py) produce garbage
+    if not os.environ.get('HLA_BENCH_NOCHECK'):     # timing-ablation library builds (tools/ab_libs.py) produce garbage
         assert all(torch.isfinite(o).all() for o in out)
 
     headline_cfg = (a.model == 'kitti' and B == 32 and a.sat_a == 512 and tuple(a.grd_hw) == (256, 1024) and a.n_iters == 5)
@@ -617,7 +617,7 @@ def main(argv=None):
     by_precision, secondary = None, None
     if world == 1 and headline_cfg and not a.no_extra_legs:
         by_precision = {}
-        for p in ('fp32', 'fp16x3', 'bf16'):
+        for p in ('fp32', 'fp16x3', 'bf16', 'fp16'):     # (fp16: the dtype configs[4] names, on configs[1]'s workload)
             try:
                 if p == a.precision:
                     e = {'value': round(B * a.steps / dt, 3), 'ms_per_step': round(dt / a.steps * 1e3, 3), 'steps': a.steps}
