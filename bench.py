@@ -518,6 +518,7 @@ def main(argv=None):
     if a.n_iters is None:
         a.n_iters = 10 if a.model == 'ford' else 5
 
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')    # (also when a launcher started us: before the first HIP call)
     wr = resolve_world(a.gpus, os.environ)
     if wr is None:                       # `python bench.py --gpus N` with no launcher: be the launcher
         sys.exit(self_launch(a.gpus, argv))
