@@ -1243,15 +1243,12 @@ static void launch_conv(hipStream_t st, ConvArgs a, bool pool) {
   a.tiles_x = (a.W + 31) / 32;
   a.tiles_y = (a.H - a.row_begin + 7) / 8;
   // (the 64-channel block at three workgroups per CU for the Cout >= 128 layers as well: 259 against 244 us per launch, same-box A/B)
-#ifndef HLA_SMALLK
-#define HLA_SMALLK 0
-#endif
-  const bool big = a.Cout >= 128 && !(a.C1 + a.C2 <= HLA_SMALLK && !a.sumsq);
-  const dim3 grid(a.tiles_x * a.tiles_y * a.B, big ? a.Cout / 128 : a.Cout / 64);
+  const bool big = a.Cout >= 128;
+  const dim3 grid(a.tiles_x * a.tiles_y * a.B, big ? a.Cout / 128 : 1);
   const size_t es = sizeof(T), P = (size_t)a.B * (a.H - a.row_begin) * a.W, Po = pool ? P / 4 : P;
   const double flops = 2.0 * 9.0 * (a.C1 + a.C2) * a.Cout * (double)P;
   const double bytes = (double)P * ((a.up1 ? a.C1 / 4.0 : a.C1) + a.C2) * es + (double)Po * a.Cout * ((a.out_act ? es : 0) + (a.out_raw ? 4 : 0));
-  hla_prof_begin(big ? (pool ? K_CONV_NT2_POOL : K_CONV_NT2) : (pool ? K_CONV_NT1_POOL : K_CONV_NT1), flops, bytes, st);
+  hla_prof_begin(a.Cout >= 128 ? (pool ? K_CONV_NT2_POOL : K_CONV_NT2) : (pool ? K_CONV_NT1_POOL : K_CONV_NT1), flops, bytes, st);
   // Cout >= 128: block = 8x32 pixels x 128 channels, waves 2(M) x 2(N), wave tile 128 px x 64 ch, weights 1 tap ahead
   // Cout == 64 : block = 8x32 pixels x  64 channels, waves 2 x 2,       wave tile 128 px x 32 ch, weights 2 taps ahead
   if (big) {
