@@ -55,6 +55,8 @@ def _param_table(module: 'VGGUnet'):
         prm.w[i] = w.data_ptr()
         if i < 7:
             b = sd[name + '.bias']
+            if i == 0:          # conv0's bias is part of the packed fragments (include/hla.h): a change of it alone repacks
+                versions.append((b.data_ptr(), b._version))
             b = b.detach().contiguous().float()
             keep.append(b)
             prm.b[i] = b.data_ptr()

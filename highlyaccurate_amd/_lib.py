@@ -17,7 +17,7 @@ HLA_F32, HLA_BF16, HLA_F16, HLA_F16X3 = 0, 1, 2, 3
 HLA_VGG_WANT_CONF, HLA_VGG_DEFER_NORM, HLA_VGG_SAVE_FOR_BACKWARD, HLA_VGG_FEAT16 = 1, 2, 4, 8
 HLA_VGG_BWD_SCALE_INVARIANT = 1
 HLA_VGG_BWD_DENSE = 2
-ABI_VERSION = 17
+ABI_VERSION = 18
 
 
 class HlaError(RuntimeError):

@@ -817,6 +817,9 @@ template <typename T, int WD>
 // the 168-register cap costs it 31 spills: 1430 us per launch either way, same-box A/B)
 __global__ __launch_bounds__(256, Prec<T>::SPLIT ? 2 : 3) void conv02_kernel(Conv02Args a0) {
   constexpr bool SPLIT = Prec<T>::SPLIT;
+  // 16-bit types: conv0's bias and the zeroing of halo pixels outside the image ride in the MFMA (k slots 27 / 28 = bias hi / lo
+  // against an input of 1.0; an all-zero input column for a pixel outside) instead of 64 adds + 64 selects per 32 pixels and lane
+  constexpr bool FOLD = sizeof(T) == 2 && !SPLIT;      // (513 / 517 -> 508 / 504 us per launch, 132 -> 128 registers; same-box A/B x2)
   constexpr int EPL = Prec<T>::CEPL, KC = SB / sizeof(T), NSG = 64 / KC, NFRAG = 32 / (2 * EPL), NH = SPLIT ? 2 : 1;
   constexpr int MT = 4, NT = 1, WN = 2, TH = 8, HPIX = (TH + 2) * HWID, BUF = HPIX * PSTR, IW = 36, IH = 12;
   constexpr int ROUNDS = conv02_rounds<T>(), SPR = NSG / ROUNDS, JPR = 2 / ROUNDS;   // stages / 32-channel halves per round
@@ -899,12 +902,15 @@ __global__ __launch_bounds__(256, Prec<T>::SPLIT ? 2 : 3) void conv02_kernel(Con
   for (int rd = 0; rd < ROUNDS; ++rd) {
   const int j0 = rd * JPR;                           // first 32-channel half of conv0's output this round produces
   if (rd > 0) load_w0(j0);
-  load_b0(j0);
+  if (!FOLD) load_b0(j0);
   if (rd > 0) __syncthreads();                       // the previous round's MFMAs are done with the buffers
   for (int m = wv; m * 32 < HPIX; m += 4) {
     const int p = m * 32 + x, pc = p < HPIX ? p : HPIX - 1;
     const int hy = pc / HWID, hx = pc - hy * HWID;
     const float* ib = in + hy * IW + hx;
+    // conv2 zero-pads conv0's OUTPUT map: halo pixels outside the image are 0, not conv0 of padded input
+    const int yy = y0 - 1 + hy, xx = x0 - 1 + hx;
+    const bool inside = yy >= 0 && yy < a0.H && xx >= 0 && xx < a0.W;
     f32x16 c0[2];
 #pragma unroll
     for (int j = j0; j < j0 + JPR; ++j)
@@ -920,8 +926,8 @@ __global__ __launch_bounds__(256, Prec<T>::SPLIT ? 2 : 3) void conv02_kernel(Con
         const int ol = kl < 27 ? (kl / 9) * IH * IW + ((kl % 9) / 3) * IW + (kl % 9) % 3 : 0;
         const int oh = kh < 27 ? (kh / 9) * IH * IW + ((kh % 9) / 3) * IW + (kh % 9) % 3 : 0;
         float v = ib[g ? oh : ol];
-        if (kh >= 27 && g) v = 0.f;                          // padded k (27..31) only occurs in the upper half
-        if (kl >= 27 && !g) v = 0.f;
+        if (kh >= 27 && g) v = (FOLD && kh <= 28) ? 1.f : 0.f;      // padded k (27..31) only occurs in the upper half;
+        if (kl >= 27 && !g) v = (FOLD && kl <= 28) ? 1.f : 0.f;     //   FOLD: 27 / 28 multiply the bias (hi, lo)
         ev[jj] = v;
       }
       if constexpr (SPLIT) {
@@ -939,14 +945,12 @@ __global__ __launch_bounds__(256, Prec<T>::SPLIT ? 2 : 3) void conv02_kernel(Con
         T e[EPL];
 #pragma unroll
         for (int jj = 0; jj < EPL; ++jj) e[jj] = (T)ev[jj];
-        const uint4 pf = __builtin_bit_cast(uint4, e);
+        uint4 pf = __builtin_bit_cast(uint4, e);
+        if (FOLD && !inside) pf = make_uint4(0u, 0u, 0u, 0u);
 #pragma unroll
         for (int j = j0; j < j0 + JPR; ++j) mma16<T>(c0[j], wf0[j - j0][f][0], pf);
       }
     }
-    // conv2 zero-pads conv0's OUTPUT map: halo pixels outside the image are 0, not conv0 of padded input
-    const int yy = y0 - 1 + hy, xx = x0 - 1 + hx;
-    const bool inside = yy >= 0 && yy < a0.H && xx >= 0 && xx < a0.W;
     if (p < HPIX) {
 #pragma unroll
       for (int j = j0; j < j0 + JPR; ++j)
@@ -954,10 +958,16 @@ __global__ __launch_bounds__(256, Prec<T>::SPLIT ? 2 : 3) void conv02_kernel(Con
         for (int q = 0; q < 4; ++q) {
           const int co = j * 32 + q * 8 + g * 4, sl = co / KC - rd * SPR;      // channel, its stage buffer within this round
           const int byte = (co % KC) * (SPLIT ? 2 : (int)sizeof(T));           // where the 4 channels start inside the pixel's stage
-          const float4 bb = bias0[j - j0][q];
-          float v0 = fmaxf(c0[j][q * 4 + 0] * d0 + bb.x, 0.f), v1 = fmaxf(c0[j][q * 4 + 1] * d0 + bb.y, 0.f);
-          float v2 = fmaxf(c0[j][q * 4 + 2] * d0 + bb.z, 0.f), v3 = fmaxf(c0[j][q * 4 + 3] * d0 + bb.w, 0.f);
-          if (!inside) v0 = v1 = v2 = v3 = 0.f;
+          float v0, v1, v2, v3;
+          if constexpr (FOLD) {
+            v0 = fmaxf(c0[j][q * 4 + 0], 0.f); v1 = fmaxf(c0[j][q * 4 + 1], 0.f);
+            v2 = fmaxf(c0[j][q * 4 + 2], 0.f); v3 = fmaxf(c0[j][q * 4 + 3], 0.f);
+          } else {
+            const float4 bb = bias0[j - j0][q];
+            v0 = fmaxf(c0[j][q * 4 + 0] * d0 + bb.x, 0.f); v1 = fmaxf(c0[j][q * 4 + 1] * d0 + bb.y, 0.f);
+            v2 = fmaxf(c0[j][q * 4 + 2] * d0 + bb.z, 0.f); v3 = fmaxf(c0[j][q * 4 + 3] * d0 + bb.w, 0.f);
+            if (!inside) v0 = v1 = v2 = v3 = 0.f;
+          }
           if constexpr (SPLIT) {
             uint2 hi, lo;
             split4(v0, v1, v2, v3, s_a0, hi, lo);
@@ -1029,9 +1039,11 @@ __global__ __launch_bounds__(256, Prec<T>::SPLIT ? 2 : 3) void conv02_kernel(Con
 //   Every layer's buffer is padded by two taps of fragments (the kernels prefetch up to 2 taps ahead).
 //   mode 2 (dgrad): the packed conv is the transpose: Cout' = Cin_orig, Cin' = Cout_orig, taps flipped:
 //            v = w_orig[cin'][cout'][8 - tap]  with w_orig laid out [Cout_orig = Cin'][Cin_orig = Cout'][9]
+// conv0 (first == 1) with `b0`: k = 27 / 28 hold the bias as (hi, lo) of the packed type -- the fused kernel feeds 1.0 there
+// for the 16-bit types, so the bias rides in the MFMA (its rounding error 2^-17 relative; for T = float lo is exactly 0)
 template <typename T>
 __device__ __forceinline__ void pack_weights_body(const float* __restrict__ w, T* __restrict__ out, int Cout, int Cin, int first,
-                                                  size_t e0, size_t stride) {
+                                                  size_t e0, size_t stride, const float* __restrict__ b0 = nullptr) {
   constexpr int EPL = 16 / sizeof(T), KC = SB / sizeof(T), NFRAG = 32 / (2 * EPL);
   const size_t total = first == 1 ? (size_t)(Cout / 32) * NFRAG * 64 * EPL : (size_t)Cout * Cin * 9;
   for (size_t e = e0; e < total; e += stride) {
@@ -1044,6 +1056,8 @@ __device__ __forceinline__ void pack_weights_body(const float* __restrict__ w, T
       const int nt = (int)r;
       const int k = f * 2 * EPL + (lane >> 5) * EPL + j, cout = nt * 32 + (lane & 31);
       if (k < 27) v = w[(size_t)cout * 27 + k];
+      else if (b0 && k == 27) v = (float)(T)b0[cout];
+      else if (b0 && k == 28) v = b0[cout] - (float)(T)b0[cout];
     } else {
       const int kg = r % 2; r /= 2;
       const int tap = r % 9; r /= 9;
@@ -1065,12 +1079,13 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, T* __restrict__
 struct PackTable {
   const float* w[16]; size_t off[16];      // source weights, byte offset of the packed layer
   int cout[16], cin[16], first[16];
+  const float* b0;                         // conv0's bias (rides in its padded k slots, see pack_weights_body), or null
 };
 template <typename T>
 __global__ void pack_weights_multi_kernel(PackTable tb, char* __restrict__ packed) {
   const int l = blockIdx.y;
   pack_weights_body<T>(tb.w[l], (T*)(packed + tb.off[l]), tb.cout[l], tb.cin[l], tb.first[l],
-                       (size_t)blockIdx.x * blockDim.x + threadIdx.x, (size_t)gridDim.x * blockDim.x);
+                       (size_t)blockIdx.x * blockDim.x + threadIdx.x, (size_t)gridDim.x * blockDim.x, tb.first[l] == 1 ? tb.b0 : nullptr);
 }
 
 // Split-fp16 packing: the same fragment order with the two k-groups of a stage replaced by (hi, lo) of ONE 16-channel

@@ -12,6 +12,7 @@ void vgg_pack_all(const hla_vgg_params* prm, char* packed, int dtype, hipStream_
   if (Prec<T>::SPLIT) (void)hipMemsetAsync(tail, 0, kPackTailBytes, st);
   if constexpr (!Prec<T>::SPLIT) {
     PackTable tb{};
+    tb.b0 = prm->b[0];
     int n = 0;
     for (int l = 0; l < kAllLayers; ++l) {
       if (l >= kPackedLayers && !prm->w[l]) continue;      // conv_dec3.* only when the caller supplies its padded weights
@@ -197,6 +198,7 @@ extern "C" size_t hla_vgg_packed_weight_bytes(int dtype) {
 extern "C" int hla_vgg_pack_weights(const hla_vgg_params* params, void* packed, int dtype, hla_stream_t stream) {
   HLA_REQUIRE(params && packed, "hla_vgg_pack_weights: null argument");
   HLA_REQUIRE(hla_dtype_ok(dtype), "hla_vgg_pack_weights: bad dtype %d", dtype);
+  HLA_REQUIRE(params->w[0] && params->b[0], "hla_vgg_pack_weights: conv0's weight and bias are required (the bias is packed with it)");
   if (dtype == HLA_BF16) vgg_pack_all<bf16>(params, (char*)packed, dtype, (hipStream_t)stream);
   else if (dtype == HLA_F16) vgg_pack_all<f16>(params, (char*)packed, dtype, (hipStream_t)stream);
   else if (dtype == HLA_F16X3) vgg_pack_all<split32>(params, (char*)packed, dtype, (hipStream_t)stream);

@@ -60,7 +60,7 @@ const char* hla_last_error(void);
  * with its own struct sizes (ctypes structs are positional: a mismatch corrupts silently).  highlyaccurate_amd/_lib.py
  * does both at load time, and rebuilds or refuses a binary whose hla_source_hash() is not the hash of the sources
  * next to it (the library is git-ignored but shipped prebuilt). */
-#define HLA_ABI_VERSION 17
+#define HLA_ABI_VERSION 18
 int hla_abi_version(void);
 const char* hla_source_hash(void); /* sha256 (hex) of the csrc sources, this header and the compiler flags at build time */
 typedef enum hla_struct_id {
@@ -95,8 +95,9 @@ enum {
 };
 
 /* Weights are re-laid-out once into MFMA fragment order (bf16 or fp32) and reused until they change.
- * hla_vgg_pack_weights reads params->w[0..10] (conv0..conv_dec2.3) and fills `packed`
- * (hla_vgg_packed_weight_bytes(dtype) bytes).  Call it again after an optimizer step. */
+ * hla_vgg_pack_weights reads params->w[0..10] (conv0..conv_dec2.3) AND params->b[0] (conv0's bias rides in the padded k slots
+ * of its fragments: the fused conv0 + conv2 kernel adds it inside the matrix product for the 16-bit types) and fills `packed`
+ * (hla_vgg_packed_weight_bytes(dtype) bytes).  Call it again after an optimizer step -- also when only conv0's bias changed. */
 size_t hla_vgg_packed_weight_bytes(int dtype);
 int hla_vgg_pack_weights(const hla_vgg_params* params, void* packed, int dtype, hla_stream_t stream);
 

@@ -91,6 +91,34 @@ def test_vgg_small_vs_golden(kat, precision, tol):
         assert ec < max(tol, 2e-6), (precision, l, ec)
 
 
+@pytest.mark.parametrize('precision', ['bf16', 'fp16', 'fp32'])
+def test_conv0_bias_change_alone_repacks(precision):
+    """conv0's bias is part of the packed weight fragments (it rides in the padded k slots of the fused conv0 + conv2 kernel for
+    the 16-bit types; include/hla.h): an in-place change of that bias ALONE must invalidate the module's packed-weight cache --
+    the maps change, and they equal, bit for bit, those of a fresh module built from the same state dict."""
+    from oracle import ref_cpu as O
+    from highlyaccurate_amd.VGG import VGGUnet
+    d = _dev()
+    rs = np.random.RandomState(33)
+    sd = O.synth_vgg_state(rs, bias_scale=0.05)
+    x = T(rs.random_sample((2, 3, 32, 64)).astype(np.float32)).to(d)
+    net = VGGUnet(3, precision=precision)
+    net.load_state_dict(sd)
+    net = net.to(d)
+    with torch.no_grad():
+        f0 = [f.clone() for f in net(x)[0]]
+        net.conv0.bias.add_(0.25 * torch.sign(net.conv0.bias) + 0.1)
+        f1 = [f.clone() for f in net(x)[0]]
+    assert any(not torch.equal(a, b) for a, b in zip(f0, f1)), 'the changed bias did not reach the kernel'
+    fresh = VGGUnet(3, precision=precision)
+    fresh.load_state_dict(net.state_dict())
+    fresh = fresh.to(d)
+    with torch.no_grad():
+        f2 = fresh(x)[0]
+    for a, b in zip(f1, f2):
+        assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize('precision,tol', [('fp32', 1e-5), ('fp16x3', 1e-5), ('bf16', 3e-2)])
 def test_vgg_level4_vs_golden(kat, precision, tol):
     """VGGUnet(level=4): the fourth map x24 (conv_dec3 on cat(up(x21), x2), 16 channels at full resolution) and conf3
