@@ -1,3 +1,11 @@
+"""Per-launch durations of the split-K reductions (reduce_partials4_kernel) of ONE training step, from a rocprofv3 kernel trace:
+
+    cd /tmp && rocprofv3 --kernel-trace --output-format csv -d $REPO/gpurun_out/tr -- python $REPO/bench.py --steps 1 --warmup 0 \
+        --no-cpu-baseline --no-kernel-timing --no-extra-legs --train-steps 2;  cd $REPO && python tools/probes/reduce_trace.py
+
+What it showed (round 3): on the stream that owns the chip a reduction takes 13-96 us (75 MB of partials each); on the side stream,
+next to the other branch's MFMA kernels, the SAME launches show 31-453 us -- they wait for workgroup slots.  The 7.8 % this
+kernel has in the training step's rocprof --stats CSV is mostly that waiting, not work."""
 import csv, glob, sys
 f=glob.glob('gpurun_out/tr/**/*kernel_trace.csv', recursive=True)[0]
 rows=list(csv.DictReader(open(f)))
