@@ -287,7 +287,9 @@ __device__ __forceinline__ int epilogue_mode(const ConvArgs& a) {
 }
 // R16: the raw copy is written in fp16 (16-bit activation types only) instead of fp32; its sum of squares is that of the
 // ROUNDED values, so that inv_norm normalises exactly the map the LM loop will read.
-template <typename T, int MT, int NT, bool POOL, int EPI = EPI_GENERIC, bool R16 = false>
+// STGW: bytes of the wave's row stager.  The activation-only form (EPI_ACT) stages as many output rows side by side as fit there
+// and stores them together: the LDS write -> read turn-around is paid once per batch instead of once per row.
+template <typename T, int MT, int NT, bool POOL, int EPI = EPI_GENERIC, bool R16 = false, int STGW = 0>
 __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[MT][NT], const ConvArgs& a, int b, int yrow0, int x0,
                                               int cb, float* red, char* stage, float dsc = 1.f,
                                               PixBox addb = PixBox{0, 1 << 30, 0, 1 << 30}) {
@@ -322,8 +324,52 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[MT][NT], const ConvA
   const int xo0 = POOL ? x0 >> 1 : x0;
   const int nvalid = min(NPX, Wo - xo0);              // pixels of this row segment inside the image
   float ss = 0.f, mx = 0.f;
+  constexpr int ROWB = 32 * RowStager<T, NT>::PITCH;
+  constexpr bool BATCH = EPI == EPI_ACT && STGW >= 2 * ROWB;
+  if constexpr (BATCH) {
+    constexpr int STEP = POOL ? 2 : 1, NR = MT / STEP;
+    constexpr int RB = STGW / ROWB >= NR ? NR : 2;       // output rows per batch
+    static_assert(NR % RB == 0, "row batches");
 #pragma unroll
-  for (int i = 0; i < MT; i += (POOL ? 2 : 1)) {
+    for (int r0 = 0; r0 < NR; r0 += RB) {
+#pragma unroll
+      for (int rr = 0; rr < RB; ++rr) {
+        const int i = (r0 + rr) * STEP;
+        const bool lane_ok = (yrow0 + i < a.H) && (x0 + x < a.W) && (!POOL || !(x & 1));
+        const int px = POOL ? x >> 1 : x;
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            float w[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              float t = acc[i][j][q * 4 + e];
+              if (POOL) {
+                t = fmaxf(t, acc[i + 1][j][q * 4 + e]);
+                t = fmaxf(t, __shfl_xor(t, 1, 64));
+              }
+              if (Prec<T>::SPLIT) t *= dsc;
+              w[e] = t;
+            }
+            w[0] = fmaxf(w[0] + bias[j][q].x, 0.f); w[1] = fmaxf(w[1] + bias[j][q].y, 0.f);
+            w[2] = fmaxf(w[2] + bias[j][q].z, 0.f); w[3] = fmaxf(w[3] + bias[j][q].w, 0.f);
+            if (Prec<T>::SPLIT && lane_ok) mx = fmaxf(fmaxf(mx, fmaxf(w[0], w[1])), fmaxf(w[2], w[3]));
+            if (!POOL || !(x & 1)) RowStager<T, NT>::put(stage + rr * ROWB, px, j * 32 + q * 8 + g * 4, w[0], w[1], w[2], w[3]);
+          }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int rr = 0; rr < RB; ++rr) {
+        const int y = yrow0 + (r0 + rr) * STEP;
+        const size_t pix0 = ((size_t)b * Ho + (POOL ? y >> 1 : y)) * Wo + xo0;
+        if (y < a.H) RowStager<T, NT>::template flush<true>(stage + rr * ROWB, (T*)a.out_act + pix0 * a.Cout + cb, NPX, nvalid, a.Cout, lane);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < (BATCH ? 0 : MT); i += (POOL ? 2 : 1)) {
     const int y = yrow0 + i;
     const int yo = POOL ? y >> 1 : y;
     const bool row_ok = y < a.H;                      // wave-uniform
@@ -765,7 +811,7 @@ __global__ __launch_bounds__(256, NT == 1 ? 3 : 2) void conv3x3_kernel(ConvArgs 
     // the generic path's 21 k -- so only its bias-free form is compiled there; that is the one the model uses: dec1.3)
     constexpr bool RAW_SPECIAL = POOL || NT == 1;
     constexpr bool T16 = sizeof(T) == 2;
-    if (mode == EPI_ACT) conv_epilogue<T, MT, NT, POOL, EPI_ACT>(acc, a, b, y0 + wm * MT, x0, ntg0 * 32, red, stager, dsc, addb);
+    if (mode == EPI_ACT) conv_epilogue<T, MT, NT, POOL, EPI_ACT, false, LDSB / 4>(acc, a, b, y0 + wm * MT, x0, ntg0 * 32, red, stager, dsc, addb);
     // (16-bit raw copy, HLA_VGG_FEAT16: only the three feature layers ask for it -- conv14: pooled + bias; dec1.3 / dec2.3:
     // no bias -- and exactly those forms are compiled)
     else if (T16 && RAW_SPECIAL && a.raw16 && mode == EPI_ACT_RAW)
@@ -1024,11 +1070,11 @@ __global__ __launch_bounds__(256, Prec<T>::SPLIT ? 2 : 3) void conv02_kernel(Con
   if (a0.a2_out) {   // the epilogue only reads the accumulators: run it twice, un-pooled first
     ConvArgs f = a;
     f.out_act = a0.a2_out; f.idx_out = nullptr; f.amax_out = a0.amax_a2_out;
-    conv_epilogue<T, MT, NT, false, EPI_ACT>(acc, f, b, y0 + wm * MT, x0, wn * 32, red, lds + wv * (SPR * BUF / 4), dsc2);
+    conv_epilogue<T, MT, NT, false, EPI_ACT, false, SPR * BUF / 4>(acc, f, b, y0 + wm * MT, x0, wn * 32, red, lds + wv * (SPR * BUF / 4), dsc2);
     if (SPLIT) __syncthreads();     // `red` is reused by the second epilogue's maximum
   }
   if (a.idx_out) conv_epilogue<T, MT, NT, true, EPI_GENERIC>(acc, a, b, y0 + wm * MT, x0, wn * 32, red, lds + wv * (SPR * BUF / 4), dsc2);
-  else conv_epilogue<T, MT, NT, true, EPI_ACT>(acc, a, b, y0 + wm * MT, x0, wn * 32, red, lds + wv * (SPR * BUF / 4), dsc2);
+  else conv_epilogue<T, MT, NT, true, EPI_ACT, false, SPR * BUF / 4>(acc, a, b, y0 + wm * MT, x0, wn * 32, red, lds + wv * (SPR * BUF / 4), dsc2);
 }
 
 // ---------------------------------------------------------------------------------------------
