@@ -628,9 +628,14 @@ def main(argv=None):
                     torch.cuda.empty_cache()
                     net = build_net('kitti', p, 5, dev)
                     k = 10 if p == 'fp32' else 20
+                    # (two blocks of k steps, the faster one counts, both are reported: these short secondary legs run right after
+                    #  a new library module was first used; one-off stalls of tens of ms showed up in them on fresh boxes)
                     pdt, pout = timed_infer(net, sat, grd, extra, k, 3, None)
+                    pdt2, pout = timed_infer(net, sat, grd, extra, k, 0, None)
                     assert all(torch.isfinite(o).all() for o in pout)
-                    e = {'value': round(B * k / pdt, 3), 'ms_per_step': round(pdt / k * 1e3, 3), 'steps': k}
+                    blocks = [round(t / k * 1e3, 3) for t in (pdt, pdt2)]
+                    pdt = min(pdt, pdt2)
+                    e = {'value': round(B * k / pdt, 3), 'ms_per_step': round(pdt / k * 1e3, 3), 'steps': k, 'blocks_ms_per_step': blocks}
                     prec_recs = kernel_pass(net, sat, grd, extra, 5)[0] if not a.no_kernel_timing else []
                 e['unit'] = 'pairs/s'
                 if prec_recs:
