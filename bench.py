@@ -654,8 +654,12 @@ def main(argv=None):
                 net = build_net(kw['model'], kw['precision'], kw['n_iters'], dev)
                 s2, g2, x2 = make_inputs(kw['model'], kw['B'], kw['grd_hw'], kw['sat_a'], dev, rank)
                 sdt, sout = timed_infer(net, s2, g2, x2, kw['steps'], 5, None)
+                sdt2, sout = timed_infer(net, s2, g2, x2, kw['steps'], 0, None)      # (two blocks, as for by_precision above)
+                sblocks = [round(t / kw['steps'] * 1e3, 3) for t in (sdt, sdt2)]
+                sdt = min(sdt, sdt2)
                 secondary[tag] = {'value': round(kw['B'] * kw['steps'] / sdt, 3), 'unit': 'pairs/s', 'dtype': kw['precision'],
-                                  'ms_per_step': round(sdt / kw['steps'] * 1e3, 3), 'steps': kw['steps'], 'pairs_per_gpu': kw['B'],
+                                  'ms_per_step': round(sdt / kw['steps'] * 1e3, 3), 'blocks_ms_per_step': sblocks,
+                                  'steps': kw['steps'], 'pairs_per_gpu': kw['B'],
                                   'finite': bool(all(torch.isfinite(o).all() for o in sout)),
                                   'workload': workload_name(kw['model'], kw['sat_a'], kw['grd_hw'], kw['n_iters'])}
                 del s2, g2, x2

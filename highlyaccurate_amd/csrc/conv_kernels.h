@@ -295,7 +295,10 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[MT][NT], const ConvA
                                               PixBox addb = PixBox{0, 1 << 30, 0, 1 << 30}) {
   using RawT = std::conditional_t<R16, f16, float>;      // 16-bit raw maps are fp16 also in bf16 mode: 11 significand bits for the LM loop
   constexpr bool GEN = EPI == EPI_GENERIC, RAW = EPI == EPI_ACT_RAW || EPI == EPI_ACT_RAW_NOBIAS, DG = EPI == EPI_DGRAD;
-  constexpr bool NOBIAS = EPI == EPI_ACT_RAW_NOBIAS || DG;
+  // 16-bit types: the kernels START their accumulators at the bias (conv3x3_kernel / conv02_kernel), nothing to add here.
+  // (The 4-byte types keep the add behind the sum: in exact-fp32 mode the other order moved max-pool near-ties of a small
+  //  gradient test -- an equally valid rounding, but not worth re-baselining the fp32-class parity numbers for.)
+  constexpr bool NOBIAS = EPI == EPI_ACT_RAW_NOBIAS || DG || sizeof(T) == 2;
   const bool has_raw = GEN ? a.out_raw != nullptr : RAW;
   const bool has_act = GEN ? a.out_act != nullptr : true;
   const bool relu = GEN ? a.relu_act != 0 : !DG;
@@ -352,8 +355,8 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[MT][NT], const ConvA
               if (Prec<T>::SPLIT) t *= dsc;
               w[e] = t;
             }
-            w[0] = fmaxf(w[0] + bias[j][q].x, 0.f); w[1] = fmaxf(w[1] + bias[j][q].y, 0.f);
-            w[2] = fmaxf(w[2] + bias[j][q].z, 0.f); w[3] = fmaxf(w[3] + bias[j][q].w, 0.f);
+            if (!NOBIAS) { w[0] += bias[j][q].x; w[1] += bias[j][q].y; w[2] += bias[j][q].z; w[3] += bias[j][q].w; }
+            w[0] = fmaxf(w[0], 0.f); w[1] = fmaxf(w[1], 0.f); w[2] = fmaxf(w[2], 0.f); w[3] = fmaxf(w[3], 0.f);
             if (Prec<T>::SPLIT && lane_ok) mx = fmaxf(fmaxf(mx, fmaxf(w[0], w[1])), fmaxf(w[2], w[3]));
             if (!POOL || !(x & 1)) RowStager<T, NT>::put(stage + rr * ROWB, px, j * 32 + q * 8 + g * 4, w[0], w[1], w[2], w[3]);
           }
@@ -756,16 +759,23 @@ __global__ __launch_bounds__(256, NT == 1 ? 3 : 2) void conv3x3_kernel(ConvArgs 
     }
   };
 
+  const int ntg0 = (blockIdx.y * WN + wn) * NT;     // first global 32-channel output tile of this wave
+  // The accumulators start at the bias (16-bit types; it commutes with the max-pool, and the epilogues then have neither
+  // the 8 x NT bias registers nor the adds); the 4-byte types add it in the epilogue (split mode: after its power-of-two descale).
   f32x16 acc[MT][NT];
 #pragma unroll
-  for (int i = 0; i < MT; ++i)
+  for (int j = 0; j < NT; ++j)
 #pragma unroll
-    for (int j = 0; j < NT; ++j)
+    for (int q = 0; q < 4; ++q) {
+      float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (sizeof(T) == 2 && a.bias) b4 = *(const float4*)(a.bias + (ntg0 + j) * 32 + q * 8 + (lane >> 5) * 4);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+      for (int i = 0; i < MT; ++i) {
+        acc[i][j][q * 4 + 0] = b4.x; acc[i][j][q * 4 + 1] = b4.y; acc[i][j][q * 4 + 2] = b4.z; acc[i][j][q * 4 + 3] = b4.w;
+      }
+    }
 
   const FragOff fo = frag_offsets(lane, wm * MT);
-  const int ntg0 = (blockIdx.y * WN + wn) * NT;     // first global 32-channel output tile of this wave
   // packed weights: [ntile][stage][tap][kg(2)][lane] 16-B fragments
   WeightRing<T, MT, NT, WD> ring;
 #pragma unroll
@@ -939,10 +949,6 @@ __global__ __launch_bounds__(256, Prec<T>::SPLIT ? 2 : 3) void conv02_kernel(Con
   }
   // conv2's accumulators and weight stream live across the rounds
   f32x16 acc[MT][NT];
-#pragma unroll
-  for (int i = 0; i < MT; ++i)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[i][0][r] = 0.f;
   const FragOff fo = frag_offsets(lane, wm * MT);
 #pragma unroll
   for (int rd = 0; rd < ROUNDS; ++rd) {
@@ -1057,6 +1063,17 @@ __global__ __launch_bounds__(256, Prec<T>::SPLIT ? 2 : 3) void conv02_kernel(Con
   }
 
   // phase C: conv2 over this round's resident stages (no further loads, no barriers)
+  if (rd == 0) {                // (16-bit types: the accumulators start at conv2's bias, like conv3x3_kernel's)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (sizeof(T) == 2) b4 = *(const float4*)(a0.b2 + wn * 32 + q * 8 + g * 4);
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        acc[i][0][q * 4 + 0] = b4.x; acc[i][0][q * 4 + 1] = b4.y; acc[i][0][q * 4 + 2] = b4.z; acc[i][0][q * 4 + 3] = b4.w;
+      }
+    }
+  }
   if (rd == 0) stagger_priority();
 #pragma unroll 1
   for (int sg = 0; sg < SPR; ++sg)
