@@ -898,14 +898,25 @@ __global__ __launch_bounds__(256, Prec<T>::SPLIT ? 2 : 3) void conv02_kernel(Con
   ring.prime();
 
   // phase A: input patch (2-pixel border) -> LDS
+  // (all of a thread's loads are requested before the first one is awaited: as a rolled loop this was six dependent
+  //  load -> wait -> LDS write round trips at the head of every workgroup's 11 us life)
   float amx = 0.f;
-  for (int e = t; e < 3 * IH * IW; e += 256) {
+  constexpr int NIN = (3 * IH * IW + 255) / 256;
+  float vin[NIN];
+#pragma unroll
+  for (int it = 0; it < NIN; ++it) {
+    const int e = t + it * 256;
     const int c = e / (IH * IW), r = e % (IH * IW), iy = r / IW, ix = r % IW;
     const int y = y0 - 2 + iy, xx = x0 - 2 + ix;
-    float v = 0.f;
-    if (y >= 0 && y < a0.H && xx >= 0 && xx < a0.W) v = a0.x[((size_t)b * 3 + c) * a0.x_plane + (size_t)y * a0.W + xx];
-    in[e] = v;
-    if (SPLIT) amx = fmaxf(amx, fabsf(v));
+    vin[it] = 0.f;
+    if (e < 3 * IH * IW && y >= 0 && y < a0.H && xx >= 0 && xx < a0.W)
+      vin[it] = a0.x[((size_t)b * 3 + c) * a0.x_plane + (size_t)y * a0.W + xx];
+  }
+#pragma unroll
+  for (int it = 0; it < NIN; ++it) {
+    const int e = t + it * 256;
+    if (e < 3 * IH * IW) in[e] = vin[it];
+    if (SPLIT) amx = fmaxf(amx, fabsf(vin[it]));
   }
   // conv0's weight fragments and biases of the 32-channel halves ONE round produces ([..][0] = hi, [..][1] = lo in split mode).
   // With two rounds (4-byte activation types) they are fetched per round: holding both halves' cost 32 registers, which kept
