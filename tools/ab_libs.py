@@ -17,4 +17,5 @@ for lib in libs:
     if d.get('train'):
         tk = d['train']['kernels']
         print(f"{lib:16s} train {d['train']['ms_per_step']:7.2f} ms  " + '  '.join(f"{n}:{v['avg_us']:.0f}us" for n, v in tk.items() if v['share'] > 0.03), flush=True)
-    print(f"{lib:16s} {d['value']:8.1f} pairs/s {d['ms_per_step']:7.3f} ms  " + '  '.join(f'{n}:{u:.0f}us/{t:.0f}TF' for n, (u, t) in conv.items()), flush=True)
+    lm = '  '.join(f"{n}:{v['avg_us']:.1f}us" for n, v in k.items() if n.startswith('lm_'))
+    print(f"{lib:16s} {d['value']:8.1f} pairs/s {d['ms_per_step']:7.3f} ms  " + '  '.join(f'{n}:{u:.0f}us/{t:.0f}TF' for n, (u, t) in conv.items()) + '  ' + lm, flush=True)
