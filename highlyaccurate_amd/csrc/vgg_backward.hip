@@ -459,20 +459,39 @@ __global__ __launch_bounds__(256) void wgrad0_kernel(Wgrad0Args a) {
     int b, y0, x0, gx0, gx1;
     tl.origin(tile, b, y0, x0, gx0, gx1);
     __syncthreads();
-    for (int e = t; e < 3 * (WG_TH + 2) * IW; e += 256) {
+    // (every load of a tile is requested before the first LDS write: as two rolled loops this was 14 dependent
+    //  load -> wait -> write round trips per tile against a few microseconds of MFMA work -- the kernel ran at 68 TF)
+    constexpr int NI = (3 * (WG_TH + 2) * IW + 255) / 256, NG = WG_TH * 32 * PPX / 256;
+    static_assert(WG_TH * 32 * PPX % 256 == 0, "gradient tile pieces per thread");
+    float vi[NI];
+    uint4 vg[NG];
+#pragma unroll
+    for (int it = 0; it < NI; ++it) {
+      const int e = t + it * 256;
       const int c = e / ((WG_TH + 2) * IW), r = e % ((WG_TH + 2) * IW), iy = r / IW, ix = r % IW;
       const int y = y0 - 1 + iy, x = x0 - 1 + ix;
-      float v = 0.f;
-      if (ix < HWID && y >= 0 && y < a.H && x >= 0 && x < a.W) v = a.x[((size_t)b * 3 + c) * a.x_plane + (size_t)y * a.W + x];
-      in[e] = v;
+      vi[it] = 0.f;
+      if (e < 3 * (WG_TH + 2) * IW && ix < HWID && y >= 0 && y < a.H && x >= 0 && x < a.W)
+        vi[it] = a.x[((size_t)b * 3 + c) * a.x_plane + (size_t)y * a.W + x];
     }
-    for (int e = t; e < WG_TH * 32 * PPX; e += 256) {
+#pragma unroll
+    for (int it = 0; it < NG; ++it) {
+      const int e = t + it * 256;
       const int pix = e / PPX, part = e % PPX;
       const int y = y0 + pix / 32, x = x0 + pix % 32;
-      uint4 v = make_uint4(0, 0, 0, 0);
+      vg[it] = make_uint4(0, 0, 0, 0);
       if (y < a.H && x >= gx0 && x < gx1)
-        v = *(const uint4*)((const T*)a.g + (((size_t)b * a.H + y) * a.W + x) * 64 + part * EPL);
-      *(uint4*)(Gs + pix * STR + part * 16) = v;
+        vg[it] = *(const uint4*)((const T*)a.g + (((size_t)b * a.H + y) * a.W + x) * 64 + part * EPL);
+    }
+#pragma unroll
+    for (int it = 0; it < NI; ++it) {
+      const int e = t + it * 256;
+      if (e < 3 * (WG_TH + 2) * IW) in[e] = vi[it];
+    }
+#pragma unroll
+    for (int it = 0; it < NG; ++it) {
+      const int e = t + it * 256;
+      *(uint4*)(Gs + (e / PPX) * STR + (e % PPX) * 16) = vg[it];
     }
     __syncthreads();
 #pragma unroll
