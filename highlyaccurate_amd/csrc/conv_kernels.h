@@ -612,7 +612,11 @@ __device__ __forceinline__ void stage_mma(f32x16 (&acc)[MT][NT], const char* cur
 // Occupancy: the 64-channel wave tile (NT = 2) holds 128 accumulator registers: two workgroups per CU.  The 32-channel one
 // (NT = 1, the Cout = 64 layers) fits three -- 43.5 KB of LDS each since the halo pixels lost their pad, <= 168 registers since
 // the halo staging went through half as many -- which is what hides its per-tile prologue and epilogue.
-template <typename T, int MT, int NT, int WM, int WN, bool POOL, int WD>
+// UNPOOL: the source is the gradient of a max-pooled map, expanded on the fly with the forward argmax bytes (ConvArgs::unpool_idx;
+// the data-gradient convolutions of conv2 / conv7 / conv14).  A separate instantiation: its halo loader carries the argmax bytes
+// of a piece next to the piece and applies them when the piece is WRITTEN to LDS -- masking right behind the load put an
+// s_waitcnt vmcnt(0) after every single piece, six full memory round trips per stage in the middle of the MFMA stream.
+template <typename T, int MT, int NT, int WM, int WN, bool POOL, int WD, bool UNPOOL = false>
 __global__ __launch_bounds__(256, NT == 1 ? 3 : 2) void conv3x3_kernel(ConvArgs a) {
   static_assert(WM * WN == 4, "4 waves per block");
   constexpr int EPL = 16 / sizeof(T), KC = SB / sizeof(T);     // channels per stage: 32 (bf16) / 16 (fp32)
@@ -702,7 +706,10 @@ __global__ __launch_bounds__(256, NT == 1 ? 3 : 2) void conv3x3_kernel(ConvArgs 
       wo[i] = pix >= HPIX ? -1 : (Prec<T>::SPLIT ? halo_off(pix, hx, part >> 1) + (part & 1) * 8 : halo_off(pix, hx, part));
     }
   }
-  auto load_stage = [&](int sg, int half, uint4 (&st)[NHALF]) __attribute__((always_inline)) {
+  // UNPOOL: the EPL argmax bytes of a piece (one per element) travel with it from load_stage to write_stage
+  constexpr int IDW = UNPOOL ? (EPL == 8 ? 2 : 1) : 1;
+  struct StageIds { unsigned w[NHALF][IDW]; };
+  auto load_stage = [&](int sg, int half, uint4 (&st)[NHALF], StageIds& ids) __attribute__((always_inline)) {
     const int c0 = sg * KC;
     const bool first = c0 < a.C1;       // wave-uniform
     const char* base = first ? s1b + (size_t)c0 * ES : s2b + (size_t)(c0 - a.C1) * ES;
@@ -711,43 +718,51 @@ __global__ __launch_bounds__(256, NT == 1 ? 3 : 2) void conv3x3_kernel(ConvArgs 
       const int i = half * NHALF + ii;
       uint4 v = make_uint4(0, 0, 0, 0);
       const int o = i < NPIECE ? (first ? off1[i] : off2[i]) : -1;
+      if constexpr (UNPOOL) {
+#pragma unroll
+        for (int k = 0; k < IDW; ++k) ids.w[ii][k] = 0xffffffffu;     // (matches no position: the piece stays zero)
+      }
       if (o >= 0) {
         const unsigned ob = (unsigned)o & ~15u;
         v = *(const uint4*)(base + ob);
-        if (a.unpool_idx) {          // keep only the elements whose forward argmax is this (y&1, x&1) position
-          const unsigned pos = (unsigned)o & 3u;
+        if constexpr (UNPOOL) {
           const unsigned char* idp = idxb + ob / ES + c0;      // one argmax byte per element
-          if constexpr (sizeof(T) == 2) {
-            // 8 argmax bytes -> eight 16-bit keep masks with packed 16-bit math: (id ^ pos) - 1 is negative only for a match
-            typedef short s16x2 __attribute__((ext_vector_type(2)));
-            const uint2 id = *(const uint2*)idp;
-            const unsigned m0 = id.x ^ (pos * 0x01010101u), m1 = id.y ^ (pos * 0x01010101u);
-            auto keep = [](unsigned m, unsigned sel) {
-              s16x2 w = __builtin_bit_cast(s16x2, __builtin_amdgcn_perm(0u, m, sel));   // two id bytes, zero-extended
-              w = (w - (short)1) >> 15;
-              return __builtin_bit_cast(unsigned, w);
-            };
-            v.x &= keep(m0, 0x0c010c00u); v.y &= keep(m0, 0x0c030c02u);
-            v.z &= keep(m1, 0x0c010c00u); v.w &= keep(m1, 0x0c030c02u);
-          } else {
-            T e[EPL];
-            unsigned char id[EPL];
-            __builtin_memcpy(e, &v, 16);
-            __builtin_memcpy(id, idp, EPL);
 #pragma unroll
-            for (int k = 0; k < EPL; ++k) if (id[k] != pos) e[k] = (T)0.f;
-            __builtin_memcpy(&v, e, 16);
-          }
+          for (int k = 0; k < IDW; ++k) ids.w[ii][k] = ((const unsigned*)idp)[k];
         }
       }
       st[ii] = v;
     }
   };
-  auto write_stage = [&](char* buf, int half, const uint4 (&st)[NHALF]) __attribute__((always_inline)) {
+  auto write_stage = [&](char* buf, int sg, int half, uint4 (&st)[NHALF], const StageIds& ids) __attribute__((always_inline)) {
 #pragma unroll
     for (int ii = 0; ii < NHALF; ++ii) {
       const int i = half * NHALF + ii;
       const int w = i < NPIECE ? wo[i] : -1;
+      if constexpr (UNPOOL) {      // keep only the elements whose forward argmax is this (y&1, x&1) position
+        const bool first = sg * KC < a.C1;
+        const unsigned pos = (unsigned)(i < NPIECE ? (first ? off1[i] : off2[i]) : 0) & 3u;
+        uint4 v = st[ii];
+        if constexpr (sizeof(T) == 2) {
+          // 8 argmax bytes -> eight 16-bit keep masks with packed 16-bit math: (id ^ pos) - 1 is negative only for a match
+          typedef short s16x2 __attribute__((ext_vector_type(2)));
+          const unsigned m0 = ids.w[ii][0] ^ (pos * 0x01010101u), m1 = ids.w[ii][1] ^ (pos * 0x01010101u);
+          auto keep = [](unsigned m, unsigned sel) {
+            s16x2 w2 = __builtin_bit_cast(s16x2, __builtin_amdgcn_perm(0u, m, sel));   // two id bytes, zero-extended
+            w2 = (w2 - (short)1) >> 15;
+            return __builtin_bit_cast(unsigned, w2);
+          };
+          v.x &= keep(m0, 0x0c010c00u); v.y &= keep(m0, 0x0c030c02u);
+          v.z &= keep(m1, 0x0c010c00u); v.w &= keep(m1, 0x0c030c02u);
+        } else {
+          T e[EPL];
+          __builtin_memcpy(e, &v, 16);
+#pragma unroll
+          for (int k = 0; k < EPL; ++k) if (((ids.w[ii][0] >> (8 * k)) & 0xffu) != pos) e[k] = (T)0.f;
+          __builtin_memcpy(&v, e, 16);
+        }
+        st[ii] = v;
+      }
       if constexpr (Prec<T>::SPLIT) {
         // a stage = 16 channels: [pixel][hi: 16 x fp16 | lo: 16 x fp16]; lane half g of the MFMA reads channels 8g..8g+7
         uint2 hi, lo;
@@ -782,13 +797,15 @@ __global__ __launch_bounds__(256, NT == 1 ? 3 : 2) void conv3x3_kernel(ConvArgs 
   for (int j = 0; j < NT; ++j) ring.wq[j] = a.wpk + (size_t)(ntg0 + j) * nstage * 18 * 64 + lane;
 
   uint4 st[NHALF];
+  StageIds ids;
   ring.prime();              // the first weight fragments do not depend on the halo tile: request them ahead of it
   {
     uint4 st1[NHALF];        // the prologue has registers to spare: both halves are requested back to back
-    load_stage(0, 0, st);
-    load_stage(0, 1, st1);
-    write_stage(lds, 0, st);
-    write_stage(lds, 1, st1);
+    StageIds ids1;
+    load_stage(0, 0, st, ids);
+    load_stage(0, 1, st1, ids1);
+    write_stage(lds, 0, 0, st, ids);
+    write_stage(lds, 0, 1, st1, ids1);
   }
   __syncthreads();
   stagger_priority();
@@ -797,10 +814,10 @@ __global__ __launch_bounds__(256, NT == 1 ? 3 : 2) void conv3x3_kernel(ConvArgs 
     const bool more = sg + 1 < nstage;
     char* nxt = lds + ((sg + 1) & 1) * BUF;
     stage_mma<T, MT, NT, WD>(acc, lds + (sg & 1) * BUF, fo, ring, [&](int tap) __attribute__((always_inline)) {
-      if (tap == HALO_TAP0 && more) load_stage(sg + 1, 0, st);
-      if (tap == HALO_TAP1 && more) { write_stage(nxt, 0, st); load_stage(sg + 1, 1, st); }
+      if (tap == HALO_TAP0 && more) load_stage(sg + 1, 0, st, ids);
+      if (tap == HALO_TAP1 && more) { write_stage(nxt, sg + 1, 0, st, ids); load_stage(sg + 1, 1, st, ids); }
     });
-    if (more) write_stage(nxt, 1, st);
+    if (more) write_stage(nxt, sg + 1, 1, st, ids);
     __syncthreads();
   }
   // the loop's last barrier guarantees nobody still reads the halo buffers: reuse them as 4 wave-private stagers
@@ -1327,8 +1344,14 @@ static __global__ __launch_bounds__(256) void scale_kernel(float* __restrict__ x
 
 // ---------------------------------------------------------------------------------------------
 // host: pick the tile configuration for a 3x3 conv launch (forward convs and the dgrad convs of the backward)
-template <typename T>
+// BWD: the caller is the backward pass, whose conv2 / conv7 / conv14 data gradients read a virtually un-pooled source
+// (ConvArgs::unpool_idx): only then are the UNPOOL instantiations compiled into the translation unit.
+template <typename T, bool BWD = false>
 static void launch_conv(hipStream_t st, ConvArgs a, bool pool) {
+  if (a.unpool_idx && !(BWD && !pool)) {      // (cannot happen from this library's callers; the plain kernels ignore the field)
+    fprintf(stderr, "launch_conv: an un-pooled source needs the UNPOOL kernel\n");
+    abort();
+  }
   a.tiles_x = (a.W + 31) / 32;
   a.tiles_y = (a.H - a.row_begin + 7) / 8;
   // (the 64-channel block at three workgroups per CU for the Cout >= 128 layers as well: 259 against 244 us per launch, same-box A/B)
@@ -1343,9 +1366,11 @@ static void launch_conv(hipStream_t st, ConvArgs a, bool pool) {
   if (big) {
     // (weights two taps ahead for this tile as well: spills, -1 %)
     if (pool) hipLaunchKernelGGL((conv3x3_kernel<T, 4, 2, 2, 2, true, 1>), grid, dim3(256), 0, st, a);
+    else if (BWD && a.unpool_idx) hipLaunchKernelGGL((conv3x3_kernel<T, 4, 2, 2, 2, false, 1, BWD>), grid, dim3(256), 0, st, a);
     else hipLaunchKernelGGL((conv3x3_kernel<T, 4, 2, 2, 2, false, 1>), grid, dim3(256), 0, st, a);
   } else {
     if (pool) hipLaunchKernelGGL((conv3x3_kernel<T, 4, 1, 2, 2, true, 2>), grid, dim3(256), 0, st, a);
+    else if (BWD && a.unpool_idx) hipLaunchKernelGGL((conv3x3_kernel<T, 4, 1, 2, 2, false, 2, BWD>), grid, dim3(256), 0, st, a);
     else hipLaunchKernelGGL((conv3x3_kernel<T, 4, 1, 2, 2, false, 2>), grid, dim3(256), 0, st, a);
   }
   hla_prof_end(st);

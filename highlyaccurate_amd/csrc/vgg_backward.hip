@@ -1168,7 +1168,7 @@ int vgg_backward_t(const float* x, size_t x_plane, const hla_vgg_params* prm, co
     a.out_act = out; a.mask_act = mask; a.add_src = add; a.pool_sum = pool_sum ? 1 : 0;
     a.B = B; a.H = Hout; a.W = Wout; a.Cout = n; a.relu_act = 0;
     a.row_begin = row_begin > 0 ? row_begin : 0; a.src_row_lo = src_lo > 0 ? src_lo : 0; a.add_row_lo = add_lo > 0 ? add_lo : 0;
-    launch_conv<T>(st, a, pool_sum);
+    launch_conv<T, true>(st, a, pool_sum);
   };
   // (fa1 / fa2 / ga, split mode: the amax slots of its input activation(s) and of the gradient map)
   auto wgrad = [&](int l, const void* x1, int C1, const void* x2, int C2, int up1, const void* g, const unsigned char* unpool,
