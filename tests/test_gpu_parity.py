@@ -91,6 +91,37 @@ def test_vgg_small_vs_golden(kat, precision, tol):
         assert ec < max(tol, 2e-6), (precision, l, ec)
 
 
+@pytest.mark.parametrize('shape', [(1, 40, 72), (2, 56, 200), (3, 88, 104), (1, 8, 8), (2, 264, 40)])
+@pytest.mark.parametrize('level', [3, 4])
+def test_vgg_16bit_modes_on_ragged_shapes_vs_fp32_mode(shape, level):
+    """The 16-bit types have code of their own (conv0's bias inside the matrix product, accumulators that start at the bias, the
+    batched activation epilogue) that the randomised fp32-class harness never runs.  Image sizes that are multiples of 8 but not
+    of the 8 x 32-pixel conv tiles, non-zero biases: every map of the bf16 / fp16 modes against the library's own exact-fp32
+    mode (itself gated against the reference) within the modes' rounding -- a boundary bug shows up as O(1), not as 1e-2."""
+    from oracle import ref_cpu as O
+    from highlyaccurate_amd.VGG import VGGUnet
+    d = _dev()
+    B, H, W = shape
+    rs = np.random.RandomState(1000 * H + W)
+    sd = O.synth_vgg_state(rs, bias_scale=0.05)
+    x = T(rs.random_sample((B, 3, H, W)).astype(np.float32)).to(d)
+    outs = {}
+    for precision in ('fp32', 'bf16', 'fp16'):
+        net = VGGUnet(level, precision=precision)
+        net.load_state_dict(sd)
+        net = net.to(d)
+        with torch.no_grad():
+            f, c = net(x)
+        outs[precision] = ([t.float().cpu().numpy() for t in f], [t.float().cpu().numpy() for t in c])
+    for precision, tol in (('bf16', 4e-2), ('fp16', 6e-3)):
+        for l in range(len(outs['fp32'][0])):
+            ref, got = outs['fp32'][0][l], outs[precision][0][l]
+            assert got.shape == ref.shape and np.isfinite(got).all()
+            e = np.abs(got - ref).max() / np.abs(ref).max()
+            ec = np.abs(outs[precision][1][l] - outs['fp32'][1][l]).max()
+            assert e < tol and ec < tol, (precision, l, e, ec)
+
+
 @pytest.mark.parametrize('precision', ['bf16', 'fp16', 'fp32'])
 def test_conv0_bias_change_alone_repacks(precision):
     """conv0's bias is part of the packed weight fragments (it rides in the padded k slots of the fused conv0 + conv2 kernel for
