@@ -34,6 +34,9 @@ struct SolveArgs {
   const int* in_view;    // [B] pixels in view in this step (count_in_view), or null
   LmSolveCfg cfg;
   LmGeom next;           // geometry of the level the NEXT step runs on
+  // init launch only (part == null): what used to be two hipMemsetAsync launches in front of every forward
+  unsigned* zero_ticket; // [steps][B] arrival counters of all steps, or null
+  int zero_steps, zero_pose;   // zero_pose: no initial pose was given, start from 0
 };
 
 // One wave closes a step for sample b.  COHERENT: the tile partials were written by OTHER workgroups of the same launch
@@ -41,6 +44,14 @@ struct SolveArgs {
 template <bool COHERENT>
 __device__ __forceinline__ void lm_solve_body(const SolveArgs& a, int b, int lane) {
   float su = a.pose[b * 3 + 0], sv = a.pose[b * 3 + 1], th = a.pose[b * 3 + 2];
+  if (!a.part) {          // the init launch also clears this sample's arrival counters and, without an initial pose, its pose
+    if (a.zero_ticket)
+      for (int k = lane; k < a.zero_steps; k += 64) a.zero_ticket[(size_t)k * a.B + b] = 0u;
+    if (a.zero_pose) {
+      su = sv = th = 0.f;
+      if (lane < 3) a.pose[b * 3 + lane] = 0.f;
+    }
+  }
 
   if (a.part) {
     double s[14];
@@ -387,7 +398,7 @@ extern "C" int hla_s2g_lm_solve(const hla_s2g_config* cfg, const hla_s2g_level* 
   double* part = (double*)(ws + opart);
 
   if (pose0) HLA_CHECK_HIP(hipMemcpyAsync(pose, pose0, (size_t)B * 3 * sizeof(float), hipMemcpyDeviceToDevice, st));
-  else HLA_CHECK_HIP(hipMemsetAsync(pose, 0, (size_t)B * 3 * sizeof(float), st));
+  // (otherwise the init launch below starts the pose at zero; it also clears the arrival counters: two memset launches less)
 
   const int L = cfg->n_levels, N = cfg->n_iters, steps = L * N;
   auto step_level = [&](int k) { return cfg->level_first ? k / N : k % L; };
@@ -402,7 +413,6 @@ extern "C" int hla_s2g_lm_solve(const hla_s2g_config* cfg, const hla_s2g_level* 
   double* adam = (double*)(ws + need - hla_align_up((size_t)B * 6 * sizeof(double), 256));
   int* in_view = (int*)((char*)adam - hla_align_up((size_t)B * steps * sizeof(int), 256));
   unsigned* ticket = (unsigned*)((char*)in_view - hla_align_up((size_t)B * steps * sizeof(unsigned), 256));
-  HLA_CHECK_HIP(hipMemsetAsync(ticket, 0, (size_t)B * steps * sizeof(unsigned), st));
   const bool count = cfg->count_in_view && normal_eq;
   if (count) HLA_CHECK_HIP(hipMemsetAsync(in_view, 0, (size_t)B * steps * sizeof(int), st));
   if (cfg->optimizer == 2) HLA_CHECK_HIP(hipMemsetAsync(adam, 0, (size_t)B * 6 * sizeof(double), st));
@@ -416,7 +426,9 @@ extern "C" int hla_s2g_lm_solve(const hla_s2g_config* cfg, const hla_s2g_level* 
 
   // init launch: coefficients of step 0
   sa.part = nullptr; sa.next = geom(step_level(0));
+  sa.zero_ticket = ticket; sa.zero_steps = steps; sa.zero_pose = pose0 ? 0 : 1;
   hipLaunchKernelGGL(lm_solve, dim3(B), dim3(64), 0, st, sa);
+  sa.zero_ticket = nullptr; sa.zero_steps = 0; sa.zero_pose = 0;
 
   for (int k = 0; k < steps; ++k) {
     const int l = step_level(k), it = step_iter(k);
