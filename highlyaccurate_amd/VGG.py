@@ -141,7 +141,10 @@ def vgg_forward_nhwc(module: 'VGGUnet', x: torch.Tensor, want_conf: bool = True,
     # ws is only used by work already enqueued on this stream; the caching allocator keeps the block
     # stream-ordered, so dropping the Python reference here is safe.
     if save_for_backward:
-        return feats, confs, inv_norm, dict(x=x, x_plane=x_plane, ws=ws, feats=feats, inv_norm=inv_norm, dt=dt, L=L)
+        # The backward reads x again (conv0's weight gradient) and x may be a window of the caller's own image storage: like
+        # autograd's saved tensors, remember its version counter -- an in-place change before backward() raises there instead of
+        # silently producing the gradient of another image.
+        return feats, confs, inv_norm, dict(x=x, x_version=x._version, x_plane=x_plane, ws=ws, feats=feats, inv_norm=inv_norm, dt=dt, L=L)
     return feats, confs, inv_norm
 
 
@@ -162,6 +165,9 @@ def vgg_backward_nhwc(module: 'VGGUnet', ctx: dict, d_feats, confs=None, d_confs
     the data- and weight-gradient launches; both 0 when the call took the dense walk."""
     lib = _lib.load()
     x, dt = ctx['x'], ctx['dt']
+    if x._version != ctx.get('x_version', x._version):
+        raise RuntimeError('the input image saved for the backward of VGGUnet has been modified by an inplace operation '
+                           f"(version {x._version}, expected {ctx['x_version']}): conv0's weight gradient reads it again")
     B, _, H, W = x.shape
     prm, keep, versions = _param_table(module)
     cache = module.__dict__.setdefault('_hla_packed_T', {})

@@ -1346,11 +1346,12 @@ static __global__ __launch_bounds__(256) void scale_kernel(float* __restrict__ x
 // host: pick the tile configuration for a 3x3 conv launch (forward convs and the dgrad convs of the backward)
 // BWD: the caller is the backward pass, whose conv2 / conv7 / conv14 data gradients read a virtually un-pooled source
 // (ConvArgs::unpool_idx): only then are the UNPOOL instantiations compiled into the translation unit.
+// Returns false (with the library's error string set, nothing launched) for a combination no kernel was compiled for.
 template <typename T, bool BWD = false>
-static void launch_conv(hipStream_t st, ConvArgs a, bool pool) {
+static bool launch_conv(hipStream_t st, ConvArgs a, bool pool) {
   if (a.unpool_idx && !(BWD && !pool)) {      // (cannot happen from this library's callers; the plain kernels ignore the field)
-    fprintf(stderr, "launch_conv: an un-pooled source needs the UNPOOL kernel\n");
-    abort();
+    hla_set_error("launch_conv: an un-pooled source needs the UNPOOL kernel (backward, no pooling epilogue)");
+    return false;
   }
   a.tiles_x = (a.W + 31) / 32;
   a.tiles_y = (a.H - a.row_begin + 7) / 8;
@@ -1374,4 +1375,5 @@ static void launch_conv(hipStream_t st, ConvArgs a, bool pool) {
     else hipLaunchKernelGGL((conv3x3_kernel<T, 4, 1, 2, 2, false, 2>), grid, dim3(256), 0, st, a);
   }
   hla_prof_end(st);
+  return true;
 }

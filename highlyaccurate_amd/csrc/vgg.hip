@@ -80,6 +80,7 @@ int vgg_forward_t(const float* x, size_t x_plane, const hla_vgg_params* prm, con
   }
   const bool train = flags & HLA_VGG_SAVE_FOR_BACKWARD;
   int np_used[4] = {pl.np[0], pl.np[1], pl.np[2], pl.np[3]};
+  bool launch_ok = true;
   auto conv = [&](int l, const void* s1, int C1, int H_, int W_h, void* act, int relu, bool pool, const void* s2 = nullptr,
                   int C2 = 0, int up1 = 0, void* raw = nullptr, double* ss = nullptr, unsigned char* idx = nullptr,
                   int row_begin = 0, int norm_level = -1) {
@@ -97,7 +98,7 @@ int vgg_forward_t(const float* x, size_t x_plane, const hla_vgg_params* prm, con
                                              {AM_X18, AM_X3, AM_D2A}, {AM_D2A, -1, AM_X21}, {AM_X21, AM_X2, AM_D3A}, {AM_D3A, -1, AM_X24}};
       a.amax1 = AM(kAm[l][0]); a.amax2 = AM(kAm[l][1]); a.amax_out = AM(kAm[l][2]); a.wscale = wtail + l;
     }
-    launch_conv<T>(st, a, pool);
+    if (!launch_conv<T>(st, a, pool)) launch_ok = false;
     if (norm_level >= 0)      // sum-of-squares partials actually written by this launch: one per (tile, 128-cout block)
       np_used[norm_level] = ((W_h + 31) / 32) * ((H_ - a.row_begin + 7) / 8) * (a.Cout >= 128 ? a.Cout / 128 : 1);
   };
@@ -177,7 +178,7 @@ int vgg_forward_t(const float* x, size_t x_plane, const hla_vgg_params* prm, con
     }
   }
   HLA_CHECK_HIP(hipGetLastError());
-  return HLA_OK;
+  return launch_ok ? HLA_OK : HLA_ERR_ARG;
 }
 
 #if HLA_TU_DTYPE >= 0

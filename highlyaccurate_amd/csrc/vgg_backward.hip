@@ -1156,6 +1156,7 @@ int vgg_backward_t(const float* x, size_t x_plane, const hla_vgg_params* prm, co
   // ---- helpers
   // data gradient of layer l restricted to its input channels [c0, c0+n): a forward conv on the transposed weights
   // (ga_src / ga_out, split mode: the amax slots of the gradient map it reads and of the one it writes)
+  bool launch_ok = true;
   auto dgrad = [&](int l, int c0, int n, const void* gsrc, const unsigned char* unpool, int Hout, int Wout, void* out,
                    const void* mask, const void* add, bool pool_sum, int row_begin = 0, int src_lo = 0, int add_lo = 0, int dc = -1,
                    int ga_src = -1, int ga_out = -1) {
@@ -1168,7 +1169,7 @@ int vgg_backward_t(const float* x, size_t x_plane, const hla_vgg_params* prm, co
     a.out_act = out; a.mask_act = mask; a.add_src = add; a.pool_sum = pool_sum ? 1 : 0;
     a.B = B; a.H = Hout; a.W = Wout; a.Cout = n; a.relu_act = 0;
     a.row_begin = row_begin > 0 ? row_begin : 0; a.src_row_lo = src_lo > 0 ? src_lo : 0; a.add_row_lo = add_lo > 0 ? add_lo : 0;
-    launch_conv<T, true>(st, a, pool_sum);
+    if (!launch_conv<T, true>(st, a, pool_sum)) launch_ok = false;
   };
   // (fa1 / fa2 / ga, split mode: the amax slots of its input activation(s) and of the gradient map)
   auto wgrad = [&](int l, const void* x1, int C1, const void* x2, int C2, int up1, const void* g, const unsigned char* unpool,
@@ -1268,7 +1269,7 @@ int vgg_backward_t(const float* x, size_t x_plane, const hla_vgg_params* prm, co
     if (gr->db[0]) hipLaunchKernelGGL(reduce_partials_kernel, dim3(4), dim3(256), 0, st, a.bpart, gr->db[0], (size_t)64, a.KS * 2, 64, 1, 1);
   }
   HLA_CHECK_HIP(hipGetLastError());
-  return HLA_OK;
+  return launch_ok ? HLA_OK : HLA_ERR_ARG;
 }
 
 #if HLA_TU_DTYPE >= 0

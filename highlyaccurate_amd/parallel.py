@@ -47,7 +47,7 @@ class GradSync:
     (``vgg_backward_nhwc(..., flat=True)``; every tensor of ``grads`` that lies inside it is a view of it): it is summed IN
     PLACE by one asynchronous all-reduce -- no gather copy, no scatter copy.  Tensors of ``grads`` outside ``flat`` (the
     confidence heads, level 4's padded layers, ``damping``) and callers without a flat buffer go through a small staged
-    bucket.  ``finish(handle)`` waits and divides by the world size.  Used by the model's backward (``model.grad_sync``) so
+    bucket.  ``finish(handle)`` waits (RCCL: the collective itself averages, ``ReduceOp.AVG``; gloo: sum, then one division).  Used by the model's backward (``model.grad_sync``) so
     that the satellite branch's 9.9 MB bucket is in flight on the xGMI links while the ground branch's backward kernels run."""
 
     def __init__(self, group=None, force=False):
@@ -55,6 +55,9 @@ class GradSync:
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.force = bool(force) and dist.is_initialized()
+        # RCCL averages inside the collective (ncclAvg): no div_ pass over the 19.8 MB afterwards.  gloo has no AVG.
+        self.avg_in_collective = dist.is_initialized() and dist.get_backend(group) == 'nccl'
+        self.op = dist.ReduceOp.AVG if self.avg_in_collective else dist.ReduceOp.SUM
         self.bytes_reduced = 0
         self.collectives = 0
 
@@ -72,13 +75,13 @@ class GradSync:
             rest = {n: g for n, g in grads.items() if not self._inside(g, flat)}
             self.bytes_reduced += flat.numel() * 4
             self.collectives += 1
-            works.append((dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True), flat, None, None))
+            works.append((dist.all_reduce(flat, op=self.op, group=self.group, async_op=True), flat, None, None))
         if rest:
             names = sorted(rest)                      # identical order on every rank
             stage = torch.cat([rest[n].reshape(-1).float() for n in names])
             self.bytes_reduced += stage.numel() * 4
             self.collectives += 1
-            works.append((dist.all_reduce(stage, op=dist.ReduceOp.SUM, group=self.group, async_op=True), stage, names, rest))
+            works.append((dist.all_reduce(stage, op=self.op, group=self.group, async_op=True), stage, names, rest))
         return works
 
     def finish(self, handle):
@@ -86,7 +89,8 @@ class GradSync:
             return
         for work, buf, names, grads in handle:
             work.wait()
-            buf.div_(self.world)
+            if not self.avg_in_collective:
+                buf.div_(self.world)
             if names is None:
                 continue                              # reduced in place: the gradient tensors ARE views of buf
             o = 0

@@ -104,7 +104,11 @@ int hla_vgg_pack_weights(const hla_vgg_params* params, void* packed, int dtype, 
 /* Bytes of scratch hla_vgg_forward needs for this shape. */
 size_t hla_vgg_workspace_bytes(int B, int H, int W, int level, int dtype);
 
-/* x        [B,3,H,W] NCHW fp32 (what the reference's DataLoader hands over)
+/* B, H, W  H and W multiples of 8, >= 8, and H*W < 2^23 pixels (8 388 608, e.g. below 2896 x 2896): the convolution kernels
+ *          address a sample's activation map with signed 32-bit BYTE offsets and the largest map is H x W x 64 fp32.
+ *          hla_vgg_forward / hla_vgg_backward return HLA_ERR_ARG above that.  B is unbounded (samples use 64-bit bases).
+ * x        [B,3,H,W] NCHW fp32 (what the reference's DataLoader hands over).  With HLA_VGG_SAVE_FOR_BACKWARD the kernels of
+ *          hla_vgg_backward read x AGAIN (conv0's weight gradient): the caller keeps it alive AND UNMODIFIED until then
  * x_plane  elements between consecutive channel planes of x: 0 = H*W (a dense tensor); larger when x is a window of H rows
  *          inside a taller image (rows stay W apart, samples 3*x_plane apart) -- mode='test' runs the ground extractor on the
  *          image rows that can reach the LM loop without first copying them out

@@ -1274,6 +1274,27 @@ def test_standalone_vggunet_is_differentiable_like_the_reference(level):
     assert all(torch.equal(a, b) for a, b in zip(f2, feats)) and all(torch.equal(a, b) for a, b in zip(c2, confs))
 
 
+def test_input_modified_before_backward_raises_like_autograd():
+    """The backward reads the input image again (conv0's weight gradient) and keeps no copy of it -- the image may be a row window
+    of the caller's own storage.  Like a tensor autograd saved, an in-place change between forward and backward must raise
+    instead of silently giving the gradient of another image."""
+    from oracle import ref_cpu as O
+    from highlyaccurate_amd.VGG import VGGUnet
+    d = _dev()
+    rs = np.random.RandomState(43)
+    net = VGGUnet(3)
+    net.load_state_dict(O.synth_vgg_state(rs, bias_scale=0.05))
+    net = net.to(d)
+    img = T(rs.random_sample((2, 3, 48, 64)).astype(np.float32)).to(d)
+    feats, _ = net(img[:, :, 16:, :])                         # a row window: passed to the kernels without a copy
+    img.mul_(0.5)
+    with pytest.raises(RuntimeError, match='modified by an inplace operation'):
+        sum(f.sum() for f in feats).backward()
+    feats, _ = net(img[:, :, 16:, :])                         # untouched: fine
+    sum(f.sum() for f in feats).backward()
+    assert all(torch.isfinite(p.grad).all() for p in net.parameters() if p.grad is not None)
+
+
 @pytest.mark.parametrize('kw', [dict(), dict(using_weight=1, train_damping=1)])
 def test_two_rank_real_model_gradients_match_full_batch(kw, tmp_path):
     """the batch shards over ranks and the only exchange is the gradient all-reduce.  Two processes (gloo; they

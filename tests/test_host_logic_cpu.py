@@ -38,3 +38,21 @@ def test_image_window_is_passed_without_a_copy():
         x, plane = _image_window(odd)
         assert x.is_contiguous() and x.dtype == torch.float32 and plane == x.shape[2] * x.shape[3]
         assert torch.equal(x, odd.float())
+
+
+@pytest.mark.parametrize('family', ['kitti', 'ford'])
+def test_product_ground_plane_tables_are_the_references_bit_for_bit(kat, family):
+    """`_s2gp.ground_plane_table` / `S2GPBase.xyz_tables` -- the tables the HIP LM kernels read -- against the tables the REAL
+    reference built (grd_img2cam, models_kitti.py:655-682 / models_ford.py:110-155; recorded by oracle/make_golden.py):
+    bit-identical fp32, levels 0 and 2 (the level-2 fixture is stored on a stride-8 lattice)."""
+    import numpy as np
+    from oracle import ref_cpu as O
+    from highlyaccurate_amd.models_kitti import LM_S2GP
+    from highlyaccurate_amd.models_ford import LM_S2GP_Ford
+    net = (LM_S2GP if family == 'kitti' else LM_S2GP_Ford)(O.default_args())
+    tables = net.xyz_tables(256, 1024, 'cpu')
+    for level, st in ((0, 1), (2, 8)):
+        ref = kat[f'{family}_xyz_l{level}']
+        got = tables[level].numpy()[None, ::st, ::st]
+        assert got.dtype == np.float32 and got.shape == ref.shape
+        np.testing.assert_array_equal(got, ref)

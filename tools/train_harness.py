@@ -124,6 +124,13 @@ def main(argv=None):
     if world > 1:
         net.grad_sync = P.GradSync()
     gen = torch.Generator().manual_seed(2022 + rank)
+    # The model draws its out-of-range re-initialisation values from torch's GLOBAL CPU generator every LM step
+    # (models_kitti.py:1028-1029): after the replicas have been built identically, give every rank its own stream
+    # (seed base + rank), or all ranks would re-initialise their shards with the same numbers.
+    if world > 1:
+        torch.manual_seed(2022 + rank)
+        import numpy as _np
+        _np.random.seed(2022 + rank)          # args.dropout's keep masks come from numpy's global generator (968-974)
     log = []
     save_path = args.save_path
     if args.test:                                                                  # train_kitti.py:545-548
