@@ -58,12 +58,13 @@ def _cpu_model():
     return 'unknown'
 
 
-def cpu_baseline(budget_s=45.0):
+def cpu_baseline(budget_s=80.0):
     """The CPU oracle (oracle/ref_cpu.py, a port of the reference's PyTorch path; kind = "port") on THIS host's cores, as
     SURVEY 8(d) specifies it: KITTI shapes, fp32, B = 1 and B = 8 inference (forward(mode='test'), no_grad) and a B = 1
-    training step (forward(mode='train') + backward), each on a bounded sample.  The torch thread count is chosen by a
-    two-point probe on this host (HLA_CPU_THREADS overrides), not assumed: on one MI355X host (256 logical CPUs) a B = 1
-    forward took 1.40 / 1.21 / 1.29 / 2.58 / 204 s with 8 / 16 / 32 / 64 / 256 threads -- oversubscription kills it."""
+    training step (forward(mode='train') + backward), each on a bounded sample.  The torch thread count is PROBED on this host,
+    separately for the single-pair and the batched forward (B = 1 and B = 4 passes over {16, 32, 64} threads; HLA_CPU_THREADS
+    overrides), not assumed: on one MI355X host (256 logical CPUs) a B = 1 forward took 1.40 / 1.21 / 1.29 / 2.58 / 204 s with
+    8 / 16 / 32 / 64 / 256 threads -- oversubscription kills it, and a batch can use more threads than a single pair."""
     from oracle import ref_cpu as O
     t_begin = time.time()
     ncpu = os.cpu_count() or 1
@@ -79,7 +80,7 @@ def cpu_baseline(budget_s=45.0):
     if os.environ.get('HLA_CPU_THREADS'):
         cands = [min(ncpu, int(os.environ['HLA_CPU_THREADS']))]
     else:
-        cands = sorted({min(ncpu, 16), min(ncpu, 32)})
+        cands = sorted({min(ncpu, 16), min(ncpu, 32), min(ncpu, 64)})
     torch.set_num_threads(cands[0])
     fwd(1)                                              # warm-up (allocator, oneDNN primitives); not counted
     probe = {}
@@ -96,14 +97,27 @@ def cpu_baseline(budget_s=45.0):
            'thread_probe_s_per_pair': {str(k): round(v, 3) for k, v in probe.items()},
            'inference_b1': round(inf1, 4), 'inference_b8': None, 'training_b1': None}
     notes = [f'{reps} x B=1 forward(mode=test, no_grad) after 1 warm-up']
-    est = 8.0 / inf1
+    # the batched forward gets its own probe (B = 4 passes, about 4 / inf1 seconds each): a batch parallelises over samples too
+    cores8, probe8 = cores, {}
+    for c in cands:
+        if time.time() - t_begin + 4.0 / inf1 + 8.0 / inf1 > budget_s - 10.0:
+            break
+        torch.set_num_threads(c)
+        probe8[c] = fwd(4) / 4.0
+    if probe8:
+        cores8 = min(probe8, key=probe8.get)
+        out['thread_probe_b4_s_per_pair'] = {str(k): round(v, 3) for k, v in probe8.items()}
+    torch.set_num_threads(cores8)
+    est = 8.0 * (probe8[cores8] if probe8 else 1.0 / inf1)
     if time.time() - t_begin + est < budget_s:          # B = 8 inference: one pass (8 pairs)
         t8 = fwd(8)
         out['inference_b8'] = round(8.0 / t8, 4)
-        notes.append('1 x B=8 forward(mode=test, no_grad)')
+        out['cores_b8'] = cores8
+        notes.append(f'1 x B=8 forward(mode=test, no_grad) on {cores8} threads')
     else:
         notes.append('B=8 skipped (would exceed the time budget)')
-    if time.time() - t_begin + 6.0 / inf1 < budget_s:   # B = 1 training step: forward(train) + backward, one pass
+    torch.set_num_threads(cores)
+    if time.time() - t_begin + 6.0 / inf1 < budget_s + 15.0:   # B = 1 training step: forward(train) + backward, one pass
         net.zero_grad(set_to_none=True)
         t0 = time.time()
         r = net(sat[:1], grd[:1], gu[:1], gv[:1], gh[:1], mode='train')
@@ -112,10 +126,12 @@ def cpu_baseline(budget_s=45.0):
         notes.append('1 x B=1 forward(mode=train) + backward')
     else:
         notes.append('training skipped (would exceed the time budget)')
-    out['value'] = max(v for v in (out['inference_b1'], out['inference_b8']) if v)        # the CPU's best inference rate
+    best_b8 = (out['inference_b8'] or 0.0) > out['inference_b1']
+    out['value'] = out['inference_b8'] if best_b8 else out['inference_b1']        # the CPU's best inference rate ...
+    out['cores'] = cores8 if best_b8 else cores                                   # ... and the threads THAT rate was measured on
     out['sample'] = ('KITTI shapes, fp32, 5 LM iters x 3 levels: ' + '; '.join(notes) +
-                     f'; torch {torch.__version__} CPU, {cores} of {ncpu} logical CPUs (two-point probe), '
-                     f'{time.time() - t_begin:.0f} s in all')
+                     f'; torch {torch.__version__} CPU, {cores} (B=1) / {cores8} (batched) of {ncpu} logical CPUs '
+                     f'(probed over {cands}), {time.time() - t_begin:.0f} s in all')
     return out
 
 
@@ -518,6 +534,9 @@ def main(argv=None):
     ap.add_argument('--no-kernel-timing', action='store_true')
     ap.add_argument('--no-extra-legs', action='store_true', help='skip by_precision and the secondary configs (N=1 extras)')
     ap.add_argument('--train-steps', type=int, default=6, help='extra: time this many training steps (0 = skip)')
+    ap.add_argument('--train-precision', default='fp16x3', choices=['bf16', 'fp16', 'fp32', 'fp16x3'],
+                    help="arithmetic mode of the `train` object (default fp16x3: the fastest mode whose gradients match the reference's "
+                         "autograd inside the fp32 gates; bf16 / fp16 steps are reported under train.by_precision as non-parity extras)")
     a = ap.parse_args(argv)
     if a.n_iters is None:
         a.n_iters = 10 if a.model == 'ford' else 5
@@ -587,8 +606,19 @@ def main(argv=None):
     # ---- extra: the training step (forward(train) + HIP backward + gradient all-reduce + Adam), same shapes
     train = None
     if a.train_steps > 0:
+        # train.value is measured in the mode whose GRADIENTS are the reference's (the bf16 step's gradients differ
+        # from the reference autograd by 0.24 relative L2, the fp16 step's by 0.077 -- the 16-bit dgrad / wgrad products' own
+        # rounding, amplified by the cancellation in these gradient sums; the same figures come out behind an exact forward, and
+        # gradient scaling changes nothing: DESIGN 6, tools/probes/mixed_bwd_fidelity.py): --train-precision, default fp16x3.
+        # The bf16 / fp16 steps stay in the line as train.by_precision entries marked parity_grade: false.
         try:
-            train = train_leg(net, a, sat, grd, extra, B, world, rank, dist, dev, want_kt)
+            tnet = net if a.train_precision == a.precision else build_net(a.model, a.train_precision, a.n_iters, dev)
+            train = train_leg(tnet, a, sat, grd, extra, B, world, rank, dist, dev, want_kt)
+            train['dtype'] = a.train_precision
+            train['parity_grade'] = a.train_precision in ('fp32', 'fp16x3')
+            if tnet is not net:
+                del tnet
+                torch.cuda.empty_cache()
         except Exception as e:      # the headline line must still be printed
             train = {'error': repr(e)[:300]}
 
@@ -596,9 +626,9 @@ def main(argv=None):
     # autograd (the reference trains in fp32: 'fp16x3' is the mode that matches it, on split-fp16 dgrad / wgrad kernels)
     if train and 'error' not in train and world == 1 and headline_cfg and not a.no_extra_legs:
         tbp = {}
-        for p in ('fp32', 'fp16x3', 'bf16'):
+        for p in ('fp32', 'fp16x3', 'fp16', 'bf16'):
             try:
-                if p == a.precision:
+                if p == a.train_precision:
                     e = {'value': train['value'], 'ms_per_step': train['ms_per_step'], 'steps': train['steps']}
                 else:
                     net = None
@@ -610,6 +640,7 @@ def main(argv=None):
                     e = {'value': t2['value'], 'ms_per_step': t2['ms_per_step'], 'steps': t2['steps']}
                 e['unit'] = 'pairs/s'
                 e['gradients'] = gradient_fidelity(p, dev)
+                e['parity_grade'] = p in ('fp32', 'fp16x3')      # gradients inside the fp32 gates of the reference-autograd goldens
                 tbp[p] = e
             except Exception as ex:
                 tbp[p] = {'error': repr(ex)[:300]}

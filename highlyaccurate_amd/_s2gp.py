@@ -85,8 +85,11 @@ class S2GPBase(nn.Module):
         self.N_iters = args.N_iters
         self.using_weight = args.using_weight
         self.loss_method = args.loss_method
-        if args.level not in (3, 4):
-            raise NotImplementedError('args.level must be 3 (x15, x18, x21) or 4 (+ x24)')
+        # level 2 = [x18, x21] with the H/4 and H/2 ground-plane tables: coherent in the Ford class only (models_ford.py:59-65;
+        # the KITTI class pairs x18 with its H/8 table at level 2 and fails on the shapes)
+        if args.level not in ((2, 3, 4) if self.ford else (3, 4)):
+            raise NotImplementedError('args.level must be 3 (x15, x18, x21) or 4 (+ x24)' +
+                                      (', or 2 (x18, x21)' if self.ford else "; the reference's KITTI model is shape-inconsistent at level 2"))
         if getattr(args, 'proj', 'geo') != 'geo':
             raise NotImplementedError("only proj='geo' is in scope")
         opt = getattr(args, 'Optimizer', 'LM')
@@ -124,7 +127,14 @@ class S2GPBase(nn.Module):
             K = ford_K_network_input() if self.ford else KITTI_K
             self._tables[key] = [ground_plane_table(K, grd_H / 2 ** (3 - l), grd_W / 2 ** (3 - l), 256, 1024).to(device)
                                  for l in range(4)]
-        return self._tables[key]
+        # level 2 (Ford, models_ford.py:59-65): grd_img2cam(H / 2^(2 - l)) for l = 0, 1 = the H/4 and H/2 tables
+        return self._tables[key][1:3] if self.level == 2 else self._tables[key]
+
+    def _levels(self, maps):
+        """The extractor always computes x15, x18, x21 (x15 feeds the decoder); level 2 uses the last two (VGG.py:183-184,198-199)."""
+        if self.level != 2 or maps is None:
+            return maps
+        return maps[1:]
 
     # -- LM options -> C structs -------------------------------------------------------------
     def _config(self, n_levels: int, level_first: int) -> _lib.S2GConfig:
@@ -311,7 +321,8 @@ class S2GPBase(nn.Module):
         f8 = f8 if f8 >= 4 else 0
         grd_feats, grd_confs, grd_inv = vgg_forward_nhwc(self.GrdFeatureNet, grd_in, want_conf=want_conf, defer_norm=True,
                                                          first_row8=f8, feat16=f16)
-        return sat_feats, sat_inv, grd_feats, grd_confs, grd_inv
+        L = self._levels
+        return L(sat_feats), L(sat_inv), L(grd_feats), L(grd_confs), L(grd_inv)
 
     @_lib.on_device(lambda self, sat_map, *a, **k: sat_map)
     def localise(self, sat_map, grd_img, want_conf, extra, level_first, init_pose, return_confs=True):
@@ -422,6 +433,9 @@ class _LocaliseFn(torch.autograd.Function):
         grd_in = grd_img[:, :, skip:, :] if skip else grd_img      # (a view: the extractor takes the window's plane stride)
         grd_feats, grd_confs, grd_inv, cg = vgg_forward_nhwc(model.GrdFeatureNet, grd_in, want_conf=want_conf,
                                                              defer_norm=True, save_for_backward=True)
+        L = model._levels
+        ctx.conf0 = grd_confs[0] if (model.level == 2 and grd_confs is not None) else None      # (the head's backward needs its own map)
+        sat_feats, sat_inv, grd_feats, grd_confs, grd_inv = L(sat_feats), L(sat_inv), L(grd_feats), L(grd_confs), L(grd_inv)
         trace = model.lm_solve(sat_feats, grd_feats, grd_confs, grd_img.shape[-2:], extra, level_first, init_pose,
                                sat_inv, grd_inv, keep_normal_eq=True)
         ctx.model, ctx.names, ctx.extra, ctx.level_first, ctx.init_pose = model, names, extra, level_first, init_pose
@@ -446,10 +460,16 @@ class _LocaliseFn(torch.autograd.Function):
         inv = getattr(model.args, 'Optimizer', 'LM') == 'LM'
         trim = bool(getattr(model.args, 'bwd_trim', 1))
         # the ground maps' gradient lives in rows h_l/2.. (all the LM loop reads): the backward skips the rows above its support
-        f8 = (grd_hw[0] // 8) // 2 - (grd_hw[0] - grd_feats[2].shape[1] * 2) // 8
+        x21 = grd_feats[1 if model.level == 2 else 2]       # the H/2 map (level 2: [x18, x21])
+        f8 = (grd_hw[0] // 8) // 2 - (grd_hw[0] - x21.shape[1] * 2) // 8
         f8 = f8 if (inv and f8 >= 4 and model.level == 3 and trim) else 0
         d_sat, d_grd, d_conf, d_lam = model.lm_backward(sat_feats, grd_feats, grd_confs, grd_hw, trace, neq, d_trace, ctx.extra,
                                                    ctx.level_first, ctx.init_pose, sat_inv, grd_inv, keep, grd_first_row8=f8)
+        if model.level == 2:        # x15 takes no part in the loop: its gradient (and its confidence map's) is zero
+            zf = lambda cx: torch.zeros_like(cx['feats'][0], dtype=torch.float32)
+            d_sat, d_grd = [zf(cs)] + list(d_sat), [zf(cg)] + list(d_grd)
+            if grd_confs is not None and all(c is not None for c in d_conf):
+                grd_confs, d_conf = [ctx.conf0] + list(grd_confs), [torch.zeros_like(ctx.conf0)] + list(d_conf)
         sync = getattr(model, 'grad_sync', None)        # optional: overlap the sat-branch all-reduce with the grd backward
         # LM_update renormalises both projected maps (models_kitti.py:982-990), so the loss does not depend on the per-sample
         # scale of either extractor's output: d_feat is orthogonal to feat and the L2_norm backward needs no (x . dy) pass

@@ -423,6 +423,9 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[MT][NT], const ConvA
               RowStager<T, NT>::put(stage2, px, j * 32 + q * 8 + g * 4, fmaxf(w0, 0.f), fmaxf(w1, 0.f), fmaxf(w2, 0.f), fmaxf(w3, 0.f));
           }
       }
+      // (the row's sum of squares is complete HERE: left to itself the compiler sank the 32 multiply-adds below the flush and kept
+      //  their inputs alive across it -- 16 spilled registers and a scratch allocation for every wave of the kernel)
+      asm volatile("" : "+v"(ss));
       __builtin_amdgcn_sched_barrier(0);
       if (row_ok) {
         RowStager<RawT, NT>::template flush<true>(stage, (RawT*)a.out_raw + pix0 * a.Cout + cb, NPX, nvalid, a.Cout, lane);
@@ -512,13 +515,13 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[MT][NT], const ConvA
 // offsets into it: the wave's first row, the lane's pixel and the swizzled slot of its k-half).  Weight fragments come from global memory through a ring of
 // WD+1 register sets filled WD taps ahead; `mid(tap)` runs right after the weight loads of each tap (used to
 // issue the next stage's halo loads BEHIND them: VM loads of a wave retire in order).
-template <typename T, int MT, int NT, int WD>
+template <typename T, int MT, int NT, int WD, int PF = (NT == 1 ? 4 : 3)>
 struct WeightRing {
   static constexpr int RS = WD + 1;
   uint4 wb[RS][2][NT];
   // pixel fragments in flight ahead of the MFMAs (one MFMA per fragment at NT = 1: four reads = 128 matrix-pipe cycles of cover;
   // six, round 2's choice at two workgroups per CU, cost the three-workgroup kernel 27 spilled registers: 804 against 1100 TF)
-  static constexpr int PFD = NT == 1 ? 4 : 3;     // (NT = 2: 2 and 4 measure the same as 3)
+  static constexpr int PFD = PF;     // default: 4 at NT = 1, 3 at NT = 2 (NT = 2: 2 and 4 measure the same as 3)
   uint4 pf[PFD + 1];     // pixel-fragment pipeline of the non-upfront MFMA loop (lives across taps)
   const uint4* wq[NT];   // per-lane pointer to this stage's fragments of output tile j: [tap][kg][lane]
 
@@ -562,9 +565,9 @@ __device__ __forceinline__ void stagger_priority() {
   if (slot & 1) __builtin_amdgcn_s_setprio(1);
 }
 
-template <typename T, int MT, int NT, int WD, typename Mid>
+template <typename T, int MT, int NT, int WD, int PF, typename Mid>
 __device__ __forceinline__ void stage_mma(f32x16 (&acc)[MT][NT], const char* cur, const FragOff& fo,
-                                          WeightRing<T, MT, NT, WD>& ring, Mid&& mid) {
+                                          WeightRing<T, MT, NT, WD, PF>& ring, Mid&& mid) {
   constexpr int RS = WD + 1;
 #pragma unroll
   for (int tap = 0; tap < 9; ++tap) {
@@ -577,7 +580,7 @@ __device__ __forceinline__ void stage_mma(f32x16 (&acc)[MT][NT], const char* cur
     // straightforward "read the fragments of a row, multiply" order leaves every ds_read_b128 one LDS latency -- about 100
     // cycles -- ahead of its first MFMA with only 64 cycles of matrix work queued behind it: the pipe idled ~4 x 50 cycles per
     // tap.  Requesting all fragments of a tap up front measured 906 against 960 TF on the 32-channel wave tile.)
-    constexpr int FPT = MT * 2, DEPTH = WeightRing<T, MT, NT, WD>::PFD;   // fragments per tap: (row i, k-group kg), kg fastest
+    constexpr int FPT = MT * 2, DEPTH = PF;   // fragments per tap: (row i, k-group kg), kg fastest
     auto frag_ptr = [&](int f) {                          // f counts fragments within THIS tap; f >= FPT spills into the next tap
       const int tp = tap + f / FPT, r = f % FPT;
       return cur + fo.o[tp % 3][r & 1] + (tp / 3 + (r >> 1)) * HWID * PSTR;
@@ -792,7 +795,10 @@ __global__ __launch_bounds__(256, NT == 1 ? 3 : 2) void conv3x3_kernel(ConvArgs 
 
   const FragOff fo = frag_offsets(lane, wm * MT);
   // packed weights: [ntile][stage][tap][kg(2)][lane] 16-B fragments
-  WeightRing<T, MT, NT, WD> ring;
+  // (the un-pooling loader carries a piece's argmax bytes next to it: at the three-workgroup register cap that costs the 32-channel
+  //  wave tile one fragment of read-ahead -- with four, 7 registers spilled and 3 scratch accesses sat inside the MFMA stream)
+  constexpr int PF = NT == 1 ? (UNPOOL && sizeof(T) == 2 ? 3 : 4) : 3;
+  WeightRing<T, MT, NT, WD, PF> ring;
 #pragma unroll
   for (int j = 0; j < NT; ++j) ring.wq[j] = a.wpk + (size_t)(ntg0 + j) * nstage * 18 * 64 + lane;
 
@@ -813,7 +819,7 @@ __global__ __launch_bounds__(256, NT == 1 ? 3 : 2) void conv3x3_kernel(ConvArgs 
   for (int sg = 0; sg < nstage; ++sg) {
     const bool more = sg + 1 < nstage;
     char* nxt = lds + ((sg + 1) & 1) * BUF;
-    stage_mma<T, MT, NT, WD>(acc, lds + (sg & 1) * BUF, fo, ring, [&](int tap) __attribute__((always_inline)) {
+    stage_mma<T, MT, NT, WD, PF>(acc, lds + (sg & 1) * BUF, fo, ring, [&](int tap) __attribute__((always_inline)) {
       if (tap == HALO_TAP0 && more) load_stage(sg + 1, 0, st, ids);
       if (tap == HALO_TAP1 && more) { write_stage(nxt, sg + 1, 0, st, ids); load_stage(sg + 1, 1, st, ids); }
     });

@@ -398,6 +398,20 @@ def gen_ford(mf, seeds, B=1):
     np.savez_compressed(os.path.join(GOLD, 'e2e_ford.npz'), **out)
 
 
+def gen_ford_level2(mf, seed, B=1):
+    """LM_S2GP_Ford(level=2) (models_ford.py:59-65: two ground-plane tables, H/4 and H/2; VGG.py:183-184,198-199 returns
+    [x18, x21]): 5 iterations x 2 levels, iteration-first and level-first, fp32 and fp64.  (The KITTI class indexes its tables
+    wrongly at level 2 -- SURVEY Appendix A-3 -- so only the Ford model has this mode.)"""
+    out = {'seed': np.array(seed), 'B': np.array(B)}
+    for tag, lf in (('iterfirst', 0), ('levelfirst', 1)):
+        a = O.default_args(N_iters=5, level=2)
+        t64, f64, _, _ = run_e2e(mf, 'LM_S2GP_Ford', a, seed, B, torch.float64, extra=ford_extra(B), level_first=lf)
+        t32, f32, _, _ = run_e2e(mf, 'LM_S2GP_Ford', a, seed, B, torch.float32, extra=ford_extra(B), level_first=lf)
+        out[f'trace64_{tag}'], out[f'trace32_{tag}'], out[f'final64_{tag}'] = t64, t32, f64
+        print(f'ford level 2 {tag}: steps {t64.shape[1]} gap {np.abs(t32 - t64).max():.2e} final {f64.tolist()}', flush=True)
+    np.savez_compressed(os.path.join(GOLD, 'e2e_ford_l2.npz'), **out)
+
+
 def gen_ford_gn(mf, seed, B=1):
     """Optimizer='GN' (GN_update, models_ford.py:534-598, dispatched at 775-781): undamped Gauss-Newton without
     renormalising the ground map.  Traces with and without confidence weighting, fp32 and fp64."""
@@ -530,6 +544,8 @@ if __name__ == '__main__':
         gen_e2e(mk, seeds or [1, 2, 3])
     if a.only in ('all', 'ford'):
         gen_ford(mf, (seeds or [1])[:2])
+    if a.only in ('all', 'fordl2'):
+        gen_ford_level2(mf, (seeds or [1])[0])
     if a.only in ('all', 'fordgn'):
         gen_ford_gn(mf, (seeds or [1])[0])
     if a.only in ('all', 'train'):

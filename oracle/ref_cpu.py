@@ -428,7 +428,8 @@ class _S2GPBase(nn.Module):
 
     # level index into xyz_grds for feature-list position `pos`
     def _table(self, pos):
-        return self.xyz_grds[pos]
+        # level 2 (Ford only, models_ford.py:59-65): positions 0, 1 = [x18, x21] use grd_img2cam(H / 2^(2 - pos)) = the H/4, H/2 tables
+        return self.xyz_grds[pos + 1 if self.level == 2 else pos]
 
     def _pose_to_uv(self, pos, A, su, sv, th, extra, require_jac=True):
         xyz, mask = self._table(pos)

@@ -52,7 +52,7 @@ def knife_edge(make_oracle, sd, evaluate, ref, seed):
     return worst
 
 
-def case_setup(seed, hip=True):
+def case_setup(seed, hip=True, precision=None):
     """Everything a case consists of: the drawn configuration, the fp64 oracle, the HIP model (hip=False: None, for CPU-only
     probes of the oracle), the inputs."""
     rs = np.random.RandomState(seed)
@@ -73,7 +73,7 @@ def case_setup(seed, hip=True):
         lf = 0
     train = seed % 2 == 1
     args = O.default_args(**kw)
-    args.precision = os.environ.get('HLA_FUZZ_PRECISION', 'fp32')
+    args.precision = precision or os.environ.get('HLA_FUZZ_PRECISION', 'fp32')
     sd = O.synth_model_state(seed, bias_scale=0.02, rotation_range=10.0 if ford else args.rotation_range)
     if kw['train_damping']:
         sd['damping'] = torch.from_numpy(rs.uniform(-1, 1, tuple(sd['damping'].shape))).float()
@@ -98,8 +98,8 @@ def case_setup(seed, hip=True):
                 gu=gu, gv=gv, gt=gt, extra_o=extra_o, extra_g=extra_g, onet=onet, mk=mk, net=net)
 
 
-def one_case(seed):
-    c = case_setup(seed)
+def one_case(seed, precision=None):
+    c = case_setup(seed, precision=precision)
     fam, ford, g2s, B, gh, gw, sa, kw, lf, train = (c[k] for k in ('fam', 'ford', 'g2s', 'B', 'gh', 'gw', 'sa', 'kw', 'lf', 'train'))
     args, sd, sat, grd, gu, gv, gt = (c[k] for k in ('args', 'sd', 'sat', 'grd', 'gu', 'gv', 'gt'))
     extra_o, extra_g, onet, mk, net = (c[k] for k in ('extra_o', 'extra_g', 'onet', 'mk', 'net'))
@@ -188,6 +188,32 @@ def one_case(seed):
             worst, wname = cos, n
     ok = lerr < 1e-3 and worst > 0.995
     note = ''
+    if not ok and worst <= 0.995 and np.isfinite(lerr) and np.isfinite(worst):
+        # A gradient tensor on the wrong side of the cosine gate.  Ill-conditioned?  Then the REFERENCE's own fp32 autograd must
+        # miss its fp64 autograd on the SAME tensor as well (checked, not assumed: seed 2515, LM_G2SP with use_hessian +
+        # train_damping -- the 3-element `damping` gradient is a difference of terms that cancel to ~1e-3 of their size, and the
+        # reference's fp32 run lands on the other side of its sign change too).  Every OTHER tensor still has to pass.
+        o32 = type(onet)(args) if g2s else type(onet)(args, grd_hw=(gh, gw))
+        o32.load_state_dict(sd)
+        ex32 = tuple(e.float() if torch.is_tensor(e) else e for e in extra_o)
+        torch.manual_seed(seed)
+        r32 = o32(sat, grd, *ex32, *[g.float() for g in gts_o], mode='train', **lfkw)
+        r32[0].backward()
+        g32, g64 = dict(o32.named_parameters()), dict(onet.named_parameters())
+        excused, still_bad = [], []
+        for n, p in net.named_parameters():
+            if g64[n].grad is None or float(g64[n].grad.norm()) < 1e-12:
+                continue
+            a, b, c = p.grad.detach().double().cpu().flatten(), g64[n].grad.flatten(), g32[n].grad.double().flatten()
+            cos = lambda u, v: float((u @ v) / (u.norm() * v.norm() + 1e-300)) if u.numel() > 1 else 1.0 - abs(float(u - v)) / abs(float(v))
+            if cos(a, b) > 0.995:
+                continue
+            (excused if cos(c, b) <= 0.995 else still_bad).append(f'{n} (ours {cos(a, b):.4f}, reference fp32 {cos(c, b):.4f})')
+        l32 = float(r32[0].detach())
+        gap = abs(l32 - float(ro[0].detach())) / max(abs(float(ro[0].detach())), 1e-9)
+        ok = not still_bad and lerr < max(1e-3, 2 * gap)
+        note = f'; tensors beyond the cosine gate whose REFERENCE fp32 gradient is beyond it too: {excused}; others: {still_bad}; ' \
+               f'reference fp32-vs-fp64 gap of the loss {gap:.1e}'
     if not ok and worst > 0.995 and np.isfinite(lerr):
         # ill-conditioned case?  the same gate as for the forward cases: the reference's own fp32-vs-fp64 gap on the loss
         o32 = type(onet)(args) if g2s else type(onet)(args, grd_hw=(gh, gw))

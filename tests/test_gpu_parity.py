@@ -453,6 +453,75 @@ def test_e2e_ford_variants_vs_golden(tag, kw, lf):
     _pose_gate(trace, g[f'trace64_{tag}'], g[f'trace32_{tag}'], f'ford {tag}')
 
 
+@pytest.mark.parametrize('precision', ['fp32', 'fp16x3'])
+@pytest.mark.parametrize('tag,lf', [('iterfirst', 0), ('levelfirst', 1)])
+def test_e2e_ford_level2_vs_golden(tag, lf, precision):
+    """LM_S2GP_Ford(level=2) -- the two-level pyramid [x18, x21] with the H/4 and H/2 tables (models_ford.py:59-65; VGG.py:198-199):
+    10-step traces of both loop orders against the REAL reference's runs, in both fp32-class modes; the KITTI class rejects it
+    (its level-2 table indexing is shape-inconsistent in the reference)."""
+    from oracle import ref_cpu as O
+    from highlyaccurate_amd.models_ford import LM_S2GP_Ford
+    from highlyaccurate_amd.models_kitti import LM_S2GP
+    g = load_golden('e2e_ford_l2.npz')
+    seed, B = int(g['seed']), int(g['B'])
+    d = _dev()
+    net = LM_S2GP_Ford(O.default_args(N_iters=5, level=2, precision=precision))
+    net.load_state_dict(O.synth_model_state(seed))
+    net = net.to(d)
+    sat, grd, *_ = O.synth_images(seed + 100, B)
+    R_FL = torch.tensor([[[0., 0., 1.], [1., 0., 0.], [0., 1., 0.]]]).repeat(B, 1, 1)
+    T_FL = torch.tensor([[1.7, 0.3, -1.2]]).repeat(B, 1)
+    torch.manual_seed(seed)
+    with torch.no_grad():
+        res = net(sat.to(d), grd.to(d), 112.64, R_FL.to(d), T_FL.to(d), mode='test', level_first=lf)
+    assert tuple(net.last_trace.shape) == (B, 5, 2, 3)
+    trace = _exec_order(net.last_trace, lf).cpu().numpy().astype(np.float64)
+    _pose_gate(trace, g[f'trace64_{tag}'], g[f'trace32_{tag}'], f'ford level 2 {tag} {precision}')
+    np.testing.assert_array_equal(torch.stack(res, -1).cpu().numpy(), trace[:, -1].astype(np.float32))
+    with pytest.raises(NotImplementedError):
+        LM_S2GP(O.default_args(level=2))
+
+
+def test_ford_level2_train_step_vs_oracle_autograd():
+    """The same model in mode='train' on a small image: loss and every parameter gradient against the fp64 oracle's autograd
+    (x15 takes no part in the loop: conv14 still trains through the decoder, conf0 and x15's own gradient are zero)."""
+    from oracle import ref_cpu as O
+    from highlyaccurate_amd.models_ford import LM_S2GP_Ford
+    d = _dev()
+    seed, B, hw, A = 7, 2, (64, 256), 128
+    args = O.default_args(N_iters=2, level=2, using_weight=1, train_damping=1)
+    sd = O.synth_model_state(seed)
+    onet = O.LM_S2GP_Ford(args, grd_hw=hw)
+    onet.load_state_dict(sd)
+    onet = onet.double()
+    sat, grd, gu, gv, gt = O.synth_images(seed + 100, B, grd_hw=hw, sat_a=A)
+    R_FL = torch.tensor([[[0., 0., 1.], [1., 0., 0.], [0., 1., 0.]]]).repeat(B, 1, 1)
+    T_FL = torch.tensor([[1.7, 0.3, -1.2]]).repeat(B, 1)
+    gts = [x.double().reshape(-1) for x in (gu, gv, gt)]
+    torch.manual_seed(seed)
+    ro = onet(sat.double(), grd.double(), 0.22 * A, R_FL.double(), T_FL.double(), *gts, mode='train')
+    ro[0].backward()
+    net = LM_S2GP_Ford(args)
+    net.load_state_dict(sd)
+    net = net.to(d)
+    torch.manual_seed(seed)
+    r = net(sat.to(d), grd.to(d), 0.22 * A, R_FL.to(d), T_FL.to(d), *[x.to(d) for x in gts], mode='train')
+    r[0].backward()
+    assert len(r) == 14 and len(r[13]) == 2 and tuple(r[13][0].shape) == (B, 1, hw[0] // 4, hw[1] // 4)
+    assert abs(float(r[0].detach()) - float(ro[0].detach())) < 1e-5 * abs(float(ro[0].detach()))
+    worst, nchk = 0.0, 0
+    for (n, p), (_, po) in zip(net.named_parameters(), onet.named_parameters()):
+        if po.grad is None or float(po.grad.norm()) < 1e-12:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, n
+            continue
+        a, b = p.grad.double().cpu().flatten(), po.grad.flatten()
+        e = float((a - b).norm() / b.norm())
+        worst, nchk = max(worst, e), nchk + 1
+        assert e < 5e-3, (n, e)          # (max-pool flip noise bounds the encoder tensors, as in the level-3 tests)
+    print(f'ford level 2 train step: {nchk} gradients, worst rel L2 {worst:.2e}')
+    assert nchk >= 36
+
+
 @pytest.mark.parametrize('precision', ['bf16', 'fp16'])
 def test_reduced_precision_pose_deviation_reported(precision):
     g = load_golden('e2e_kitti.npz')
@@ -1894,6 +1963,33 @@ def test_bench_gpus_flag_spawns_its_ranks_and_reports_them():
     assert 'roofline' in j and 'scale_reads' in j
 
 
+def test_bench_eight_rank_rehearsal_of_configs2_shard_arithmetic():
+    """BASELINE configs[2] is 8 ranks; no 8-GPU node has been available to any round.  What CAN run here is its rank count: a plain
+    `python bench.py --gpus 8 --batch 4` spawns eight ranks that share this box's GPU (rehearsal: gloo, flagged) -- the census
+    must see 8 ranks, the global batch is 8 x 4 = 32 pairs, every training step all-reduces the 19.78 MB of live gradients once,
+    rank 0 prints ONE line.  Control flow and shard arithmetic at the real rank count; not a measurement of anything."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT',
+                                                            'HLA_BENCH_REHEARSE')}
+    env['OMP_NUM_THREADS'] = '4'
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '8', '--steps', '2', '--warmup', '1',
+                        '--train-steps', '1', '--train-precision', 'bf16', '--batch', '4', '--no-cpu-baseline', '--no-kernel-timing'],
+                       env=env, capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, r.stdout[-2000:]
+    j = json.loads(lines[0])
+    ndev = torch.cuda.device_count()
+    assert j['n_gpus'] == 8 and j['collective_ranks_seen'] == 8 and j['self_launched'] is True
+    assert j['rehearsal'] == (ndev < 8) and j['n_gpus_physical'] == min(8, ndev)
+    assert j['config']['global_batch'] == 32 and j['config']['pairs_per_gpu'] == 4 and j['value'] > 0 and j['scaling'] == 'weak'
+    t = j['train']
+    assert 'error' not in t, t
+    assert abs(t['allreduce_bytes_per_step'] - 19.78e6) < 0.02e6, t['allreduce_bytes_per_step']
+    assert t['loss_finite'] and t['value'] > 0 and t['single_rank_value'] > 0
+
+
 def test_bench_single_rank_through_rccl():
     """The N > 1 code path on the REAL transport, as far as a one-GPU box can take it: HLA_BENCH_FORCE_DIST=1 runs the N = 1 job
     through a one-rank RCCL process group, so every collective call of the multi-GPU path -- the census all-reduce, the barriers,
@@ -1989,14 +2085,32 @@ def test_fuzz_slice_vs_oracle(chunk):
     assert not bad, f'fuzz seeds beyond their bound: {bad}'
 
 
-@pytest.mark.parametrize('precision', ['fp32', 'fp16x3', 'bf16'])
+@pytest.mark.parametrize('precision', ['fp32', 'fp16x3'])
+def test_fuzz_ill_conditioned_seed_2515_is_excused_by_the_reference_itself(precision):
+    """ADVICE r03: the one recorded failure of the split-fp16 backward's fuzz run (seed 2515: LM_G2SP, use_hessian + train_damping;
+    the `damping` gradient came out with cosine -1) was explained as ill-conditioning in prose only.  The harness now checks the
+    explanation: a tensor beyond the cosine gate is excused only if the REFERENCE's own fp32 autograd is beyond the gate on the
+    same tensor (against its fp64 autograd), and every other tensor still has to pass.  Both fp32-class modes."""
+    import importlib.util, os
+    p = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'diag', 'fuzz_e2e.py')
+    spec = importlib.util.spec_from_file_location('fuzz_e2e', p)
+    fz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fz)
+    assert fz.one_case(2515, precision=precision)
+
+
+@pytest.mark.parametrize('precision', ['fp32', 'fp16x3', 'bf16', 'fp16'])
 def test_train_step_gradient_fidelity_by_precision(precision):
     """The number bench.py reports as train.by_precision.<mode>.gradients, gated: worst per-tensor relative L2 error and cosine
     of the full-shape training-step gradients against the REAL reference's autograd (tests/golden/train_kitti.npz, fp64 run).
     fp32 / fp16x3 (the matched-accuracy training mode: split-fp16 dgrad + wgrad kernels): within 3x the reference's OWN
-    fp32-vs-fp64 gap (max-pool flip noise, see test_train_step_gradients_vs_reference_golden).  bf16, the throughput mode the
-    training leg of bench.py runs in: 3x its measured deviation (0.237 / cosine 0.9726 on MI355X), so that a regression of a
-    factor of three fails instead of hiding behind a 0.3 bound on a 32x64 image."""
+    fp32-vs-fp64 gap (max-pool flip noise, see test_train_step_gradients_vs_reference_golden) -- bench.py's train.value is the
+    fp16x3 step for that reason.  bf16 / fp16, the reduced-precision steps (reported as parity_grade: false): 3x their measured
+    deviation (bf16 0.237 / cosine 0.9726, fp16 0.0774 / 0.99700 on MI355X), so that a regression of a factor of three fails.
+    Their error is the BACKWARD's own rounding and no format choice repairs it: behind an EXACT forward + LM loop (fp16x3), the
+    extractors' backward alone in fp16 / bf16 gives the same 0.077 / 0.23 (tools/probes/mixed_bwd_fidelity.py; gradient scaling by
+    2^0..2^16 changes nothing: no underflow) -- these weight gradients are sums that cancel to 1/20..1/300 of their terms, so 8 or
+    11 significand bits in either operand of the 16-bit dgrad / wgrad products are amplified by that factor."""
     import os, sys
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     import bench
@@ -2004,6 +2118,8 @@ def test_train_step_gradient_fidelity_by_precision(precision):
     print(f'gradient fidelity [{precision}]: {r}')
     if precision == 'bf16':
         assert r['worst_rel_l2'] < 3 * 0.237 and r['worst_cosine'] > 1 - 3 * (1 - 0.9726) and r['loss_rel_err'] < 3 * 3.2e-4
+    elif precision == 'fp16':
+        assert r['worst_rel_l2'] < 3 * 0.0774 and r['worst_cosine'] > 1 - 3 * (1 - 0.99700) and r['loss_rel_err'] < 3 * 5.9e-5
     else:
         assert r['worst_rel_l2'] < 3 * r['reference_fp32_vs_fp64_worst_rel_l2'] and r['worst_cosine'] > 0.99998
         assert r['loss_rel_err'] < 1e-6

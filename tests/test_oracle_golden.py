@@ -164,6 +164,27 @@ def test_oracle_e2e_ford_matches_reference_golden():
     assert err < 1e-7      # fp64 both sides; only the summation order differs
 
 
+@pytest.mark.parametrize('tag,lf', [('iterfirst', 0), ('levelfirst', 1)])
+def test_oracle_ford_level2_matches_reference_golden(tag, lf):
+    """LM_S2GP_Ford(level=2): [x18, x21] against the H/4 and H/2 ground-plane tables (models_ford.py:59-65; VGG.py:183-184,198-199),
+    5 iterations x 2 levels, both loop orders, against the REAL reference's fp64 traces."""
+    g = load_golden('e2e_ford_l2.npz')
+    seed, B = int(g['seed']), int(g['B'])
+    net = O.build('ford', O.default_args(N_iters=5, level=2), seed, torch.float64)
+    sat, grd, *_ = O.synth_images(seed + 100, B)
+    R_FL = torch.tensor([[[0., 0., 1.], [1., 0., 0.], [0., 1., 0.]]], dtype=torch.float64).repeat(B, 1, 1)
+    T_FL = torch.tensor([[1.7, 0.3, -1.2]], dtype=torch.float64).repeat(B, 1)
+    torch.manual_seed(seed)
+    with torch.no_grad():
+        res = net(sat.double(), grd.double(), 112.64, R_FL, T_FL, mode='test', level_first=lf)
+    tr = _oracle_trace(net, lf)
+    assert tr.shape == g[f'trace64_{tag}'].shape == (B, 10, 3)
+    err = np.abs(tr - g[f'trace64_{tag}']).max()
+    print(f'oracle vs reference, ford level 2 {tag} fp64: max pose err', err)
+    assert err < 1e-7
+    np.testing.assert_allclose(torch.stack(res, -1).numpy(), g[f'final64_{tag}'], atol=1e-7)
+
+
 def test_oracle_ford_gauss_newton_matches_reference_golden():
     """Optimizer='GN' (GN_update, models_ford.py:534-598), with and without confidence weighting."""
     g = load_golden('e2e_ford_gn.npz')

@@ -6,7 +6,8 @@ root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 libs = sys.argv[1:] or ['libhla.so']
 for lib in libs:
     env = dict(os.environ, HLA_BENCH_NOCHECK='1', HLA_ALLOW_STALE='1', HLA_LIB=os.path.join(root, 'highlyaccurate_amd', lib))
-    out = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--steps', '5', '--warmup', '2', '--no-cpu-baseline', '--train-steps', os.environ.get('VARIANTS_TRAIN', '0'), '--no-extra-legs', '--precision', os.environ.get('VARIANTS_PRECISION', 'bf16')],
+    out = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--steps', '5', '--warmup', '2', '--no-cpu-baseline', '--train-steps', os.environ.get('VARIANTS_TRAIN', '0'), '--no-extra-legs', '--precision', os.environ.get('VARIANTS_PRECISION', 'bf16'),
+                          '--train-precision', os.environ.get('VARIANTS_TRAIN_PRECISION', os.environ.get('VARIANTS_PRECISION', 'bf16'))],
                          env=env, capture_output=True, text=True)
     try:
         d = json.loads(out.stdout.strip().splitlines()[-1])

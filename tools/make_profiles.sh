@@ -4,7 +4,7 @@
 # Every bench invocation below is the headline leg only (--no-extra-legs --train-steps 0: BASELINE configs[1], B = 32, bf16), so
 # that a kernel's average duration in a CSV is directly comparable with roofline.avg_launch_us of the JSON printed by that very run.
 set -x
-TAG=${1:-r03}
+TAG=${1:-r04}
 ROOT=$PWD
 OUT=$ROOT/gpurun_out/profiles_$TAG
 mkdir -p $OUT
@@ -26,11 +26,11 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python $RO
 cp $OUT/stats/*/*kernel_stats.csv $OUT/${TAG}_rocprofv3_kernel_stats_fp16x3.csv
 rm -rf $OUT/stats
 # and the training leg on its own (forward(train) + backward + Adam), inference steps reduced to the minimum
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python $ROOT/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-kernel-timing --no-extra-legs --train-steps 10 > $OUT/${TAG}_bench_train_under_rocprof.json 2>> $OUT/bench.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python $ROOT/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-kernel-timing --no-extra-legs --train-precision bf16 --train-steps 10 > $OUT/${TAG}_bench_train_under_rocprof.json 2>> $OUT/bench.err
 cp $OUT/stats/*/*kernel_stats.csv $OUT/${TAG}_rocprofv3_kernel_stats_train.csv
 # ... and the matched-accuracy training mode (split-fp16 dgrad / wgrad kernels)
 rm -rf $OUT/stats
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python $ROOT/bench.py --precision fp16x3 --steps 1 --warmup 0 --no-cpu-baseline --no-kernel-timing --no-extra-legs --train-steps 6 > $OUT/${TAG}_bench_train_fp16x3_under_rocprof.json 2>> $OUT/bench.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python $ROOT/bench.py --precision fp16x3 --train-precision fp16x3 --steps 1 --warmup 0 --no-cpu-baseline --no-kernel-timing --no-extra-legs --train-steps 6 > $OUT/${TAG}_bench_train_fp16x3_under_rocprof.json 2>> $OUT/bench.err
 cp $OUT/stats/*/*kernel_stats.csv $OUT/${TAG}_rocprofv3_kernel_stats_train_fp16x3.csv
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $OUT/pmc_sq -- python $ROOT/bench.py --steps 2 --warmup 1 --no-kernel-timing $HEAD > /dev/null 2>> $OUT/bench.err
 python $ROOT/tools/pmc_summary.py $OUT/pmc_sq > $OUT/${TAG}_pmc_sq_counters.txt
