@@ -259,6 +259,24 @@ def conv_roofline(agg, precision, pmc, pmc_src, headline_cfg):
             'flops_per_launch': round(fl / n / 1e9, 3), 'flops_unit': 'GFLOP (algorithmic: 2*9*Cin*Cout*pixels)'}
 
 
+def mfma_sustained(precision, achieved):
+    """roofline.peak is the NOMINAL dense MFMA peak (2.5 PFLOP/s at 2.4 GHz).  What the matrix pipe of this box sustains is
+    measured here, in the same process: back-to-back MFMAs on register-resident operands (hla_prof_mfma_peak: no LDS, no memory,
+    two waves per SIMD, ~8 ms) on zero operands, random operands and random operands with half the elements zero (post-ReLU-like).
+    Only the first reaches the nominal figure; on real data the package power limit sets the rate, for ANY kernel."""
+    from highlyaccurate_amd import _lib
+    code = _lib.HLA_BF16 if precision == 'bf16' else _lib.HLA_F16
+    div = 3.0 if precision == 'fp16x3' else 1.0            # three MFMAs per product (algorithmic FLOPs, like roofline.achieved)
+    try:
+        tf = {k: round(_lib.mfma_sustained_tflops(code, d) / div, 1) for k, d in (('zeros', 0), ('random', 1), ('random_half_zeros', 2))}
+    except Exception as e:
+        return {'error': repr(e)[:200]}
+    return {'unit': 'TFLOP/s', **tf, 'frac_of_random_half_zeros': round(achieved / tf['random_half_zeros'], 4),
+            'frac_of_random': round(achieved / tf['random'], 4),
+            'what': 'hla_prof_mfma_peak: back-to-back v_mfma_f32_32x32x16 on register-resident operands, 2 waves/SIMD, all CUs, ~8 ms '
+                    'per case, measured in this run; the ceiling of any MFMA-bound kernel on this box on such data'}
+
+
 def lm_roofline(agg, pmc, pmc_src):
     """The LM accumulate kernels against HBM.  `achieved` uses COUNTER bytes (what actually crossed the HBM interface per
     launch, committed PMC passes) over the live launch time; the algorithmic model (whole satellite map + ground half once
@@ -739,6 +757,8 @@ def main(argv=None):
             tot_ms = sum(v[1] for v in agg.values())
             res['events_pass_ms_per_step'] = round(dt_ev / n_ev * 1e3, 3)
             res['roofline'] = conv_roofline(agg, a.precision, pmc, pmc_src, headline_cfg)
+            if a.precision in ('bf16', 'fp16', 'fp16x3'):
+                res['roofline']['mfma_sustained'] = mfma_sustained(a.precision, res['roofline']['achieved'])
             lmr = lm_roofline(agg, pmc if headline_cfg else None, pmc_src)
             if lmr:
                 res['lm_roofline'] = lmr

@@ -17,7 +17,7 @@ HLA_F32, HLA_BF16, HLA_F16, HLA_F16X3 = 0, 1, 2, 3
 HLA_VGG_WANT_CONF, HLA_VGG_DEFER_NORM, HLA_VGG_SAVE_FOR_BACKWARD, HLA_VGG_FEAT16 = 1, 2, 4, 8
 HLA_VGG_BWD_SCALE_INVARIANT = 1
 HLA_VGG_BWD_DENSE = 2
-ABI_VERSION = 18
+ABI_VERSION = 19
 
 
 class HlaError(RuntimeError):
@@ -153,6 +153,8 @@ def load() -> C.CDLL:
     lib.hla_prof_enable.argtypes = [i]
     lib.hla_prof_kernel_name.restype = C.c_char_p
     lib.hla_prof_kernel_name.argtypes = [i]
+    lib.hla_prof_mfma_peak.restype = i
+    lib.hla_prof_mfma_peak.argtypes = [i, i, C.c_float, C.POINTER(C.c_float), vp]
     lib.hla_prof_fetch.restype = i
     lib.hla_prof_fetch.argtypes = [C.POINTER(ProfRecord), i, C.POINTER(i)]
     _lib = lib
@@ -218,3 +220,11 @@ def require_gpu(t: torch.Tensor, name: str) -> None:
 
 def ptr(t) -> C.c_void_p:
     return C.c_void_p(0 if t is None else t.data_ptr())
+
+
+def mfma_sustained_tflops(dtype_code: int, data: int, ms_target: float = 8.0) -> float:
+    """TFLOP/s the matrix pipe of the current device sustains on register-resident operands (include/hla.h, hla_prof_mfma_peak):
+    data 0 = zeros, 1 = random, 2 = random with half the elements zero."""
+    out = C.c_float(0.0)
+    check(load().hla_prof_mfma_peak(dtype_code, data, ms_target, C.byref(out), stream_ptr()), 'hla_prof_mfma_peak')
+    return float(out.value)

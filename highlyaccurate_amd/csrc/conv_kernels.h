@@ -15,9 +15,11 @@
 //                                          pre-packed in fragment order, so a fragment is one coalesced 1 KiB load
 //     N (MFMA cols) = 32 consecutive pixels of one image row; B operand = pixel fragment from the LDS halo tile
 //     K             = 9 taps x Cin, walked as  stage (64 B of channels) -> tap -> 2 k-groups of 16 B per lane
-//   The (TH+2)x34 input halo tile of a stage is written to LDS once (80-B pixel stride: conflict-free
-//   ds_read_b128) and reused by all 9 taps; LDS is double-buffered, one barrier per stage; the next stage's
-//   tile is prefetched into registers mid-stage; weights are prefetched 1-2 taps ahead into a register ring.
+//   The (TH+2)x34 input halo tile of a stage lands in LDS once (64-B pixels, XOR-swizzled 16-B slots: conflict-free
+//   ds_read_b128) and is reused by all 9 taps; LDS is double-buffered, one barrier per stage.  16-bit types: the next stage's
+//   tile goes HBM -> LDS directly (buffer_load ... lds, requested mid-stage, awaited with a counted vmcnt before the stage's
+//   barrier; the zero border comes from the buffer descriptor's range check); the 4-byte types and the un-pooling loader of the
+//   backward stage it through registers.  Weights are prefetched 1-2 taps ahead into a register ring.
 //   The loader handles "virtual concat + nearest 2x upsample" (VGG.py:144-151) without materialising it.
 //   The epilogue fuses bias, 2x2 max-pool, ReLU, the raw fp32 feature copy and its per-sample sum of squares.
 // conv02_kernel -- conv0 (3->64 on the NCHW fp32 input, K = 27 padded to 32) computed by MFMA directly into the
@@ -197,6 +199,12 @@ __device__ __forceinline__ int halo_off(int pix, int hx, int slot) { return pix 
 // (measured, same-box A/B of (TAP0, TAP1): (2, 6) beats (1, 5) by 3 % on the pooled 64-channel-wave-tile kernel and by 1 % on the
 // un-pooled one; (0, 4) the same; (3, 7) and (1, 6) lose 1-4 %; (3, 6) costs the 32-channel wave tile 20 %)
 constexpr int HALO_TAP0 = 2, HALO_TAP1 = 6;
+// The 16-bit plain kernels fetch a stage's halo tile HBM -> LDS directly (conv3x3_kernel, DMA): -DHLA_CONV_HALO_DMA=0 builds the
+// register-staged loader for them too (same-box A/B); the tap at whose weight loads the tile is requested (0 / 1 / 3 measure the same).
+#ifndef HLA_CONV_HALO_DMA
+#define HLA_CONV_HALO_DMA 1
+#endif
+constexpr int HLA_CONV_DMA_TAP = 1;
 // per-lane byte offsets of a wave's pixel fragments: [kx][kg] -> (x + kx) * PSTR + swizzled slot of (lane half g, k-group kg),
 // relative to the wave's first halo row
 struct FragOff { int o[3][2]; };
@@ -276,7 +284,7 @@ enum { EPI_GENERIC = 0,   // everything, decided at run time (backward / trainin
        EPI_ACT_RAW = 2,   // + the raw fp32 copy and its per-sample sum of squares (the three feature layers)
        EPI_ACT_RAW_NOBIAS = 3,    // the same for a layer without bias (the decoder's): 32 registers less
        EPI_DGRAD = 4 };   // backward data gradient: out_act = (mask > 0 ? acc : 0) [+ add], no bias, no ReLU of its own
-__device__ __forceinline__ int epilogue_mode(const ConvArgs& a) {
+__host__ __device__ __forceinline__ int epilogue_mode(const ConvArgs& a) {
   if (a.mask_act && a.out_act && !a.relu_act && !a.bias && !a.out_raw && !a.sumsq && !a.idx_out && !a.pool_sum) return EPI_DGRAD;
   // (a 16-bit raw copy without the activation output: the last decoder layer when nothing consumes relu(x21) -- vgg.hip)
   if (!a.out_act && a.out_raw && a.raw16 && a.sumsq && !a.bias && !a.mask_act && !a.add_src && !a.idx_out && !a.pool_sum)
@@ -623,8 +631,15 @@ template <typename T, int MT, int NT, int WM, int WN, bool POOL, int WD, bool UN
 __global__ __launch_bounds__(256, NT == 1 ? 3 : 2) void conv3x3_kernel(ConvArgs a) {
   static_assert(WM * WN == 4, "4 waves per block");
   constexpr int EPL = 16 / sizeof(T), KC = SB / sizeof(T);     // channels per stage: 32 (bf16) / 16 (fp32)
-  constexpr int TH = WM * MT, HPIX = (TH + 2) * HWID, BUF = HPIX * PSTR;
+  constexpr int TH = WM * MT, HPIX = (TH + 2) * HWID;
   constexpr int NPIECE = (HPIX * 4 + 255) / 256;               // 16-B pieces per thread per stage ...
+  // DMA (HLA_CONV_HALO_DMA, 16-bit types, plain loader): the halo tile of a stage goes HBM -> LDS directly (buffer_load ... lds),
+  // no staging registers, no ds_write.  The LDS image of such a load is lane-linear (lane L's 16 B at M0 + 16 L), so the XOR
+  // swizzle is applied to WHICH 16-B slot of its pixel a lane fetches; a pixel outside the image / the source's written part
+  // gets an out-of-range offset and the buffer descriptor's range check writes zeros (tools/probes/lds_dma_probe.hip pins both).
+  // A stage buffer is padded to whole 64-pixel pieces: the lanes past the tile's last pixel write zeros there.
+  constexpr bool DMA = HLA_CONV_HALO_DMA && sizeof(T) == 2 && !UNPOOL && !Prec<T>::SPLIT;
+  constexpr int BUF = (DMA ? NPIECE * 64 : HPIX) * PSTR;
   constexpr int NHALF = (NPIECE + 1) / 2;                      // ... fetched in two halves through NHALF staging registers
   // the epilogue reuses the halo buffers as four wave-private row stagers; the widest form stages a raw fp32 row and a 16-bit
   // activation row side by side (EPI_ACT_RAW on 16-bit types), everything else one row of at most NT*32 fp32
@@ -703,8 +718,10 @@ __global__ __launch_bounds__(256, NT == 1 ? 3 : 2) void conv3x3_kernel(ConvArgs 
       const int y = y0 - 1 + hy, x = x0 - 1 + hx;
       const int xlo = hy == 0 ? lo0 : (hy == TH + 1 ? lo2 : lo1), xhi = hy == 0 ? hi0 : (hy == TH + 1 ? hi2 : hi1);
       const bool ok = pix < HPIX && y >= sy0 && y < sy1 && x >= xlo && x < xhi;
-      off1[i] = ok ? ((((y >> sh1) * Ws1 + (x >> sh1)) * a.C1 * ES + part * 16) | ((y & 1) << 1) | (x & 1)) : -1;
-      off2[i] = ok ? ((y * a.W + x) * a.C2 * ES + part * 16) : -1;
+      const int psrc = DMA ? (part ^ halo_key(hx)) : part;      // DMA: the lane's LDS slot is `part`; it holds channel slot part ^ key
+      constexpr int BAD = DMA ? (int)0x80000000 : -1;           // DMA: an offset beyond any buffer's range -> the load writes zeros
+      off1[i] = ok ? ((((y >> sh1) * Ws1 + (x >> sh1)) * a.C1 * ES + psrc * 16) | (DMA ? 0 : (((y & 1) << 1) | (x & 1)))) : BAD;
+      off2[i] = ok ? ((y * a.W + x) * a.C2 * ES + psrc * 16) : BAD;
       // split mode: this thread's 4 channels are 8 B of slot part>>1 (hi); the lo half sits 2 slots further = offset ^ 32
       wo[i] = pix >= HPIX ? -1 : (Prec<T>::SPLIT ? halo_off(pix, hx, part >> 1) + (part & 1) * 8 : halo_off(pix, hx, part));
     }
@@ -777,6 +794,48 @@ __global__ __launch_bounds__(256, NT == 1 ? 3 : 2) void conv3x3_kernel(ConvArgs 
     }
   };
 
+  // DMA loader: two raw buffer descriptors (one per source: base = this sample's map, range = its bytes) and, per stage, ONE asm
+  // statement of NPIECE loads -- hipcc neither counts them (their completion is awaited by hand before the stage's barrier) nor
+  // sees an LDS write it would have to order every following ds_read behind.
+  typedef int rsrc_t __attribute__((ext_vector_type(4)));
+  rsrc_t rs1 = {0, 0, 0, 0x00020000}, rs2 = {0, 0, 0, 0x00020000};
+  unsigned lds_wave = 0;
+  if constexpr (DMA) {
+    const unsigned long long p1 = (unsigned long long)s1b, p2 = (unsigned long long)s2b;
+    rs1[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)p1); rs1[1] = __builtin_amdgcn_readfirstlane((int)(unsigned)(p1 >> 32));
+    rs1[2] = __builtin_amdgcn_readfirstlane(Hs1 * Ws1 * a.C1 * ES);
+    rs2[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)p2); rs2[1] = __builtin_amdgcn_readfirstlane((int)(unsigned)(p2 >> 32));
+    rs2[2] = __builtin_amdgcn_readfirstlane(a.src2 ? a.H * a.W * a.C2 * ES : 0);
+    lds_wave = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)lds) + wv * (16 * PSTR);
+  }
+  auto dma_stage = [&](int sg, int bufsel) __attribute__((always_inline)) {
+    static_assert(!DMA || NPIECE == 6, "six pieces per thread (8 x 32 tile)");
+    const int c0 = sg * KC;
+    const bool first = c0 < a.C1;       // wave-uniform
+    const rsrc_t rs = first ? rs1 : rs2;
+    const int soff = (first ? c0 : c0 - a.C1) * ES;
+    const unsigned dst = lds_wave + bufsel * BUF;
+    unsigned keep;
+    if (first)
+      asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %9\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %7, %8 offen lds\n\t"
+                   "s_add_u32 m0, m0, 0x1000\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %7, %8 offen lds\n\t"
+                   "s_add_u32 m0, m0, 0x1000\n\ts_nop 0\n\tbuffer_load_dwordx4 %3, %7, %8 offen lds\n\t"
+                   "s_add_u32 m0, m0, 0x1000\n\ts_nop 0\n\tbuffer_load_dwordx4 %4, %7, %8 offen lds\n\t"
+                   "s_add_u32 m0, m0, 0x1000\n\ts_nop 0\n\tbuffer_load_dwordx4 %5, %7, %8 offen lds\n\t"
+                   "s_add_u32 m0, m0, 0x1000\n\ts_nop 0\n\tbuffer_load_dwordx4 %6, %7, %8 offen lds\n\ts_mov_b32 m0, %0"
+                   : "=&s"(keep) : "v"(off1[0]), "v"(off1[1]), "v"(off1[2]), "v"(off1[3]), "v"(off1[4]), "v"(off1[5]), "s"(rs), "s"(soff), "s"(dst)
+                   : "memory", "scc");
+    else
+      asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %9\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %7, %8 offen lds\n\t"
+                   "s_add_u32 m0, m0, 0x1000\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %7, %8 offen lds\n\t"
+                   "s_add_u32 m0, m0, 0x1000\n\ts_nop 0\n\tbuffer_load_dwordx4 %3, %7, %8 offen lds\n\t"
+                   "s_add_u32 m0, m0, 0x1000\n\ts_nop 0\n\tbuffer_load_dwordx4 %4, %7, %8 offen lds\n\t"
+                   "s_add_u32 m0, m0, 0x1000\n\ts_nop 0\n\tbuffer_load_dwordx4 %5, %7, %8 offen lds\n\t"
+                   "s_add_u32 m0, m0, 0x1000\n\ts_nop 0\n\tbuffer_load_dwordx4 %6, %7, %8 offen lds\n\ts_mov_b32 m0, %0"
+                   : "=&s"(keep) : "v"(off2[0]), "v"(off2[1]), "v"(off2[2]), "v"(off2[3]), "v"(off2[4]), "v"(off2[5]), "s"(rs), "s"(soff), "s"(dst)
+                   : "memory", "scc");
+  };
+
   const int ntg0 = (blockIdx.y * WN + wn) * NT;     // first global 32-channel output tile of this wave
   // The accumulators start at the bias (16-bit types; it commutes with the max-pool, and the epilogues then have neither
   // the 8 x NT bias registers nor the adds); the 4-byte types add it in the epilogue (split mode: after its power-of-two descale).
@@ -805,7 +864,10 @@ __global__ __launch_bounds__(256, NT == 1 ? 3 : 2) void conv3x3_kernel(ConvArgs 
   uint4 st[NHALF];
   StageIds ids;
   ring.prime();              // the first weight fragments do not depend on the halo tile: request them ahead of it
-  {
+  if constexpr (DMA) {
+    dma_stage(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  } else {
     uint4 st1[NHALF];        // the prologue has registers to spare: both halves are requested back to back
     StageIds ids1;
     load_stage(0, 0, st, ids);
@@ -820,10 +882,20 @@ __global__ __launch_bounds__(256, NT == 1 ? 3 : 2) void conv3x3_kernel(ConvArgs 
     const bool more = sg + 1 < nstage;
     char* nxt = lds + ((sg + 1) & 1) * BUF;
     stage_mma<T, MT, NT, WD, PF>(acc, lds + (sg & 1) * BUF, fo, ring, [&](int tap) __attribute__((always_inline)) {
-      if (tap == HALO_TAP0 && more) load_stage(sg + 1, 0, st, ids);
-      if (tap == HALO_TAP1 && more) { write_stage(nxt, sg + 1, 0, st, ids); load_stage(sg + 1, 1, st, ids); }
+      if constexpr (DMA) {
+        if (tap == HLA_CONV_DMA_TAP && more) dma_stage(sg + 1, (sg + 1) & 1);
+      } else {
+        if (tap == HALO_TAP0 && more) load_stage(sg + 1, 0, st, ids);
+        if (tap == HALO_TAP1 && more) { write_stage(nxt, sg + 1, 0, st, ids); load_stage(sg + 1, 1, st, ids); }
+      }
     });
-    if (more) write_stage(nxt, sg + 1, 1, st, ids);
+    if constexpr (DMA) {
+      // the next stage's tile has landed when at most the youngest 2 * NT * WD loads -- the weight fragments primed for the next
+      // stage, all requested after the tile -- are still in flight
+      if (more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NT * WD) : "memory");
+    } else {
+      if (more) write_stage(nxt, sg + 1, 1, st, ids);
+    }
     __syncthreads();
   }
   // the loop's last barrier guarantees nobody still reads the halo buffers: reuse them as 4 wave-private stagers
@@ -1371,7 +1443,8 @@ static bool launch_conv(hipStream_t st, ConvArgs a, bool pool) {
   // Cout >= 128: block = 8x32 pixels x 128 channels, waves 2(M) x 2(N), wave tile 128 px x 64 ch, weights 1 tap ahead
   // Cout == 64 : block = 8x32 pixels x  64 channels, waves 2 x 2,       wave tile 128 px x 32 ch, weights 2 taps ahead
   if (big) {
-    // (weights two taps ahead for this tile as well: spills, -1 %)
+    // (weights two taps ahead for this tile as well: spills with the register-staged loader, -1 %; with the LDS-DMA loader it
+    //  fits -- 232 registers -- and measures the same: 4876 / 4871 against 4870 / 4841 pairs/s)
     if (pool) hipLaunchKernelGGL((conv3x3_kernel<T, 4, 2, 2, 2, true, 1>), grid, dim3(256), 0, st, a);
     else if (BWD && a.unpool_idx) hipLaunchKernelGGL((conv3x3_kernel<T, 4, 2, 2, 2, false, 1, BWD>), grid, dim3(256), 0, st, a);
     else hipLaunchKernelGGL((conv3x3_kernel<T, 4, 2, 2, 2, false, 1>), grid, dim3(256), 0, st, a);

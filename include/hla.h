@@ -60,7 +60,7 @@ const char* hla_last_error(void);
  * with its own struct sizes (ctypes structs are positional: a mismatch corrupts silently).  highlyaccurate_amd/_lib.py
  * does both at load time, and rebuilds or refuses a binary whose hla_source_hash() is not the hash of the sources
  * next to it (the library is git-ignored but shipped prebuilt). */
-#define HLA_ABI_VERSION 18
+#define HLA_ABI_VERSION 19
 int hla_abi_version(void);
 const char* hla_source_hash(void); /* sha256 (hex) of the csrc sources, this header and the compiler flags at build time */
 typedef enum hla_struct_id {
@@ -340,6 +340,12 @@ typedef struct hla_prof_record {
 int hla_prof_enable(int on);
 const char* hla_prof_kernel_name(int kernel_id);
 int hla_prof_fetch(hla_prof_record* out, int max_records, int* n_out); /* also clears the log */
+/* What the matrix pipe of this device SUSTAINS: back-to-back v_mfma_f32_32x32x16_{bf16,f16} on register-resident operands (no LDS,
+ * no memory), two waves per SIMD, every CU busy for about ms_target milliseconds (0 < ms_target <= 200); synchronises the stream.
+ * dtype HLA_BF16 / HLA_F16; data 0 = zero operands (reaches the nominal peak), 1 = random values, 2 = random with half the
+ * elements zero (post-ReLU-like activations): on real data the package power limit, not the pipe, sets the rate.
+ * tflops_out: achieved TFLOP/s.  bench.py reports it as roofline.mfma_sustained next to the nominal roofline.peak. */
+int hla_prof_mfma_peak(int dtype, int data, float ms_target, float* tflops_out, hla_stream_t stream);
 
 #ifdef __cplusplus
 }
