@@ -1257,13 +1257,19 @@ __global__ void pack_weights_multi_kernel(PackTable tb, char* __restrict__ packe
                        (size_t)blockIdx.x * blockDim.x + threadIdx.x, (size_t)gridDim.x * blockDim.x, tb.first[l] == 1 ? tb.b0 : nullptr);
 }
 
+// Split mode, every layer of a network in ONE launch each (blockIdx.y = table row), like pack_weights_multi_kernel: a training
+// step repacks both directions of both networks after the optimizer step -- 84 launches of ~10 us when done layer by layer.
+struct SplitPackTable {
+  const float* w[16]; size_t off[16];      // source weights, byte offset of the packed layer
+  int cout[16], cin[16], first[16], slot[16];      // slot: the layer's index into the |w| maxima / scale words behind the packed layers
+};
 // Split-fp16 packing: the same fragment order with the two k-groups of a stage replaced by (hi, lo) of ONE 16-channel
 // k-group, elements fp16 of s_w * w:
 //   generic: idx = ((((nt*nstage + sg)*9 + tap)*2 + hl)*64 + lane)*8 + j,  cout = nt*32 + (lane&31), cin = sg*16 + (lane>>5)*8 + j
 //   conv0:   idx = (((nt*2 + f)*2 + hl)*64 + lane)*8 + j,                   k = f*16 + (lane>>5)*8 + j  (k = cin*9+tap, <27)
 // wmax_bits = fp32 bit pattern of max |w| (absmax_kernel); thread 0 of block 0 publishes the scale for the conv kernels.
-static __global__ void pack_weights_split_kernel(const float* __restrict__ w, f16* __restrict__ out, int Cout, int Cin, int first,
-                                          const unsigned* __restrict__ wmax_bits, float* __restrict__ scale_out) {
+static __device__ __forceinline__ void pack_weights_split_body(const float* __restrict__ w, f16* __restrict__ out, int Cout, int Cin, int first,
+                                                               const unsigned* __restrict__ wmax_bits, float* __restrict__ scale_out) {
   const float sw = split_scale(*wmax_bits);
   if (blockIdx.x == 0 && threadIdx.x == 0) *scale_out = sw;
   const size_t total = first == 1 ? (size_t)(Cout / 32) * 2 * 2 * 64 * 8 : (size_t)Cout * Cin * 9 * 2;
@@ -1292,6 +1298,31 @@ static __global__ void pack_weights_split_kernel(const float* __restrict__ w, f1
     out[e] = hl ? (f16)(v - (float)h) : h;
   }
 }
+static __global__ void pack_weights_split_kernel(const float* __restrict__ w, f16* __restrict__ out, int Cout, int Cin, int first,
+                                          const unsigned* __restrict__ wmax_bits, float* __restrict__ scale_out) {
+  pack_weights_split_body(w, out, Cout, Cin, first, wmax_bits, scale_out);
+}
+static __global__ void pack_weights_split_multi_kernel(SplitPackTable tb, char* __restrict__ packed, const unsigned* __restrict__ amax,
+                                                       float* __restrict__ scales) {
+  const int l = blockIdx.y;
+  pack_weights_split_body(tb.w[l], (f16*)(packed + tb.off[l]), tb.cout[l], tb.cin[l], tb.first[l], amax + tb.slot[l], scales + tb.slot[l]);
+}
+static __global__ void absmax_multi_kernel(SplitPackTable tb, unsigned* __restrict__ amax, unsigned* __restrict__ l1max0) {
+  const int l = blockIdx.y;
+  const float* w = tb.w[l];
+  const size_t n = (size_t)tb.cout[l] * tb.cin[l] * 9;
+  float m = 0.f;
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) m = fmaxf(m, fabsf(w[e]));
+  m = wave_max_f32(m);
+  if ((threadIdx.x & 63) == 0) atomicMax(amax + tb.slot[l], __float_as_uint(m));
+  if (tb.first[l] == 1 && l1max0 && blockIdx.x == 0)      // conv0: max over output channels of sum_k |w[co][k]| (the bound its fused kernel scales by)
+    for (size_t r0 = threadIdx.x; r0 * 27 < n; r0 += blockDim.x) {
+      float sum = 0.f;
+      for (int k = 0; k < 27; ++k) sum += fabsf(w[r0 * 27 + k]);
+      atomicMax(l1max0, __float_as_uint(sum));
+    }
+}
+
 // max |w| (as fp32 bits) and, for conv0, max over output channels of sum_k |w[co][k]| (row = 27): both atomicMax'ed into
 // zero-initialised words
 static __global__ void absmax_kernel(const float* __restrict__ w, size_t n, int row, unsigned* __restrict__ amax, unsigned* __restrict__ l1max) {

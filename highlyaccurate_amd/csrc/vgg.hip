@@ -25,20 +25,18 @@ void vgg_pack_all(const hla_vgg_params* prm, char* packed, int dtype, hipStream_
     hla_prof_end(st);
     return;
   }
-  for (int l = 0; l < kAllLayers; ++l) {
-    if (l >= kPackedLayers && !prm->w[l]) continue;        // conv_dec3.* only when the caller supplies its padded weights
-    const size_t n = l == 0 ? (size_t)2 * 32 * 32 : (size_t)kLayers[l].cin * kLayers[l].cout * 9;
-    const int grid = (int)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024);
-    hla_prof_begin(K_PACK, 0, (double)n * (4 + sizeof(T)), st);
-    if constexpr (Prec<T>::SPLIT) {
-      const size_t nw = (size_t)kLayers[l].cin * kLayers[l].cout * 9;
-      const int g1 = (int)((nw + 255) / 256 < 256 ? (nw + 255) / 256 : 256);
-      hipLaunchKernelGGL(absmax_kernel, dim3(g1), dim3(256), 0, st, prm->w[l], nw, 27, scratch + l,
-                         l == 0 ? (unsigned*)tail + 16 : (unsigned*)nullptr);
-      hipLaunchKernelGGL(pack_weights_split_kernel, dim3(grid), dim3(256), 0, st, prm->w[l],
-                         (f16*)(packed + packed_offset(l, dtype)), kLayers[l].cout, kLayers[l].cin, l == 0 ? 1 : 0,
-                         (const unsigned*)(scratch + l), tail + l);
+  if constexpr (Prec<T>::SPLIT) {      // two launches for the whole network: the |w| maxima, then the (hi, lo) fragments scaled by them
+    SplitPackTable tb{};
+    int n = 0;
+    for (int l = 0; l < kAllLayers; ++l) {
+      if (l >= kPackedLayers && !prm->w[l]) continue;        // conv_dec3.* only when the caller supplies its padded weights
+      tb.w[n] = prm->w[l]; tb.off[n] = packed_offset(l, dtype); tb.cout[n] = kLayers[l].cout; tb.cin[n] = kLayers[l].cin;
+      tb.first[n] = l == 0 ? 1 : 0; tb.slot[n] = l;
+      ++n;
     }
+    hla_prof_begin(K_PACK, 0, (double)packed_offset(kAllLayers, dtype) * 3.0, st);
+    hipLaunchKernelGGL(absmax_multi_kernel, dim3(64, n), dim3(256), 0, st, tb, scratch, (unsigned*)tail + 16);
+    hipLaunchKernelGGL(pack_weights_split_multi_kernel, dim3(256, n), dim3(256), 0, st, tb, packed, (const unsigned*)scratch, tail);
     hla_prof_end(st);
   }
 }

@@ -998,14 +998,17 @@ void vgg_pack_all_T(const hla_vgg_params* prm, char* packed, int dtype, hipStrea
     float* tail = (float*)(packed + packed_offset(kAllLayers, dtype));
     unsigned* scratch = (unsigned*)tail + 32;
     (void)hipMemsetAsync(tail, 0, kPackTailBytes, st);
-    for (int l = 1; l < kAllLayers; ++l) {
+    SplitPackTable tb{};
+    int n = 0;
+    for (int l = 1; l < kAllLayers; ++l) {          // conv0 needs no data gradient
       if (l >= kPackedLayers && !prm->w[l]) continue;
-      const size_t nw = (size_t)kLayers[l].cin * kLayers[l].cout * 9;
-      const int g1 = (int)((nw + 255) / 256 < 256 ? (nw + 255) / 256 : 256), g2 = (int)((nw + 255) / 256 < 1024 ? (nw + 255) / 256 : 1024);
-      hipLaunchKernelGGL(absmax_kernel, dim3(g1), dim3(256), 0, st, prm->w[l], nw, 27, scratch + l, (unsigned*)nullptr);
-      hipLaunchKernelGGL(pack_weights_split_kernel, dim3(g2), dim3(256), 0, st, prm->w[l], (f16*)(packed + packed_offset(l, dtype)),
-                         kLayers[l].cin, kLayers[l].cout, 2, (const unsigned*)(scratch + l), tail + l);
+      // transposed conv: Cout' = cin, Cin' = cout (pack mode 2 transposes and flips the taps)
+      tb.w[n] = prm->w[l]; tb.off[n] = packed_offset(l, dtype); tb.cout[n] = kLayers[l].cin; tb.cin[n] = kLayers[l].cout;
+      tb.first[n] = 2; tb.slot[n] = l;
+      ++n;
     }
+    hipLaunchKernelGGL(absmax_multi_kernel, dim3(64, n), dim3(256), 0, st, tb, scratch, (unsigned*)nullptr);
+    hipLaunchKernelGGL(pack_weights_split_multi_kernel, dim3(256, n), dim3(256), 0, st, tb, packed, (const unsigned*)scratch, tail);
   } else {
     PackTable tb{};
     int n = 0;
