@@ -599,9 +599,13 @@ __global__ __launch_bounds__(256) void l2bwd_apply_kernel(const float* __restric
                                                           const double* __restrict__ part, const double* __restrict__ inv,
                                                           T* __restrict__ out, size_t per_sample, int nblk,
                                                           int* __restrict__ rowiv = nullptr, int C = 1, int Wl = 1,
-                                                          size_t skip = 0) {      // floats at the start of a sample that are neither
+                                                          size_t skip = 0,        // floats at the start of a sample that are neither
                                                                                  // read nor written (the caller's static first rows)
+                                                          unsigned* __restrict__ amax = nullptr) {   // split mode: [B] atomicMax target
+                                                                                 // for max |out| per sample (the scale the map's consumer
+                                                                                 // uses), instead of a separate pass over the map
   const int b = blockIdx.x / nblk, k = blockIdx.x % nblk;
+  float mx = 0.f;
   double dot = 0.0;
   if (!ORTHO)
     for (int i = 0; i < nblk; ++i) dot += part[(size_t)b * nblk + i];
@@ -624,6 +628,7 @@ __global__ __launch_bounds__(256) void l2bwd_apply_kernel(const float* __restric
     for (size_t i = start + threadIdx.x; i < end; i += 256) {
       const float4 v = pd[i];
       store4(po + i * 4, c1 * v.x, c1 * v.y, c1 * v.z, c1 * v.w);
+      mx = fmaxf(fmaxf(mx, fmaxf(fabsf(c1 * v.x), fabsf(c1 * v.y))), fmaxf(fabsf(c1 * v.z), fabsf(c1 * v.w)));
       const bool nz = v.x != 0.f || v.y != 0.f || v.z != 0.f || v.w != 0.f;
       const unsigned long long m = __ballot(nz);
       if (m) {
@@ -652,16 +657,25 @@ __global__ __launch_bounds__(256) void l2bwd_apply_kernel(const float* __restric
       if (siv[2 * threadIdx.x] > __hip_atomic_load(r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(r, siv[2 * threadIdx.x]);
       if (siv[2 * threadIdx.x + 1] > __hip_atomic_load(r + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(r + 1, siv[2 * threadIdx.x + 1]);
     }
+    if (amax) {
+      mx = wave_max_f32(mx);
+      if ((threadIdx.x & 63) == 0 && mx > 0.f) atomicMax(amax + b, __float_as_uint(mx));
+    }
     return;
   }
   for (size_t i = skip / 4 + (size_t)k * 256 + threadIdx.x; i < per_sample / 4; i += (size_t)nblk * 256) {
     const float4 v = pd[i];
     if (ORTHO) {       // HLA_VGG_BWD_SCALE_INVARIANT: x . dy = 0 analytically, dx = dy / ||x||; x is not read
       store4(po + i * 4, c1 * v.x, c1 * v.y, c1 * v.z, c1 * v.w);
+      mx = fmaxf(fmaxf(mx, fmaxf(fabsf(c1 * v.x), fabsf(c1 * v.y))), fmaxf(fabsf(c1 * v.z), fabsf(c1 * v.w)));
     } else {
       const float4 u = px[i];
       store4(po + i * 4, c1 * v.x - c3 * u.x, c1 * v.y - c3 * u.y, c1 * v.z - c3 * u.z, c1 * v.w - c3 * u.w);
     }
+  }
+  if (ORTHO && amax) {
+    mx = wave_max_f32(mx);
+    if ((threadIdx.x & 63) == 0 && mx > 0.f) atomicMax(amax + b, __float_as_uint(mx));
   }
 }
 
@@ -1097,6 +1111,7 @@ int vgg_backward_t(const float* x, size_t x_plane, const hla_vgg_params* prm, co
   // ... and the L2-norm backward below starts at n_x15 / n_x18 / n_x21 as well: the rows of d_feat[l] above f * 2^l - 2 are neither
   // read nor written (the caller need not even zero them)
   const int l2_row0[4] = {n_x15, n_x18, n_x21, 0};
+  bool l2_recorded_amax = false;
   for (int l = 0; l < NL; ++l) {
     int nblk = (int)(per[l] / 4 / 256 / 8);
     nblk = nblk < 1 ? 1 : (nblk > 64 ? 64 : nblk);
@@ -1105,9 +1120,13 @@ int vgg_backward_t(const float* x, size_t x_plane, const hla_vgg_params* prm, co
       const int Cl[4] = {256, 128, 64, 64};
       const size_t skip = (size_t)l2_row0[l] * (W >> (3 - l)) * Cl[l];
       hla_prof_begin(K_ELEMWISE, 0, (double)B * (per[l] - skip) * (4 + sizeof(T)), st);
+      // split mode: the finest map's gradient (g_x21 / g_x24) is READ by a convolution, which needs its per-sample maximum; the
+      // pass that writes it records it, unless the confidence heads still add into it (then absmax_map below does)
+      unsigned* am = (SPLIT && l == NL - 1 && !(conf && d_conf)) ? GA(level4 ? GA_X24 : GA_X21) : (unsigned*)nullptr;
+      l2_recorded_amax = l2_recorded_amax || am != nullptr;
       hipLaunchKernelGGL((l2bwd_apply_kernel<ET, true>), dim3(B * nblk), dim3(256), 0, st, feat[l], d_feat[l], part,
                          inv_norm + (size_t)l * B, (ET*)l2out[l], per[l], nblk, dynamic ? dynp + dl.seed[l] : (int*)nullptr,
-                         Cl[l], W >> (3 - l), skip);
+                         Cl[l], W >> (3 - l), skip, am);
     } else {
       hla_prof_begin(K_ELEMWISE, 0, (double)B * per[l] * (16 + sizeof(T)), st);
       hipLaunchKernelGGL(l2bwd_dot_kernel, dim3(B * nblk), dim3(256), 0, st, feat[l], d_feat[l], part, per[l], nblk);
@@ -1151,7 +1170,7 @@ int vgg_backward_t(const float* x, size_t x_plane, const hla_vgg_params* prm, co
     hipLaunchKernelGGL(absmax_map_kernel, dim3(B * nblk), dim3(256), 0, st, (const float*)map, per_sample, skip, nblk, GA(slot));
     hla_prof_end(st);
   };
-  if (SPLIT) {
+  if (SPLIT && !l2_recorded_amax) {
     if (level4) absmax_map(G(bp.g_x24), per[3], 0, GA_X24);
     else absmax_map(G(bp.g_x21), per[2], (size_t)l2_row0[2] * (W / 2) * 64, GA_X21);
   }
