@@ -78,6 +78,7 @@ class S2GPBase(nn.Module):
     #   bwd_trim           1: the backward skips rows / tiles whose gradient is exactly zero; 0: dense walk     DESIGN.md 6
     #   bwd_two_streams    1: the two extractors' backward passes run on two streams (single-GPU training)       DESIGN.md 6
     #   strict_errors      0; 1: reproduce jacobian.py:172's AssertionError (costs a host sync per forward)     DESIGN.md 1
+    #   small_batch_two_streams  4: inference batches up to this size run the two extractors on two streams        DESIGN.md 5
     def __init__(self, args):
         super().__init__()
         self.args = args
@@ -308,7 +309,20 @@ class S2GPBase(nn.Module):
         # 16-bit maps and 30 % faster than on fp32 ones: +7 % pairs/s.  args.lm_feat16 = 0 keeps fp32 maps; the fp32-class modes
         # and every training path always do.
         f16 = (self.SatFeatureNet.precision in ('bf16', 'fp16') and self.level == 3 and bool(getattr(self.args, 'lm_feat16', 1)))
-        sat_feats, _, sat_inv = vgg_forward_nhwc(self.SatFeatureNet, sat_map, want_conf=False, defer_norm=True, feat16=f16)
+        # A small batch cannot fill the chip (a B = 1 conv launch is 8-256 workgroups on 256 CUs) and the forward is then a chain of
+        # ~70 dependent launches: the two extractors are independent, so the satellite branch runs on a side stream next to the
+        # ground branch's (B <= args.small_batch_two_streams, default 4: B = 1 0.700 -> 0.615 ms, B = 4 1.195 -> 1.122; at B = 32, where both are dense, the same split measured
+        # 2 % slower: DESIGN 3.1).
+        small = sat_map.shape[0] <= int(getattr(self.args, 'small_batch_two_streams', 4))
+        if small:
+            cur = torch.cuda.current_stream()
+            side = _side_stream(sat_map.device)
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                sat_feats, _, sat_inv = vgg_forward_nhwc(self.SatFeatureNet, sat_map, want_conf=False, defer_norm=True, feat16=f16)
+            sat_map.record_stream(side)
+        else:
+            sat_feats, _, sat_inv = vgg_forward_nhwc(self.SatFeatureNet, sat_map, want_conf=False, defer_norm=True, feat16=f16)
         grd_in = grd_img
         # (only LM_update renormalises the ground features; SGD / ADAM see the whole-map L2_norm scale, so they need every row)
         dead_ok = (not return_confs and self.level == 3 and getattr(self.args, 'Optimizer', 'LM') == 'LM'
@@ -321,6 +335,10 @@ class S2GPBase(nn.Module):
         f8 = f8 if f8 >= 4 else 0
         grd_feats, grd_confs, grd_inv = vgg_forward_nhwc(self.GrdFeatureNet, grd_in, want_conf=want_conf, defer_norm=True,
                                                          first_row8=f8, feat16=f16)
+        if small:
+            cur.wait_stream(side)
+            for t in list(sat_feats) + [sat_inv]:        # allocated on the side stream, consumed (LM loop) on this one
+                t.record_stream(cur)
         L = self._levels
         return L(sat_feats), L(sat_inv), L(grd_feats), L(grd_confs), L(grd_inv)
 
