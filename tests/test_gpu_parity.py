@@ -715,6 +715,15 @@ def test_determinism_and_batch_independence():
     n1.zero_grad()
     n1(sat.to(d), grd.to(d), gu.to(d), gv.to(d), gh.to(d), mode='train')[0].backward()
     assert all(torch.isfinite(p.grad).all() for p in n1.parameters() if p.grad is not None)
+    # Full KITTI shape, B = 9 (one stream, XCD-affine LM block map) against the same samples alone (B <= 4: the two extractors on
+    # two streams, the plain block map): bitwise equal
+    sat, grd, *_ = O.synth_images(31, 9)
+    with torch.no_grad():
+        n1(sat.to(d), grd.to(d), mode='test')
+        big = n1.last_trace.clone()
+        for k in (0, 8):
+            n1(sat[k:k + 1].to(d), grd[k:k + 1].to(d), mode='test')
+            assert torch.equal(big[k:k + 1], n1.last_trace), k
 
 
 def test_train_mode_forward_values_vs_golden():
