@@ -2094,6 +2094,20 @@ def test_fuzz_slice_vs_oracle(chunk):
     assert not bad, f'fuzz seeds beyond their bound: {bad}'
 
 
+def test_fuzz_16bit_kernels_slice_vs_fp32_mode():
+    """A fixed slice of tests/diag/fuzz_16bit.py: the 16-bit kernels' own code paths (LDS-DMA halo loader -- source-side swizzle,
+    range-checked zero border --, bias-initialised accumulators, batched epilogue; in the backward the same loader under the
+    data-dependent tile lists) on random ragged shapes, levels 3 / 4, forward maps and parameter gradients against the library's
+    exact-fp32 mode.  (The harness's 120 cases of round 4: profiles/r04_fuzz_16bit_kernels_120_cases.txt.)"""
+    import importlib.util, os
+    p = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'diag', 'fuzz_16bit.py')
+    spec = importlib.util.spec_from_file_location('fuzz_16bit', p)
+    fz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fz)
+    bad = [s for s in range(5000, 5016) if not fz.one_case(s)]
+    assert not bad, f'16-bit fuzz seeds beyond their bound: {bad}'
+
+
 @pytest.mark.parametrize('precision', ['fp32', 'fp16x3'])
 def test_fuzz_ill_conditioned_seed_2515_is_excused_by_the_reference_itself(precision):
     """ADVICE r03: the one recorded failure of the split-fp16 backward's fuzz run (seed 2515: LM_G2SP, use_hessian + train_damping;
