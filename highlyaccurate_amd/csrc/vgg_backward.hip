@@ -253,6 +253,171 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// wgrad_dma_kernel: the same contraction for the 16-bit types with the tiles fetched HBM -> LDS by LDS-DMA and the NEXT tile's
+// loads in flight under the current tile's MFMA phase.  wgrad_kernel stages a tile through 44 registers and runs
+// load -> barrier -> LDS write -> barrier -> MFMA with nothing but the co-resident workgroup to overlap the phases; here the X
+// halo tile is double-buffered, and the G tile -- whose fragments all sit in registers for the whole MFMA phase -- is refilled in
+// place as soon as every wave holds them: 2 x 28 KB + 16 KB = 72 KB, still two workgroups per CU, and no staging registers.
+// LDS image: 128-B pixels with NO pad (a DMA's image is lane-linear); the transposing reads stay conflict-free through an XOR of
+// the 16-B chunk index with 2 (pixel & 3), applied to the SOURCE chunk a lane fetches and to the read address: a 16-lane group
+// of ds_read_b64_tr_b16 touches 4 consecutive pixels x 32 B, which the key spreads over 4 different 32-B segments of the two
+// 128-B bank halves.  Zero fill (outside the image / the written part of g) by the buffer descriptors' range check.
+// Plain launches only (no virtual unpool: that loader masks elements on the way into LDS).
+#ifndef HLA_WGRAD_DMA
+#define HLA_WGRAD_DMA 1
+#endif
+constexpr int WGD_XBLK = 28, WGD_GBLK = 16;             // 1-KiB blocks (8 pixels) per X buffer (204 pixels + pad) / G buffer
+constexpr int wgd_lds_bytes() { return (2 * WGD_XBLK + WGD_GBLK) * 1024; }
+
+template <typename T>
+__global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(WgradArgs a) {
+  static_assert(sizeof(T) == 2, "16-bit types");
+  constexpr int XPIX = (WG_TH + 2) * HWID, XB = WGD_XBLK * 1024, NXJ = WGD_XBLK / 4, NGJ = WGD_GBLK / 4;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* Gs = smem + 2 * XB;
+  const int t = threadIdx.x, lane = t & 63, wv = __builtin_amdgcn_readfirstlane(t >> 6), ct = wv >> 1, it = wv & 1;
+  const int ks = blockIdx.x, ci0 = blockIdx.y * 64, co0 = blockIdx.z * 64;
+  const bool first = ci0 < a.C1;
+  const char* xsrc = first ? (const char*)a.x1 : (const char*)a.x2;
+  const int Cs = first ? a.C1 : a.C2, coff = first ? ci0 : ci0 - a.C1, sh = (first && a.up1) ? 1 : 0;
+  const int Hs = a.H >> sh, Ws = a.W >> sh;
+  const bool want_bias = a.bpart && blockIdx.y == 0 && it == 0;
+
+  f32x16 acc[9], accb;
+#pragma unroll
+  for (int k = 0; k < 9; ++k)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[k][r] = 0.f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) accb[r] = 0.f;
+  const uint4 ones = frag_ones<T>();
+
+  // what a lane fetches: block k = wv + 4 j of a buffer, pixel 8 k + (lane >> 3) of the tile, LDS chunk position lane & 7, which holds
+  // channel chunk (lane & 7) ^ 2 (pixel & 3)
+  const int q = lane >> 3, cp = lane & 7;
+  int xhy[NXJ], xhx[NXJ], xc[NXJ];
+#pragma unroll
+  for (int j = 0; j < NXJ; ++j) {
+    const int p = 8 * (wv + 4 * j) + q;
+    xhy[j] = p < XPIX ? p / HWID : 1 << 20;            // (past the tile: never inside the image -> zeros into the pad)
+    xhx[j] = p % HWID;
+    xc[j] = (cp ^ (2 * (p & 3))) * 16;
+  }
+  typedef int rsrc_t __attribute__((ext_vector_type(4)));
+  const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)smem) + wv * 1024;
+  const WgTiles tl(a.dyn, a.dyn_desc, a.H, a.W, a.row_begin, a.tiles_x, a.tiles_y, a.ntile, a.B, 0);
+  auto dma_tile = [&](int tile, int xbuf) __attribute__((always_inline)) {
+    int b, y0, x0, gx0, gx1;
+    tl.origin(tile, b, y0, x0, gx0, gx1);
+    const unsigned long long px = (unsigned long long)xsrc + (size_t)b * Hs * Ws * Cs * 2;
+    const unsigned long long pg = (unsigned long long)a.g + (size_t)b * a.H * a.W * a.Cout * 2;
+    rsrc_t rx, rg;
+    rx[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)px); rx[1] = __builtin_amdgcn_readfirstlane((int)(unsigned)(px >> 32));
+    rx[2] = __builtin_amdgcn_readfirstlane(Hs * Ws * Cs * 2); rx[3] = 0x00020000;
+    rg[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)pg); rg[1] = __builtin_amdgcn_readfirstlane((int)(unsigned)(pg >> 32));
+    rg[2] = __builtin_amdgcn_readfirstlane(a.H * a.W * a.Cout * 2); rg[3] = 0x00020000;
+    int ox[NXJ], og[NGJ];
+#pragma unroll
+    for (int j = 0; j < NXJ; ++j) {
+      const int y = y0 - 1 + xhy[j], x = x0 - 1 + xhx[j];
+      const bool ok = y >= 0 && y < a.H && x >= 0 && x < a.W;
+      ox[j] = ok ? (((y >> sh) * Ws + (x >> sh)) * Cs + coff) * 2 + xc[j] : (int)0x80000000;
+    }
+#pragma unroll
+    for (int j = 0; j < NGJ; ++j) {
+      const int p = 8 * (wv + 4 * j) + q, y = y0 + p / 32, x = x0 + p % 32;
+      const bool ok = y < a.H && x >= gx0 && x < gx1;
+      og[j] = ok ? ((y * a.W + x) * a.Cout + co0) * 2 + (cp ^ (2 * (p & 3))) * 16 : (int)0x80000000;
+    }
+    const unsigned dx = lds0 + xbuf * XB, dg = lds0 + 2 * XB;
+    const int zero = 0;
+    unsigned keep;
+    static_assert(NXJ == 7 && NGJ == 4, "asm below");
+    asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %10\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %8, %9 offen lds\n\t"
+                 "s_add_u32 m0, m0, 0x1000\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %8, %9 offen lds\n\t"
+                 "s_add_u32 m0, m0, 0x1000\n\ts_nop 0\n\tbuffer_load_dwordx4 %3, %8, %9 offen lds\n\t"
+                 "s_add_u32 m0, m0, 0x1000\n\ts_nop 0\n\tbuffer_load_dwordx4 %4, %8, %9 offen lds\n\t"
+                 "s_add_u32 m0, m0, 0x1000\n\ts_nop 0\n\tbuffer_load_dwordx4 %5, %8, %9 offen lds\n\t"
+                 "s_add_u32 m0, m0, 0x1000\n\ts_nop 0\n\tbuffer_load_dwordx4 %6, %8, %9 offen lds\n\t"
+                 "s_add_u32 m0, m0, 0x1000\n\ts_nop 0\n\tbuffer_load_dwordx4 %7, %8, %9 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(ox[0]), "v"(ox[1]), "v"(ox[2]), "v"(ox[3]), "v"(ox[4]), "v"(ox[5]), "v"(ox[6]), "s"(rx), "s"(zero), "s"(dx)
+                 : "memory", "scc");
+    asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %7\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %5, %6 offen lds\n\t"
+                 "s_add_u32 m0, m0, 0x1000\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %5, %6 offen lds\n\t"
+                 "s_add_u32 m0, m0, 0x1000\n\ts_nop 0\n\tbuffer_load_dwordx4 %3, %5, %6 offen lds\n\t"
+                 "s_add_u32 m0, m0, 0x1000\n\ts_nop 0\n\tbuffer_load_dwordx4 %4, %5, %6 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(og[0]), "v"(og[1]), "v"(og[2]), "v"(og[3]), "s"(rg), "s"(zero), "s"(dg)
+                 : "memory", "scc");
+  };
+  // read side: byte offset of this lane's 8 bytes inside a buffer for a fragment whose first pixel px0 has px0 & 3 == m, WITHOUT
+  // px0 * 128 (compile-time: it goes into the instruction's offset): row part + swizzled column part
+  const int tq = (lane & 15) >> 2, g5 = lane >> 5;
+  int scG[4], scX[4];
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+    const int key = (2 * ((m + tq) & 3)) << 4;
+    const int rowb = (tq + 8 * g5) * 128;
+    scG[m] = rowb + ((((ct * 32 + 16 * ((lane >> 4) & 1)) + 4 * (lane & 3)) * 2) ^ key);
+    scX[m] = rowb + ((((it * 32 + 16 * ((lane >> 4) & 1)) + 4 * (lane & 3)) * 2) ^ key);
+  }
+  auto frag = [&](const char* buf, int px0, const int (&sc)[4]) __attribute__((always_inline)) {
+    const char* p = buf + px0 * 128 + sc[px0 & 3];
+    const v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s*)(p));
+    const v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s*)(p + 4 * 128));
+    uint4 r;
+    __builtin_memcpy(&r.x, &lo, 8);
+    __builtin_memcpy(&r.z, &hi, 8);
+    return r;
+  };
+
+  int tile = ks, cur = 0;
+  if (tile < tl.ntile) dma_tile(tile, 0);
+  for (; tile < tl.ntile; tile += a.KS) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's share of X(tile) and G(tile) has landed ...
+    __syncthreads();                                       // ... and so has everyone's; the previous tile's MFMA phase is over
+    const char* Xs = smem + cur * XB;
+    uint4 Af[WG_TH][2];
+#pragma unroll
+    for (int r = 0; r < WG_TH; ++r)
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) Af[r][kk] = frag(Gs, r * 32 + kk * 16, scG);
+    __syncthreads();                                       // every wave holds its G fragments: the G buffer can be refilled
+    if (tile + a.KS < tl.ntile) dma_tile(tile + a.KS, cur ^ 1);
+    if (want_bias) {
+#pragma unroll
+      for (int r = 0; r < WG_TH; ++r)
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) mma16<T>(accb, Af[r][kk], ones);
+    }
+#pragma unroll
+    for (int rho = 0; rho < WG_TH + 2; ++rho) {
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+          const uint4 Bf = frag(Xs, rho * HWID + kx + kk * 16, scX);
+#pragma unroll
+          for (int ky = 0; ky < 3; ++ky) {
+            const int r = rho - ky;
+            if (r >= 0 && r < WG_TH) mma16<T>(acc[ky * 3 + kx], Af[r][kk], Bf);
+          }
+        }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    cur ^= 1;
+  }
+  const int ci = ci0 + it * 32 + (lane & 31);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int co = co0 + ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * g5;
+    float* o = a.part + (((size_t)ks * a.Cout + co) * a.Cin + ci) * 9;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) o[tap] = acc[tap][r];
+    if (want_bias && (lane & 31) == 0) a.bpart[(size_t)ks * a.Cout + co] = accb[r];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Split-fp16 weight gradient (precision 'fp16x3'): the same contraction over pixels with both operands fed to the matrix cores
 // as hi + lo = fp16(s v) + fp16(s v - hi): G X ~= Ghi Xhi + Glo Xhi + Ghi Xlo, three v_mfma_f32_32x32x16_f16 per product, fp32
 // accumulate -- fp32-class gradients at a third of the fp16 MFMA rate instead of the exact-fp32 kernels' sixteenth.
@@ -1052,8 +1217,13 @@ int vgg_backward_t(const float* x, size_t x_plane, const hla_vgg_params* prm, co
   HLA_CHECK_HIP(attr_once.run([] {
     if constexpr (SPLIT)
       return hipFuncSetAttribute((const void*)wgrad_split_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, wgs_lds_bytes());
-    else
+    else {
+      if constexpr (sizeof(T) == 2 && HLA_WGRAD_DMA) {
+        const hipError_t e = hipFuncSetAttribute((const void*)wgrad_dma_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, wgd_lds_bytes());
+        if (e != hipSuccess) return e;
+      }
       return hipFuncSetAttribute((const void*)wgrad_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, wg_lds_bytes<T>());
+    }
   }));
   auto F = [&](size_t off) { return (const void*)(fw + off); };
   auto G = [&](size_t off) { return (void*)(bw + off); };
@@ -1210,6 +1380,9 @@ int vgg_backward_t(const float* x, size_t x_plane, const hla_vgg_params* prm, co
     if constexpr (SPLIT) {
       WgradSplitExtra ex{FA(fa1), FA(fa2), GA(ga)};
       hipLaunchKernelGGL(wgrad_split_kernel, dim3(a.KS, a.Cin / 64, a.Cout / 64), dim3(256), wgs_lds_bytes(), st, a, ex);
+    } else if constexpr (sizeof(T) == 2 && HLA_WGRAD_DMA) {
+      if (!unpool) hipLaunchKernelGGL((wgrad_dma_kernel<T>), dim3(a.KS, a.Cin / 64, a.Cout / 64), dim3(256), wgd_lds_bytes(), st, a);
+      else hipLaunchKernelGGL((wgrad_kernel<T>), dim3(a.KS, a.Cin / 64, a.Cout / 64), dim3(256), wg_lds_bytes<T>(), st, a);
     } else {
       hipLaunchKernelGGL((wgrad_kernel<T>), dim3(a.KS, a.Cin / 64, a.Cout / 64), dim3(256), wg_lds_bytes<T>(), st, a);
     }
