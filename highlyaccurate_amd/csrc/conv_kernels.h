@@ -205,6 +205,9 @@ constexpr int HALO_TAP0 = 2, HALO_TAP1 = 6;
 #define HLA_CONV_HALO_DMA 1
 #endif
 constexpr int HLA_CONV_DMA_TAP = 1;
+#ifndef HLA_CONV_SMALL_GRID
+#define HLA_CONV_SMALL_GRID 320      // workgroups: below this a forward launch takes 4-row tiles (launch_conv)
+#endif
 // per-lane byte offsets of a wave's pixel fragments: [kx][kg] -> (x + kx) * PSTR + swizzled slot of (lane half g, k-group kg),
 // relative to the wave's first halo row
 struct FragOff { int o[3][2]; };
@@ -809,31 +812,35 @@ __global__ __launch_bounds__(256, NT == 1 ? 3 : 2) void conv3x3_kernel(ConvArgs 
     lds_wave = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)lds) + wv * (16 * PSTR);
   }
   auto dma_stage = [&](int sg, int bufsel) __attribute__((always_inline)) {
-    static_assert(!DMA || NPIECE == 6, "six pieces per thread (8 x 32 tile)");
+    static_assert(!DMA || NPIECE == 6 || NPIECE == 4, "six pieces per thread (8 x 32 tile) or four (4 x 32)");
     const int c0 = sg * KC;
     const bool first = c0 < a.C1;       // wave-uniform
     const rsrc_t rs = first ? rs1 : rs2;
     const int soff = (first ? c0 : c0 - a.C1) * ES;
     const unsigned dst = lds_wave + bufsel * BUF;
     unsigned keep;
-    if (first)
-      asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %9\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %7, %8 offen lds\n\t"
-                   "s_add_u32 m0, m0, 0x1000\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %7, %8 offen lds\n\t"
-                   "s_add_u32 m0, m0, 0x1000\n\ts_nop 0\n\tbuffer_load_dwordx4 %3, %7, %8 offen lds\n\t"
-                   "s_add_u32 m0, m0, 0x1000\n\ts_nop 0\n\tbuffer_load_dwordx4 %4, %7, %8 offen lds\n\t"
-                   "s_add_u32 m0, m0, 0x1000\n\ts_nop 0\n\tbuffer_load_dwordx4 %5, %7, %8 offen lds\n\t"
-                   "s_add_u32 m0, m0, 0x1000\n\ts_nop 0\n\tbuffer_load_dwordx4 %6, %7, %8 offen lds\n\ts_mov_b32 m0, %0"
-                   : "=&s"(keep) : "v"(off1[0]), "v"(off1[1]), "v"(off1[2]), "v"(off1[3]), "v"(off1[4]), "v"(off1[5]), "s"(rs), "s"(soff), "s"(dst)
-                   : "memory", "scc");
-    else
-      asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %9\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %7, %8 offen lds\n\t"
-                   "s_add_u32 m0, m0, 0x1000\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %7, %8 offen lds\n\t"
-                   "s_add_u32 m0, m0, 0x1000\n\ts_nop 0\n\tbuffer_load_dwordx4 %3, %7, %8 offen lds\n\t"
-                   "s_add_u32 m0, m0, 0x1000\n\ts_nop 0\n\tbuffer_load_dwordx4 %4, %7, %8 offen lds\n\t"
-                   "s_add_u32 m0, m0, 0x1000\n\ts_nop 0\n\tbuffer_load_dwordx4 %5, %7, %8 offen lds\n\t"
-                   "s_add_u32 m0, m0, 0x1000\n\ts_nop 0\n\tbuffer_load_dwordx4 %6, %7, %8 offen lds\n\ts_mov_b32 m0, %0"
-                   : "=&s"(keep) : "v"(off2[0]), "v"(off2[1]), "v"(off2[2]), "v"(off2[3]), "v"(off2[4]), "v"(off2[5]), "s"(rs), "s"(soff), "s"(dst)
-                   : "memory", "scc");
+#define HLA_DMA_HEAD(NDST) "s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %" #NDST "\n\ts_nop 0\n\t"
+#define HLA_DMA_LD(K, NRS, NSO) "buffer_load_dwordx4 %" #K ", %" #NRS ", %" #NSO " offen lds\n\t"
+#define HLA_DMA_STEP "s_add_u32 m0, m0, 0x1000\n\ts_nop 0\n\t"
+    if constexpr (NPIECE == 6) {
+#define HLA_DMA6(O)                                                                                                                    \
+      asm volatile(HLA_DMA_HEAD(9) HLA_DMA_LD(1, 7, 8) HLA_DMA_STEP HLA_DMA_LD(2, 7, 8) HLA_DMA_STEP HLA_DMA_LD(3, 7, 8) HLA_DMA_STEP    \
+                   HLA_DMA_LD(4, 7, 8) HLA_DMA_STEP HLA_DMA_LD(5, 7, 8) HLA_DMA_STEP HLA_DMA_LD(6, 7, 8) "s_mov_b32 m0, %0"             \
+                   : "=&s"(keep) : "v"(O[0]), "v"(O[1]), "v"(O[2]), "v"(O[3]), "v"(O[4]), "v"(O[5]), "s"(rs), "s"(soff), "s"(dst)      \
+                   : "memory", "scc")
+      if (first) HLA_DMA6(off1); else HLA_DMA6(off2);
+#undef HLA_DMA6
+    } else if constexpr (NPIECE == 4) {
+#define HLA_DMA4(O)                                                                                                                    \
+      asm volatile(HLA_DMA_HEAD(7) HLA_DMA_LD(1, 5, 6) HLA_DMA_STEP HLA_DMA_LD(2, 5, 6) HLA_DMA_STEP HLA_DMA_LD(3, 5, 6) HLA_DMA_STEP    \
+                   HLA_DMA_LD(4, 5, 6) "s_mov_b32 m0, %0"                                                                              \
+                   : "=&s"(keep) : "v"(O[0]), "v"(O[1]), "v"(O[2]), "v"(O[3]), "s"(rs), "s"(soff), "s"(dst) : "memory", "scc")
+      if (first) HLA_DMA4(off1); else HLA_DMA4(off2);
+#undef HLA_DMA4
+    }
+#undef HLA_DMA_HEAD
+#undef HLA_DMA_LD
+#undef HLA_DMA_STEP
   };
 
   const int ntg0 = (blockIdx.y * WN + wn) * NT;     // first global 32-channel output tile of this wave
@@ -1471,6 +1478,26 @@ static bool launch_conv(hipStream_t st, ConvArgs a, bool pool) {
   const double flops = 2.0 * 9.0 * (a.C1 + a.C2) * a.Cout * (double)P;
   const double bytes = (double)P * ((a.up1 ? a.C1 / 4.0 : a.C1) + a.C2) * es + (double)Po * a.Cout * ((a.out_act ? es : 0) + (a.out_raw ? 4 : 0));
   hla_prof_begin(a.Cout >= 128 ? (pool ? K_CONV_NT2_POOL : K_CONV_NT2) : (pool ? K_CONV_NT1_POOL : K_CONV_NT1), flops, bytes, st);
+  // A forward launch that cannot fill the chip (a single pair's H/4 layers are 64-128 workgroups on 256 CUs, and the forward
+  // is then a chain of such launches) takes 4-row tiles (MT = 2): twice the workgroups, each with half the work -- every output
+  // element's sum is formed in the same order, so the result is bit-identical.  Not for the three feature layers: their
+  // sum-of-squares partials are per tile, and a sample's L2 norm must not depend on its batch mates to the last bit.
+  if constexpr (!BWD) {
+    const int gy = big ? a.Cout / 128 : 1;
+    if (!a.dyn && !a.sumsq && !a.unpool_idx && a.tiles_x * a.tiles_y * a.B * gy < HLA_CONV_SMALL_GRID) {
+      a.tiles_y = (a.H - a.row_begin + 3) / 4;
+      const dim3 g4(a.tiles_x * a.tiles_y * a.B, gy);
+      if (big) {
+        if (pool) hipLaunchKernelGGL((conv3x3_kernel<T, 2, 2, 2, 2, true, 1>), g4, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((conv3x3_kernel<T, 2, 2, 2, 2, false, 1>), g4, dim3(256), 0, st, a);
+      } else {
+        if (pool) hipLaunchKernelGGL((conv3x3_kernel<T, 2, 1, 2, 2, true, 2>), g4, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((conv3x3_kernel<T, 2, 1, 2, 2, false, 2>), g4, dim3(256), 0, st, a);
+      }
+      hla_prof_end(st);
+      return true;
+    }
+  }
   // Cout >= 128: block = 8x32 pixels x 128 channels, waves 2(M) x 2(N), wave tile 128 px x 64 ch, weights 1 tap ahead
   // Cout == 64 : block = 8x32 pixels x  64 channels, waves 2 x 2,       wave tile 128 px x 32 ch, weights 2 taps ahead
   if (big) {
