@@ -12,6 +12,7 @@ void hla_set_error(const char* fmt, ...);
 enum { K_PACK = 0, K_CONV02, K_CONV_NT2, K_CONV_NT2_POOL, K_CONV_NT1, K_CONV_NT1_POOL, K_CONF, K_L2NORM,
        K_LM256, K_LM128, K_LM64, K_LM16, K_LMSOLVE, K_GRIDSAMPLE, K_LMBWD, K_WGRAD, K_ELEMWISE };
 void hla_prof_begin(int id, double flops, double bytes, hipStream_t st);
+void hla_prof_begin_dyn(int id, double flops, double bytes, hipStream_t st, const int* dev_live, int denom);
 void hla_prof_end(hipStream_t st);
 
 #define HLA_CHECK_HIP(expr)                                                              \

@@ -899,6 +899,8 @@ __global__ __launch_bounds__(256, NT == 1 ? 3 : 2) void conv3x3_kernel(ConvArgs 
     if constexpr (DMA) {
       // the next stage's tile has landed when at most the youngest 2 * NT * WD loads -- the weight fragments primed for the next
       // stage, all requested after the tile -- are still in flight
+      // (only true while the tile is requested BEFORE the first of those weight loads, which go out at taps 9-WD..8)
+      static_assert(!DMA || HLA_CONV_DMA_TAP <= 8 - WD, "the halo DMA must be issued before the next stage's weight fragments");
       if (more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NT * WD) : "memory");
     } else {
       if (more) write_stage(nxt, sg + 1, 1, st, ids);
@@ -1477,7 +1479,9 @@ static bool launch_conv(hipStream_t st, ConvArgs a, bool pool) {
   const size_t es = sizeof(T), P = (size_t)a.B * (a.H - a.row_begin) * a.W, Po = pool ? P / 4 : P;
   const double flops = 2.0 * 9.0 * (a.C1 + a.C2) * a.Cout * (double)P;
   const double bytes = (double)P * ((a.up1 ? a.C1 / 4.0 : a.C1) + a.C2) * es + (double)Po * a.Cout * ((a.out_act ? es : 0) + (a.out_raw ? 4 : 0));
-  hla_prof_begin(a.Cout >= 128 ? (pool ? K_CONV_NT2_POOL : K_CONV_NT2) : (pool ? K_CONV_NT1_POOL : K_CONV_NT1), flops, bytes, st);
+  // (a data-dependent launch visits n_live of its tiles_x * tiles_y tiles per sample: the record carries the executed share)
+  hla_prof_begin_dyn(a.Cout >= 128 ? (pool ? K_CONV_NT2_POOL : K_CONV_NT2) : (pool ? K_CONV_NT1_POOL : K_CONV_NT1), flops, bytes, st,
+                     a.dyn ? a.dyn + a.dyn_desc : nullptr, a.tiles_x * a.tiles_y);
   // A forward launch that cannot fill the chip (a single pair's H/4 layers are 64-128 workgroups on 256 CUs, and the forward
   // is then a chain of such launches) takes 4-row tiles (MT = 2): twice the workgroups, each with half the work -- every output
   // element's sum is formed in the same order, so the result is bit-identical.  Not for the three feature layers: their

@@ -5,10 +5,15 @@
 #include <vector>
 
 namespace {
-struct Rec { int id; double flops, bytes; hipEvent_t a, b; };
+struct Rec { int id; double flops, bytes; hipEvent_t a, b; int live_slot, live_denom; };
 std::vector<Rec> g_recs;
 std::mutex g_mu;
 bool g_on = false;
+// data-dependent launches (the backward's trimmed walks): the live-tile count is only known on the device; it is copied into a
+// pinned host slot on the launch stream, right behind the kernel that wrote it, and applied to the record's FLOPs at fetch time
+constexpr int kLiveSlots = 4096;
+int* g_live = nullptr;
+int g_live_used = 0;
 const char* kNames[HLA_PROF_NKERNELS] = {
     "pack_weights_kernel", "conv02_kernel", "conv3x3_kernel<MT4,NT2>", "conv3x3_kernel<MT4,NT2,pool>",
     "conv3x3_kernel<MT4,NT1>", "conv3x3_kernel<MT4,NT1,pool>", "conf_kernel", "inv_norm+scale_kernel",
@@ -17,13 +22,25 @@ const char* kNames[HLA_PROF_NKERNELS] = {
 
 bool hla_prof_on() { return g_on; }
 
-void hla_prof_begin(int id, double flops, double bytes, hipStream_t st) {
+void hla_prof_begin(int id, double flops, double bytes, hipStream_t st) { hla_prof_begin_dyn(id, flops, bytes, st, nullptr, 0); }
+
+// `dev_live` (device, or null): the number of tiles per sample this launch visits; `denom`: the tiles per sample of the dense walk.
+// flops / bytes are the DENSE launch's; the record reports them scaled by live / denom (executed work).
+void hla_prof_begin_dyn(int id, double flops, double bytes, hipStream_t st, const int* dev_live, int denom) {
   if (!g_on) return;
-  Rec r{id, flops, bytes, nullptr, nullptr};
+  Rec r{id, flops, bytes, nullptr, nullptr, -1, denom};
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (dev_live && denom > 0) {
+    if (!g_live && hipHostMalloc((void**)&g_live, kLiveSlots * sizeof(int), hipHostMallocDefault) != hipSuccess) g_live = nullptr;
+    if (g_live && g_live_used < kLiveSlots) {
+      r.live_slot = g_live_used++;
+      g_live[r.live_slot] = denom;
+      (void)hipMemcpyAsync(g_live + r.live_slot, dev_live, sizeof(int), hipMemcpyDeviceToHost, st);
+    }
+  }
   (void)hipEventCreate(&r.a);
   (void)hipEventCreate(&r.b);
   (void)hipEventRecord(r.a, st);
-  std::lock_guard<std::mutex> lk(g_mu);
   g_recs.push_back(r);
 }
 
@@ -47,11 +64,17 @@ extern "C" int hla_prof_fetch(hla_prof_record* out, int max_records, int* n_out)
   for (auto& r : g_recs) {
     float ms = 0.f;
     if (hipEventSynchronize(r.b) == hipSuccess) (void)hipEventElapsedTime(&ms, r.a, r.b);
-    if (out && n < max_records) { out[n].kernel_id = r.id; out[n].flops = r.flops; out[n].bytes = r.bytes; out[n].ms = ms; ++n; }
+    double frac = 1.0;
+    if (r.live_slot >= 0 && g_live) {
+      const int live = g_live[r.live_slot];
+      frac = live < 0 ? 0.0 : (live > r.live_denom ? 1.0 : (double)live / r.live_denom);
+    }
+    if (out && n < max_records) { out[n].kernel_id = r.id; out[n].flops = r.flops * frac; out[n].bytes = r.bytes * frac; out[n].ms = ms; ++n; }
     (void)hipEventDestroy(r.a);
     (void)hipEventDestroy(r.b);
   }
   g_recs.clear();
+  g_live_used = 0;
   if (n_out) *n_out = n;
   return HLA_OK;
 }
@@ -105,7 +128,10 @@ extern "C" int hla_prof_mfma_peak(int dtype, int data, float ms_target, float* t
   uint4* src = nullptr;
   float* out = nullptr;
   HLA_CHECK_HIP(hipMalloc(&src, 4096 * sizeof(uint4)));
-  HLA_CHECK_HIP(hipMalloc(&out, (size_t)grid * 256 * sizeof(float)));
+  {
+    const hipError_t em = hipMalloc(&out, (size_t)grid * 256 * sizeof(float));
+    if (em != hipSuccess) { (void)hipFree(src); HLA_CHECK_HIP(em); }
+  }
   std::vector<unsigned> h(4096 * 4);
   unsigned long long x = 88172645463325252ull;      // xorshift: the same operands on every box
   for (auto& w : h) {

@@ -2,6 +2,10 @@
 #include "conv_kernels.h"
 #include "vgg_layers.h"
 #include <type_traits>
+#include <stdlib.h>
+#ifndef HLA_VGG_CHUNK_DEFAULT
+#define HLA_VGG_CHUNK_DEFAULT 0      // 0: whole batch per launch
+#endif
 
 template <typename T>
 void vgg_pack_all(const hla_vgg_params* prm, char* packed, int dtype, hipStream_t st) {
@@ -41,6 +45,15 @@ void vgg_pack_all(const hla_vgg_params* prm, char* packed, int dtype, hipStream_
   }
 }
 
+// Samples per launch of the full- / half-resolution layers (see vgg_forward_t).  HLA_VGG_CHUNK=n overrides (tooling: same-box A/B).
+static int vgg_chunk(int B, int H, int W, size_t es) {
+  static const int env = [] { const char* e = getenv("HLA_VGG_CHUNK"); return e ? atoi(e) : -1; }();
+  int c = env >= 0 ? env : HLA_VGG_CHUNK_DEFAULT;
+  (void)H; (void)W; (void)es;
+  if (c <= 0 || c > B) c = B;
+  return c;
+}
+
 template <typename T>
 int vgg_forward_t(const float* x, size_t x_plane, const hla_vgg_params* prm, const char* packed, int dtype, void* const feat[4],
                          float* const conf[4], double* inv_norm, char* ws, const VggPlan& pl, int B, int H, int W,
@@ -55,46 +68,65 @@ int vgg_forward_t(const float* x, size_t x_plane, const hla_vgg_params* prm, con
   auto AM = [&](int slot) { return (SPLIT && slot >= 0) ? amax + (size_t)slot * B : (unsigned*)nullptr; };
   if (SPLIT) HLA_CHECK_HIP(hipMemsetAsync(amax, 0, (size_t)kAmaxSlots * B * sizeof(unsigned), st));
   // conv0 + conv2 + pool fused (VGG.py:123-128): relu(x3)
-  {
+  auto conv02 = [&](int b0, int nb) -> int {
     Conv02Args a{};
-    a.x = x; a.x_plane = x_plane ? x_plane : (size_t)H * W; a.w0 = W_(0); a.b0 = prm->b[0]; a.w2 = W_(1); a.b2 = prm->b[1]; a.out_act = w + pl.x3;
-    if (flags & HLA_VGG_SAVE_FOR_BACKWARD) { a.a0_out = w + pl.a0; a.idx_out = (unsigned char*)(w + pl.idx3); }
-    if (level4) a.a2_out = w + pl.x2r;
-    a.wtail = wtail; a.amax_out = AM(AM_X3); a.amax_a2_out = level4 ? AM(AM_X2) : nullptr;
-    a.amax_a0_out = (flags & HLA_VGG_SAVE_FOR_BACKWARD) ? AM(AM_A0) : nullptr;
+    const size_t es = sizeof(T), px = (size_t)H * W;      // (sample range [b0, b0 + nb): every pointer moves by b0 samples)
+    a.x_plane = x_plane ? x_plane : px;
+    a.x = x + (size_t)b0 * 3 * a.x_plane; a.w0 = W_(0); a.b0 = prm->b[0]; a.w2 = W_(1); a.b2 = prm->b[1];
+    a.out_act = w + pl.x3 + (size_t)b0 * (px / 4) * 64 * es;
+    if (flags & HLA_VGG_SAVE_FOR_BACKWARD) {
+      a.a0_out = w + pl.a0 + (size_t)b0 * px * 64 * es;
+      a.idx_out = (unsigned char*)(w + pl.idx3) + (size_t)b0 * (px / 4) * 64;
+    }
+    if (level4) a.a2_out = w + pl.x2r + (size_t)b0 * px * 64 * es;
+    auto AMb = [&](int slot) { unsigned* p = AM(slot); return p ? p + b0 : p; };
+    a.wtail = wtail; a.amax_out = AMb(AM_X3); a.amax_a2_out = level4 ? AMb(AM_X2) : nullptr;
+    a.amax_a0_out = (flags & HLA_VGG_SAVE_FOR_BACKWARD) ? AMb(AM_A0) : nullptr;
     // (first_row8, see below: x3 is needed from row 4f-16 on = conv2 row 8f-32)
     const int f0 = (level4 || (flags & HLA_VGG_SAVE_FOR_BACKWARD)) ? 0 : first_row8;
     a.row_begin = f0 ? 8 * f0 - 32 : 0;
-    a.B = B; a.H = H; a.W = W; a.tiles_x = (W + 31) / 32; a.tiles_y = (H - a.row_begin + 7) / 8;
-    const double P = (double)B * (H - a.row_begin) * W;
+    a.B = nb; a.H = H; a.W = W; a.tiles_x = (W + 31) / 32; a.tiles_y = (H - a.row_begin + 7) / 8;
+    const double P = (double)nb * (H - a.row_begin) * W;
     constexpr int lds_bytes = conv02_lds_bytes<T>();
     static HlaPerDeviceOnce attr_once;
     HLA_CHECK_HIP(attr_once.run([] {
       return hipFuncSetAttribute((const void*)conv02_kernel<T, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
     }));
     hla_prof_begin(K_CONV02, 2.0 * 9 * (3 + 64) * 64 * P, P * (3 * 4 + 16 * sizeof(T)), st);
-    hipLaunchKernelGGL((conv02_kernel<T, 2>), dim3(a.tiles_x * a.tiles_y * B), dim3(256), lds_bytes, st, a);
+    hipLaunchKernelGGL((conv02_kernel<T, 2>), dim3(a.tiles_x * a.tiles_y * nb), dim3(256), lds_bytes, st, a);
     hla_prof_end(st);
-  }
+    return HLA_OK;
+  };
   const bool train = flags & HLA_VGG_SAVE_FOR_BACKWARD;
   int np_used[4] = {pl.np[0], pl.np[1], pl.np[2], pl.np[3]};
   bool launch_ok = true;
   auto conv = [&](int l, const void* s1, int C1, int H_, int W_h, void* act, int relu, bool pool, const void* s2 = nullptr,
                   int C2 = 0, int up1 = 0, void* raw = nullptr, double* ss = nullptr, unsigned char* idx = nullptr,
-                  int row_begin = 0, int norm_level = -1) {
+                  int row_begin = 0, int norm_level = -1, int b0 = 0, int nb = -1) {
     ConvArgs a{};
-    a.idx_out = train ? idx : nullptr;
-    a.src1 = s1; a.src2 = s2; a.C1 = C1; a.C2 = C2; a.up1 = up1; a.wpk = W_(l);
-    a.bias = kLayers[l].has_bias ? prm->b[l] : nullptr;
-    a.out_act = act; a.out_raw = (float*)raw; a.sumsq = ss; a.B = B; a.H = H_; a.W = W_h; a.Cout = kLayers[l].cout;
+    if (nb < 0) nb = B;
+    // sample range [b0, b0 + nb): every per-sample pointer moves by b0 samples (the chunked high-resolution chain below)
+    const size_t es = sizeof(T), Cout = kLayers[l].cout;
+    const size_t in1 = (size_t)(H_ >> up1) * (W_h >> up1) * C1 * es, in2 = (size_t)H_ * W_h * C2 * es;
+    const size_t opx = pool ? (size_t)(H_ / 2) * (W_h / 2) : (size_t)H_ * W_h;
     a.raw16 = (raw && (flags & HLA_VGG_FEAT16)) ? 1 : 0;
-    a.relu_act = relu;
     a.row_begin = row_begin < 0 ? 0 : row_begin;
+    const size_t npart = (size_t)((W_h + 31) / 32) * ((H_ - a.row_begin + 7) / 8) * (Cout >= 128 ? Cout / 128 : 1);
+    a.idx_out = (train && idx) ? idx + (size_t)b0 * opx * Cout : nullptr;
+    a.src1 = (const char*)s1 + (size_t)b0 * in1; a.src2 = s2 ? (const char*)s2 + (size_t)b0 * in2 : nullptr;
+    a.C1 = C1; a.C2 = C2; a.up1 = up1; a.wpk = W_(l);
+    a.bias = kLayers[l].has_bias ? prm->b[l] : nullptr;
+    a.out_act = act ? (char*)act + (size_t)b0 * opx * Cout * es : nullptr;
+    a.out_raw = raw ? (float*)((char*)raw + (size_t)b0 * opx * Cout * (a.raw16 ? 2 : 4)) : nullptr;
+    a.sumsq = ss ? ss + (size_t)b0 * npart : nullptr;
+    a.B = nb; a.H = H_; a.W = W_h; a.Cout = (int)Cout;
+    a.relu_act = relu;
     if (SPLIT) {      // which per-sample maxima the layer reads (its one or two sources) and writes (its activation output)
       static const signed char kAm[13][3] = {{-1, -1, -1}, {-1, -1, -1}, {AM_X3, -1, AM_A5}, {AM_A5, -1, AM_X8}, {AM_X8, -1, AM_A10},
                                              {AM_A10, -1, AM_A12}, {AM_A12, -1, AM_X15}, {AM_X15, AM_X8, AM_D1A}, {AM_D1A, -1, AM_X18},
                                              {AM_X18, AM_X3, AM_D2A}, {AM_D2A, -1, AM_X21}, {AM_X21, AM_X2, AM_D3A}, {AM_D3A, -1, AM_X24}};
-      a.amax1 = AM(kAm[l][0]); a.amax2 = AM(kAm[l][1]); a.amax_out = AM(kAm[l][2]); a.wscale = wtail + l;
+      auto AMb = [&](int slot) { unsigned* p = AM(slot); return p ? p + b0 : p; };
+      a.amax1 = AMb(kAm[l][0]); a.amax2 = AMb(kAm[l][1]); a.amax_out = AMb(kAm[l][2]); a.wscale = wtail + l;
     }
     if (!launch_conv<T>(st, a, pool)) launch_ok = false;
     if (norm_level >= 0)      // sum-of-squares partials actually written by this launch: one per (tile, 128-cout block)
@@ -114,9 +146,18 @@ int vgg_forward_t(const float* x, size_t x_plane, const hla_vgg_params* prm, con
             r_c14 = f ? 2 * f - 4 : 0, r_d11 = f ? 2 * f - 2 - wc : 0, r_d13 = f ? 2 * f - 1 - wc : 0,
             r_d21 = f ? 4 * f - 1 - wc : 0, r_d23 = f ? 4 * f - wc : 0;
   // encoder (VGG.py:129-141).  ReLU commutes with max-pool, so pooled maps are stored post-ReLU.
-  conv(2, w + pl.x3, 64, H / 2, W / 2, w + pl.a5, 1, false, nullptr, 0, 0, nullptr, nullptr, nullptr, r_c5);      // conv5
-  conv(3, w + pl.a5, 128, H / 2, W / 2, w + pl.x8, 1, true, nullptr, 0, 0, nullptr, nullptr,
-       (unsigned char*)(w + pl.idx8), r_c7);                                          // conv7 + pool -> relu(x8)
+  // The full- and half-resolution chain conv0+2 -> conv5 -> conv7+pool runs in CHUNKS of `chunk` samples, so that a chunk's x3 and a5
+  // (8.4 + 16.8 MB per sample in 16-bit storage) are still in the 256 MB Infinity Cache when the next layer reads them; the H/4
+  // layers keep the whole batch per launch.  Samples are independent and every kernel's per-sample arithmetic does not depend on
+  // the launch's batch, so the result is bit-identical to the unchunked walk.
+  const int chunk = vgg_chunk(B, H, W, sizeof(T));
+  for (int b0 = 0; b0 < B; b0 += chunk) {
+    const int nb = B - b0 < chunk ? B - b0 : chunk;
+    if (const int rc = conv02(b0, nb)) return rc;
+    conv(2, w + pl.x3, 64, H / 2, W / 2, w + pl.a5, 1, false, nullptr, 0, 0, nullptr, nullptr, nullptr, r_c5, -1, b0, nb);      // conv5
+    conv(3, w + pl.a5, 128, H / 2, W / 2, w + pl.x8, 1, true, nullptr, 0, 0, nullptr, nullptr,
+         (unsigned char*)(w + pl.idx8), r_c7, -1, b0, nb);                              // conv7 + pool -> relu(x8)
+  }
   conv(4, w + pl.x8, 128, H / 4, W / 4, w + pl.a10, 1, false, nullptr, 0, 0, nullptr, nullptr, nullptr, r_c10);   // conv10
   conv(5, w + pl.a10, 256, H / 4, W / 4, w + pl.a12, 1, false, nullptr, 0, 0, nullptr, nullptr, nullptr, r_c12);  // conv12
   conv(6, w + pl.a12, 256, H / 4, W / 4, w + pl.x15r, 1, true, nullptr, 0, 0, feat[0],
@@ -125,12 +166,15 @@ int vgg_forward_t(const float* x, size_t x_plane, const hla_vgg_params* prm, con
   conv(7, w + pl.x15r, 256, H / 4, W / 4, w + pl.d1a, 1, false, w + pl.x8, 128, 1, nullptr, nullptr, nullptr, r_d11);   // dec1.1
   conv(8, w + pl.d1a, 128, H / 4, W / 4, w + pl.x18r, 1, false, nullptr, 0, 0, feat[1],
        (double*)(w + pl.ss[1]), nullptr, r_d13, 1);                                   // dec1.3 -> x18
-  conv(9, w + pl.x18r, 128, H / 2, W / 2, w + pl.d2a, 1, false, w + pl.x3, 64, 1, nullptr, nullptr, nullptr, r_d21);    // dec2.1
   // relu(x21) feeds conv_dec3 (level 4), the conf2 head and the training backward only: without them the 16-bit feature path
   // stores just the raw map
   const bool x21r_dead = !level4 && !wc && !train && (flags & HLA_VGG_FEAT16) && sizeof(T) == 2;
-  conv(10, w + pl.d2a, 64, H / 2, W / 2, x21r_dead ? (char*)nullptr : w + pl.x21r, 1, false, nullptr, 0, 0, feat[2],
-       (double*)(w + pl.ss[2]), nullptr, r_d23, 2);                                   // dec2.3 -> x21
+  for (int b0 = 0; b0 < B; b0 += chunk) {      // (the half-resolution decoder pair in the same chunks: d2a is read once, right away)
+    const int nb = B - b0 < chunk ? B - b0 : chunk;
+    conv(9, w + pl.x18r, 128, H / 2, W / 2, w + pl.d2a, 1, false, w + pl.x3, 64, 1, nullptr, nullptr, nullptr, r_d21, -1, b0, nb);    // dec2.1
+    conv(10, w + pl.d2a, 64, H / 2, W / 2, x21r_dead ? (char*)nullptr : w + pl.x21r, 1, false, nullptr, 0, 0, feat[2],
+         (double*)(w + pl.ss[2]), nullptr, r_d23, 2, b0, nb);                           // dec2.3 -> x21
+  }
   if (level4) {      // VGG.py:153-155: conv_dec3 on cat(up(x21), x2), zero-padded to 64 channels (vgg_layers.h)
     conv(11, w + pl.x21r, 64, H, W, w + pl.d3a, 1, false, w + pl.x2r, 64, 1);          // dec3.1
     conv(12, w + pl.d3a, 64, H, W, w + pl.x24r, 1, false, nullptr, 0, 0, feat[3],

@@ -469,67 +469,72 @@ static __global__ __launch_bounds__(256, 2) void wgrad_split_kernel(WgradArgs a,
   const uint4 ones = frag_ones<f16>();
 
   constexpr int NX = (XPIX * PPX + 255) / 256, NG = GPIX * PPX / 256, PSTEP = 256 / PPX;
+  static_assert(GPIX * PPX % 256 == 0, "gradient tile pieces per thread");
   const int part = t % PPX, pix0 = t / PPX;
   const WgTiles tl(a.dyn, a.dyn_desc, a.H, a.W, a.row_begin, a.tiles_x, a.tiles_y, a.ntile, a.B, a.g_unpool ? 1 : 0);
+  // Tile loads: raw buffer loads through one descriptor per operand and sample (base = the sample's map, range = its bytes).  A piece
+  // outside the image / the written part of g gets an offset beyond the range and reads as ZERO: no branch around a load, so all of a
+  // half tile's 13 (+ 4 argmax) loads are in flight together.  (With `if (inside) v = *p` hipcc put each load into its own exec-masked
+  // block with an s_waitcnt vmcnt(0) at its end: 13 dependent memory round trips per half tile -- the kernel ran at 0.37 of its
+  // MFMA ceiling where the forward kernels reach 0.55.)
+  constexpr int OOB = (int)0x80000000;
+  const size_t xs_bytes = (size_t)Hs * Ws * Cs * 4, gs_bytes = (size_t)Hg * Wg * a.Cout * 4;
+  auto rsrc = [](const void* base, size_t bytes) __attribute__((always_inline)) {
+    const unsigned long long p = (unsigned long long)base;
+    const void* pu = (const void*)(((unsigned long long)__builtin_amdgcn_readfirstlane((int)(unsigned)(p >> 32)) << 32) |
+                                   (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)p));
+    return __builtin_amdgcn_make_buffer_rsrc((void*)pu, 0, __builtin_amdgcn_readfirstlane((int)bytes), 0x00020000);
+  };
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
   for (int tile2 = 2 * ks; tile2 < 2 * tl.ntile; tile2 += (tile2 & 1) ? 2 * a.KS - 1 : 1) {      // (tile, half 0), (tile, half 1), next tile
     int b, y0, x0, gx0, gx1;
     tl.origin(tile2 >> 1, b, y0, x0, gx0, gx1);
     y0 += (tile2 & 1) * WGS_TH;
     if (y0 >= a.H) continue;                           // (uniform: the lower half of a tile at the image's last rows)
-    __syncthreads();                                   // previous half tile fully consumed
-    // input halo tile (zero outside the image) and output-gradient tile, in batches of 4 pieces = 16 staging registers
+    const __amdgpu_buffer_rsrc_t rx = rsrc((const char*)xsrc + (size_t)b * xs_bytes, xs_bytes);
+    const __amdgpu_buffer_rsrc_t rg = rsrc((const char*)a.g + (size_t)b * gs_bytes, gs_bytes);
+    const __amdgpu_buffer_rsrc_t ri = rsrc(a.g_unpool ? a.g_unpool + (size_t)b * (gs_bytes / 4) : (const unsigned char*)a.g, a.g_unpool ? gs_bytes / 4 : 0);
+    u32x4 xr[NX], gr[NG];
+    unsigned gid[NG];
 #pragma unroll
-    for (int lo = 0; lo < NX; lo += 4) {
-      uint4 xr[4];
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const int pix = pix0 + (lo + k) * PSTEP;
-        const int hy = pix / HWID, hx = pix - hy * HWID, y = y0 - 1 + hy, x = x0 - 1 + hx;
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (lo + k < NX && pix < XPIX && y >= 0 && y < a.H && x >= 0 && x < a.W)
-          v = *(const uint4*)(xsrc + (((size_t)b * Hs + (y >> sh)) * Ws + (x >> sh)) * Cs + coff + part * 4);
-        xr[k] = v;
-      }
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const int pix = pix0 + (lo + k) * PSTEP;
-        uint2 hi, lw;
-        split4(__uint_as_float(xr[k].x), __uint_as_float(xr[k].y), __uint_as_float(xr[k].z), __uint_as_float(xr[k].w), s_x, hi, lw);
-        if (lo + k < NX && pix < XPIX) { *(uint2*)(Xh + pix * STR + part * 8) = hi; *(uint2*)(Xl + pix * STR + part * 8) = lw; }
-      }
+    for (int k = 0; k < NX; ++k) {                     // input halo tile, zero outside the image
+      const int pix = pix0 + k * PSTEP;
+      const int hy = pix / HWID, hx = pix - hy * HWID, y = y0 - 1 + hy, x = x0 - 1 + hx;
+      const bool ok = pix < XPIX && y >= 0 && y < a.H && x >= 0 && x < a.W;
+      const int off = ok ? (((y >> sh) * Ws + (x >> sh)) * Cs + coff + part * 4) * 4 : OOB;
+      xr[k] = __builtin_amdgcn_raw_buffer_load_b128(rx, off, 0, 0);
     }
 #pragma unroll
-    for (int lo = 0; lo < NG; lo += 4) {
-      uint4 gr[4];
-      unsigned gid[4];
+    for (int k = 0; k < NG; ++k) {                     // output-gradient tile (virtual unpool: + the forward argmax)
+      const int pix = pix0 + k * PSTEP;
+      const int y = y0 + pix / 32, x = x0 + pix % 32;
+      const bool ok = y < a.H && x >= gx0 && x < gx1;
+      const int e0 = ok ? ((y >> gsh) * Wg + (x >> gsh)) * a.Cout + co0 + part * 4 : OOB;
+      gr[k] = __builtin_amdgcn_raw_buffer_load_b128(rg, ok ? e0 * 4 : OOB, 0, 0);
+      gid[k] = a.g_unpool ? __builtin_amdgcn_raw_buffer_load_b32(ri, e0, 0, 0) : 0u;
+    }
+    __syncthreads();                                   // previous half tile fully consumed (the loads above are in flight across it)
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const int pix = pix0 + (lo + k) * PSTEP;
-        const int y = y0 + pix / 32, x = x0 + pix % 32;
-        uint4 v = make_uint4(0, 0, 0, 0);
-        unsigned id = 0;
-        if (y < a.H && x >= gx0 && x < gx1) {
-          const size_t e0 = (((size_t)b * Hg + (y >> gsh)) * Wg + (x >> gsh)) * a.Cout + co0 + part * 4;
-          v = *(const uint4*)((const float*)a.g + e0);
-          if (a.g_unpool) id = *(const unsigned*)(a.g_unpool + e0);
-        }
-        gr[k] = v; gid[k] = id;
-      }
+    for (int k = 0; k < NX; ++k) {
+      const int pix = pix0 + k * PSTEP;
+      uint2 hi, lw;
+      split4(__uint_as_float(xr[k].x), __uint_as_float(xr[k].y), __uint_as_float(xr[k].z), __uint_as_float(xr[k].w), s_x, hi, lw);
+      if (pix < XPIX) { *(uint2*)(Xh + pix * STR + part * 8) = hi; *(uint2*)(Xl + pix * STR + part * 8) = lw; }
+    }
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const int pix = pix0 + (lo + k) * PSTEP;
-        float e0 = __uint_as_float(gr[k].x), e1 = __uint_as_float(gr[k].y), e2 = __uint_as_float(gr[k].z), e3 = __uint_as_float(gr[k].w);
-        if (a.g_unpool) {                              // keep the elements whose forward argmax is this (y&1, x&1)
-          const unsigned pos = (((y0 + pix / 32) & 1) << 1) | ((x0 + pix % 32) & 1);
-          if ((gid[k] & 0xff) != pos) e0 = 0.f;
-          if (((gid[k] >> 8) & 0xff) != pos) e1 = 0.f;
-          if (((gid[k] >> 16) & 0xff) != pos) e2 = 0.f;
-          if ((gid[k] >> 24) != pos) e3 = 0.f;
-        }
-        uint2 hi, lw;
-        split4(e0, e1, e2, e3, s_g, hi, lw);
-        *(uint2*)(Gh + pix * STR + part * 8) = hi; *(uint2*)(Gl + pix * STR + part * 8) = lw;
+    for (int k = 0; k < NG; ++k) {
+      const int pix = pix0 + k * PSTEP;
+      float e0 = __uint_as_float(gr[k].x), e1 = __uint_as_float(gr[k].y), e2 = __uint_as_float(gr[k].z), e3 = __uint_as_float(gr[k].w);
+      if (a.g_unpool) {                                // keep the elements whose forward argmax is this (y&1, x&1)
+        const unsigned pos = (((y0 + pix / 32) & 1) << 1) | ((x0 + pix % 32) & 1);
+        if ((gid[k] & 0xff) != pos) e0 = 0.f;
+        if (((gid[k] >> 8) & 0xff) != pos) e1 = 0.f;
+        if (((gid[k] >> 16) & 0xff) != pos) e2 = 0.f;
+        if ((gid[k] >> 24) != pos) e3 = 0.f;
       }
+      uint2 hi, lw;
+      split4(e0, e1, e2, e3, s_g, hi, lw);
+      *(uint2*)(Gh + pix * STR + part * 8) = hi; *(uint2*)(Gl + pix * STR + part * 8) = lw;
     }
     __syncthreads();
     // one K-step (16 pixels) at a time: the G fragments of the tile's four rows (hi and lo: 32 registers) stay resident while
@@ -1376,7 +1381,8 @@ int vgg_backward_t(const float* x, size_t x_plane, const hla_vgg_params* prm, co
     a.part = (float*)(bw + bp.part);
     a.bpart = (kLayers[l].has_bias && gr->db[l]) ? (float*)(bw + bp.bpart) : nullptr;
     const double P = (double)B * (Hout - a.row_begin) * Wout;
-    hla_prof_begin(K_WGRAD, 2.0 * 9 * a.Cin * a.Cout * P, P * (a.Cin + a.Cout) * sizeof(T), st);
+    hla_prof_begin_dyn(K_WGRAD, 2.0 * 9 * a.Cin * a.Cout * P, P * (a.Cin + a.Cout) * sizeof(T), st,
+                       a.dyn ? a.dyn + a.dyn_desc : nullptr, a.tiles_x * a.tiles_y);
     if constexpr (SPLIT) {
       WgradSplitExtra ex{FA(fa1), FA(fa2), GA(ga)};
       hipLaunchKernelGGL(wgrad_split_kernel, dim3(a.KS, a.Cin / 64, a.Cout / 64), dim3(256), wgs_lds_bytes(), st, a, ex);
@@ -1457,7 +1463,8 @@ int vgg_backward_t(const float* x, size_t x_plane, const hla_vgg_params* prm, co
     // (split mode: conv0's weight gradient -- K = pixels, N = 27 -- runs on the exact-fp32 kernel: 34 GFLOP, 0.2 ms at B = 32)
     const int lds = WG_TH * 32 * wg_stride<ET>() + 3 * (WG_TH + 2) * 48 * 4;
     const double P = (double)B * (H - a.row_begin) * W;
-    hla_prof_begin(K_WGRAD, 2.0 * 27 * 64 * P, P * (12 + 64 * sizeof(ET)), st);
+    hla_prof_begin_dyn(K_WGRAD, 2.0 * 27 * 64 * P, P * (12 + 64 * sizeof(ET)), st, a.dyn ? a.dyn + a.dyn_desc : nullptr,
+                       a.tiles_x * a.tiles_y);
     hipLaunchKernelGGL((wgrad0_kernel<ET>), dim3(a.KS), dim3(256), lds, st, a);
     hla_prof_end(st);
     hipLaunchKernelGGL(reduce_partials_kernel, dim3((64 * 27 + 15) / 16), dim3(256), 0, st, a.part, gr->dw[0], (size_t)64 * 27, a.KS * 2, 64 * 32, 27, 32);

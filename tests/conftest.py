@@ -13,6 +13,8 @@ GOLD = os.path.join(ROOT, 'tests', 'golden')
 
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+    config.addinivalue_line('markers', 'multirank: spawns bench.py ranks as subprocesses (control flow of the N > 1 path; part of -m gpu, '
+                                       'deselect with -m "gpu and not multirank" when gating a kernel change)')
 
 
 def load_golden(name):

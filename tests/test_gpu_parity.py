@@ -1945,6 +1945,7 @@ def test_training_steps_do_not_accumulate_memory():
         gc.enable()
 
 
+@pytest.mark.multirank
 def test_bench_gpus_flag_spawns_its_ranks_and_reports_them():
     """`python bench.py --gpus 2` with NO launcher and no WORLD_SIZE must spawn two ranks itself and say so in its one JSON line
     (round 2's bench parsed --gpus and ignored it).  On this one-GPU box the two ranks share the device (rehearsal: gloo instead
@@ -1972,6 +1973,7 @@ def test_bench_gpus_flag_spawns_its_ranks_and_reports_them():
     assert 'roofline' in j and 'scale_reads' in j
 
 
+@pytest.mark.multirank
 def test_bench_eight_rank_rehearsal_of_configs2_shard_arithmetic():
     """BASELINE configs[2] is 8 ranks; no 8-GPU node has been available to any round.  What CAN run here is its rank count: a plain
     `python bench.py --gpus 8 --batch 4` spawns eight ranks that share this box's GPU (rehearsal: gloo, flagged) -- the census
@@ -1984,7 +1986,7 @@ def test_bench_eight_rank_rehearsal_of_configs2_shard_arithmetic():
     env['OMP_NUM_THREADS'] = '4'
     r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '8', '--steps', '2', '--warmup', '1',
                         '--train-steps', '1', '--train-precision', 'bf16', '--batch', '4', '--no-cpu-baseline', '--no-kernel-timing'],
-                       env=env, capture_output=True, text=True, timeout=1200)
+                       env=env, capture_output=True, text=True, timeout=420)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
     assert len(lines) == 1, r.stdout[-2000:]
@@ -1999,6 +2001,7 @@ def test_bench_eight_rank_rehearsal_of_configs2_shard_arithmetic():
     assert t['loss_finite'] and t['value'] > 0 and t['single_rank_value'] > 0
 
 
+@pytest.mark.multirank
 def test_bench_single_rank_through_rccl():
     """The N > 1 code path on the REAL transport, as far as a one-GPU box can take it: HLA_BENCH_FORCE_DIST=1 runs the N = 1 job
     through a one-rank RCCL process group, so every collective call of the multi-GPU path -- the census all-reduce, the barriers,
