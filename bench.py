@@ -169,8 +169,9 @@ def make_inputs(model, B, grd_hw, sat_a, dev, rank):
     return sat, grd, extra
 
 
-def timed_infer(net, sat, grd, extra, steps, warmup, dist):
-    """W untimed steps, then exactly K steps bracketed by barrier + synchronize; MAX over ranks.  Returns (seconds, last output)."""
+def timed_infer(net, sat, grd, extra, steps, warmup, dist, tele=None):
+    """W untimed steps, then exactly K steps bracketed by barrier + synchronize; MAX over ranks.  Returns (seconds, last output).
+    tele: a Telemetry sampled over exactly the timed region (a side thread reading two sysfs files; nothing on the GPU)."""
     def step():
         with torch.no_grad():
             return net(sat, grd, *extra, mode='test')
@@ -180,6 +181,8 @@ def timed_infer(net, sat, grd, extra, steps, warmup, dist):
     if dist:
         dist.barrier()
     torch.cuda.synchronize()
+    if tele:
+        tele.__enter__()
     t0 = time.perf_counter()
     out = None
     for _ in range(steps):
@@ -189,6 +192,8 @@ def timed_infer(net, sat, grd, extra, steps, warmup, dist):
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    if tele:
+        tele.__exit__()
     if dist:
         tt = torch.tensor([dt], device=sat.device, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -217,6 +222,86 @@ def aggregate(recs):
         e = agg.setdefault(name, [0, 0.0, 0.0, 0.0])
         e[0] += 1; e[1] += ms; e[2] += fl; e[3] += by
     return agg
+
+
+class Telemetry:
+    """Shader clock (sclk) and socket power of ONE GPU, sampled from its hwmon sysfs files on a side thread (default 100 Hz;
+    two small file reads per sample) while a timed region runs.  `roofline.peak` is the NOMINAL 2.5 PFLOP/s at 2.4 GHz; these
+    fields say at what clock and power the timed region (and the mfma_sustained probe) actually ran, so that "0.5 of nominal =
+    0.65-0.75 of what the chip sustains" can be checked by a reader who was not there (MI355X_MICROARCH.md, DVFS section)."""
+
+    def __init__(self, device_index=0, hz=100.0):
+        import threading
+        self.dt = 1.0 / hz
+        self.files = self._find(device_index)
+        self.samples = []
+        self._stop = threading.Event()
+        self._th = None
+
+    @staticmethod
+    def _bus_id(device_index):
+        try:
+            pr = torch.cuda.get_device_properties(device_index)
+            return f'{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0'
+        except Exception:
+            pass
+        try:
+            import ctypes
+            hip = ctypes.CDLL('libamdhip64.so')
+            buf = ctypes.create_string_buffer(32)
+            if hip.hipDeviceGetPCIBusId(buf, 32, int(device_index)) == 0:
+                return buf.value.decode().lower()
+        except Exception:
+            pass
+        return None
+
+    @classmethod
+    def _find(cls, device_index):
+        bus = cls._bus_id(device_index)
+        cands = []
+        for dev in sorted(glob.glob('/sys/class/drm/card*/device')):
+            if bus and os.path.basename(os.path.realpath(dev)).lower() != bus:
+                continue
+            for hw in glob.glob(os.path.join(dev, 'hwmon', 'hwmon*')):
+                f, pw = os.path.join(hw, 'freq1_input'), os.path.join(hw, 'power1_input')
+                if not os.path.exists(pw):
+                    pw = os.path.join(hw, 'power1_average')
+                if os.path.exists(f) and os.path.exists(pw):
+                    cands.append((f, pw))
+        return cands[0] if len(cands) == 1 else None      # (ambiguous or absent: no telemetry rather than another GPU's)
+
+    def _run(self):
+        f, pw = self.files
+        while not self._stop.is_set():
+            try:
+                self.samples.append((float(open(f).read()) / 1e6, float(open(pw).read()) / 1e6))
+            except Exception:
+                pass
+            self._stop.wait(self.dt)
+
+    def __enter__(self):
+        import threading
+        if self.files:
+            self.samples, self._stop = [], threading.Event()
+            self._th = threading.Thread(target=self._run, daemon=True)
+            self._th.start()
+        return self
+
+    def __exit__(self, *exc):
+        if self._th:
+            self._stop.set()
+            self._th.join()
+            self._th = None
+
+    def summary(self):
+        """{'clock_mhz_mean', 'clock_mhz_min', 'power_w_mean', 'power_w_max', 'samples'} or {'samples': 0, 'why': ...}"""
+        if not self.files:
+            return {'samples': 0, 'why': 'no unambiguous hwmon freq1_input / power1_input for this device'}
+        if not self.samples:
+            return {'samples': 0, 'why': 'region shorter than one sampling period'}
+        c, w = [x[0] for x in self.samples], [x[1] for x in self.samples]
+        return {'clock_mhz_mean': round(sum(c) / len(c), 1), 'clock_mhz_min': round(min(c), 1), 'power_w_mean': round(sum(w) / len(w), 1),
+                'power_w_max': round(max(w), 1), 'samples': len(c), 'source': 'hwmon freq1_input (sclk) / power1_input (socket), 100 Hz side thread'}
 
 
 _PMC_SYMBOL = {'conv3x3_kernel<MT4,NT2>': 'Li4ELi2ELi2ELi2ELb0', 'conv3x3_kernel<MT4,NT2,pool>': 'Li4ELi2ELi2ELi2ELb1',
@@ -267,13 +352,20 @@ def mfma_sustained(precision, achieved):
     from highlyaccurate_amd import _lib
     code = _lib.HLA_BF16 if precision == 'bf16' else _lib.HLA_F16
     div = 3.0 if precision == 'fp16x3' else 1.0            # three MFMAs per product (algorithmic FLOPs, like roofline.achieved)
+    tele_out = {}
     try:
-        tf = {k: round(_lib.mfma_sustained_tflops(code, d) / div, 1) for k, d in (('zeros', 0), ('random', 1), ('random_half_zeros', 2))}
+        tf = {}
+        for k, d in (('zeros', 0), ('random', 1), ('random_half_zeros', 2)):
+            # 150 ms per case: long enough for the power management to settle and for ~15 telemetry samples
+            tl = Telemetry(torch.cuda.current_device())
+            with tl:
+                tf[k] = round(_lib.mfma_sustained_tflops(code, d, ms_target=150.0) / div, 1)
+            tele_out[k] = {kk: vv for kk, vv in tl.summary().items() if kk != 'source'}
     except Exception as e:
         return {'error': repr(e)[:200]}
     return {'unit': 'TFLOP/s', **tf, 'frac_of_random_half_zeros': round(achieved / tf['random_half_zeros'], 4),
-            'frac_of_random': round(achieved / tf['random'], 4),
-            'what': 'hla_prof_mfma_peak: back-to-back v_mfma_f32_32x32x16 on register-resident operands, 2 waves/SIMD, all CUs, ~8 ms '
+            'frac_of_random': round(achieved / tf['random'], 4), 'telemetry': tele_out,
+            'what': 'hla_prof_mfma_peak: back-to-back v_mfma_f32_32x32x16 on register-resident operands, 2 waves/SIMD, all CUs, 150 ms '
                     'per case, measured in this run; the ceiling of any MFMA-bound kernel on this box on such data'}
 
 
@@ -443,8 +535,15 @@ def train_leg(net, a, sat, grd, extra, B, world, rank, dist, dev, want_kt, extra
     # block of the same process (profiles/r03: 48.1 ms against 22.5-23.7 ms before and after it; a one-off stall of ~0.15 s
     # inside six steps, not a property of the step): the median ignores one such block without reporting a best-of.
     tdts = []
+    tele = Telemetry(torch.cuda.current_device()) if rank == 0 else None
     for blk in range(3):
-        tb, lossv = timed(a.train_steps) if blk == 0 else timed(a.train_steps, warm=0)
+        if tele and blk == 1:
+            tele.__enter__()
+        # (four warm-up steps, round 5: with two, the first block of a fresh process came out 2-47 % slower than the other two --
+        #  Adam state, the caching allocator's backward-workspace segments on BOTH streams, and the clocks settling)
+        tb, lossv = timed(a.train_steps, warm=4) if blk == 0 else timed(a.train_steps, warm=0)
+        if tele and blk == 1:
+            tele.__exit__()
         tdts.append(tb)
     blocks = [round(t / a.train_steps * 1e3, 3) for t in tdts]
     tdt = sorted(tdts)[1]
@@ -487,9 +586,24 @@ def train_leg(net, a, sat, grd, extra, B, world, rank, dist, dev, want_kt, extra
         net.args.train_ground_crop = 0
         train['with_train_ground_crop'] = {'value': round(B * world * a.train_steps / cdt, 3), 'unit': 'pairs/s',
                                            'ms_per_step': round(cdt / a.train_steps * 1e3, 3)}
+    if tele:
+        train['telemetry'] = tele.summary()      # sclk / socket power over the middle timed block
     if trecs:
         tagg = aggregate(trecs)
         tot = sum(v[1] for v in tagg.values())
+        # The step against the MFMA roofline, on EXECUTED FLOPs: every conv / dgrad / wgrad launch logs 2*9*Cin*Cout*pixels for
+        # the rows it computes, and a data-dependent launch of the backward (satellite branch: only the tiles whose gradient is
+        # not exactly zero) logs the share of its tiles it visited (hla_prof_begin_dyn).  `achieved` = those FLOPs of ONE step
+        # over the un-instrumented step time of train.value; peak = the dense MFMA peak of the step's arithmetic (fp16x3:
+        # 2500 / 3 TFLOP/s of algorithmic FLOPs -- three MFMAs per product).
+        prec = getattr(net.args, 'precision', 'fp32')
+        fl_step = sum(v[2] for v in tagg.values()) / 2.0          # two instrumented steps
+        ach = fl_step / (tdt / a.train_steps) / 1e12
+        train['gflop_per_pair_executed'] = round(fl_step / B / 1e9, 2)
+        train['roofline'] = {'bound': 'mfma', 'achieved': round(ach, 2), 'peak': round(PEAK_TFLOPS[prec], 1), 'unit': 'TFLOP/s',
+                             'frac': round(ach / PEAK_TFLOPS[prec], 4),
+                             'flops': 'executed: forward(train) convs + data gradients + weight gradients of one step, trimmed rows / tiles excluded',
+                             'by_kernel_tflops_instrumented': {k: round(v[2] / (v[1] * 1e-3) / 1e12, 1) for k, v in tagg.items() if v[2] > 0}}
         # (no TFLOP/s here: the backward skips the tiles whose gradient is exactly zero -- data-dependent, DESIGN.md 6 -- so
         #  the FLOPs a dgrad / wgrad launch executes are not the dense layer's; per-launch numbers: tools/probes/train_launches.py)
         train['kernels'] = {k: {'launches': v[0], 'avg_us': round(v[1] / v[0] * 1e3, 1), 'share': round(v[1] / tot, 3)}
@@ -606,7 +720,8 @@ def main(argv=None):
     want_kt = (rank == 0) and not a.no_kernel_timing
 
     # ---- the timed region: exactly K steps, no instrumentation
-    dt, out = timed_infer(net, sat, grd, extra, a.steps, a.warmup, dist)
+    tele = Telemetry(local) if rank == 0 else None
+    dt, out = timed_infer(net, sat, grd, extra, a.steps, a.warmup, dist, tele)
     # ---- the same steps once more on rank 0 with a HIP-event pair around every kernel launch: per-kernel durations for the
     # rooflines.  Kept out of `value` (measured: 8.73 vs 7.97 ms/step), and it would make rank 0 the slowest rank of every multi-GPU run.
     recs, dt_ev = [], None
@@ -648,14 +763,20 @@ def main(argv=None):
             try:
                 if p == a.train_precision:
                     e = {'value': train['value'], 'ms_per_step': train['ms_per_step'], 'steps': train['steps']}
+                    if 'roofline' in train:
+                        e['roofline'] = {k_: train['roofline'][k_] for k_ in ('bound', 'achieved', 'peak', 'unit', 'frac')}
+                        e['gflop_per_pair_executed'] = train['gflop_per_pair_executed']
                 else:
                     net = None
                     torch.cuda.empty_cache()
                     net = build_net('kitti', p, 5, dev)
                     sub = argparse.Namespace(**vars(a))
-                    sub.train_steps, sub.no_kernel_timing = (3 if p == 'fp32' else 4), True
-                    t2 = train_leg(net, sub, sat, grd, extra, B, 1, 0, None, dev, False, extras=False)
-                    e = {'value': t2['value'], 'ms_per_step': t2['ms_per_step'], 'steps': t2['steps']}
+                    sub.train_steps, sub.no_kernel_timing = (3 if p == 'fp32' else 4), a.no_kernel_timing
+                    t2 = train_leg(net, sub, sat, grd, extra, B, 1, 0, None, dev, want_kt, extras=False)
+                    e = {'value': t2['value'], 'ms_per_step': t2['ms_per_step'], 'steps': t2['steps'], 'blocks_ms_per_step': t2['blocks_ms_per_step']}
+                    if 'roofline' in t2:
+                        e['roofline'] = {k_: t2['roofline'][k_] for k_ in ('bound', 'achieved', 'peak', 'unit', 'frac')}
+                        e['gflop_per_pair_executed'] = t2['gflop_per_pair_executed']
                 e['unit'] = 'pairs/s'
                 e['gradients'] = gradient_fidelity(p, dev)
                 e['parity_grade'] = p in ('fp32', 'fp16x3')      # gradients inside the fp32 gates of the reference-autograd goldens
@@ -757,8 +878,17 @@ def main(argv=None):
             tot_ms = sum(v[1] for v in agg.values())
             res['events_pass_ms_per_step'] = round(dt_ev / n_ev * 1e3, 3)
             res['roofline'] = conv_roofline(agg, a.precision, pmc, pmc_src, headline_cfg)
+            # clock and power of the TIMED region (and, inside mfma_sustained, of each probe case): VERDICT r04 #5
+            ts = tele.summary() if tele else {'samples': 0}
+            res['roofline']['clock_mhz_mean'] = ts.get('clock_mhz_mean')
+            res['roofline']['power_w_mean'] = ts.get('power_w_mean')
+            res['roofline']['telemetry'] = ts
             if a.precision in ('bf16', 'fp16', 'fp16x3'):
-                res['roofline']['mfma_sustained'] = mfma_sustained(a.precision, res['roofline']['achieved'])
+                ms_ = mfma_sustained(a.precision, res['roofline']['achieved'])
+                res['roofline']['mfma_sustained'] = ms_
+                probe = (ms_.get('telemetry') or {}).get('random_half_zeros') or {}
+                res['roofline']['mfma_sustained_clock_mhz_mean'] = probe.get('clock_mhz_mean')
+                res['roofline']['mfma_sustained_power_w_mean'] = probe.get('power_w_mean')
             lmr = lm_roofline(agg, pmc if headline_cfg else None, pmc_src)
             if lmr:
                 res['lm_roofline'] = lmr
