@@ -205,6 +205,9 @@ constexpr int HALO_TAP0 = 2, HALO_TAP1 = 6;
 #define HLA_CONV_HALO_DMA 1
 #endif
 constexpr int HLA_CONV_DMA_TAP = 1;
+#ifndef HLA_A0_ABL
+#define HLA_A0_ABL 0
+#endif
 #ifndef HLA_CONV_SMALL_GRID
 #define HLA_CONV_SMALL_GRID 320      // workgroups: below this a forward launch takes 4-row tiles (launch_conv)
 #endif
@@ -303,7 +306,8 @@ __host__ __device__ __forceinline__ int epilogue_mode(const ConvArgs& a) {
 template <typename T, int MT, int NT, bool POOL, int EPI = EPI_GENERIC, bool R16 = false, int STGW = 0>
 __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[MT][NT], const ConvArgs& a, int b, int yrow0, int x0,
                                               int cb, float* red, char* stage, float dsc = 1.f,
-                                              PixBox addb = PixBox{0, 1 << 30, 0, 1 << 30}) {
+                                              PixBox addb = PixBox{0, 1 << 30, 0, 1 << 30},
+                                              const float4* prebias = nullptr) {      // [NT * 4] bias values the caller already holds
   using RawT = std::conditional_t<R16, f16, float>;      // 16-bit raw maps are fp16 also in bf16 mode: 11 significand bits for the LM loop
   constexpr bool GEN = EPI == EPI_GENERIC, RAW = EPI == EPI_ACT_RAW || EPI == EPI_ACT_RAW_NOBIAS, DG = EPI == EPI_DGRAD;
   // 16-bit types: the kernels START their accumulators at the bias (conv3x3_kernel / conv02_kernel), nothing to add here.
@@ -329,7 +333,12 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[MT][NT], const ConvA
 #pragma unroll
     for (int q = 0; q < 4; ++q)
       bias[j][q] = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (!NOBIAS && a.bias) {
+  if (!NOBIAS && prebias) {
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) bias[j][q] = prebias[j * 4 + q];
+  } else if (!NOBIAS && a.bias) {
 #pragma unroll
     for (int j = 0; j < NT; ++j)
 #pragma unroll
@@ -515,8 +524,10 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[MT][NT], const ConvA
         const int tile = (xcd_contiguous(blockIdx.x, gridDim.x) % (a.tiles_x * a.tiles_y)) * gridDim.y + blockIdx.y;
         a.sumsq[(size_t)b * np + tile] = ((double)red[0] + (double)red[1]) + ((double)red[2] + (double)red[3]);
       }
-      if (want_max)      // non-negative floats order like their bit patterns
-        atomicMax(a.amax_out + b, __float_as_uint(fmaxf(fmaxf(red[4], red[5]), fmaxf(red[6], red[7]))));
+      if (want_max) {    // non-negative floats order like their bit patterns; the plain read only filters (a stale value costs one
+        const unsigned mb = __float_as_uint(fmaxf(fmaxf(red[4], red[5]), fmaxf(red[6], red[7])));      // redundant atomic, never a missed one)
+        if (mb > __hip_atomic_load(a.amax_out + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(a.amax_out + b, mb);
+      }
     }
   }
 }
@@ -987,6 +998,8 @@ __global__ __launch_bounds__(256, Prec<T>::SPLIT ? 2 : 3) void conv02_kernel(Con
   char* lds = smem;                                  // SPR halo buffers (conv0's channels of the current round)
   float* in = (float*)(smem + SPR * BUF);            // [3][12][36] input patch
   __shared__ float red[8];
+  __shared__ float red2[4];
+  float a0mx = 0.f;                                  // split mode, training: max of the relu(conv0) copy this thread wrote
 
   const int t = threadIdx.x, lane = t & 63, wv = __builtin_amdgcn_readfirstlane(t >> 6), wm = wv / WN, wn = wv % WN;
   int bid = blockIdx.x;                    // (the XCD-contiguous order measured 2-3 % slower for this kernel)
@@ -1064,13 +1077,15 @@ __global__ __launch_bounds__(256, Prec<T>::SPLIT ? 2 : 3) void conv02_kernel(Con
   }
   // conv2's accumulators and weight stream live across the rounds
   f32x16 acc[MT][NT];
+  float4 bias2[4];                                   // 4-byte types: conv2's bias of this wave's channels, for the epilogue
+#pragma unroll
+  for (int q = 0; q < 4; ++q) bias2[q] = make_float4(0.f, 0.f, 0.f, 0.f);
   const FragOff fo = frag_offsets(lane, wm * MT);
 #pragma unroll
   for (int rd = 0; rd < ROUNDS; ++rd) {
   const int j0 = rd * JPR;                           // first 32-channel half of conv0's output this round produces
-  if (rd > 0) load_w0(j0);
-  if (!FOLD) load_b0(j0);
-  if (rd > 0) __syncthreads();                       // the previous round's MFMAs are done with the buffers
+  if (rd == 0 && !FOLD) load_b0(0);                  // (later rounds: requested at the end of the round before, ahead of its a0 stores)
+  if (rd > 0) __syncthreads();                       // the previous round's MFMAs (and its a0 copy) are done with the buffers
   for (int m = wv; m * 32 < HPIX; m += 4) {
     const int p = m * 32 + x, pc = p < HPIX ? p : HPIX - 1;
     const int hy = pc / HWID, hx = pc - hy * HWID;
@@ -1148,35 +1163,6 @@ __global__ __launch_bounds__(256, Prec<T>::SPLIT ? 2 : 3) void conv02_kernel(Con
   }
   __syncthreads();
 
-  if (a0.a0_out) {     // training: the backward pass needs relu(conv0) (conv2's wgrad input and ReLU mask)
-    constexpr int PPP = 64 * (int)sizeof(T) / 16 / ROUNDS;          // 16-B pieces per pixel over this round's stages
-    float a0mx = 0.f;
-    for (int e = t; e < TH * 32 * PPP; e += 256) {
-      const int pxl = e / PPP, piece = e % PPP, sgi = piece / 4, part = piece % 4;
-      const int r = pxl / 32, c = pxl % 32, yy = y0 + r, xx = x0 + c;
-      if (yy < a0.H && xx < a0.W) {
-        char* dst = (char*)a0.a0_out + (((size_t)b * a0.H + yy) * a0.W + xx) * 64 * sizeof(T) + (rd * PPP + piece) * 16;
-        const char* sb = lds + sgi * BUF;
-        const int hpix = (r + 1) * HWID + c + 1;
-        if constexpr (SPLIT) {      // what conv2 actually consumes: (hi + lo) / s, 23 of relu(conv0)'s 24 significand bits
-          const f16x4 h = __builtin_bit_cast(f16x4, *(const uint2*)(sb + halo_off(hpix, c + 1, part >> 1) + (part & 1) * 8));
-          const f16x4 l = __builtin_bit_cast(f16x4, *(const uint2*)(sb + halo_off(hpix, c + 1, 2 + (part >> 1)) + (part & 1) * 8));
-          const float is = 1.f / s_a0;
-          const float4 o4 = make_float4(((float)h[0] + (float)l[0]) * is, ((float)h[1] + (float)l[1]) * is,
-                                        ((float)h[2] + (float)l[2]) * is, ((float)h[3] + (float)l[3]) * is);
-          *(float4*)dst = o4;
-          a0mx = fmaxf(fmaxf(a0mx, fmaxf(o4.x, o4.y)), fmaxf(o4.z, o4.w));        // (post-ReLU: non-negative)
-        } else {
-          *(uint4*)dst = *(const uint4*)(sb + halo_off(hpix, c + 1, part));
-        }
-      }
-    }
-    if (SPLIT && a0.amax_a0_out) {       // kernel-uniform
-      a0mx = wave_max_f32(a0mx);
-      if (lane == 0) atomicMax(a0.amax_a0_out + b, __float_as_uint(a0mx));
-    }
-  }
-
   // phase C: conv2 over this round's resident stages (no further loads, no barriers)
   if (rd == 0) {                // (16-bit types: the accumulators start at conv2's bias, like conv3x3_kernel's)
 #pragma unroll
@@ -1190,23 +1176,106 @@ __global__ __launch_bounds__(256, Prec<T>::SPLIT ? 2 : 3) void conv02_kernel(Con
     }
   }
   if (rd == 0) stagger_priority();
+  // What the code BEHIND this round's a0 copy loads first -- the next round's conv0 fragments / biases, or conv2's bias for the
+  // epilogue -- is requested here, ahead of the round's MFMAs, and pinned below: vmcnt retires in issue order, so a load queued
+  // behind the copy's stores makes its consumer wait for their write acknowledgements.
+  if (rd + 1 < ROUNDS) { load_w0(j0 + JPR); if (!FOLD) load_b0(j0 + JPR); }
+  else if (sizeof(T) == 4) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) bias2[q] = *(const float4*)(a0.b2 + wn * 32 + q * 8 + g * 4);
+  }
 #pragma unroll 1
   for (int sg = 0; sg < SPR; ++sg)
     stage_mma<T, MT, NT, WD>(acc, lds + sg * BUF, fo, ring, [](int) {});
+  if (rd + 1 < ROUNDS) {
+#pragma unroll
+    for (int jj = 0; jj < JPR; ++jj) {
+#pragma unroll
+      for (int f = 0; f < NFRAG; ++f)
+#pragma unroll
+        for (int h = 0; h < NH; ++h) asm volatile("" : "+v"(wf0[jj][f][h].x), "+v"(wf0[jj][f][h].y), "+v"(wf0[jj][f][h].z), "+v"(wf0[jj][f][h].w));
+      if (!FOLD) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) asm volatile("" : "+v"(bias0[jj][q].x), "+v"(bias0[jj][q].y), "+v"(bias0[jj][q].z), "+v"(bias0[jj][q].w));
+      }
+    }
+  } else if (sizeof(T) == 4) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) asm volatile("" : "+v"(bias2[q].x), "+v"(bias2[q].y), "+v"(bias2[q].z), "+v"(bias2[q].w));
+  }
+  // (last round: the weight ring's look-ahead past the last tap is still in flight; the epilogue re-uses those registers, and at
+  //  the join behind the branchy copy below the compiler can no longer count what is pending -- it would wait with vmcnt(0) for
+  //  the copy's stores.  Drained here, before the stores, that wait is gone.)
+  if (rd + 1 == ROUNDS) __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0), expcnt / lgkmcnt untouched (both paths: they join below)
+  if (a0.a0_out) {     // training: the backward pass needs relu(conv0) (conv2's wgrad input and ReLU mask)
+    // Copied out of the halo buffers AFTER the round's MFMAs (nothing overwrites them before the next barrier), branch-free and
+    // unrolled: raw buffer stores, a pixel outside the image gets an offset beyond the descriptor's range and is dropped.  Round 4
+    // issued this copy between phase B's barrier and phase C from a rolled loop with a branch around each store: the compiler
+    // could not count the stores in flight, so the first weight fragments of phase C waited with vmcnt(0) -- for the write
+    // acknowledgements of the copy, twice per workgroup (training variant 3.04 ms per launch against 1.83 without the copy).
+    constexpr int PPP = 64 * (int)sizeof(T) / 16 / ROUNDS;          // 16-B pieces per pixel over this round's stages
+    static_assert(TH * 32 * PPP % 256 == 0, "a0 pieces per thread");
+    const size_t a0s = (size_t)a0.H * a0.W * 64 * sizeof(T);
+    const unsigned long long pb = (unsigned long long)a0.a0_out + (size_t)b * a0s;
+    const void* pu = (const void*)(((unsigned long long)__builtin_amdgcn_readfirstlane((int)(unsigned)(pb >> 32)) << 32) |
+                                   (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)pb));
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)pu, 0, __builtin_amdgcn_readfirstlane((int)a0s), 0x00020000);
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+    for (int it = 0; it < TH * 32 * PPP / 256; ++it) {
+      const int e = t + it * 256;
+      const int pxl = e / PPP, piece = e % PPP, sgi = piece / 4, part = piece % 4;
+      const int r = pxl / 32, c = pxl % 32, yy = y0 + r, xx = x0 + c;
+      const bool ok = yy < a0.H && xx < a0.W;
+      const int off = ok ? (yy * a0.W + xx) * 64 * (int)sizeof(T) + (rd * PPP + piece) * 16 : (int)0x80000000;
+      const char* sb = lds + sgi * BUF;
+      const int hpix = (r + 1) * HWID + c + 1;
+      if constexpr (SPLIT) {      // what conv2 actually consumes: (hi + lo) / s, 23 of relu(conv0)'s 24 significand bits
+        const f16x4 h = __builtin_bit_cast(f16x4, *(const uint2*)(sb + halo_off(hpix, c + 1, part >> 1) + (part & 1) * 8));
+        const f16x4 l = __builtin_bit_cast(f16x4, *(const uint2*)(sb + halo_off(hpix, c + 1, 2 + (part >> 1)) + (part & 1) * 8));
+        const float is = 1.f / s_a0;
+        const float4 o4 = make_float4(((float)h[0] + (float)l[0]) * is, ((float)h[1] + (float)l[1]) * is,
+                                      ((float)h[2] + (float)l[2]) * is, ((float)h[3] + (float)l[3]) * is);
+#if HLA_A0_ABL == 1       // timing-only ablations of the copy (tools/ab_libs.py): 1 = no store instruction, 2 = nt stores
+        if (o4.x == 12345.678f) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o4), ra, off, 0, 0);
+#elif HLA_A0_ABL == 2
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o4), ra, off, 0, 2);
+#else
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o4), ra, off, 0, 0);
+#endif
+        if (ok) a0mx = fmaxf(fmaxf(a0mx, fmaxf(o4.x, o4.y)), fmaxf(o4.z, o4.w));        // (post-ReLU: non-negative)
+      } else {
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, *(const uint4*)(sb + halo_off(hpix, c + 1, part))), ra, off, 0, 0);
+      }
+    }
+  }
   }     // rounds
+  // the copy's per-sample maximum: ONE filtered atomic per workgroup.  (Round 4 issued one per wave and round -- 262 144 atomics per
+  // launch on 32 addresses, which the L2 executes one after the other per address: 1.2 ms of the training variant's 3.0, taken for
+  // the cost of the copy's stores until an ablation without any store instruction measured the same 3.0 ms.)
+  if (SPLIT && a0.a0_out && a0.amax_a0_out) {       // kernel-uniform
+    a0mx = wave_max_f32(a0mx);
+    if (lane == 0) red2[wv] = a0mx;
+  }
 
   ConvArgs a{};
   a.bias = a0.b2; a.out_act = a0.out_act; a.B = a0.B; a.H = a0.H; a.W = a0.W; a.Cout = 64; a.relu_act = 1;
   a.tiles_x = a0.tiles_x; a.tiles_y = a0.tiles_y; a.idx_out = a0.idx_out; a.amax_out = a0.amax_out;
   __syncthreads();   // all waves are done with the halo buffers; reuse them as wave-private stagers
+  if (SPLIT && a0.a0_out && a0.amax_a0_out && t == 0) {
+    const unsigned mb = __float_as_uint(fmaxf(fmaxf(red2[0], red2[1]), fmaxf(red2[2], red2[3])));
+    // (the plain read only filters: a stale value costs one redundant atomic, never a missed one)
+    if (mb > __hip_atomic_load(a0.amax_a0_out + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(a0.amax_a0_out + b, mb);
+  }
+  const float4* pb2 = sizeof(T) == 4 ? bias2 : nullptr;
   if (a0.a2_out) {   // the epilogue only reads the accumulators: run it twice, un-pooled first
     ConvArgs f = a;
     f.out_act = a0.a2_out; f.idx_out = nullptr; f.amax_out = a0.amax_a2_out;
-    conv_epilogue<T, MT, NT, false, EPI_ACT, false, SPR * BUF / 4>(acc, f, b, y0 + wm * MT, x0, wn * 32, red, lds + wv * (SPR * BUF / 4), dsc2);
+    conv_epilogue<T, MT, NT, false, EPI_ACT, false, SPR * BUF / 4>(acc, f, b, y0 + wm * MT, x0, wn * 32, red, lds + wv * (SPR * BUF / 4), dsc2, PixBox{0, 1 << 30, 0, 1 << 30}, pb2);
     if (SPLIT) __syncthreads();     // `red` is reused by the second epilogue's maximum
   }
-  if (a.idx_out) conv_epilogue<T, MT, NT, true, EPI_GENERIC>(acc, a, b, y0 + wm * MT, x0, wn * 32, red, lds + wv * (SPR * BUF / 4), dsc2);
-  else conv_epilogue<T, MT, NT, true, EPI_ACT, false, SPR * BUF / 4>(acc, a, b, y0 + wm * MT, x0, wn * 32, red, lds + wv * (SPR * BUF / 4), dsc2);
+  if (a.idx_out) conv_epilogue<T, MT, NT, true, EPI_GENERIC>(acc, a, b, y0 + wm * MT, x0, wn * 32, red, lds + wv * (SPR * BUF / 4), dsc2, PixBox{0, 1 << 30, 0, 1 << 30}, pb2);
+  else conv_epilogue<T, MT, NT, true, EPI_ACT, false, SPR * BUF / 4>(acc, a, b, y0 + wm * MT, x0, wn * 32, red, lds + wv * (SPR * BUF / 4), dsc2, PixBox{0, 1 << 30, 0, 1 << 30}, pb2);
 }
 
 // ---------------------------------------------------------------------------------------------

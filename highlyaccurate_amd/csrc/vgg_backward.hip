@@ -593,7 +593,8 @@ static __global__ __launch_bounds__(256) void absmax_map_kernel(const float* __r
     m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
   }
   m = wave_max_f32(m);
-  if ((threadIdx.x & 63) == 0) atomicMax(amax + b, __float_as_uint(m));
+  if ((threadIdx.x & 63) == 0 && __float_as_uint(m) > __hip_atomic_load(amax + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+    atomicMax(amax + b, __float_as_uint(m));
 }
 
 // conv0: dW0[co][k = c*9+tap] over the NCHW fp32 input (k padded to 32 as one "ci tile").
@@ -829,7 +830,8 @@ __global__ __launch_bounds__(256) void l2bwd_apply_kernel(const float* __restric
     }
     if (amax) {
       mx = wave_max_f32(mx);
-      if ((threadIdx.x & 63) == 0 && mx > 0.f) atomicMax(amax + b, __float_as_uint(mx));
+      if ((threadIdx.x & 63) == 0 && mx > 0.f && __float_as_uint(mx) > __hip_atomic_load(amax + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+        atomicMax(amax + b, __float_as_uint(mx));      // (the plain read only filters)
     }
     return;
   }
@@ -845,7 +847,8 @@ __global__ __launch_bounds__(256) void l2bwd_apply_kernel(const float* __restric
   }
   if (ORTHO && amax) {
     mx = wave_max_f32(mx);
-    if ((threadIdx.x & 63) == 0 && mx > 0.f) atomicMax(amax + b, __float_as_uint(mx));
+    if ((threadIdx.x & 63) == 0 && mx > 0.f && __float_as_uint(mx) > __hip_atomic_load(amax + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+      atomicMax(amax + b, __float_as_uint(mx));
   }
 }
 
