@@ -60,13 +60,36 @@ __device__ __host__ __forceinline__ float split_scale(unsigned amax_bits) {
   return f;
 }
 // four fp32 values -> four (hi, lo) fp16 pairs of s x
+// Eight instructions: v_fma_mix{lo,hi}_f16 forms fp16(x * s + 0) (s is a power of two: the product is exact in fp32, one rounding to
+// nearest even) straight into one half of the destination, and fp16(x * s - hi) with the fp16 hi read as the addend (the fp32 FMA
+// result is exact before its one rounding).  Value for value what the plain C++ below computes -- hipcc needs 12-16 instructions
+// for it (packed multiplies, cvt_pk, converts back, packs) -- and the split is what the loaders of every split-mode kernel spend
+// their VALU time on.  -DHLA_SPLIT4_ASM=0 builds the C++ form (tools/probes/bitcmp_libs.py compares the two bit for bit).
+#ifndef HLA_SPLIT4_ASM
+#define HLA_SPLIT4_ASM 1
+#endif
 __device__ __forceinline__ void split4(float x0, float x1, float x2, float x3, float s, uint2& hi, uint2& lo) {
+#if HLA_SPLIT4_ASM
+  unsigned h01, h23, l01, l23;
+  asm("v_fma_mixlo_f16 %0, %4, %8, 0\n\t"
+      "v_fma_mixlo_f16 %1, %6, %8, 0\n\t"
+      "v_fma_mixhi_f16 %0, %5, %8, 0\n\t"
+      "v_fma_mixhi_f16 %1, %7, %8, 0\n\t"
+      "v_fma_mixlo_f16 %2, %4, %8, -%0 op_sel_hi:[0,0,1]\n\t"
+      "v_fma_mixlo_f16 %3, %6, %8, -%1 op_sel_hi:[0,0,1]\n\t"
+      "v_fma_mixhi_f16 %2, %5, %8, -%0 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
+      "v_fma_mixhi_f16 %3, %7, %8, -%1 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
+      : "=&v"(h01), "=&v"(h23), "=&v"(l01), "=&v"(l23) : "v"(x0), "v"(x1), "v"(x2), "v"(x3), "v"(s));
+  hi = make_uint2(h01, h23);
+  lo = make_uint2(l01, l23);
+#else
   x0 *= s; x1 *= s; x2 *= s; x3 *= s;
   const f16 h0 = (f16)x0, h1 = (f16)x1, h2 = (f16)x2, h3 = (f16)x3;     // round to nearest even
   const f16x4 h = {h0, h1, h2, h3};
   const f16x4 l = {(f16)(x0 - (float)h0), (f16)(x1 - (float)h1), (f16)(x2 - (float)h2), (f16)(x3 - (float)h3)};
   hi = __builtin_bit_cast(uint2, h);
   lo = __builtin_bit_cast(uint2, l);
+#endif
 }
 
 // Every dtype's kernels are compiled in their own translation unit (build.py passes -DHLA_TU_DTYPE=0|1|2); the
@@ -944,8 +967,8 @@ __global__ __launch_bounds__(256, NT == 1 ? 3 : 2) void conv3x3_kernel(ConvArgs 
     else if (T16 && a.raw16 && mode == EPI_ACT_RAW_NOBIAS)
       conv_epilogue<T, MT, NT, POOL, T16 ? EPI_ACT_RAW_NOBIAS : EPI_GENERIC, T16>(acc, a, b, y0 + wm * MT, x0, ntg0 * 32, red, stager, dsc, addb);
     else if (RAW_SPECIAL && mode == EPI_ACT_RAW) conv_epilogue<T, MT, NT, POOL, RAW_SPECIAL ? EPI_ACT_RAW : EPI_GENERIC>(acc, a, b, y0 + wm * MT, x0, ntg0 * 32, red, stager, dsc, addb);
-    else if (!Prec<T>::SPLIT && mode == EPI_DGRAD)
-      conv_epilogue<T, MT, NT, POOL, Prec<T>::SPLIT ? EPI_GENERIC : EPI_DGRAD>(acc, a, b, y0 + wm * MT, x0, ntg0 * 32, red, stager, dsc, addb);
+    else if (mode == EPI_DGRAD)
+      conv_epilogue<T, MT, NT, POOL, EPI_DGRAD>(acc, a, b, y0 + wm * MT, x0, ntg0 * 32, red, stager, dsc, addb);
     else if ((RAW_SPECIAL || sizeof(T) == 2) && mode == EPI_ACT_RAW_NOBIAS)      // (4-byte storage: two passes, spills as well)
       conv_epilogue<T, MT, NT, POOL, (RAW_SPECIAL || sizeof(T) == 2) ? EPI_ACT_RAW_NOBIAS : EPI_GENERIC>(acc, a, b, y0 + wm * MT, x0, ntg0 * 32, red, stager, dsc, addb);
     else conv_epilogue<T, MT, NT, POOL, EPI_GENERIC>(acc, a, b, y0 + wm * MT, x0, ntg0 * 32, red, stager, dsc, addb);

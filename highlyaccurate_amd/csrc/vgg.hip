@@ -80,6 +80,11 @@ int vgg_forward_t(const float* x, size_t x_plane, const hla_vgg_params* prm, con
     }
     if (level4) a.a2_out = w + pl.x2r + (size_t)b0 * px * 64 * es;
     auto AMb = [&](int slot) { unsigned* p = AM(slot); return p ? p + b0 : p; };
+    {      // timing-only ablations (tools/probes/conv02_probe.py): HLA_ABL_C02 bit 0 = no relu(conv0) copy, bit 1 = no pool argmax
+      static const int abl = [] { const char* e = getenv("HLA_ABL_C02"); return e ? atoi(e) : 0; }();
+      if (abl & 1) a.a0_out = nullptr;
+      if (abl & 2) a.idx_out = nullptr;
+    }
     a.wtail = wtail; a.amax_out = AMb(AM_X3); a.amax_a2_out = level4 ? AMb(AM_X2) : nullptr;
     a.amax_a0_out = (flags & HLA_VGG_SAVE_FOR_BACKWARD) ? AMb(AM_A0) : nullptr;
     // (first_row8, see below: x3 is needed from row 4f-16 on = conv2 row 8f-32)

@@ -9,6 +9,7 @@
 //     (tools/probes/tr16_probe.hip documents the lane semantics), for fp32 a lane needs one element per MFMA
 //     so plain ds_read_b32 suffices.  Bias gradients ride along as one extra MFMA against an all-ones fragment.
 #include <vector>
+#include <stdlib.h>
 #include "conv_kernels.h"
 #include "vgg_layers.h"
 
@@ -581,6 +582,269 @@ static __global__ __launch_bounds__(256, 2) void wgrad_split_kernel(WgradArgs a,
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// wgrad_split_ws_kernel: the same contraction, WAVE-SPECIALISED (round 5).  wgrad_split_kernel runs load -> split -> barrier ->
+// MFMA in every wave, with nothing but the second resident workgroup to overlap the phases: 0.47 of its MFMA ceiling where the
+// forward kernels reach 0.55.  Here a workgroup is EIGHT waves on one CU: waves 4-7 are LOADERS (they fetch a half tile's fp32
+// pieces two half tiles ahead, split them into the fp16 hi / lo planes and write them into the idle LDS buffer -- the ~400 VALU
+// instructions per half tile that used to sit between two MFMA phases), waves 0-3 are the MATRIX waves (one per SIMD: transposing
+// LDS reads and MFMAs only, fragments requested one halo row ahead of the MFMAs that consume them).  A matrix wave and a loader
+// share each SIMD, so the split's VALU work and the global-load latency run under the MFMAs instead of between them.  One
+// workgroup barrier per half tile; LDS: two buffers of {Xh, Xl, Gh, Gl} = 115 KB, one workgroup per CU, 256 registers per wave.
+// Same tile lists, same order of every partial sum's terms as wgrad_split_kernel (bit-identical partials for the same KS).
+#ifndef HLA_WGRAD_SPLIT_WS
+#define HLA_WGRAD_SPLIT_WS 1
+#endif
+#ifndef HLA_WS_ABL
+#define HLA_WS_ABL 0
+#endif
+constexpr int wgs_ws_buf_bytes() { return 2 * ((WGS_TH + 2) * HWID + WGS_TH * 32) * WGS_STR; }
+constexpr int wgs_ws_lds_bytes() { return 2 * wgs_ws_buf_bytes(); }
+
+static __global__ __launch_bounds__(512, 1) void wgrad_split_ws_kernel(WgradArgs a, WgradSplitExtra sx) {
+  typedef f16 H;
+  constexpr int STR = WGS_STR, PPX = 16;                   // 16-B fp32 pieces per pixel (64 channels)
+  constexpr int XPIX = (WGS_TH + 2) * HWID, GPIX = WGS_TH * 32, KPX = 16, BUFB = wgs_ws_buf_bytes();
+  constexpr int oXh = 0, oXl = XPIX * STR, oGh = 2 * XPIX * STR, oGl = 2 * XPIX * STR + GPIX * STR;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int t = threadIdx.x, lane = t & 63, wv = __builtin_amdgcn_readfirstlane(t >> 6);
+  const bool loader = wv >= 4;                             // wave-uniform role
+  const int ks = blockIdx.x, ci0 = blockIdx.y * 64, co0 = blockIdx.z * 64;
+  const bool first = ci0 < a.C1;
+  const float* xsrc = first ? (const float*)a.x1 : (const float*)a.x2;
+  const int Cs = first ? a.C1 : a.C2, coff = first ? ci0 : ci0 - a.C1, sh = (first && a.up1) ? 1 : 0;
+  const int Hs = a.H >> sh, Ws = a.W >> sh;
+  const int gsh = a.g_unpool ? 1 : 0, Hg = a.H >> gsh, Wg = a.W >> gsh;
+  const WgTiles tl(a.dyn, a.dyn_desc, a.H, a.W, a.row_begin, a.tiles_x, a.tiles_y, a.ntile, a.B, a.g_unpool ? 1 : 0);
+  // the half-tile walk of this k-slice: (tile, half 0), (tile, half 1), next tile; the lower half of a tile at the image's last
+  // rows may be empty.  Both roles step through it identically (they meet at one barrier per half tile).
+  const int n2 = 2 * tl.ntile;
+  auto half_y0 = [&](int t2, int& b, int& x0, int& gx0, int& gx1) {
+    int y0;
+    tl.origin(t2 >> 1, b, y0, x0, gx0, gx1);
+    return y0 + (t2 & 1) * WGS_TH;
+  };
+  auto next_t2 = [&](int t2) {                             // the next non-empty half tile after t2, or -1
+    for (;;) {
+      t2 += (t2 & 1) ? 2 * a.KS - 1 : 1;
+      if (t2 >= n2) return -1;
+      int b, x0, g0, g1;
+      if (half_y0(t2, b, x0, g0, g1) < a.H) return t2;
+    }
+  };
+  int t_first = 2 * ks;
+  if (t_first >= n2) t_first = -1;                         // (the upper half of a listed tile is never empty)
+
+  if (loader) {
+    // ---------------- loader waves: global -> registers (two half tiles in flight) -> split -> LDS planes of the idle buffer
+    const int tl_ = t - 256, part = tl_ % PPX, pix0 = tl_ / PPX;
+    constexpr int NX = (XPIX * PPX + 255) / 256, NG = GPIX * PPX / 256, PSTEP = 256 / PPX;
+    static_assert(GPIX * PPX % 256 == 0, "gradient tile pieces per thread");
+    unsigned mx = 0, mg = 0;
+    const unsigned* ax = first ? sx.amax_x1 : sx.amax_x2;
+    for (int b = 0; b < a.B; ++b) { mx = max(mx, ax[b]); mg = max(mg, sx.amax_g[b]); }
+    const float s_x = split_scale(mx), s_g = split_scale(mg);
+    constexpr int OOB = (int)0x80000000;
+    const size_t xs_bytes = (size_t)Hs * Ws * Cs * 4, gs_bytes = (size_t)Hg * Wg * a.Cout * 4;
+    auto rsrc = [](const void* base, size_t bytes) __attribute__((always_inline)) {
+      const unsigned long long p = (unsigned long long)base;
+      const void* pu = (const void*)(((unsigned long long)__builtin_amdgcn_readfirstlane((int)(unsigned)(p >> 32)) << 32) |
+                                     (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)p));
+      return __builtin_amdgcn_make_buffer_rsrc((void*)pu, 0, __builtin_amdgcn_readfirstlane((int)bytes), 0x00020000);
+    };
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    struct Stage { u32x4 xr[NX]; u32x4 gr[NG]; unsigned gid[NG]; int ypar, xpar; };
+    // A piece's place in the half tile is fixed for the thread's life: its halo row / column (hy, hx) and, relative to the tile's
+    // origin, its byte offset in the source map -- the origin (a multiple of 2 rows x 32 columns) splits off exactly, also through
+    // the nearest-upsample shift.  Per half tile a piece then costs one add, the bounds compares and a select.
+    int xrel[NX], xhyx[NX], grel[NG];
+#pragma unroll
+    for (int k = 0; k < NX; ++k) {
+      const int pix = pix0 + k * PSTEP, hy = pix / HWID, hx = pix - hy * HWID;
+      xhyx[k] = pix < XPIX ? (hy << 8) | hx : (200 << 8);                          // (a row no image has: never valid)
+      xrel[k] = ((((hy - 1) >> sh) * Ws + ((hx - 1) >> sh)) * Cs + coff + part * 4) * 4;      // (arithmetic shifts: floor)
+    }
+#pragma unroll
+    for (int k = 0; k < NG; ++k) {
+      const int pix = pix0 + k * PSTEP;
+      grel[k] = (((pix / 32) >> gsh) * Wg + ((pix % 32) >> gsh)) * a.Cout + co0 + part * 4;
+    }
+    // every load is issued unconditionally (a half tile that does not exist gets out-of-range offsets everywhere and reads
+    // zeros): straight-line code, so the compiler can COUNT the loads in flight and wait for one stage while the next one's are
+    // still outstanding.  (A branch around the loads makes the wait a vmcnt(0).)
+    auto issue = [&](int t2, Stage& S) __attribute__((always_inline)) {
+      int b = 0, x0 = 0, gx0 = 0, gx1 = 0, y0 = 0;
+      const bool live = t2 >= 0;
+      if (live) y0 = half_y0(t2, b, x0, gx0, gx1);
+      S.ypar = y0; S.xpar = x0;
+      const __amdgpu_buffer_rsrc_t rx = rsrc((const char*)xsrc + (size_t)b * xs_bytes, xs_bytes);
+      const __amdgpu_buffer_rsrc_t rg = rsrc((const char*)a.g + (size_t)b * gs_bytes, gs_bytes);
+      const __amdgpu_buffer_rsrc_t ri = rsrc(a.g_unpool ? a.g_unpool + (size_t)b * (gs_bytes / 4) : (const unsigned char*)a.g, a.g_unpool ? gs_bytes / 4 : 0);
+      // uniform: the tile origin's offset (y0 is even and x0 a multiple of 32, so the upsample / unpool shifts split off), and the
+      // valid ranges of hy / hx (input halo) and of the gradient tile's rows / columns
+      const int xbase = __builtin_amdgcn_readfirstlane(((y0 >> sh) * Ws + (x0 >> sh)) * Cs * 4);
+      const int gbase = __builtin_amdgcn_readfirstlane(((y0 >> gsh) * Wg + (x0 >> gsh)) * a.Cout);
+      const int hy_lo = live ? max(0, 1 - y0) : 255, hy_hi = a.H - y0 + 1, hx_lo = max(0, 1 - x0), hx_hi = a.W - x0 + 1;
+      const int gy_hi = live ? a.H - y0 : 0, gx_lo = gx0 - x0, gx_hi = gx1 - x0;
+#pragma unroll
+      for (int k = 0; k < NX; ++k) {                   // input halo tile, zero outside the image
+        const int hy = xhyx[k] >> 8, hx = xhyx[k] & 255;
+        const bool ok = hy >= hy_lo && hy < hy_hi && hx >= hx_lo && hx < hx_hi;
+        S.xr[k] = __builtin_amdgcn_raw_buffer_load_b128(rx, ok ? xbase + xrel[k] : OOB, 0, 0);
+      }
+#pragma unroll
+      for (int k = 0; k < NG; ++k) {                   // output-gradient tile (virtual unpool: + the forward argmax)
+        const int pix = pix0 + k * PSTEP, py = pix / 32, px = pix % 32;
+        const bool ok = py < gy_hi && px >= gx_lo && px < gx_hi;
+        const int e0 = ok ? gbase + grel[k] : OOB;
+        S.gr[k] = __builtin_amdgcn_raw_buffer_load_b128(rg, ok ? e0 * 4 : OOB, 0, 0);
+        S.gid[k] = __builtin_amdgcn_raw_buffer_load_b32(ri, e0, 0, 0);      // (no unpool: a zero-sized descriptor, reads 0)
+      }
+    };
+    auto commit = [&](const Stage& S, int buf) __attribute__((always_inline)) {
+      char* base = smem + buf * BUFB;
+#pragma unroll
+      for (int k = 0; k < NX; ++k) {
+        const int pix = pix0 + k * PSTEP;
+        uint2 hi, lw;
+#if HLA_WS_ABL == 2      // timing-only: no split arithmetic
+        hi = make_uint2(S.xr[k].x, S.xr[k].y); lw = make_uint2(S.xr[k].z, S.xr[k].w);
+#else
+        split4(__uint_as_float(S.xr[k].x), __uint_as_float(S.xr[k].y), __uint_as_float(S.xr[k].z), __uint_as_float(S.xr[k].w), s_x, hi, lw);
+#endif
+        if (pix < XPIX) { *(uint2*)(base + oXh + pix * STR + part * 8) = hi; *(uint2*)(base + oXl + pix * STR + part * 8) = lw; }
+      }
+#pragma unroll
+      for (int k = 0; k < NG; ++k) {
+        const int pix = pix0 + k * PSTEP;
+        float e0 = __uint_as_float(S.gr[k].x), e1 = __uint_as_float(S.gr[k].y), e2 = __uint_as_float(S.gr[k].z), e3 = __uint_as_float(S.gr[k].w);
+        if (a.g_unpool) {                              // keep the elements whose forward argmax is this (y&1, x&1)
+          const unsigned pos = (((S.ypar + pix / 32) & 1) << 1) | ((S.xpar + pix % 32) & 1);
+          if ((S.gid[k] & 0xff) != pos) e0 = 0.f;
+          if (((S.gid[k] >> 8) & 0xff) != pos) e1 = 0.f;
+          if (((S.gid[k] >> 16) & 0xff) != pos) e2 = 0.f;
+          if ((S.gid[k] >> 24) != pos) e3 = 0.f;
+        }
+        uint2 hi, lw;
+#if HLA_WS_ABL == 2
+        hi = make_uint2(__float_as_uint(e0), __float_as_uint(e1)); lw = make_uint2(__float_as_uint(e2), __float_as_uint(e3));
+#else
+        split4(e0, e1, e2, e3, s_g, hi, lw);
+#endif
+        *(uint2*)(base + oGh + pix * STR + part * 8) = hi; *(uint2*)(base + oGl + pix * STR + part * 8) = lw;
+      }
+    };
+    Stage A, Bq;
+    int ta = t_first, tb = ta >= 0 ? next_t2(ta) : -1;
+    issue(ta, A);
+    issue(tb, Bq);
+    commit(A, 0);
+    __syncthreads();                                     // barrier 0: buffer 0 holds the first half tile
+    int cur = 0;
+#if HLA_WS_ABL == 3      // timing only: the loaders do nothing but keep the barrier count
+    while (ta >= 0) { __syncthreads(); ta = next_t2(ta); }
+    return;
+#endif
+    // at the top: the matrix waves work on half tile `ta` in buffer `cur`; Bq holds (in flight) the loads of `tb`; A is free
+    while (ta >= 0) {
+      int tc = tb >= 0 ? next_t2(tb) : -1;
+      issue(tc, A);
+      commit(Bq, cur ^ 1);
+      __syncthreads();
+      ta = tb; tb = tc; cur ^= 1;
+      if (ta < 0) break;
+      tc = tb >= 0 ? next_t2(tb) : -1;
+      issue(tc, Bq);
+      commit(A, cur ^ 1);
+      __syncthreads();
+      ta = tb; tb = tc; cur ^= 1;
+    }
+    return;
+  }
+
+  // ---------------- matrix waves
+  const int ct = wv >> 1, it = wv & 1;
+  const bool want_bias = a.bpart && blockIdx.y == 0 && it == 0;
+  unsigned mx = 0, mg = 0;
+  {
+    const unsigned* ax = first ? sx.amax_x1 : sx.amax_x2;
+    for (int b = 0; b < a.B; ++b) { mx = max(mx, ax[b]); mg = max(mg, sx.amax_g[b]); }
+  }
+  const float s_x = split_scale(mx), s_g = split_scale(mg);
+  f32x16 acc[9], accb;
+#pragma unroll
+  for (int k = 0; k < 9; ++k)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[k][r] = 0.f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) accb[r] = 0.f;
+  const uint4 ones = frag_ones<f16>();
+  __syncthreads();                                       // barrier 0
+  int cur = 0;
+  for (int t2 = t_first; t2 >= 0; t2 = next_t2(t2)) {
+    const char* base = smem + cur * BUFB;
+    const char *Xh = base + oXh, *Xl = base + oXl, *Gh = base + oGh, *Gl = base + oGl;
+    // one K-step (16 pixels) at a time: the G fragments of the half tile's two rows (hi and lo) stay resident; the X fragments of
+    // halo row rho + 1 are requested before the MFMAs of row rho (this wave has the SIMD's matrix pipe to itself: nothing else
+    // would cover the LDS latency); a fragment feeds the up to two taps ky that use it.  Term order per accumulator as in
+    // wgrad_split_kernel: (hi hi, lo hi, hi lo) per (kk, rho, kx, ky).
+#pragma unroll
+    for (int kk = 0; kk < (HLA_WS_ABL == 1 ? 0 : 32 / KPX); ++kk) {      // (HLA_WS_ABL 1, timing only: no matrix work)
+      uint4 Ah[WGS_TH], Al[WGS_TH];
+#pragma unroll
+      for (int r = 0; r < WGS_TH; ++r) {
+        Ah[r] = frag_kmajor<H>(Gh, STR, r * 32 + kk * KPX, ct * 32, lane);
+        Al[r] = frag_kmajor<H>(Gl, STR, r * 32 + kk * KPX, ct * 32, lane);
+      }
+      uint4 Bh[2][3], Bl[2][3];
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        Bh[0][kx] = frag_kmajor<H>(Xh, STR, kx + kk * KPX, it * 32, lane);
+        Bl[0][kx] = frag_kmajor<H>(Xl, STR, kx + kk * KPX, it * 32, lane);
+      }
+      if (want_bias) {
+#pragma unroll
+        for (int r = 0; r < WGS_TH; ++r) { mma16<H>(accb, Ah[r], ones); mma16<H>(accb, Al[r], ones); }
+      }
+#pragma unroll
+      for (int rho = 0; rho < WGS_TH + 2; ++rho) {
+        if (rho + 1 < WGS_TH + 2) {
+#pragma unroll
+          for (int kx = 0; kx < 3; ++kx) {
+            Bh[(rho + 1) & 1][kx] = frag_kmajor<H>(Xh, STR, (rho + 1) * HWID + kx + kk * KPX, it * 32, lane);
+            Bl[(rho + 1) & 1][kx] = frag_kmajor<H>(Xl, STR, (rho + 1) * HWID + kx + kk * KPX, it * 32, lane);
+          }
+        }
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+          for (int ky = 0; ky < 3; ++ky) {
+            const int r = rho - ky;
+            if (r >= 0 && r < WGS_TH) {
+              mma16<H>(acc[ky * 3 + kx], Ah[r], Bh[rho & 1][kx]);
+              mma16<H>(acc[ky * 3 + kx], Al[r], Bh[rho & 1][kx]);
+              mma16<H>(acc[ky * 3 + kx], Ah[r], Bl[rho & 1][kx]);
+            }
+          }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    __syncthreads();                                     // the loaders have filled the other buffer; this one is free
+    cur ^= 1;
+  }
+  // D[i = co][j = ci]: lane -> ci = ci0 + it*32 + (lane&31); reg r -> co = co0 + ct*32 + (r&3) + 8(r>>2) + 4(lane>>5)
+  const float inv = 1.f / (s_x * s_g), invg = 1.f / s_g;
+  const int ci = ci0 + it * 32 + (lane & 31), g5 = lane >> 5;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int co = co0 + ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * g5;
+    float* o = a.part + (((size_t)ks * a.Cout + co) * a.Cin + ci) * 9;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) o[tap] = acc[tap][r] * inv;
+    if (want_bias && (lane & 31) == 0) a.bpart[(size_t)ks * a.Cout + co] = accb[r] * invg;
+  }
+}
+
 // per-sample max |x| of an fp32 map (fp32 bit pattern, atomicMax into a zeroed word): the scale of a gradient map that no
 // convolution epilogue produced (the L2-norm backward's outputs, with the confidence heads' contribution added)
 static __global__ __launch_bounds__(256) void absmax_map_kernel(const float* __restrict__ x, size_t per_sample, size_t skip, int nblk,
@@ -1133,9 +1397,10 @@ struct BwdPlan {
 enum { GA_X21 = 0, GA_D2A, GA_X18, GA_X3P, GA_D1A, GA_X15, GA_X8P, GA_A12, GA_A10, GA_X8, GA_A5, GA_X3, GA_A0, GA_X24, GA_D3A,
        GA_X2P, GA_C2, kGradAmaxSlots = 24 };
 
-static int wgrad_ksplit(int Cout, int Cin, int ntile) {
+static std::atomic<unsigned long long> g_wgrad_ws_ok{0};      // per device: wgrad_split_ws_kernel's LDS request was accepted
+static int wgrad_ksplit(int Cout, int Cin, int ntile, int resident = 512) {
   const int pairs = (Cout / 64) * (Cin / 64);
-  int ks = 512 / (pairs > 0 ? pairs : 1);          // 512 workgroups = one resident generation (2 per CU)
+  int ks = resident / (pairs > 0 ? pairs : 1);     // 512 workgroups = one resident generation (2 per CU)
   if (ks < 1) ks = 1;
   if (ks > ntile) ks = ntile;
   return ks;
@@ -1223,8 +1488,17 @@ int vgg_backward_t(const float* x, size_t x_plane, const hla_vgg_params* prm, co
   using ET = std::conditional_t<SPLIT, float, T>;      // element type of the stored maps (split mode: fp32): the elementwise kernels
   static HlaPerDeviceOnce attr_once;
   HLA_CHECK_HIP(attr_once.run([] {
-    if constexpr (SPLIT)
+    if constexpr (SPLIT) {
+      // (the wave-specialised form needs 115 KB of dynamic LDS: where the device refuses it, the launches below fall back to
+      //  wgrad_split_kernel -- ws_ok, per device)
+      if (HLA_WGRAD_SPLIT_WS) {
+        int d = 0;
+        (void)hipGetDevice(&d);
+        const bool ok = hipFuncSetAttribute((const void*)wgrad_split_ws_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, wgs_ws_lds_bytes()) == hipSuccess;
+        if (ok) g_wgrad_ws_ok.fetch_or(1ull << (d & 63)); else (void)hipGetLastError();
+      }
       return hipFuncSetAttribute((const void*)wgrad_split_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, wgs_lds_bytes());
+    }
     else {
       if constexpr (sizeof(T) == 2 && HLA_WGRAD_DMA) {
         const hipError_t e = hipFuncSetAttribute((const void*)wgrad_dma_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, wgd_lds_bytes());
@@ -1381,6 +1655,13 @@ int vgg_backward_t(const float* x, size_t x_plane, const hla_vgg_params* prm, co
     a.row_begin = row_begin > 0 ? row_begin : 0;
     a.tiles_x = (Wout + 31) / 32; a.tiles_y = (Hout - a.row_begin + WG_TH - 1) / WG_TH; a.ntile = B * a.tiles_x * a.tiles_y;
     a.KS = wgrad_ksplit(a.Cout, a.Cin, a.ntile);
+    bool ws = false;
+    if constexpr (SPLIT) {      // wave-specialised kernel: one 8-wave workgroup per CU -> 256 workgroups are one resident generation
+      int d = 0;
+      (void)hipGetDevice(&d);
+      ws = HLA_WGRAD_SPLIT_WS && (g_wgrad_ws_ok.load() >> (d & 63) & 1) && !getenv("HLA_WGRAD_NO_WS");
+      if (ws) a.KS = wgrad_ksplit(a.Cout, a.Cin, a.ntile, 256);
+    }
     a.part = (float*)(bw + bp.part);
     a.bpart = (kLayers[l].has_bias && gr->db[l]) ? (float*)(bw + bp.bpart) : nullptr;
     const double P = (double)B * (Hout - a.row_begin) * Wout;
@@ -1388,7 +1669,8 @@ int vgg_backward_t(const float* x, size_t x_plane, const hla_vgg_params* prm, co
                        a.dyn ? a.dyn + a.dyn_desc : nullptr, a.tiles_x * a.tiles_y);
     if constexpr (SPLIT) {
       WgradSplitExtra ex{FA(fa1), FA(fa2), GA(ga)};
-      hipLaunchKernelGGL(wgrad_split_kernel, dim3(a.KS, a.Cin / 64, a.Cout / 64), dim3(256), wgs_lds_bytes(), st, a, ex);
+      if (ws) hipLaunchKernelGGL(wgrad_split_ws_kernel, dim3(a.KS, a.Cin / 64, a.Cout / 64), dim3(512), wgs_ws_lds_bytes(), st, a, ex);
+      else hipLaunchKernelGGL(wgrad_split_kernel, dim3(a.KS, a.Cin / 64, a.Cout / 64), dim3(256), wgs_lds_bytes(), st, a, ex);
     } else if constexpr (sizeof(T) == 2 && HLA_WGRAD_DMA) {
       if (!unpool) hipLaunchKernelGGL((wgrad_dma_kernel<T>), dim3(a.KS, a.Cin / 64, a.Cout / 64), dim3(256), wgd_lds_bytes(), st, a);
       else hipLaunchKernelGGL((wgrad_kernel<T>), dim3(a.KS, a.Cin / 64, a.Cout / 64), dim3(256), wg_lds_bytes<T>(), st, a);
