@@ -784,51 +784,62 @@ static __global__ __launch_bounds__(512, 1) void wgrad_split_ws_kernel(WgradArgs
   for (int t2 = t_first; t2 >= 0; t2 = next_t2(t2)) {
     const char* base = smem + cur * BUFB;
     const char *Xh = base + oXh, *Xl = base + oXl, *Gh = base + oGh, *Gl = base + oGl;
-    // one K-step (16 pixels) at a time: the G fragments of the half tile's two rows (hi and lo) stay resident; the X fragments of
-    // halo row rho + 1 are requested before the MFMAs of row rho (this wave has the SIMD's matrix pipe to itself: nothing else
-    // would cover the LDS latency); a fragment feeds the up to two taps ky that use it.  Term order per accumulator as in
-    // wgrad_split_kernel: (hi hi, lo hi, hi lo) per (kk, rho, kx, ky).
+    // A flat walk over the half tile's 8 steps (K-step kk = 16 pixels, halo row rho): the G fragments of a K-step (two rows, hi and
+    // lo) stay resident while its four halo rows pass; the X fragments of step s + 1 -- and, in a K-step's last row, the G
+    // fragments of the next one -- are REQUESTED AT THE TOP of step s, ahead of its 9-18 MFMAs (this wave has the SIMD's matrix pipe
+    // to itself: nothing else covers the LDS latency; left to the scheduler the requests sank to just before the step's last MFMA
+    // and every step started with an LDS round trip: 0.77 of the pipe with the loaders idle).  A fragment feeds the up to two taps
+    // ky that use it.  Term order per accumulator as in wgrad_split_kernel: (hi hi, lo hi, hi lo) per (kk, rho, kx, ky).
+    constexpr int NSTEP = (32 / KPX) * (WGS_TH + 2);
+    uint4 Ah[2][WGS_TH], Al[2][WGS_TH], Bh[2][3], Bl[2][3];
+#if HLA_WS_ABL != 1
 #pragma unroll
-    for (int kk = 0; kk < (HLA_WS_ABL == 1 ? 0 : 32 / KPX); ++kk) {      // (HLA_WS_ABL 1, timing only: no matrix work)
-      uint4 Ah[WGS_TH], Al[WGS_TH];
+    for (int r = 0; r < WGS_TH; ++r) {
+      Ah[0][r] = frag_kmajor<H>(Gh, STR, r * 32, ct * 32, lane);
+      Al[0][r] = frag_kmajor<H>(Gl, STR, r * 32, ct * 32, lane);
+    }
 #pragma unroll
-      for (int r = 0; r < WGS_TH; ++r) {
-        Ah[r] = frag_kmajor<H>(Gh, STR, r * 32 + kk * KPX, ct * 32, lane);
-        Al[r] = frag_kmajor<H>(Gl, STR, r * 32 + kk * KPX, ct * 32, lane);
-      }
-      uint4 Bh[2][3], Bl[2][3];
+    for (int kx = 0; kx < 3; ++kx) {
+      Bh[0][kx] = frag_kmajor<H>(Xh, STR, kx, it * 32, lane);
+      Bl[0][kx] = frag_kmajor<H>(Xl, STR, kx, it * 32, lane);
+    }
 #pragma unroll
-      for (int kx = 0; kx < 3; ++kx) {
-        Bh[0][kx] = frag_kmajor<H>(Xh, STR, kx + kk * KPX, it * 32, lane);
-        Bl[0][kx] = frag_kmajor<H>(Xl, STR, kx + kk * KPX, it * 32, lane);
-      }
-      if (want_bias) {
+    for (int st = 0; st < NSTEP; ++st) {
+      const int kk = st / (WGS_TH + 2), rho = st % (WGS_TH + 2);
+      if (st + 1 < NSTEP) {
+        const int kn = (st + 1) / (WGS_TH + 2), rn = (st + 1) % (WGS_TH + 2);
 #pragma unroll
-        for (int r = 0; r < WGS_TH; ++r) { mma16<H>(accb, Ah[r], ones); mma16<H>(accb, Al[r], ones); }
-      }
+        for (int kx = 0; kx < 3; ++kx) {
+          Bh[(st + 1) & 1][kx] = frag_kmajor<H>(Xh, STR, rn * HWID + kx + kn * KPX, it * 32, lane);
+          Bl[(st + 1) & 1][kx] = frag_kmajor<H>(Xl, STR, rn * HWID + kx + kn * KPX, it * 32, lane);
+        }
+        if (rn == 0) {
 #pragma unroll
-      for (int rho = 0; rho < WGS_TH + 2; ++rho) {
-        if (rho + 1 < WGS_TH + 2) {
-#pragma unroll
-          for (int kx = 0; kx < 3; ++kx) {
-            Bh[(rho + 1) & 1][kx] = frag_kmajor<H>(Xh, STR, (rho + 1) * HWID + kx + kk * KPX, it * 32, lane);
-            Bl[(rho + 1) & 1][kx] = frag_kmajor<H>(Xl, STR, (rho + 1) * HWID + kx + kk * KPX, it * 32, lane);
+          for (int r = 0; r < WGS_TH; ++r) {
+            Ah[kn & 1][r] = frag_kmajor<H>(Gh, STR, r * 32 + kn * KPX, ct * 32, lane);
+            Al[kn & 1][r] = frag_kmajor<H>(Gl, STR, r * 32 + kn * KPX, ct * 32, lane);
           }
         }
-#pragma unroll
-        for (int kx = 0; kx < 3; ++kx)
-#pragma unroll
-          for (int ky = 0; ky < 3; ++ky) {
-            const int r = rho - ky;
-            if (r >= 0 && r < WGS_TH) {
-              mma16<H>(acc[ky * 3 + kx], Ah[r], Bh[rho & 1][kx]);
-              mma16<H>(acc[ky * 3 + kx], Al[r], Bh[rho & 1][kx]);
-              mma16<H>(acc[ky * 3 + kx], Ah[r], Bl[rho & 1][kx]);
-            }
-          }
-        __builtin_amdgcn_sched_barrier(0);
       }
+      __builtin_amdgcn_sched_barrier(0);
+      if (rho == 0 && want_bias) {
+#pragma unroll
+        for (int r = 0; r < WGS_TH; ++r) { mma16<H>(accb, Ah[kk & 1][r], ones); mma16<H>(accb, Al[kk & 1][r], ones); }
+      }
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+          const int r = rho - ky;
+          if (r >= 0 && r < WGS_TH) {
+            mma16<H>(acc[ky * 3 + kx], Ah[kk & 1][r], Bh[st & 1][kx]);
+            mma16<H>(acc[ky * 3 + kx], Al[kk & 1][r], Bh[st & 1][kx]);
+            mma16<H>(acc[ky * 3 + kx], Ah[kk & 1][r], Bl[st & 1][kx]);
+          }
+        }
+      __builtin_amdgcn_sched_barrier(0);
     }
+#endif
     __syncthreads();                                     // the loaders have filled the other buffer; this one is free
     cur ^= 1;
   }
