@@ -419,6 +419,208 @@ __global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(WgradArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// wgrad_ws_kernel: the 16-bit weight gradient, WAVE-SPECIALISED (round 5; the split-mode twin is wgrad_split_ws_kernel below, which
+// explains the scheme).  One 8-wave workgroup per CU: waves 4-7 fetch a 4-row tile's pieces two tiles ahead through registers
+// (raw buffer loads, zero fill by the descriptors' range check, the virtual unpool's argmax mask applied on the way into LDS) and
+// write them into the idle one of two LDS buffers; waves 0-3 -- one per SIMD -- only read fragments and multiply, the next halo
+// row's fragments requested ahead of the current row's MFMAs.  One barrier per tile.  Plain AND un-pooling launches (wgrad_kernel
+// and wgrad_dma_kernel ran load -> barrier -> MFMA phases in every wave: 0.30 of the MFMA peak where the forward reaches 0.48).
+#ifndef HLA_WGRAD_WS
+#define HLA_WGRAD_WS 1
+#endif
+template <typename T> constexpr int wg_ws_buf_bytes() { return ((WG_TH + 2) * HWID + WG_TH * 32) * wg_stride<T>(); }
+template <typename T> constexpr int wg_ws_lds_bytes() { return 2 * wg_ws_buf_bytes<T>(); }
+
+template <typename T>
+__global__ __launch_bounds__(512, 1) void wgrad_ws_kernel(WgradArgs a) {
+  static_assert(sizeof(T) == 2, "16-bit types");
+  constexpr int STR = wg_stride<T>(), PPX = 8, XPIX = (WG_TH + 2) * HWID, GPIX = WG_TH * 32, KPX = 16, BUFB = wg_ws_buf_bytes<T>();
+  constexpr int oX = 0, oG = XPIX * STR;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int t = threadIdx.x, lane = t & 63, wv = __builtin_amdgcn_readfirstlane(t >> 6);
+  const bool loader = wv >= 4;
+  const int ks = blockIdx.x, ci0 = blockIdx.y * 64, co0 = blockIdx.z * 64;
+  const bool first = ci0 < a.C1;
+  const T* xsrc = first ? (const T*)a.x1 : (const T*)a.x2;
+  const int Cs = first ? a.C1 : a.C2, coff = first ? ci0 : ci0 - a.C1, sh = (first && a.up1) ? 1 : 0;
+  const int Hs = a.H >> sh, Ws = a.W >> sh;
+  const int gsh = a.g_unpool ? 1 : 0, Hg = a.H >> gsh, Wg = a.W >> gsh;
+  const WgTiles tl(a.dyn, a.dyn_desc, a.H, a.W, a.row_begin, a.tiles_x, a.tiles_y, a.ntile, a.B, a.g_unpool ? 1 : 0);
+  const int ntile = tl.ntile;
+  const int t_first = ks < ntile ? ks : -1;
+  auto next_tile = [&](int tt) { tt += a.KS; return tt < ntile ? tt : -1; };
+
+  if (loader) {
+    const int tl_ = t - 256, part = tl_ % PPX, pix0 = tl_ / PPX;
+    constexpr int NX = (XPIX * PPX + 255) / 256, NG = GPIX * PPX / 256, PSTEP = 256 / PPX;
+    static_assert(GPIX * PPX % 256 == 0, "gradient tile pieces per thread");
+    constexpr int OOB = (int)0x80000000;
+    const size_t xs_bytes = (size_t)Hs * Ws * Cs * 2, gs_bytes = (size_t)Hg * Wg * a.Cout * 2;
+    auto rsrc = [](const void* base, size_t bytes) __attribute__((always_inline)) {
+      const unsigned long long p = (unsigned long long)base;
+      const void* pu = (const void*)(((unsigned long long)__builtin_amdgcn_readfirstlane((int)(unsigned)(p >> 32)) << 32) |
+                                     (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)p));
+      return __builtin_amdgcn_make_buffer_rsrc((void*)pu, 0, __builtin_amdgcn_readfirstlane((int)bytes), 0x00020000);
+    };
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    struct Stage { u32x4 xr[NX]; u32x4 gr[NG]; u32x2 gid[NG]; int ypar, xpar; };
+    int xrel[NX], xhyx[NX], grel[NG];
+#pragma unroll
+    for (int k = 0; k < NX; ++k) {
+      const int pix = pix0 + k * PSTEP, hy = pix / HWID, hx = pix - hy * HWID;
+      xhyx[k] = pix < XPIX ? (hy << 8) | hx : (200 << 8);
+      xrel[k] = ((((hy - 1) >> sh) * Ws + ((hx - 1) >> sh)) * Cs + coff + part * 8) * 2;
+    }
+#pragma unroll
+    for (int k = 0; k < NG; ++k) {
+      const int pix = pix0 + k * PSTEP;
+      grel[k] = (((pix / 32) >> gsh) * Wg + ((pix % 32) >> gsh)) * a.Cout + co0 + part * 8;
+    }
+    auto issue = [&](int tile, Stage& S) __attribute__((always_inline)) {
+      int b = 0, x0 = 0, gx0 = 0, gx1 = 0, y0 = 0;
+      const bool live = tile >= 0;
+      if (live) tl.origin(tile, b, y0, x0, gx0, gx1);
+      S.ypar = y0; S.xpar = x0;
+      const __amdgpu_buffer_rsrc_t rx = rsrc((const char*)xsrc + (size_t)b * xs_bytes, xs_bytes);
+      const __amdgpu_buffer_rsrc_t rg = rsrc((const char*)a.g + (size_t)b * gs_bytes, gs_bytes);
+      const __amdgpu_buffer_rsrc_t ri = rsrc(a.g_unpool ? a.g_unpool + (size_t)b * (gs_bytes / 2) : (const unsigned char*)a.g, a.g_unpool ? gs_bytes / 2 : 0);
+      const int xbase = __builtin_amdgcn_readfirstlane(((y0 >> sh) * Ws + (x0 >> sh)) * Cs * 2);
+      const int gbase = __builtin_amdgcn_readfirstlane(((y0 >> gsh) * Wg + (x0 >> gsh)) * a.Cout);
+      const int hy_lo = live ? max(0, 1 - y0) : 255, hy_hi = a.H - y0 + 1, hx_lo = max(0, 1 - x0), hx_hi = a.W - x0 + 1;
+      const int gy_hi = live ? a.H - y0 : 0, gx_lo = gx0 - x0, gx_hi = gx1 - x0;
+#pragma unroll
+      for (int k = 0; k < NX; ++k) {
+        const int hy = xhyx[k] >> 8, hx = xhyx[k] & 255;
+        const bool ok = hy >= hy_lo && hy < hy_hi && hx >= hx_lo && hx < hx_hi;
+        S.xr[k] = __builtin_amdgcn_raw_buffer_load_b128(rx, ok ? xbase + xrel[k] : OOB, 0, 0);
+      }
+#pragma unroll
+      for (int k = 0; k < NG; ++k) {
+        const int pix = pix0 + k * PSTEP, py = pix / 32, px = pix % 32;
+        const bool ok = py < gy_hi && px >= gx_lo && px < gx_hi;
+        const int e0 = ok ? gbase + grel[k] : OOB;
+        S.gr[k] = __builtin_amdgcn_raw_buffer_load_b128(rg, ok ? e0 * 2 : OOB, 0, 0);
+        S.gid[k] = __builtin_amdgcn_raw_buffer_load_b64(ri, e0, 0, 0);       // (no unpool: a zero-sized descriptor, reads 0)
+      }
+    };
+    auto commit = [&](const Stage& S, int buf) __attribute__((always_inline)) {
+      char* base = smem + buf * BUFB;
+#pragma unroll
+      for (int k = 0; k < NX; ++k) {
+        const int pix = pix0 + k * PSTEP;
+        if (pix < XPIX) *(u32x4*)(base + oX + pix * STR + part * 16) = S.xr[k];
+      }
+#pragma unroll
+      for (int k = 0; k < NG; ++k) {
+        const int pix = pix0 + k * PSTEP;
+        u32x4 v = S.gr[k];
+        if (a.g_unpool) {      // keep the elements whose forward argmax is this (y&1, x&1): (id ^ pos) - 1 is negative only for a match
+          typedef short s16x2 __attribute__((ext_vector_type(2)));
+          const unsigned pos = ((((S.ypar + pix / 32) & 1) << 1) | ((S.xpar + pix % 32) & 1)) * 0x01010101u;
+          const unsigned m0 = S.gid[k].x ^ pos, m1 = S.gid[k].y ^ pos;
+          auto keep = [](unsigned m, unsigned sel) {
+            s16x2 w2 = __builtin_bit_cast(s16x2, __builtin_amdgcn_perm(0u, m, sel));
+            w2 = (w2 - (short)1) >> 15;
+            return __builtin_bit_cast(unsigned, w2);
+          };
+          v.x &= keep(m0, 0x0c010c00u); v.y &= keep(m0, 0x0c030c02u);
+          v.z &= keep(m1, 0x0c010c00u); v.w &= keep(m1, 0x0c030c02u);
+        }
+        *(u32x4*)(base + oG + pix * STR + part * 16) = v;
+      }
+    };
+    Stage A, Bq;
+    int ta = t_first, tb = ta >= 0 ? next_tile(ta) : -1;
+    issue(ta, A);
+    issue(tb, Bq);
+    commit(A, 0);
+    __syncthreads();                                     // barrier 0: buffer 0 holds the first tile
+    int cur = 0;
+    while (ta >= 0) {
+      int tc = tb >= 0 ? next_tile(tb) : -1;
+      issue(tc, A);
+      commit(Bq, cur ^ 1);
+      __syncthreads();
+      ta = tb; tb = tc; cur ^= 1;
+      if (ta < 0) break;
+      tc = tb >= 0 ? next_tile(tb) : -1;
+      issue(tc, Bq);
+      commit(A, cur ^ 1);
+      __syncthreads();
+      ta = tb; tb = tc; cur ^= 1;
+    }
+    return;
+  }
+
+  // ---------------- matrix waves
+  const int ct = wv >> 1, it = wv & 1;
+  const bool want_bias = a.bpart && blockIdx.y == 0 && it == 0;
+  f32x16 acc[9], accb;
+#pragma unroll
+  for (int k = 0; k < 9; ++k)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[k][r] = 0.f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) accb[r] = 0.f;
+  const uint4 ones = frag_ones<T>();
+  __syncthreads();                                       // barrier 0
+  int cur = 0;
+  for (int tile = t_first; tile >= 0; tile = next_tile(tile)) {
+    const char* Xs = smem + cur * BUFB + oX;
+    const char* Gs = smem + cur * BUFB + oG;
+    // the G fragments of the whole tile (4 rows x 2 K-steps) stay in registers; halo row rho's X fragments (3 column shifts x 2
+    // K-steps) are requested one row ahead of the MFMAs that consume them and feed the up to three taps ky with r = rho - ky
+    uint4 Af[WG_TH][2], Bf[2][3][2];
+#pragma unroll
+    for (int r = 0; r < WG_TH; ++r)
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) Af[r][kk] = frag_kmajor<T>(Gs, STR, r * 32 + kk * KPX, ct * 32, lane);
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) Bf[0][kx][kk] = frag_kmajor<T>(Xs, STR, kx + kk * KPX, it * 32, lane);
+#pragma unroll
+    for (int rho = 0; rho < WG_TH + 2; ++rho) {
+      if (rho + 1 < WG_TH + 2) {
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+          for (int kk = 0; kk < 2; ++kk) Bf[(rho + 1) & 1][kx][kk] = frag_kmajor<T>(Xs, STR, (rho + 1) * HWID + kx + kk * KPX, it * 32, lane);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (rho == 0 && want_bias) {
+#pragma unroll
+        for (int r = 0; r < WG_TH; ++r)
+#pragma unroll
+          for (int kk = 0; kk < 2; ++kk) mma16<T>(accb, Af[r][kk], ones);
+      }
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+          for (int ky = 0; ky < 3; ++ky) {
+            const int r = rho - ky;
+            if (r >= 0 && r < WG_TH) mma16<T>(acc[ky * 3 + kx], Af[r][kk], Bf[rho & 1][kx][kk]);
+          }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    __syncthreads();                                     // the loaders have filled the other buffer; this one is free
+    cur ^= 1;
+  }
+  const int ci = ci0 + it * 32 + (lane & 31), g5 = lane >> 5;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int co = co0 + ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * g5;
+    float* o = a.part + (((size_t)ks * a.Cout + co) * a.Cin + ci) * 9;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) o[tap] = acc[tap][r];
+    if (want_bias && (lane & 31) == 0) a.bpart[(size_t)ks * a.Cout + co] = accb[r];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Split-fp16 weight gradient (precision 'fp16x3'): the same contraction over pixels with both operands fed to the matrix cores
 // as hi + lo = fp16(s v) + fp16(s v - hi): G X ~= Ghi Xhi + Glo Xhi + Ghi Xlo, three v_mfma_f32_32x32x16_f16 per product, fp32
 // accumulate -- fp32-class gradients at a third of the fp16 MFMA rate instead of the exact-fp32 kernels' sixteenth.
@@ -1515,6 +1717,12 @@ int vgg_backward_t(const float* x, size_t x_plane, const hla_vgg_params* prm, co
         const hipError_t e = hipFuncSetAttribute((const void*)wgrad_dma_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, wgd_lds_bytes());
         if (e != hipSuccess) return e;
       }
+      if constexpr (sizeof(T) == 2 && HLA_WGRAD_WS) {      // 96 KB of dynamic LDS: refused -> the launches fall back (g_wgrad_ws_ok)
+        int d = 0;
+        (void)hipGetDevice(&d);
+        const bool ok = hipFuncSetAttribute((const void*)wgrad_ws_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, wg_ws_lds_bytes<T>()) == hipSuccess;
+        if (ok) g_wgrad_ws_ok.fetch_or(1ull << (d & 63)); else (void)hipGetLastError();
+      }
       return hipFuncSetAttribute((const void*)wgrad_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, wg_lds_bytes<T>());
     }
   }));
@@ -1667,10 +1875,10 @@ int vgg_backward_t(const float* x, size_t x_plane, const hla_vgg_params* prm, co
     a.tiles_x = (Wout + 31) / 32; a.tiles_y = (Hout - a.row_begin + WG_TH - 1) / WG_TH; a.ntile = B * a.tiles_x * a.tiles_y;
     a.KS = wgrad_ksplit(a.Cout, a.Cin, a.ntile);
     bool ws = false;
-    if constexpr (SPLIT) {      // wave-specialised kernel: one 8-wave workgroup per CU -> 256 workgroups are one resident generation
-      int d = 0;
+    if constexpr (SPLIT || (sizeof(T) == 2 && HLA_WGRAD_WS)) {      // wave-specialised kernels: one 8-wave workgroup per CU -> 256
+      int d = 0;                                                    // workgroups are one resident generation
       (void)hipGetDevice(&d);
-      ws = HLA_WGRAD_SPLIT_WS && (g_wgrad_ws_ok.load() >> (d & 63) & 1) && !getenv("HLA_WGRAD_NO_WS");
+      ws = (SPLIT ? HLA_WGRAD_SPLIT_WS : HLA_WGRAD_WS) && (g_wgrad_ws_ok.load() >> (d & 63) & 1) && !getenv("HLA_WGRAD_NO_WS");
       if (ws) a.KS = wgrad_ksplit(a.Cout, a.Cin, a.ntile, 256);
     }
     a.part = (float*)(bw + bp.part);
@@ -1683,7 +1891,8 @@ int vgg_backward_t(const float* x, size_t x_plane, const hla_vgg_params* prm, co
       if (ws) hipLaunchKernelGGL(wgrad_split_ws_kernel, dim3(a.KS, a.Cin / 64, a.Cout / 64), dim3(512), wgs_ws_lds_bytes(), st, a, ex);
       else hipLaunchKernelGGL(wgrad_split_kernel, dim3(a.KS, a.Cin / 64, a.Cout / 64), dim3(256), wgs_lds_bytes(), st, a, ex);
     } else if constexpr (sizeof(T) == 2 && HLA_WGRAD_DMA) {
-      if (!unpool) hipLaunchKernelGGL((wgrad_dma_kernel<T>), dim3(a.KS, a.Cin / 64, a.Cout / 64), dim3(256), wgd_lds_bytes(), st, a);
+      if (ws) hipLaunchKernelGGL((wgrad_ws_kernel<T>), dim3(a.KS, a.Cin / 64, a.Cout / 64), dim3(512), wg_ws_lds_bytes<T>(), st, a);
+      else if (!unpool) hipLaunchKernelGGL((wgrad_dma_kernel<T>), dim3(a.KS, a.Cin / 64, a.Cout / 64), dim3(256), wgd_lds_bytes(), st, a);
       else hipLaunchKernelGGL((wgrad_kernel<T>), dim3(a.KS, a.Cin / 64, a.Cout / 64), dim3(256), wg_lds_bytes<T>(), st, a);
     } else {
       hipLaunchKernelGGL((wgrad_kernel<T>), dim3(a.KS, a.Cin / 64, a.Cout / 64), dim3(256), wg_lds_bytes<T>(), st, a);
