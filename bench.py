@@ -547,7 +547,7 @@ def train_leg(net, a, sat, grd, extra, B, world, rank, dist, dev, want_kt, extra
         tdts.append(tb)
     blocks = [round(t / a.train_steps * 1e3, 3) for t in tdts]
     tdt = sorted(tdts)[1]
-    ar_bytes = ((net.grad_sync.bytes_reduced - ar0) // (3 * a.train_steps + 2)) if dist else 0
+    ar_bytes = ((net.grad_sync.bytes_reduced - ar0) // (3 * a.train_steps + 4)) if dist else 0      # 3 blocks of K steps + 4 warm-up steps
     trecs = []
     if not a.no_kernel_timing:  # per-kernel table from two extra steps (not part of the timing).  EVERY rank runs them --
         if want_kt:             # a training step contains the gradient all-reduce -- but only rank 0 is instrumented
