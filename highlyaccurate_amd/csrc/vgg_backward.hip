@@ -1610,6 +1610,7 @@ struct BwdPlan {
 enum { GA_X21 = 0, GA_D2A, GA_X18, GA_X3P, GA_D1A, GA_X15, GA_X8P, GA_A12, GA_A10, GA_X8, GA_A5, GA_X3, GA_A0, GA_X24, GA_D3A,
        GA_X2P, GA_C2, kGradAmaxSlots = 24 };
 
+static std::atomic<unsigned long long> g_wgrad_dma_ok{0};     // per device: wgrad_dma_kernel's LDS request was accepted
 static std::atomic<unsigned long long> g_wgrad_ws_ok{0};      // per device: wgrad_split_ws_kernel's LDS request was accepted
 static int wgrad_ksplit(int Cout, int Cin, int ntile, int resident = 512) {
   const int pairs = (Cout / 64) * (Cin / 64);
@@ -1713,9 +1714,11 @@ int vgg_backward_t(const float* x, size_t x_plane, const hla_vgg_params* prm, co
       return hipFuncSetAttribute((const void*)wgrad_split_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, wgs_lds_bytes());
     }
     else {
-      if constexpr (sizeof(T) == 2 && HLA_WGRAD_DMA) {
-        const hipError_t e = hipFuncSetAttribute((const void*)wgrad_dma_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, wgd_lds_bytes());
-        if (e != hipSuccess) return e;
+      if constexpr (sizeof(T) == 2 && HLA_WGRAD_DMA) {      // 72 KB: refused (a partition mode with a smaller per-workgroup limit) ->
+        int d = 0;                                          // the plain launches fall back to wgrad_kernel<T>
+        (void)hipGetDevice(&d);
+        const bool ok = hipFuncSetAttribute((const void*)wgrad_dma_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, wgd_lds_bytes()) == hipSuccess;
+        if (ok) g_wgrad_dma_ok.fetch_or(1ull << (d & 63)); else (void)hipGetLastError();
       }
       if constexpr (sizeof(T) == 2 && HLA_WGRAD_WS) {      // 96 KB of dynamic LDS: refused -> the launches fall back (g_wgrad_ws_ok)
         int d = 0;
@@ -1874,7 +1877,12 @@ int vgg_backward_t(const float* x, size_t x_plane, const hla_vgg_params* prm, co
     a.row_begin = row_begin > 0 ? row_begin : 0;
     a.tiles_x = (Wout + 31) / 32; a.tiles_y = (Hout - a.row_begin + WG_TH - 1) / WG_TH; a.ntile = B * a.tiles_x * a.tiles_y;
     a.KS = wgrad_ksplit(a.Cout, a.Cin, a.ntile);
-    bool ws = false;
+    bool ws = false, dma_ok = false;
+    {
+      int d = 0;
+      (void)hipGetDevice(&d);
+      dma_ok = (g_wgrad_dma_ok.load() >> (d & 63)) & 1;
+    }
     if constexpr (SPLIT || (sizeof(T) == 2 && HLA_WGRAD_WS)) {      // wave-specialised kernels: one 8-wave workgroup per CU -> 256
       int d = 0;                                                    // workgroups are one resident generation
       (void)hipGetDevice(&d);
@@ -1892,7 +1900,7 @@ int vgg_backward_t(const float* x, size_t x_plane, const hla_vgg_params* prm, co
       else hipLaunchKernelGGL(wgrad_split_kernel, dim3(a.KS, a.Cin / 64, a.Cout / 64), dim3(256), wgs_lds_bytes(), st, a, ex);
     } else if constexpr (sizeof(T) == 2 && HLA_WGRAD_DMA) {
       if (ws) hipLaunchKernelGGL((wgrad_ws_kernel<T>), dim3(a.KS, a.Cin / 64, a.Cout / 64), dim3(512), wg_ws_lds_bytes<T>(), st, a);
-      else if (!unpool) hipLaunchKernelGGL((wgrad_dma_kernel<T>), dim3(a.KS, a.Cin / 64, a.Cout / 64), dim3(256), wgd_lds_bytes(), st, a);
+      else if (!unpool && dma_ok) hipLaunchKernelGGL((wgrad_dma_kernel<T>), dim3(a.KS, a.Cin / 64, a.Cout / 64), dim3(256), wgd_lds_bytes(), st, a);
       else hipLaunchKernelGGL((wgrad_kernel<T>), dim3(a.KS, a.Cin / 64, a.Cout / 64), dim3(256), wg_lds_bytes<T>(), st, a);
     } else {
       hipLaunchKernelGGL((wgrad_kernel<T>), dim3(a.KS, a.Cin / 64, a.Cout / 64), dim3(256), wg_lds_bytes<T>(), st, a);
