@@ -135,36 +135,52 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
   const WgTiles tl(a.dyn, a.dyn_desc, a.H, a.W, a.row_begin, a.tiles_x, a.tiles_y, a.ntile, a.B, a.g_unpool ? 1 : 0);
   int gx0, gx1;                         // (set by every tile_origin call: the interval of the tile being loaded)
   auto tile_origin = [&](int tile, int& b, int& y0, int& x0) { tl.origin(tile, b, y0, x0, gx0, gx1); };
+  // raw buffer loads through one descriptor per operand and sample: a piece outside the image / the written part of g gets an
+  // offset beyond the range and reads zeros -- no branch around a load (hipcc ends every branch-guarded load's block with an
+  // s_waitcnt vmcnt(0): the exact-fp32 kernel's 29 loads per tile were 29 dependent round trips)
+  constexpr int OOB = (int)0x80000000;
+  const size_t xs_bytes = (size_t)Hs * Ws * Cs * sizeof(T), gs_bytes = (size_t)Hg * Wg * a.Cout * sizeof(T);
+  auto rsrc = [](const void* base, size_t bytes) __attribute__((always_inline)) {
+    const unsigned long long p = (unsigned long long)base;
+    const void* pu = (const void*)(((unsigned long long)__builtin_amdgcn_readfirstlane((int)(unsigned)(p >> 32)) << 32) |
+                                   (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)p));
+    return __builtin_amdgcn_make_buffer_rsrc((void*)pu, 0, __builtin_amdgcn_readfirstlane((int)bytes), 0x00020000);
+  };
+  typedef unsigned u32x4w __attribute__((ext_vector_type(4)));
+  typedef unsigned u32x2w __attribute__((ext_vector_type(2)));
   auto load_x = [&](int tile, int lo, int hi) {
     int b, y0, x0;
     tile_origin(tile, b, y0, x0);
+    const __amdgpu_buffer_rsrc_t rx = rsrc((const char*)xsrc + (size_t)b * xs_bytes, xs_bytes);
 #pragma unroll
     for (int i = 0; i < NX; ++i) {                     // input halo tile, zero outside the image
       if (i < lo || i >= hi) continue;
       const int pix = pix0 + i * PSTEP;
       const int hy = pix / HWID, hx = pix - hy * HWID, y = y0 - 1 + hy, x = x0 - 1 + hx;
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if (pix < XPIX && y >= 0 && y < a.H && x >= 0 && x < a.W)
-        v = *(const uint4*)(xsrc + (((size_t)b * Hs + (y >> sh)) * Ws + (x >> sh)) * Cs + coff + part * EPL);
-      xr[i] = v;
+      const bool ok = pix < XPIX && y >= 0 && y < a.H && x >= 0 && x < a.W;
+      const u32x4w v = __builtin_amdgcn_raw_buffer_load_b128(rx, ok ? (((y >> sh) * Ws + (x >> sh)) * Cs + coff + part * EPL) * (int)sizeof(T) : OOB, 0, 0);
+      xr[i] = make_uint4(v.x, v.y, v.z, v.w);
     }
   };
   auto load_g = [&](int tile, int lo, int hi) {
     int b, y0, x0;
     tile_origin(tile, b, y0, x0);
+    const __amdgpu_buffer_rsrc_t rg = rsrc((const char*)a.g + (size_t)b * gs_bytes, gs_bytes);
+    const __amdgpu_buffer_rsrc_t ri = rsrc(a.g_unpool ? a.g_unpool + (size_t)b * (gs_bytes / sizeof(T)) : (const unsigned char*)a.g,
+                                           a.g_unpool ? gs_bytes / sizeof(T) : 0);
 #pragma unroll
     for (int i = 0; i < NG; ++i) {                     // output-gradient tile (virtual unpool: + the forward argmax)
       if (i < lo || i >= hi) continue;
       const int pix = pix0 + i * PSTEP;
       const int y = y0 + pix / 32, x = x0 + pix % 32;
-      uint4 v = make_uint4(0, 0, 0, 0);
-      unsigned long long id = 0;
-      if (y < a.H && x >= gx0 && x < gx1) {
-        const size_t e0 = (((size_t)b * Hg + (y >> gsh)) * Wg + (x >> gsh)) * a.Cout + co0 + part * EPL;
-        v = *(const uint4*)((const T*)a.g + e0);
-        if (a.g_unpool) __builtin_memcpy(&id, a.g_unpool + e0, EPL);
-      }
-      gr[i] = v; gid[i] = id;
+      const bool ok = y < a.H && x >= gx0 && x < gx1;
+      const int e0 = ok ? ((y >> gsh) * Wg + (x >> gsh)) * a.Cout + co0 + part * EPL : OOB;
+      const u32x4w v = __builtin_amdgcn_raw_buffer_load_b128(rg, ok ? e0 * (int)sizeof(T) : OOB, 0, 0);
+      gr[i] = make_uint4(v.x, v.y, v.z, v.w);
+      unsigned long long id = 0;                       // (no unpool: a zero-sized descriptor, reads 0)
+      if constexpr (EPL == 8) { const u32x2w w = __builtin_amdgcn_raw_buffer_load_b64(ri, e0, 0, 0); id = (unsigned long long)w.x | ((unsigned long long)w.y << 32); }
+      else id = __builtin_amdgcn_raw_buffer_load_b32(ri, e0, 0, 0);
+      gid[i] = id;
     }
   };
   auto store_x = [&](int lo, int hi) {
