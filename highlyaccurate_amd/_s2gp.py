@@ -79,6 +79,8 @@ class S2GPBase(nn.Module):
     #   bwd_two_streams    1: the two extractors' backward passes run on two streams (single-GPU training)       DESIGN.md 6
     #   strict_errors      0; 1: reproduce jacobian.py:172's AssertionError (costs a host sync per forward)     DESIGN.md 1
     #   small_batch_two_streams  4: inference batches up to this size run the two extractors on two streams        DESIGN.md 5
+    #   fwd_two_streams    unset; -1 / 0: inference at ANY batch with the satellite extractor on a side stream of that priority --
+    #                      an experiment kept as a switch: 0.3-0.6 % SLOWER at B = 32 (EXPERIMENTS.md round 5)
     def __init__(self, args):
         super().__init__()
         self.args = args
@@ -314,9 +316,14 @@ class S2GPBase(nn.Module):
         # ground branch's (B <= args.small_batch_two_streams, default 4: B = 1 0.700 -> 0.615 ms, B = 4 1.195 -> 1.122; at B = 32, where both are dense, the same split measured
         # 2 % slower: DESIGN 3.1).
         small = sat_map.shape[0] <= int(getattr(self.args, 'small_batch_two_streams', 4))
+        # args.fwd_two_streams (round 5 experiment, default 0): the same split at ANY batch, the satellite branch on a side stream of
+        # the given priority (-1: high, so its chain owns the chip and the ground branch's launches fill the gaps its launch
+        # boundaries leave; 0: equal priority)
+        prio = getattr(self.args, 'fwd_two_streams', None)
+        small = small or prio is not None
         if small:
             cur = torch.cuda.current_stream()
-            side = _side_stream(sat_map.device)
+            side = _side_stream(sat_map.device, 0 if prio is None else int(prio))
             side.wait_stream(cur)
             with torch.cuda.stream(side):
                 sat_feats, _, sat_inv = vgg_forward_nhwc(self.SatFeatureNet, sat_map, want_conf=False, defer_norm=True, feat16=f16)
@@ -413,12 +420,13 @@ def raise_like_reference(trace, in_view, level_first, gn_norm2=None):
 _SIDE_STREAMS = {}
 
 
-def _side_stream(device) -> 'torch.cuda.Stream':
-    """One extra stream per device, kept OUTSIDE the modules (a Stream inside a module's __dict__ would break pickling / deepcopy)."""
-    key = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
+def _side_stream(device, priority: int = 0) -> 'torch.cuda.Stream':
+    """One extra stream per device (and priority), kept OUTSIDE the modules (a Stream inside a module's __dict__ would break pickling / deepcopy)."""
+    idx = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
+    key = (idx, priority)
     st = _SIDE_STREAMS.get(key)
     if st is None:
-        st = _SIDE_STREAMS[key] = torch.cuda.Stream(device=key)
+        st = _SIDE_STREAMS[key] = torch.cuda.Stream(device=idx, priority=priority)
     return st
 
 

@@ -14,7 +14,7 @@ def means(d, counter):
 
 fetch, nf = means(sys.argv[1], 'FETCH_SIZE')
 write, _ = means(sys.argv[2], 'WRITE_SIZE')
-out = {'_note': 'rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), mean per dispatch, bench.py --steps 2 (B=32, bf16). '
+out = {'_note': 'rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), mean per dispatch over the bench.py leg named by the file (B=32). '
                 'Counter unit is KiB. Per MI355X_MICROARCH.md (HBM section) FETCH_SIZE reports half of a wide coalesced read stream on '
                 'gfx950, so hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024; WRITE_SIZE is uncalibrated.'}
 try:      # stamp with the content hash of the kernel sources: bench.py ignores a file measured on other kernels
@@ -25,7 +25,7 @@ try:      # stamp with the content hash of the kernel sources: bench.py ignores 
 except Exception as e:
     out['_source_hash'] = None
 for k in sorted(fetch, key=lambda k: -fetch[k] * nf[k]):
-    if any(s in k for s in ('conv', 'lm_', 'wgrad')):
+    if any(s in k for s in ('conv', 'lm_', 'wgrad', 'reduce_partials', 'l2bwd')):
         out[k] = {'dispatches': nf[k], 'FETCH_SIZE_KiB': fetch[k], 'WRITE_SIZE_KiB': write.get(k, 0.0),
                   'hbm_bytes_corrected': (2 * fetch[k] + write.get(k, 0.0)) * 1024}
 json.dump(out, open(sys.argv[3], 'w'), indent=1)
