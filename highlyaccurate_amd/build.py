@@ -110,9 +110,31 @@ def build(force: bool = False, verbose: bool = False, out: str = None, defines=(
         return _build_locked(verbose, tuple(defines))
 
 
+def _prune_objects() -> int:
+    """Delete build/*.o of libraries that no longer exist next to the package (objects are named <source>.<library>.t<tu>.o; A/B
+    builds made with --out= leave 17 of them each, 4-5 MB a piece).  Objects of an existing library are kept: they are what makes a
+    rebuild of one translation unit cheap."""
+    bdir = os.path.join(HERE, 'build')
+    have = {f for f in os.listdir(HERE) if f.endswith('.so')} | {os.path.basename(LIB)}
+    n = 0
+    for f in os.listdir(bdir):
+        if not f.endswith('.o'):
+            continue
+        parts = f.split('.')           # <source>, <library name pieces...>, 't<k>', 'o'
+        lib = '.'.join(parts[1:-2])
+        if lib not in have:
+            try:
+                os.remove(os.path.join(bdir, f))
+                n += 1
+            except OSError:
+                pass
+    return n
+
+
 def _build_locked(verbose: bool, defines: tuple) -> str:
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
     srchash = source_hash()
+    _prune_objects()
     objs = []
     procs = []
     os.makedirs(os.path.join(HERE, 'build'), exist_ok=True)
