@@ -486,7 +486,7 @@ __global__ __launch_bounds__(512, 1) void wgrad_ws_kernel(WgradArgs a) {
     for (int k = 0; k < NX; ++k) {
       const int pix = pix0 + k * PSTEP, hy = pix / HWID, hx = pix - hy * HWID;
       xhyx[k] = pix < XPIX ? (hy << 8) | hx : (200 << 8);
-      xrel[k] = ((((hy - 1) >> sh) * Ws + ((hx - 1) >> sh)) * Cs + coff + part * 8) * 2;
+      xrel[k] = (((hx - 1) >> sh) * Cs + coff + part * 8) * 2;      // column part (x0 is a multiple of 32); the row part per tile
     }
 #pragma unroll
     for (int k = 0; k < NG; ++k) {
@@ -501,7 +501,10 @@ __global__ __launch_bounds__(512, 1) void wgrad_ws_kernel(WgradArgs a) {
       const __amdgpu_buffer_rsrc_t rx = rsrc((const char*)xsrc + (size_t)b * xs_bytes, xs_bytes);
       const __amdgpu_buffer_rsrc_t rg = rsrc((const char*)a.g + (size_t)b * gs_bytes, gs_bytes);
       const __amdgpu_buffer_rsrc_t ri = rsrc(a.g_unpool ? a.g_unpool + (size_t)b * (gs_bytes / 2) : (const unsigned char*)a.g, a.g_unpool ? gs_bytes / 2 : 0);
-      const int xbase = __builtin_amdgcn_readfirstlane(((y0 >> sh) * Ws + (x0 >> sh)) * Cs * 2);
+      // source row of halo row hy: (y0 - 1 + hy) >> sh = ((y0 - 1) >> sh) + ((hy + ((y0 - 1) & sh)) >> sh) -- the static first row of a
+      // trimmed ground launch may be odd, so the tile origin's parity under the upsample shift is carried (ypar)
+      const int ylo = y0 - 1, ypar = ylo & sh, rowb = Ws * Cs * 2;
+      const int xbase = __builtin_amdgcn_readfirstlane(((ylo >> sh) * Ws + (x0 >> sh)) * Cs * 2);
       const int gbase = __builtin_amdgcn_readfirstlane(((y0 >> gsh) * Wg + (x0 >> gsh)) * a.Cout);
       const int hy_lo = live ? max(0, 1 - y0) : 255, hy_hi = a.H - y0 + 1, hx_lo = max(0, 1 - x0), hx_hi = a.W - x0 + 1;
       const int gy_hi = live ? a.H - y0 : 0, gx_lo = gx0 - x0, gx_hi = gx1 - x0;
@@ -509,7 +512,7 @@ __global__ __launch_bounds__(512, 1) void wgrad_ws_kernel(WgradArgs a) {
       for (int k = 0; k < NX; ++k) {
         const int hy = xhyx[k] >> 8, hx = xhyx[k] & 255;
         const bool ok = hy >= hy_lo && hy < hy_hi && hx >= hx_lo && hx < hx_hi;
-        S.xr[k] = __builtin_amdgcn_raw_buffer_load_b128(rx, ok ? xbase + xrel[k] : OOB, 0, 0);
+        S.xr[k] = __builtin_amdgcn_raw_buffer_load_b128(rx, ok ? xbase + ((hy + ypar) >> sh) * rowb + xrel[k] : OOB, 0, 0);
       }
 #pragma unroll
       for (int k = 0; k < NG; ++k) {
@@ -873,14 +876,15 @@ static __global__ __launch_bounds__(512, 1) void wgrad_split_ws_kernel(WgradArgs
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
     struct Stage { u32x4 xr[NX]; u32x4 gr[NG]; unsigned gid[NG]; int ypar, xpar; };
     // A piece's place in the half tile is fixed for the thread's life: its halo row / column (hy, hx) and, relative to the tile's
-    // origin, its byte offset in the source map -- the origin (a multiple of 2 rows x 32 columns) splits off exactly, also through
-    // the nearest-upsample shift.  Per half tile a piece then costs one add, the bounds compares and a select.
+    // origin, the COLUMN part of its byte offset in the source map (the origin's column is a multiple of 32 and splits off exactly,
+    // also through the nearest-upsample shift; its row may be odd and does not).  Per half tile a piece then costs a shift-multiply-add,
+    // the bounds compares and a select.
     int xrel[NX], xhyx[NX], grel[NG];
 #pragma unroll
     for (int k = 0; k < NX; ++k) {
       const int pix = pix0 + k * PSTEP, hy = pix / HWID, hx = pix - hy * HWID;
       xhyx[k] = pix < XPIX ? (hy << 8) | hx : (200 << 8);                          // (a row no image has: never valid)
-      xrel[k] = ((((hy - 1) >> sh) * Ws + ((hx - 1) >> sh)) * Cs + coff + part * 4) * 4;      // (arithmetic shifts: floor)
+      xrel[k] = (((hx - 1) >> sh) * Cs + coff + part * 4) * 4;      // column part (arithmetic shift: floor; x0 is a multiple of 32)
     }
 #pragma unroll
     for (int k = 0; k < NG; ++k) {
@@ -900,7 +904,11 @@ static __global__ __launch_bounds__(512, 1) void wgrad_split_ws_kernel(WgradArgs
       const __amdgpu_buffer_rsrc_t ri = rsrc(a.g_unpool ? a.g_unpool + (size_t)b * (gs_bytes / 4) : (const unsigned char*)a.g, a.g_unpool ? gs_bytes / 4 : 0);
       // uniform: the tile origin's offset (y0 is even and x0 a multiple of 32, so the upsample / unpool shifts split off), and the
       // valid ranges of hy / hx (input halo) and of the gradient tile's rows / columns
-      const int xbase = __builtin_amdgcn_readfirstlane(((y0 >> sh) * Ws + (x0 >> sh)) * Cs * 4);
+      // source row of halo row hy: (y0 - 1 + hy) >> sh = ((y0 - 1) >> sh) + ((hy + ((y0 - 1) & sh)) >> sh) -- the static first row of a
+      // trimmed ground launch may be odd, so the origin's parity under the upsample shift is carried (ypar); columns split off
+      // exactly (x0 is a multiple of 32)
+      const int ylo = y0 - 1, ypar = ylo & sh, rowb = Ws * Cs * 4;
+      const int xbase = __builtin_amdgcn_readfirstlane(((ylo >> sh) * Ws + (x0 >> sh)) * Cs * 4);
       const int gbase = __builtin_amdgcn_readfirstlane(((y0 >> gsh) * Wg + (x0 >> gsh)) * a.Cout);
       const int hy_lo = live ? max(0, 1 - y0) : 255, hy_hi = a.H - y0 + 1, hx_lo = max(0, 1 - x0), hx_hi = a.W - x0 + 1;
       const int gy_hi = live ? a.H - y0 : 0, gx_lo = gx0 - x0, gx_hi = gx1 - x0;
@@ -908,7 +916,7 @@ static __global__ __launch_bounds__(512, 1) void wgrad_split_ws_kernel(WgradArgs
       for (int k = 0; k < NX; ++k) {                   // input halo tile, zero outside the image
         const int hy = xhyx[k] >> 8, hx = xhyx[k] & 255;
         const bool ok = hy >= hy_lo && hy < hy_hi && hx >= hx_lo && hx < hx_hi;
-        S.xr[k] = __builtin_amdgcn_raw_buffer_load_b128(rx, ok ? xbase + xrel[k] : OOB, 0, 0);
+        S.xr[k] = __builtin_amdgcn_raw_buffer_load_b128(rx, ok ? xbase + ((hy + ypar) >> sh) * rowb + xrel[k] : OOB, 0, 0);
       }
 #pragma unroll
       for (int k = 0; k < NG; ++k) {                   // output-gradient tile (virtual unpool: + the forward argmax)
