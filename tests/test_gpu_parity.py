@@ -1574,7 +1574,8 @@ def test_backward_dynamic_trimming_is_exact(precision, shape):
         assert worst < 2e-5, (tag, wk, worst)
 
 
-@pytest.mark.parametrize('kw', [dict(), dict(using_weight=1, train_damping=1), dict(train_ground_crop=1)])
+@pytest.mark.parametrize('kw', [dict(), dict(using_weight=1, train_damping=1), dict(train_ground_crop=1),
+                                dict(precision='fp16x3')])      # (fp16x3: the wave-specialised weight-gradient kernels on ODD first rows)
 def test_backward_row_trimming_is_exact(kw):
     """The ground branch's gradient lives in rows h_l/2.. of its three maps; hla_vgg_backward(first_row8) skips, layer by
     layer, the rows above the support of every activation gradient (exact zeros).  Gradients must equal the untrimmed
