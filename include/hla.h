@@ -10,7 +10,8 @@
  *   - the caller allocates every buffer (PyTorch's caching allocator in practice);
  *     the library never allocates or frees device memory and keeps no global state
  *     except a thread-local last-error string, the opt-in timing log (hla_prof_*) and
- *     per-device "kernel attribute already set" bits (dynamic-LDS opt-in of two kernels)
+ *     per-device "kernel attribute set / refused" bits (dynamic-LDS opt-in of the large-LDS kernels; a refused request
+ *     makes hla_vgg_backward fall back to its smaller-footprint weight-gradient kernels)
  *   - kernels are launched on the CURRENT device: the caller makes the device that owns the
  *     buffers and the stream current before the call (highlyaccurate_amd/_lib.py on_device)
  *   - all work is enqueued on the given hipStream_t (passed as void*); no implicit
@@ -334,8 +335,11 @@ int hla_g2s_lm_solve_bwd(const hla_s2g_config* cfg, const hla_s2g_level* levels,
 typedef struct hla_prof_record {
   int kernel_id;  /* index for hla_prof_kernel_name */
   float ms;       /* event-to-event duration on the launch stream */
-  double flops;   /* algorithmic FLOPs of the launch (2*9*Cin*Cout*H*W*B for a conv), else 0 */
-  double bytes;   /* algorithmic HBM bytes of the launch (maps read once + outputs), else 0 */
+  double flops;   /* algorithmic FLOPs of the launch (2*9*Cin*Cout*rows*W*B for a conv, the rows it computes), else 0.  A
+                     data-dependent launch of hla_vgg_backward (the satellite branch: only the tiles whose gradient is not exactly
+                     zero) reports the EXECUTED share: dense FLOPs x live tiles / tiles, the live count read back through a pinned
+                     host slot behind the kernel that wrote it */
+  double bytes;   /* algorithmic HBM bytes of the launch (maps read once + outputs), scaled likewise, else 0 */
 } hla_prof_record;
 int hla_prof_enable(int on);
 const char* hla_prof_kernel_name(int kernel_id);
