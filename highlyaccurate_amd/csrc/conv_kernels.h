@@ -1302,251 +1302,6 @@ __global__ __launch_bounds__(256, Prec<T>::SPLIT ? 2 : 3) void conv02_kernel(Con
 }
 
 // ---------------------------------------------------------------------------------------------
-// conv02_ws_kernel (16-bit types, inference form): the same fused conv0 + conv2 + pool, WAVE-SPECIALISED and persistent (round 5).
-// conv02_kernel's phases -- stage the input patch, conv0 into the halo tile (VALU-heavy im2col), conv2's 144 MFMAs, the pooled
-// epilogue -- run one after the other in every wave, and three co-resident workgroups overlap them only statistically: the matrix
-// pipe is ~55 % busy.  Here ONE 8-wave workgroup per CU walks its tiles.  Waves 0-3 (one per SIMD) are the conv2 waves: per tile
-// 144 MFMAs from one of two halo buffers, then pool + ReLU + convert in registers and 8 LDS writes -- they never touch global
-// memory except for conv2's weight stream (a ring that wraps from the tile's last tap to tap 0 of the next tile).  Waves 4-7 do
-// everything else, one tile ahead / behind: the input patch (in registers two tiles ahead), conv0 by MFMA straight into the idle
-// halo buffer, and the global stores of the previous tile's pooled rows.  Two workgroup barriers per tile:
-//   phase 1   conv2 waves: stages 0, 1 of tile i          | helper waves: store tile i-1's output, conv0 of tile i+1
-//   phase 2   conv2 waves: pool / ReLU / convert -> LDS   | helper waves: patch of tile i+2 -> LDS, request tile i+3's
-// Per tile the arithmetic is conv02_kernel's, value for value (same fragments, same order, same max / ReLU / rounding): the outputs
-// are bit-identical (test_conv02_wave_specialised_is_bit_identical).  The training / level-4 variants (relu(conv0) copy, argmax,
-// un-pooled relu(conv2)) stay on conv02_kernel.
-#ifndef HLA_CONV02_WS
-#define HLA_CONV02_WS 1
-#endif
-#ifndef HLA_C02WS_ABL
-#define HLA_C02WS_ABL 0      // timing-only ablations: 1 = the conv2 waves idle, 2 = the helper waves idle
-#endif
-constexpr int C02WS_OPIX = 64 * 2 + 16;                 // out tile: 4 pooled rows x 16 px x 64 ch (16-bit), padded pixel pitch
-constexpr int C02WS_OUT = 4 * 16 * C02WS_OPIX;
-template <typename T> constexpr int conv02_ws_lds_bytes() { return 2 * 2 * (10 * HWID * PSTR) + 3 * 12 * 36 * 4 + C02WS_OUT; }
-
-template <typename T, int WD>
-__global__ __launch_bounds__(512, 1) void conv02_ws_kernel(Conv02Args a0) {
-  static_assert(sizeof(T) == 2 && !Prec<T>::SPLIT, "16-bit types");
-  constexpr int EPL = 8, KC = 32, NSG = 2, NFRAG = 2;
-  constexpr int MT = 4, WN = 2, TH = 8, HPIX = (TH + 2) * HWID, BUF = HPIX * PSTR, IW = 36, IH = 12;
-  constexpr int TILEB = NSG * BUF;                       // one tile's two stage buffers
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* in = (float*)(smem + 2 * TILEB);                // [3][12][36] input patch (written in phase 2, read in phase 1)
-  char* outb = smem + 2 * TILEB + 3 * IH * IW * 4;       // pooled output tile (written in phase 2, read in the next phase 1)
-  const int t = threadIdx.x, lane = t & 63, wv = __builtin_amdgcn_readfirstlane(t >> 6);
-  const bool helper = wv >= 4;
-  const int x = lane & 31, g = lane >> 5;
-  const int tiles_per_img = a0.tiles_x * a0.tiles_y, ntiles = tiles_per_img * a0.B;
-  auto tile_origin = [&](int tile, int& b, int& y0, int& x0) {
-    const int tx = tile % a0.tiles_x, r = tile / a0.tiles_x;
-    b = r / a0.tiles_y;
-    y0 = a0.row_begin + (r % a0.tiles_y) * TH; x0 = tx * 32;
-  };
-  const int first = blockIdx.x, step = gridDim.x;
-  const int niter = first < ntiles ? (ntiles - first + step - 1) / step : 0;
-  // iteration it = -2 .. niter: the conv2 waves work on tile number `it` (0 <= it < niter) of this workgroup, the helpers on
-  // it - 1 (store), it + 1 (conv0), it + 2 (patch -> LDS), it + 3 (patch request).  Everybody passes bX and bY once per iteration.
-  auto nth = [&](int k) { return first + k * step; };
-
-  if (helper) {
-    const int tp = t - 256, wp = wv - 4;
-    uint4 wf0[2][NFRAG];                                 // conv0's fragments of both 32-channel halves (bias in k slots 27 / 28)
-#pragma unroll
-    for (int jj = 0; jj < 2; ++jj)
-#pragma unroll
-      for (int f = 0; f < NFRAG; ++f) wf0[jj][f] = a0.w0[((jj * NFRAG + f)) * 64 + lane];
-    constexpr int NIN = (3 * IH * IW + 255) / 256;
-    float vin[NIN];
-    auto load_patch = [&](int k) __attribute__((always_inline)) {      // tile number k of this workgroup (none: zeros, no access)
-      int b = 0, y0 = 0, x0 = 0;
-      const bool live = k >= 0 && k < niter;
-      if (live) tile_origin(nth(k), b, y0, x0);
-      // raw buffer loads, an element outside the image gets an out-of-range offset and reads 0: no branch around a load (hipcc ends
-      // a branch-guarded load's block with s_waitcnt vmcnt(0): six dependent round trips per patch)
-      const unsigned long long pb = (unsigned long long)(a0.x + (size_t)b * 3 * a0.x_plane);
-      const void* pu = (const void*)(((unsigned long long)__builtin_amdgcn_readfirstlane((int)(unsigned)(pb >> 32)) << 32) |
-                                     (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)pb));
-      const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)pu, 0, 0x7fffffff, 0x00020000);
-#pragma unroll
-      for (int i = 0; i < NIN; ++i) {
-        const int e = tp + i * 256;
-        const int c = e / (IH * IW), r = e % (IH * IW), iy = r / IW, ix = r % IW;
-        const int y = y0 - 2 + iy, xx = x0 - 2 + ix;
-        const bool ok = live && e < 3 * IH * IW && y >= 0 && y < a0.H && xx >= 0 && xx < a0.W;
-        vin[i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rx, ok ? (int)((c * a0.x_plane + (size_t)y * a0.W + xx) * 4) : (int)0x80000000, 0, 0));
-      }
-    };
-    const int Ho = a0.H >> 1, Wo = a0.W >> 1;
-    load_patch(0);
-    for (int it = -2; it <= niter; ++it) {
-#if HLA_C02WS_ABL == 2
-      __syncthreads(); __syncthreads(); continue;
-#endif
-      // ---- phase 1: store tile it-1's pooled rows; conv0 of tile it+1 into its halo buffers
-      if (it - 1 >= 0 && it - 1 < niter) {
-        int b, y0, x0;
-        tile_origin(nth(it - 1), b, y0, x0);
-        const size_t os = (size_t)Ho * Wo * 64 * sizeof(T);
-        const unsigned long long pb = (unsigned long long)a0.out_act + (size_t)b * os;
-        const void* pu = (const void*)(((unsigned long long)__builtin_amdgcn_readfirstlane((int)(unsigned)(pb >> 32)) << 32) |
-                                       (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)pb));
-        const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc((void*)pu, 0, __builtin_amdgcn_readfirstlane((int)os), 0x00020000);
-        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {                      // 4 rows x 16 px x 8 pieces of 16 B = 512 pieces
-          const int e = tp + k * 256, prow = e >> 7, px = (e >> 3) & 15, part = e & 7;
-          const int yo = (y0 >> 1) + prow, xo = (x0 >> 1) + px;
-          const bool ok = yo < Ho && xo < Wo;
-          const u32x4 v = *(const u32x4*)(outb + (prow * 16 + px) * C02WS_OPIX + part * 16);
-          __builtin_amdgcn_raw_buffer_store_b128(v, ro, ok ? ((yo * Wo + xo) * 64) * (int)sizeof(T) + part * 16 : (int)0x80000000, 0, 0);
-        }
-      }
-      if (it + 1 >= 0 && it + 1 < niter) {
-        int b, y0, x0;
-        tile_origin(nth(it + 1), b, y0, x0);
-        char* hb = smem + ((it + 1) & 1) * TILEB;
-        for (int m = wp; m * 32 < HPIX; m += 4) {
-          const int p = m * 32 + x, pc = p < HPIX ? p : HPIX - 1;
-          const int hy = pc / HWID, hx = pc - hy * HWID;
-          const float* ib = in + hy * IW + hx;
-          const int yy = y0 - 1 + hy, xx = x0 - 1 + hx;
-          const bool inside = yy >= 0 && yy < a0.H && xx >= 0 && xx < a0.W;      // conv2 zero-pads conv0's OUTPUT map
-          f32x16 c0[2];
-#pragma unroll
-          for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) c0[j][r] = 0.f;
-#pragma unroll
-          for (int f = 0; f < NFRAG; ++f) {
-            float ev[EPL];
-#pragma unroll
-            for (int jj = 0; jj < EPL; ++jj) {
-              const int kl = f * 2 * EPL + jj, kh = kl + EPL;      // compile-time
-              const int ol = kl < 27 ? (kl / 9) * IH * IW + ((kl % 9) / 3) * IW + (kl % 9) % 3 : 0;
-              const int oh = kh < 27 ? (kh / 9) * IH * IW + ((kh % 9) / 3) * IW + (kh % 9) % 3 : 0;
-              float v = ib[g ? oh : ol];
-              if (kh >= 27 && g) v = kh <= 28 ? 1.f : 0.f;          // k slots 27 / 28 multiply the bias (hi, lo)
-              if (kl >= 27 && !g) v = kl <= 28 ? 1.f : 0.f;
-              ev[jj] = v;
-            }
-            T e[EPL];
-#pragma unroll
-            for (int jj = 0; jj < EPL; ++jj) e[jj] = (T)ev[jj];
-            uint4 pf = __builtin_bit_cast(uint4, e);
-            if (!inside) pf = make_uint4(0u, 0u, 0u, 0u);
-#pragma unroll
-            for (int j = 0; j < 2; ++j) mma16<T>(c0[j], wf0[j][f], pf);
-          }
-          if (p < HPIX) {
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-              for (int q = 0; q < 4; ++q) {
-                const int co = j * 32 + q * 8 + g * 4, sl = co / KC;
-                const int byte = (co % KC) * (int)sizeof(T);
-                store4((T*)(hb + sl * BUF + halo_off(p, hx, byte >> 4) + (byte & 15)),
-                       fmaxf(c0[j][q * 4 + 0], 0.f), fmaxf(c0[j][q * 4 + 1], 0.f), fmaxf(c0[j][q * 4 + 2], 0.f), fmaxf(c0[j][q * 4 + 3], 0.f));
-              }
-          }
-        }
-      }
-      __syncthreads();                                     // bX
-      // ---- phase 2: the patch of tile it+2 (requested one iteration ago) -> LDS; request tile it+3's
-#pragma unroll
-      for (int k = 0; k < NIN; ++k) {
-        const int e = tp + k * 256;
-        if (e < 3 * IH * IW) in[e] = vin[k];
-      }
-      load_patch(it + 3);
-      __syncthreads();                                     // bY
-    }
-    return;
-  }
-
-  // ---------------- conv2 waves
-  const int wm = wv / WN, wn = wv % WN;
-  const uint4* wbase = a0.w2 + (size_t)wn * NSG * 18 * 64 + lane;      // this wave's 32 output channels: [stage][tap][kg][lane]
-  constexpr int RS = WD + 1, NTAP = NSG * 9;
-  static_assert(NTAP % RS == 0, "the ring's slot of tap 0 must be the same in every tile");
-  uint4 wb[RS][2];
-#pragma unroll
-  for (int d = 0; d < WD; ++d)
-#pragma unroll
-    for (int kg = 0; kg < 2; ++kg) wb[d][kg] = wbase[(d * 2 + kg) * 64];
-  float4 bias2[4];
-#pragma unroll
-  for (int q = 0; q < 4; ++q) bias2[q] = *(const float4*)(a0.b2 + wn * 32 + q * 8 + g * 4);
-  const FragOff fo = frag_offsets(lane, wm * MT);
-  stagger_priority();
-  for (int it = -2; it <= niter; ++it) {
-    const bool live = it >= 0 && it < niter && HLA_C02WS_ABL != 1;
-    f32x16 acc[MT];
-    if (live) {
-      const char* cb = smem + (it & 1) * TILEB;
-#pragma unroll
-      for (int q = 0; q < 4; ++q)
-#pragma unroll
-        for (int i = 0; i < MT; ++i) {
-          acc[i][q * 4 + 0] = bias2[q].x; acc[i][q * 4 + 1] = bias2[q].y; acc[i][q * 4 + 2] = bias2[q].z; acc[i][q * 4 + 3] = bias2[q].w;
-        }
-      // conv2: 2 stages x 9 taps x 2 k-groups against the halo tile; weights WD taps ahead through the ring, wrapping from the tile's
-      // last tap to tap 0 (the next tile's); pixel fragments 4 reads ahead of the MFMAs that consume them (as stage_mma)
-#pragma unroll
-      for (int sg = 0; sg < NSG; ++sg) {
-        const char* cur = cb + sg * BUF;
-        constexpr int FPT = MT * 2, DEPTH = 4;
-        uint4 pf[DEPTH + 1];
-#pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-          const int gt = sg * 9 + tap, nx = (gt + WD) % NTAP;            // compile-time
-#pragma unroll
-          for (int kg = 0; kg < 2; ++kg) wb[(gt + WD) % RS][kg] = wbase[(nx * 2 + kg) * 64];
-          auto frag_ptr = [&](int f) {
-            const int tp2 = tap + f / FPT, r = f % FPT;
-            return cur + fo.o[tp2 % 3][r & 1] + (tp2 / 3 + (r >> 1)) * HWID * PSTR;
-          };
-          if (tap == 0) {
-#pragma unroll
-            for (int f = 0; f < DEPTH; ++f) pf[f] = *(const uint4*)frag_ptr(f);
-          }
-          __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-          for (int f = 0; f < FPT; ++f) {
-            const int slot = (tap * FPT + f) % (DEPTH + 1), nslot = (tap * FPT + f + DEPTH) % (DEPTH + 1);
-            if (tap * FPT + f + DEPTH < 9 * FPT) pf[nslot] = *(const uint4*)frag_ptr(f + DEPTH);
-            mma16<T>(acc[f >> 1], wb[gt % RS][f & 1], pf[slot]);
-            __builtin_amdgcn_sched_barrier(0);
-          }
-        }
-      }
-    }
-    __syncthreads();                                       // bX
-    if (live) {
-      // 2 x 2 max-pool (vertical in registers, horizontal by one shuffle), ReLU, convert: conv_epilogue's EPI_ACT arithmetic; the even
-      // lanes write their 4 channels of the pooled pixel into the out tile, the helpers store it during the next phase 1
-#pragma unroll
-      for (int r0 = 0; r0 < MT / 2; ++r0) {
-        const int i = r0 * 2;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          float w[4];
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            float v = fmaxf(acc[i][q * 4 + e], acc[i + 1][q * 4 + e]);
-            v = fmaxf(v, __shfl_xor(v, 1, 64));
-            w[e] = fmaxf(v, 0.f);
-          }
-          if (!(x & 1))
-            store4((T*)(outb + ((wm * 2 + r0) * 16 + (x >> 1)) * C02WS_OPIX) + wn * 32 + q * 8 + g * 4, w[0], w[1], w[2], w[3]);
-        }
-      }
-    }
-    __syncthreads();                                       // bY
-  }
-}
-
-// ---------------------------------------------------------------------------------------------
 // weight packing: OIHW fp32 -> MFMA fragment order, T elements.
 //   generic: idx = ((((nt*nstage + sg)*9 + tap)*2 + kg)*64 + lane)*EPL + j
 //            cout = nt*32 + (lane&31), cin = sg*KC + kg*2*EPL + (lane>>5)*EPL + j      (KC = 64 B of channels)

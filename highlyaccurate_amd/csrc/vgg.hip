@@ -45,18 +45,6 @@ void vgg_pack_all(const hla_vgg_params* prm, char* packed, int dtype, hipStream_
   }
 }
 
-static int hla_num_cus() {      // CUs of the current device (cached per device)
-  static std::atomic<int> n[64];
-  int d = 0;
-  (void)hipGetDevice(&d);
-  int v = n[d & 63].load();
-  if (v <= 0) {
-    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, d) != hipSuccess || v <= 0) v = 256;
-    n[d & 63].store(v);
-  }
-  return v;
-}
-
 // Samples per launch of the full- / half-resolution layers (see vgg_forward_t).  HLA_VGG_CHUNK=n overrides (tooling: same-box A/B).
 static int vgg_chunk(int B, int H, int W, size_t es) {
   static const int env = [] { const char* e = getenv("HLA_VGG_CHUNK"); return e ? atoi(e) : -1; }();
@@ -110,26 +98,7 @@ int vgg_forward_t(const float* x, size_t x_plane, const hla_vgg_params* prm, con
       return hipFuncSetAttribute((const void*)conv02_kernel<T, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
     }));
     hla_prof_begin(K_CONV02, 2.0 * 9 * (3 + 64) * 64 * P, P * (3 * 4 + 16 * sizeof(T)), st);
-    bool ws = false;
-    if constexpr (sizeof(T) == 2 && HLA_CONV02_WS) {
-      // the wave-specialised, persistent form: one 8-wave workgroup per CU walking the tiles (113 KB of dynamic LDS; where the device
-      // refuses the request the three-per-CU kernel runs).  HLA_CONV02_NO_WS=1: same-box A/B and the bit-identity test.
-      static std::atomic<unsigned long long> ws_ok{0}, ws_tried{0};
-      int d = 0;
-      (void)hipGetDevice(&d);
-      const unsigned long long bit = 1ull << (d & 63);
-      if (!(ws_tried.load() & bit)) {
-        if (hipFuncSetAttribute((const void*)conv02_ws_kernel<T, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, conv02_ws_lds_bytes<T>()) == hipSuccess)
-          ws_ok.fetch_or(bit);
-        else (void)hipGetLastError();
-        ws_tried.fetch_or(bit);
-      }
-      const int ntiles = a.tiles_x * a.tiles_y * nb;
-      // (inference form only: the training / level-4 variants keep conv02_kernel)
-      ws = (ws_ok.load() & bit) && !getenv("HLA_CONV02_NO_WS") && ntiles >= 2 * hla_num_cus() && !a.a0_out && !a.idx_out && !a.a2_out;
-      if (ws) hipLaunchKernelGGL((conv02_ws_kernel<T, 2>), dim3(hla_num_cus()), dim3(512), conv02_ws_lds_bytes<T>(), st, a);
-    }
-    if (!ws) hipLaunchKernelGGL((conv02_kernel<T, 2>), dim3(a.tiles_x * a.tiles_y * nb), dim3(256), lds_bytes, st, a);
+    hipLaunchKernelGGL((conv02_kernel<T, 2>), dim3(a.tiles_x * a.tiles_y * nb), dim3(256), lds_bytes, st, a);
     hla_prof_end(st);
     return HLA_OK;
   };

@@ -2230,39 +2230,3 @@ def test_wave_specialised_wgrad_matches_the_two_phase_kernels(precision, monkeyp
             bad.append((n, e, noise))
     print(f'ws vs two-phase wgrad [{precision}]: worst relative L2 {worst:.2e} ({wn}; the same kernels twice: {wnoise:.2e}), {len(g_ws)} tensors')
     assert len(g_ws) >= 36 and not bad, bad
-
-
-@pytest.mark.parametrize('precision', ['bf16', 'fp16'])
-def test_conv02_wave_specialised_is_bit_identical(precision, monkeypatch):
-    """Round 5's persistent, wave-specialised fused conv0 + conv2 kernel (conv02_ws_kernel: conv0 producer waves, conv2 consumer
-    waves, two barriers per tile) against the three-workgroups-per-CU kernel it replaces (HLA_CONV02_NO_WS=1, read per call): the
-    same fragments multiplied in the same order, so EVERYTHING behind it must agree to the last bit -- the three feature maps and
-    the inverse norms of an inference forward (ragged image: partial tiles at the right and bottom edge; levels 3 and 4, the latter
-    also stores relu(conv2) un-pooled), and, through the training variant (relu(conv0) copy + pool argmax), every parameter gradient
-    of the extractor's own backward (fixed-order reductions: bitwise reproducible)."""
-    from highlyaccurate_amd.VGG import VGGUnet, vgg_forward_nhwc
-    d = _dev()
-    torch.manual_seed(11)
-    for level, shape in ((3, (40, 3, 200, 328)), (4, (9, 3, 136, 264))):      # 40 x 7 x 11 = 3080 tiles >= 2 x CUs: the ws path is taken
-        net = VGGUnet(level, precision=precision).to(d)
-        x = torch.rand(*shape, device=d)
-        outs = {}
-        for tag in ('ws', 'old'):
-            if tag == 'old':
-                monkeypatch.setenv('HLA_CONV02_NO_WS', '1')
-            else:
-                monkeypatch.delenv('HLA_CONV02_NO_WS', raising=False)
-            with torch.no_grad():
-                feats, _, inv = vgg_forward_nhwc(net, x, want_conf=False, defer_norm=True)
-            net.zero_grad(set_to_none=True)
-            ys = net(x)
-            ys = ys[0] if isinstance(ys[0], (list, tuple)) else ys
-            loss = sum((y * torch.linspace(-1, 1, y.numel(), device=d).reshape(y.shape)).sum() for y in ys if torch.is_tensor(y))
-            loss.backward()
-            outs[tag] = ([f.clone() for f in feats] + [inv.clone()], {n: p.grad.clone() for n, p in net.named_parameters() if p.grad is not None})
-        for a, b in zip(outs['ws'][0], outs['old'][0]):
-            assert torch.equal(a, b), (precision, level, 'forward differs')
-        assert outs['ws'][1].keys() == outs['old'][1].keys() and len(outs['ws'][1]) >= 18
-        for n in outs['ws'][1]:
-            assert torch.equal(outs['ws'][1][n], outs['old'][1][n]), (precision, level, n)
-    print(f'conv02 ws vs three-per-CU [{precision}]: forward maps, inverse norms and {len(outs["ws"][1])} gradients bit-identical')
