@@ -11,7 +11,7 @@ import torch
 from torch import nn
 
 from . import _lib, utils
-from ._s2gp import loss_func, raise_like_reference
+from ._s2gp import loss_from_trace, loss_func, raise_like_reference  # noqa: F401
 from .VGG import VGGUnet, vgg_backward_nhwc, vgg_forward_nhwc
 
 
@@ -144,9 +144,8 @@ class LM_G2SP(nn.Module):
         shift_lons, shift_lats, thetas = trace[..., 0], trace[..., 1], trace[..., 2]        # models_kitti.py:470-472
         if mode == 'train':
             a = self.args
-            out = loss_func(self.loss_method, None, None, None, shift_lats, shift_lons, thetas,
-                            gt_shift_v[:, 0], gt_shift_u[:, 0], gt_heading[:, 0], None, None,
-                            a.coe_shift_lat, a.coe_shift_lon, a.coe_heading, a.coe_L1, a.coe_L2, a.coe_L3, a.coe_L4)
+            out = loss_from_trace(self.loss_method, trace, (1, 0, 2), gt_shift_v[:, 0], gt_shift_u[:, 0], gt_heading[:, 0],
+                                  a.coe_shift_lat, a.coe_shift_lon, a.coe_heading)
             return (*out, [c.unsqueeze(1) for c in grd_confs])
         return shift_lats[:, -1, -1], shift_lons[:, -1, -1], thetas[:, -1, -1]
 

@@ -17,7 +17,7 @@ HLA_F32, HLA_BF16, HLA_F16, HLA_F16X3 = 0, 1, 2, 3
 HLA_VGG_WANT_CONF, HLA_VGG_DEFER_NORM, HLA_VGG_SAVE_FOR_BACKWARD, HLA_VGG_FEAT16 = 1, 2, 4, 8
 HLA_VGG_BWD_SCALE_INVARIANT = 1
 HLA_VGG_BWD_DENSE = 2
-ABI_VERSION = 19
+ABI_VERSION = 20
 
 
 class HlaError(RuntimeError):
@@ -55,6 +55,14 @@ class ProfRecord(C.Structure):
     _fields_ = [('kernel_id', C.c_int), ('ms', C.c_float), ('flops', C.c_double), ('bytes', C.c_double)]
 
 
+HLA_POSE_LOSS_F32, HLA_POSE_LOSS_F64 = 0, 1
+
+
+class PoseLossArgs(C.Structure):
+    _fields_ = [('x', C.c_void_p * 3), ('x_stride', (C.c_longlong * 3) * 3), ('gt', C.c_void_p * 3), ('gt_stride', C.c_longlong * 3),
+                ('coe', C.c_double * 3), ('B', C.c_int), ('N', C.c_int), ('L', C.c_int), ('gt_dtype', C.c_int)]
+
+
 _lib = None
 
 
@@ -71,7 +79,7 @@ def _check_binary(lib: C.CDLL, path: str) -> None:
     except AttributeError:
         raise HlaError(f'{path}: no hla_sizeof_struct export; rebuild it') from None
     fn.restype, fn.argtypes = C.c_size_t, [C.c_int]
-    for sid, cls in enumerate((VggParams, VggGrads, S2GLevel, S2GConfig, S2GLevelGrad, ProfRecord)):
+    for sid, cls in enumerate((VggParams, VggGrads, S2GLevel, S2GConfig, S2GLevelGrad, ProfRecord, PoseLossArgs)):
         if fn(sid) != C.sizeof(cls):
             raise HlaError(f'{path}: sizeof({cls.__name__}) is {fn(sid)} in the library and {C.sizeof(cls)} in the binding')
 
@@ -149,6 +157,10 @@ def load() -> C.CDLL:
     lib.hla_s2g_lm_solve_bwd.restype = i
     lib.hla_s2g_lm_solve_bwd.argtypes = [C.POINTER(S2GConfig), C.POINTER(S2GLevel), C.POINTER(S2GLevelGrad), vp, vp, vp, vp,
                                          vp, vp, vp, vp, sz, i, vp]
+    lib.hla_pose_loss.restype = i
+    lib.hla_pose_loss.argtypes = [C.POINTER(PoseLossArgs), vp, vp]
+    lib.hla_pose_loss_bwd.restype = i
+    lib.hla_pose_loss_bwd.argtypes = [C.POINTER(PoseLossArgs), C.POINTER(vp), C.POINTER(vp), C.POINTER((C.c_longlong * 3) * 3), vp]
     lib.hla_prof_enable.restype = i
     lib.hla_prof_enable.argtypes = [i]
     lib.hla_prof_kernel_name.restype = C.c_char_p

@@ -51,6 +51,93 @@ def ford_K_network_input():
     return out.tolist()
 
 
+def _loss_tensor_ops(shift_lats, shift_lons, thetas, gt_shift_lat, gt_shift_lon, gt_theta, coe_shift_lat, coe_shift_lon, coe_theta):
+    """models_ford.py:1073-1092 as the reference writes it (tensor ops on whatever device / dtype the inputs have)."""
+    d_lat = torch.abs(shift_lats - gt_shift_lat[:, None, None]).mean(dim=0)
+    d_lon = torch.abs(shift_lons - gt_shift_lon[:, None, None]).mean(dim=0)
+    d_th = torch.abs(thetas - gt_theta[:, None, None]).mean(dim=0)
+    losses = coe_shift_lat * d_lat + coe_shift_lon * d_lon + coe_theta * d_th
+    return (losses.mean(), losses[0] - losses[-1], d_lat[0] - d_lat[-1], d_lon[0] - d_lon[-1], d_th[0] - d_th[-1],
+            losses[-1], d_lat[-1], d_lon[-1], d_th[-1])
+
+
+def _pose_loss_args(xs, gts, coes):
+    a = _lib.PoseLossArgs()
+    B, N, L = xs[0].shape
+    for k in range(3):
+        a.x[k], a.gt[k], a.gt_stride[k], a.coe[k] = xs[k].data_ptr(), gts[k].data_ptr(), gts[k].stride(0), float(coes[k])
+        for j in range(3):
+            a.x_stride[k][j] = xs[k].stride(j)
+    a.B, a.N, a.L = B, N, L
+    a.gt_dtype = _lib.HLA_POSE_LOSS_F64 if gts[0].dtype == torch.float64 else _lib.HLA_POSE_LOSS_F32
+    return a
+
+
+class _PoseLossFn(torch.autograd.Function):
+    """loss_func method 0 as ONE launch forward (hla_pose_loss) and ONE backward (hla_pose_loss_bwd) instead of ~25 + ~40
+    element-wise launches of 5-7 us each (0.55 ms of a training step between the LM loop and its backward).
+    xs = (trace [B,N,L,3],) with ``cols`` = the trace columns holding (lat, lon, theta), or three [B,N,L] tensors (cols None)."""
+
+    @staticmethod
+    def forward(ctx, cols, coes, gt_lat, gt_lon, gt_th, *xs):
+        views = [xs[0][..., c] for c in cols] if cols is not None else list(xs)
+        gts = (gt_lat, gt_lon, gt_th)
+        L = views[0].shape[2]
+        out = torch.empty(1 + 8 * L, dtype=gt_lat.dtype, device=views[0].device)
+        args = _pose_loss_args(views, gts, coes)
+        _lib.check(_lib.load().hla_pose_loss(C.byref(args), _lib.ptr(out), _lib.stream_ptr()), 'hla_pose_loss')
+        ctx.save_for_backward(*xs, *gts)
+        ctx.cols, ctx.coes = cols, coes
+        ctx.set_materialize_grads(False)
+        return (out[0],) + tuple(out[1 + j * L:1 + (j + 1) * L] for j in range(8))
+
+    @staticmethod
+    def backward(ctx, *g):
+        cols, saved = ctx.cols, ctx.saved_tensors
+        nx = 1 if cols is not None else 3
+        xs, gts = saved[:nx], saved[nx:]
+        if cols is not None:
+            d = torch.empty_like(xs[0]) if xs[0].shape[-1] == 3 and len(set(cols)) == 3 else torch.zeros_like(xs[0])
+            views, dviews, grads = [xs[0][..., c] for c in cols], [d[..., c] for c in cols], (d,)
+        else:
+            views = list(xs)
+            grads = tuple(torch.empty(x.shape, dtype=torch.float32, device=x.device) for x in xs)
+            dviews = list(grads)
+        args = _pose_loss_args(views, gts, ctx.coes)
+        vp = C.c_void_p
+        gp, keep = (vp * 9)(), []
+        for j, t in enumerate(g):
+            if t is not None:
+                t = t.to(gts[0].dtype).contiguous()
+                keep.append(t)
+                gp[j] = t.data_ptr()
+        dp = (vp * 3)(*[v.data_ptr() for v in dviews])
+        ds = ((C.c_longlong * 3) * 3)()
+        for k in range(3):
+            for j in range(3):
+                ds[k][j] = dviews[k].stride(j)
+        _lib.check(_lib.load().hla_pose_loss_bwd(C.byref(args), gp, dp, C.byref(ds), _lib.stream_ptr()), 'hla_pose_loss_bwd')
+        return (None,) * 5 + grads
+
+
+def _pose_loss(cols, xs, gts, coes):
+    """The nine tensors of loss_func method 0.  Device fp32 poses with fp32 / fp64 ground truth on the same device go through
+    libhla (one launch each way, same values: batch means summed in fp64, then the reference's operation order in its result
+    type); anything else (CPU tensors, other dtypes, ground truth that requires grad, tensor-valued coefficients) is evaluated
+    with the reference's own tensor ops on the tensors' device -- that is the reference function, not a fallback of a kernel."""
+    views = [xs[0][..., c] for c in cols] if cols is not None else list(xs)
+    fused = (all(isinstance(c, (int, float)) for c in coes)
+             and all(v.is_cuda and v.dtype == torch.float32 and v.dim() == 3 and v.shape == views[0].shape for v in views)
+             and all(t.is_cuda and t.device == views[0].device and t.dtype == gts[0].dtype and t.dim() == 1
+                     and t.shape[0] == views[0].shape[0] and not t.requires_grad for t in gts)
+             and gts[0].dtype in (torch.float32, torch.float64) and 0 < views[0].shape[1] * views[0].shape[2] <= 512
+             and views[0].shape[0] > 0)
+    if not fused:
+        return _loss_tensor_ops(*views, *gts, *coes)
+    with torch.cuda.device(views[0].device):
+        return _PoseLossFn.apply(cols, tuple(float(c) for c in coes), *gts, *xs)
+
+
 def loss_func(loss_method, ref_feat_list, pred_feat_dict, gt_feat_dict, shift_lats, shift_lons, thetas,
               gt_shift_lat, gt_shift_lon, gt_theta, pred_uv_dict, gt_uv_dict,
               coe_shift_lat=100, coe_shift_lon=100, coe_theta=100, coe_L1=100, coe_L2=100, coe_L3=100, coe_L4=100):
@@ -58,12 +145,19 @@ def loss_func(loss_method, ref_feat_list, pred_feat_dict, gt_feat_dict, shift_la
     signature as the reference; the feature/uv dictionaries are unused by method 0 and may be None."""
     if loss_method != 0:
         raise NotImplementedError('only loss_method=0 is supported (the reference marks 1-3 as failed trials)')
-    d_lat = torch.abs(shift_lats - gt_shift_lat[:, None, None]).mean(dim=0)
-    d_lon = torch.abs(shift_lons - gt_shift_lon[:, None, None]).mean(dim=0)
-    d_th = torch.abs(thetas - gt_theta[:, None, None]).mean(dim=0)
-    losses = coe_shift_lat * d_lat + coe_shift_lon * d_lon + coe_theta * d_th
-    return (losses.mean(), losses[0] - losses[-1], d_lat[0] - d_lat[-1], d_lon[0] - d_lon[-1], d_th[0] - d_th[-1],
-            losses[-1], d_lat[-1], d_lon[-1], d_th[-1], None, None, None, None)
+    out = _pose_loss(None, (shift_lats, shift_lons, thetas), (gt_shift_lat, gt_shift_lon, gt_theta),
+                     (coe_shift_lat, coe_shift_lon, coe_theta))
+    return (*out, None, None, None, None)
+
+
+def loss_from_trace(loss_method, trace, cols, gt_shift_lat, gt_shift_lon, gt_theta, coe_shift_lat, coe_shift_lon, coe_theta):
+    """``loss_func`` for the models' own call (models_kitti.py:1304-1310, models_ford.py:848-854): the three pose tensors are
+    columns ``cols`` = (lat, lon, theta) of the LM loop's trace [B,N,L,3], so the gradient comes back as ONE d_trace tensor
+    instead of three column gradients that autograd would scatter into zero-filled copies and add up."""
+    if loss_method != 0:
+        raise NotImplementedError('only loss_method=0 is supported (the reference marks 1-3 as failed trials)')
+    out = _pose_loss(tuple(cols), (trace,), (gt_shift_lat, gt_shift_lon, gt_theta), (coe_shift_lat, coe_shift_lon, coe_theta))
+    return (*out, None, None, None, None)
 
 
 class S2GPBase(nn.Module):

@@ -4,7 +4,7 @@ from __future__ import annotations
 
 import torch
 
-from ._s2gp import S2GPBase, loss_func  # noqa: F401
+from ._s2gp import S2GPBase, loss_func, loss_from_trace  # noqa: F401
 
 
 class LM_S2GP_Ford(S2GPBase):
@@ -24,9 +24,9 @@ class LM_S2GP_Ford(S2GPBase):
             a = self.args
             coe_heading = 0 if a.rotation_range == 0 else a.coe_heading
             dev = trace.device
-            out = loss_func(self.loss_method, None, None, None, us, vs, thetas,                      # models_ford.py:837-839
-                            gt_shift_u.to(dev), gt_shift_v.to(dev), gt_theta.to(dev), None, None,
-                            a.coe_shift_lat, a.coe_shift_lon, coe_heading, a.coe_L1, a.coe_L2, a.coe_L3, a.coe_L4)
+            # loss_func(us, vs, thetas, gt_shift_u, gt_shift_v, gt_theta, ...) of models_ford.py:837-839 on the trace's columns
+            out = loss_from_trace(self.loss_method, trace, (0, 1, 2), gt_shift_u.to(dev), gt_shift_v.to(dev), gt_theta.to(dev),
+                                  a.coe_shift_lat, a.coe_shift_lon, coe_heading)
             return (*out, [c.unsqueeze(1) for c in grd_confs])
         res = (us[:, -1, -1], vs[:, -1, -1], thetas[:, -1, -1])
         if torch.is_grad_enabled():

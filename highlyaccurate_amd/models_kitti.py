@@ -8,7 +8,7 @@ from __future__ import annotations
 import torch
 
 from ._g2sp import LM_G2SP  # noqa: F401  (models_kitti.py:22-499)
-from ._s2gp import S2GPBase, loss_func  # noqa: F401  (loss_func re-exported like the reference module)
+from ._s2gp import S2GPBase, loss_func, loss_from_trace  # noqa: F401  (loss_func re-exported like the reference module)
 
 
 class LM_S2GP(S2GPBase):
@@ -29,9 +29,10 @@ class LM_S2GP(S2GPBase):
         if mode == 'train':
             a = self.args
             coe_heading = 0 if a.rotation_range == 0 else a.coe_heading
-            out = loss_func(self.loss_method, None, None, None, shift_lats, shift_lons, thetas,
-                            gt_shiftv[:, 0], gt_shiftu[:, 0], gt_heading[:, 0], None, None,
-                            a.coe_shift_lat, a.coe_shift_lon, coe_heading, a.coe_L1, a.coe_L2, a.coe_L3, a.coe_L4)
+            # loss_func(shift_lats, shift_lons, thetas, gt_shiftv[:, 0], gt_shiftu[:, 0], gt_heading[:, 0], ...) of
+            # models_kitti.py:1304-1310, on the trace's columns (lat = 1, lon = 0, theta = 2)
+            out = loss_from_trace(self.loss_method, trace, (1, 0, 2), gt_shiftv[:, 0], gt_shiftu[:, 0], gt_heading[:, 0],
+                                  a.coe_shift_lat, a.coe_shift_lon, coe_heading)
             return (*out, [c.unsqueeze(1) for c in grd_confs])
         res = (shift_lats[:, -1, -1], shift_lons[:, -1, -1], thetas[:, -1, -1])
         if torch.is_grad_enabled():

@@ -61,12 +61,12 @@ const char* hla_last_error(void);
  * with its own struct sizes (ctypes structs are positional: a mismatch corrupts silently).  highlyaccurate_amd/_lib.py
  * does both at load time, and rebuilds or refuses a binary whose hla_source_hash() is not the hash of the sources
  * next to it (the library is git-ignored but shipped prebuilt). */
-#define HLA_ABI_VERSION 19
+#define HLA_ABI_VERSION 20
 int hla_abi_version(void);
 const char* hla_source_hash(void); /* sha256 (hex) of the csrc sources, this header and the compiler flags at build time */
 typedef enum hla_struct_id {
   HLA_STRUCT_VGG_PARAMS = 0, HLA_STRUCT_VGG_GRADS = 1, HLA_STRUCT_S2G_LEVEL = 2, HLA_STRUCT_S2G_CONFIG = 3,
-  HLA_STRUCT_S2G_LEVEL_GRAD = 4, HLA_STRUCT_PROF_RECORD = 5
+  HLA_STRUCT_S2G_LEVEL_GRAD = 4, HLA_STRUCT_PROF_RECORD = 5, HLA_STRUCT_POSE_LOSS_ARGS = 6
 } hla_struct_id;
 size_t hla_sizeof_struct(int id);  /* sizeof of the struct with that hla_struct_id, 0 for an unknown id */
 
@@ -325,6 +325,33 @@ int hla_g2s_lm_solve_bwd(const hla_s2g_config* cfg, const hla_s2g_level* levels,
                          const double* normal_eq, const float* d_trace, double* d_damping, void* workspace,
                          size_t workspace_bytes, int B, hla_stream_t stream);
 
+
+/* ------------------------------------------------------------------------- *
+ * loss_func, loss_method 0  (models_ford.py:1041-1093; models_kitti.py imports the same function)
+ * ------------------------------------------------------------------------- */
+/* The pose loss of one training step and its gradient, one launch each (the reference: ~25 tensor ops + ~40 autograd nodes).
+ *   d_k[n,l] = mean_b |x_k[b,n,l] - gt_k[b]|  (k = 0 lat, 1 lon, 2 theta; models_ford.py:1073-1079)
+ *   losses   = coe[0] d_0 + coe[1] d_1 + coe[2] d_2                                   (models_ford.py:1086)
+ * out[1 + 8 L], in the order of the reference's return tuple (models_ford.py:1091-1092):
+ *   [0] mean(losses); then L values each of: losses[0]-losses[-1], d_0[0]-d_0[-1], d_1[0]-d_1[-1], d_2[0]-d_2[-1],
+ *   losses[-1], d_0[-1], d_1[-1], d_2[-1].
+ * gt_dtype selects the result type like torch's promotion does: fp32 inputs with fp32 ground truth give fp32 results
+ * (KITTI), with fp64 ground truth fp64 results (the Ford loader hands float64).  `out` and `g_out` hold that type. */
+enum { HLA_POSE_LOSS_F32 = 0, HLA_POSE_LOSS_F64 = 1 };
+typedef struct hla_pose_loss_args {
+  const float* x[3];          /* shift_lats, shift_lons, thetas [B,N,L] fp32: element (b,n,l) at x[k][b s0 + n s1 + l s2] */
+  long long x_stride[3][3];   /* (s0, s1, s2) per input, in elements (three columns of one [B,N,L,3] trace: (3NL, 3L, 3)) */
+  const void* gt[3];          /* gt_shift_lat, gt_shift_lon, gt_theta [B], fp32 or fp64 per gt_dtype */
+  long long gt_stride[3];     /* in elements */
+  double coe[3];              /* coe_shift_lat, coe_shift_lon, coe_theta */
+  int B, N, L;                /* N * L <= 512 */
+  int gt_dtype;
+} hla_pose_loss_args;
+int hla_pose_loss(const hla_pose_loss_args* args, void* out, hla_stream_t stream);
+/* g_out[j]: d(scalar)/d(out piece j) (j = 0: one value; j = 1..8: L values, contiguous) or NULL (= zero).
+ * dx[k]: gradient w.r.t. x[k], every element (b,n,l) written at dx[k][b t0 + n t1 + l t2], (t0,t1,t2) = dx_stride[k]. */
+int hla_pose_loss_bwd(const hla_pose_loss_args* args, const void* const g_out[9], float* const dx[3],
+                      const long long dx_stride[3][3], hla_stream_t stream);
 
 /* ------------------------------------------------------------------------- *
  * Measurement hooks (no reference counterpart; used by bench.py for the roofline numbers).

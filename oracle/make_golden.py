@@ -456,6 +456,42 @@ def gen_train(mk, seed, B=1, weighted=False):
     np.savez_compressed(os.path.join(GOLD, 'train_kitti_w.npz' if weighted else 'train_kitti.npz'), **out)
 
 
+def gen_loss(mf):
+    """loss_func method 0 of the REAL reference (models_ford.py:1041-1093): values of the nine tensors and, per case, the
+    gradient of a random linear functional of ALL nine w.r.t. the three pose tensors (autograd).  Cases: KITTI-like fp32 ground
+    truth, Ford-like fp64 ground truth (type promotion: fp64 results), N = 1 (losses[0] is losses[-1]), an exact zero residual."""
+    out = {}
+    cases = [(32, 5, 3, torch.float32, (100.0, 100.0, 100.0)), (3, 10, 3, torch.float64, (100.0, 50.0, 0.0)),
+             (4, 1, 2, torch.float32, (1.0, 2.0, 3.0)), (5, 2, 4, torch.float32, (100.0, 100.0, 10.0))]
+    for ci, (B, N, L, gdt, coe) in enumerate(cases):
+        g = torch.Generator().manual_seed(100 + ci)
+        xs = [torch.randn(B, N, L, generator=g) for _ in range(3)]
+        gts = [torch.randn(B, generator=g).to(gdt) for _ in range(3)]
+        if ci == 3:
+            xs[0][1, 0, 2] = gts[0][1]                # |x - gt| = 0: sign(0) = 0 in abs' backward
+        ws = [torch.randn((), generator=g)] + [torch.randn(L, generator=g) for _ in range(8)]
+        xr = [x.clone().requires_grad_(True) for x in xs]
+        res = mf.loss_func(0, None, None, None, xr[0], xr[1], xr[2], gts[0], gts[1], gts[2], None, None, coe[0], coe[1], coe[2])
+        assert all(r is None for r in res[9:]) and len(res) == 13
+        f = sum((r.double() * w.double()).sum() for r, w in zip(res[:9], ws))
+        gr = torch.autograd.grad(f, xr)
+        pre = f'c{ci}_'
+        out[pre + 'shape'] = np.array([B, N, L]); out[pre + 'coe'] = np.array(coe)
+        for k in range(3):
+            out[pre + f'x{k}'] = xs[k].numpy(); out[pre + f'gt{k}'] = gts[k].numpy(); out[pre + f'dx{k}'] = gr[k].numpy()
+        for j in range(9):
+            out[pre + f'out{j}'] = res[j].detach().numpy(); out[pre + f'w{j}'] = ws[j].numpy()
+        # the training step's own use: d(loss)/d(x) alone
+        xr = [x.clone().requires_grad_(True) for x in xs]
+        res = mf.loss_func(0, None, None, None, xr[0], xr[1], xr[2], gts[0], gts[1], gts[2], None, None, coe[0], coe[1], coe[2])
+        res[0].backward()
+        for k in range(3):
+            out[pre + f'dloss{k}'] = xr[k].grad.numpy()
+    out['n_cases'] = np.array(len(cases))
+    np.savez_compressed(os.path.join(GOLD, 'loss_kat.npz'), **out)
+    print('loss_kat.npz written')
+
+
 def gen_manifest(mk, mf):
     """State-dict manifest of the REAL reference classes (key -> shape, in state_dict order) for the configurations a
     checkpoint can come from: what `torch.save(net.state_dict())` (train_kitti.py:167-170,409-414) writes and
@@ -536,6 +572,8 @@ if __name__ == '__main__':
         gen_screen(mk)
     if a.only in ('all', 'manifest'):
         gen_manifest(mk, mf)
+    if a.only in ('all', 'loss'):
+        gen_loss(mf)
     if a.only in ('all', 'results'):
         gen_results()
     if a.only in ('all', 'kat'):

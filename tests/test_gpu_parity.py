@@ -726,6 +726,59 @@ def test_determinism_and_batch_independence():
             assert torch.equal(big[k:k + 1], n1.last_trace), k
 
 
+@pytest.mark.parametrize('form', ['three_tensors', 'trace_columns'])
+def test_pose_loss_kernels_vs_reference_golden(form):
+    """loss_func method 0 on the device = hla_pose_loss / hla_pose_loss_bwd (one launch each way) against vectors recorded from
+    the REAL reference's loss_func and its autograd: nine tensors (fp32; fp64 with the Ford loader's fp64 ground truth), the
+    gradient of a random functional of all nine, d(loss)/d(pose); N = 1 and an exactly-zero residual included.  `trace_columns`
+    is the models' own call (the poses are columns of the LM trace, one d_trace comes back)."""
+    from highlyaccurate_amd import _s2gp
+    from highlyaccurate_amd.models_kitti import loss_func
+    g = load_golden('loss_kat.npz')
+    d = _dev()
+    for ci in range(int(g['n_cases'])):
+        pre = f'c{ci}_'
+        xs = [T(g[pre + f'x{k}']).to(d) for k in range(3)]
+        gts = [T(g[pre + f'gt{k}']).to(d) for k in range(3)]
+        coe = [float(c) for c in g[pre + 'coe']]
+        for functional in (True, False):
+            if form == 'three_tensors':
+                leaves = [x.clone().requires_grad_(True) for x in xs]
+                res = loss_func(0, None, None, None, *leaves, *gts, None, None, *coe)
+            else:
+                cols = (1, 0, 2)
+                tr = torch.empty(*xs[0].shape, 3, device=d)
+                for k in range(3):
+                    tr[..., cols[k]] = xs[k]
+                leaves = [tr.requires_grad_(True)]
+                res = _s2gp.loss_from_trace(0, leaves[0], cols, *gts, *coe)
+            assert len(res) == 13 and all(r is None for r in res[9:])
+            assert res[0].grad_fn is not None and 'PoseLossFn' in type(res[0].grad_fn).__name__      # the HIP form, not tensor ops
+            for j in range(9):
+                ref = g[pre + f'out{j}']
+                assert res[j].dtype == T(ref).dtype and tuple(res[j].shape) == ref.shape
+                # (fp32: the batch means are summed in another order than torch's reduction -- an ulp of values up to ~300; the
+                #  differences losses[0] - losses[-1] inherit that absolutely)
+                f32 = ref.dtype == np.float32
+                np.testing.assert_allclose(res[j].detach().cpu().numpy(), ref, rtol=2e-6 if f32 else 1e-12, atol=4e-5 if f32 else 1e-12)
+            if functional:
+                f = sum((r.double() * T(g[pre + f'w{j}']).to(d).double()).sum() for j, r in enumerate(res[:9]))
+                gr = torch.autograd.grad(f, leaves)
+                key = 'dx'
+            else:
+                res[0].backward()
+                gr = [l.grad for l in leaves]
+                key = 'dloss'
+            for k in range(3):
+                got = gr[k] if form == 'three_tensors' else gr[0][..., (1, 0, 2)[k]]
+                np.testing.assert_allclose(got.cpu().numpy(), g[pre + f'{key}{k}'], rtol=2e-6, atol=1e-8)
+    # a CPU call runs the reference's tensor ops on the CPU tensors (no device work, no kernel): same values
+    xs = [T(g['c0_x%d' % k]) for k in range(3)]
+    gts = [T(g['c0_gt%d' % k]) for k in range(3)]
+    res = loss_func(0, None, None, None, *xs, *gts, None, None, 100, 100, 100)
+    np.testing.assert_allclose(float(res[0]), float(g['c0_out0']), rtol=1e-6)
+
+
 def test_train_mode_forward_values_vs_golden():
     """mode='train' 14-tuple values (no autograd yet) against the reference's fp64 tuple."""
     from oracle import ref_cpu as O

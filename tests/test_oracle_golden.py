@@ -400,3 +400,35 @@ def test_result_files_match_what_the_reference_writes(tmp_path):
     # appended, not overwritten (the reference opens with 'a')
     write_test_results(str(tmp_path), 'Test1', 8, 0.1, ps, ph, gs, gh, 20.0, 20.0, 10.0)
     assert len(open(tmp_path / 'Test1_results.txt').read().splitlines()) == 2 * len(ref_txt.splitlines())
+
+
+def _loss_cases():
+    g = load_golden('loss_kat.npz')
+    for ci in range(int(g['n_cases'])):
+        pre = f'c{ci}_'
+        xs = [torch.from_numpy(g[pre + f'x{k}']) for k in range(3)]
+        gts = [torch.from_numpy(g[pre + f'gt{k}']) for k in range(3)]
+        yield g, pre, xs, gts, [float(c) for c in g[pre + 'coe']]
+
+
+@pytest.mark.parametrize('which', ['oracle', 'product'])
+def test_loss_func_matches_the_reference_values_and_gradients(which):
+    """loss_func method 0 (models_ford.py:1041-1093) against vectors recorded from the REAL reference: the nine tensors, the
+    gradient of a random functional of all nine, and d(loss)/d(pose) -- the oracle's restatement and the product's function on CPU
+    tensors (there it runs the reference's own tensor ops; on the device the one-launch HIP form, tests/test_gpu_parity.py)."""
+    from oracle import ref_cpu as O
+    from highlyaccurate_amd.models_kitti import loss_func
+    for g, pre, xs, gts, coe in _loss_cases():
+        xr = [x.clone().requires_grad_(True) for x in xs]
+        if which == 'oracle':
+            res = O.loss_func(*xr, *gts, *coe)
+        else:
+            res = loss_func(0, None, None, None, *xr, *gts, None, None, *coe)
+        assert len(res) == 13 and all(r is None for r in res[9:])
+        for j in range(9):
+            assert res[j].dtype == torch.from_numpy(g[pre + f'out{j}']).dtype
+            np.testing.assert_allclose(res[j].detach().numpy(), g[pre + f'out{j}'], rtol=1e-6, atol=1e-6)
+        f = sum((r.double() * torch.from_numpy(g[pre + f'w{j}']).double()).sum() for j, r in enumerate(res[:9]))
+        gr = torch.autograd.grad(f, xr)
+        for k in range(3):
+            np.testing.assert_allclose(gr[k].numpy(), g[pre + f'dx{k}'], rtol=1e-6, atol=1e-7)
