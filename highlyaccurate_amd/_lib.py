@@ -40,7 +40,8 @@ class S2GConfig(C.Structure):
                 ('using_weight', C.c_int), ('use_hessian', C.c_int), ('dof', C.c_int),
                 ('shift_range_lat', C.c_double), ('shift_range_lon', C.c_double), ('rotation_range', C.c_double),
                 ('damping', C.c_double * 3), ('keep', C.c_void_p), ('keep_stride', C.c_size_t),
-                ('optimizer', C.c_int), ('beta1', C.c_double), ('beta2', C.c_double), ('count_in_view', C.c_int)]
+                ('optimizer', C.c_int), ('beta1', C.c_double), ('beta2', C.c_double), ('count_in_view', C.c_int),
+                ('grd_grad_overwrite', C.c_int)]
 
 
 class VggGrads(C.Structure):

@@ -372,14 +372,17 @@ class S2GPBase(nn.Module):
         if keep is not None:
             cfg.keep, cfg.keep_stride = keep.data_ptr(), keep.shape[1]
         d_sat = [torch.zeros_like(t) for t in sat_feats]
-        if grd_first_row8:      # the consumer (hla_vgg_backward(first_row8 = f)) never reads d_grd[l] above row f * 2^l - 2, and the loop
-            d_grd = []          # only writes rows h_l/2.. : the top of the maps is left uninitialised instead of zero-filled
-            for l, t in enumerate(grd_feats):
-                d = torch.empty_like(t)
-                d[:, max(0, (grd_first_row8 << l) - 2):].zero_()
-                d_grd.append(d)
-        else:
-            d_grd = [torch.zeros_like(t) for t in grd_feats]
+        # d_grd: the loop only touches rows h_l/2.. and WRITES them on each level's first visit (cfg.grd_grad_overwrite): no zero-fill
+        # and no read-modify-write of half a map there.  What still has to be zero is what the consumer reads above them: with
+        # hla_vgg_backward(first_row8 = f) two rows (it never reads d_grd[l] above row f * 2^l - 2), else the top half.
+        cfg.grd_grad_overwrite = 1
+        d_grd = []
+        for l, t in enumerate(grd_feats):
+            d = torch.empty_like(t)
+            lo, hi = (max(0, (grd_first_row8 << l) - 2) if grd_first_row8 else 0), lv[l].row0 - lv[l].grd_row_skip
+            if hi > lo:
+                d[:, lo:hi].zero_()
+            d_grd.append(d)
         d_conf = [torch.zeros_like(grd_confs[l]) if (self.using_weight and grd_confs[l] is not None) else None
                   for l in range(L)]
         gr = (_lib.S2GLevelGrad * L)()

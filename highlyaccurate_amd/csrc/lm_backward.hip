@@ -27,13 +27,15 @@ struct BwdAccumArgs {
   int A, h, w, row0, npix, TP, nt, B, xcd_affine;
   int hs, rskip;      // stored rows of grd/conf (h - grd_row_skip) and the skip itself
   const unsigned char* keep;   // dropout: [npix] of this step, 1 = pixel takes part; or null
+  int grd_assign;     // 1: d_grd rows row0.. are OVERWRITTEN by this launch (the first visit of the level: no zero-fill, no read), 0: added to
 };
 
 template <int C, bool USE_W>
-__global__ __launch_bounds__(256) void lm_bwd_accum(BwdAccumArgs a) {
+__global__ __launch_bounds__(256, USE_W ? 3 : 4) void lm_bwd_accum(BwdAccumArgs a) {
   __shared__ PixParam pp[MAX_TP];
   __shared__ float pxyz[MAX_TP][3];       // the pixel's ground-plane point (the coefficient adjoints weight by it)
   __shared__ double red[4][12];
+  __shared__ double c12s[12][256];
   int b, tile;
   if (!lm_block_map(a.xcd_affine, a.nt, a.B, b, tile)) return;
   const int t = threadIdx.x;
@@ -55,20 +57,31 @@ __global__ __launch_bounds__(256) void lm_bwd_accum(BwdAccumArgs a) {
   }
   __syncthreads();
 
+  // The 22 per-sample scalars (adjoints of the 14 sums, both inverse norms, d(uv)/d(shift)) are uniform across the block: kept in
+  // SGPRs (readfirstlane) they cost no vector registers.  Together with accumulating the tap gradients straight into the
+  // texel-cell registers the kernel went from 184 VGPRs (2 waves per SIMD) to <= 128 (4): this gather / scatter loop waits on
+  // memory, so resident waves are what it runs on.
+  auto uni = [](float x) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(x))); };
   const double* ad = a.adj + (size_t)b * 16;
-  const float gS = (float)ad[0], gG = (float)ad[1];
-  const float A00 = (float)ad[2], A01 = (float)ad[3], A02 = (float)ad[4], A11 = (float)ad[5], A12 = (float)ad[6], A22 = (float)ad[7];
-  const float gU0 = (float)ad[8], gU1 = (float)ad[9], gU2 = (float)ad[10];
-  const float gV0 = (float)ad[11], gV1 = (float)ad[12], gV2 = (float)ad[13];
-  const float as = a.sat_inv ? (float)a.sat_inv[b] : 1.f, ag = a.grd_inv ? (float)a.grd_inv[b] : 1.f;
-  const float j0u = (float)cf[8], j0v = (float)cf[9], j1u = (float)cf[10], j1v = (float)cf[11];
+  const float gS = uni((float)ad[0]), gG = uni((float)ad[1]);
+  const float A00 = uni((float)ad[2]), A01 = uni((float)ad[3]), A02 = uni((float)ad[4]), A11 = uni((float)ad[5]), A12 = uni((float)ad[6]),
+              A22 = uni((float)ad[7]);
+  const float gU0 = uni((float)ad[8]), gU1 = uni((float)ad[9]), gU2 = uni((float)ad[10]);
+  const float gV0 = uni((float)ad[11]), gV1 = uni((float)ad[12]), gV2 = uni((float)ad[13]);
+  const float as = uni(a.sat_inv ? (float)a.sat_inv[b] : 1.f), ag = uni(a.grd_inv ? (float)a.grd_inv[b] : 1.f);
+  const float j0u = uni((float)cf[8]), j0v = uni((float)cf[9]), j1u = uni((float)cf[10]), j1v = uni((float)cf[11]);
+  const float kkf = uni((float)cf[12]);
   constexpr int LPP = C / 4, PPW = 64 / LPP;
   const int lane = t & 63, wave = t >> 6;
   // lane j of a pixel's LPP lanes owns channels j, j+LPP, j+2LPP, j+3LPP: every load / atomic instruction then covers
   // LPP consecutive floats per pixel (whole cache lines) -- atomics are processed per touched line in L2
   const int sub = lane / LPP, cl = lane % LPP;
-  const size_t sat_base = (size_t)b * a.A * a.A * C + cl;
-  const size_t grd_base = ((size_t)b * a.hs * a.w + (size_t)(a.row0 - a.rskip) * a.w + p0) * C + cl;
+  // block-uniform bases (scalar registers) + 32-bit per-lane element offsets: a sample's map is < 2^31 elements
+  const float* sat_u = a.sat + (size_t)b * a.A * a.A * C;
+  float* dsat_u = a.d_sat + (size_t)b * a.A * a.A * C;
+  const size_t grd_first = ((size_t)b * a.hs * a.w + (size_t)(a.row0 - a.rskip) * a.w + p0) * C;
+  const float* grd_u = a.grd + grd_first;
+  float* dgrd_u = a.d_grd + grd_first;
 
   // Every lane group walks a CONTIGUOUS run of ground pixels.  Neighbouring ground pixels oversample the satellite
   // map (2-20x laterally at KITTI geometry), so consecutive pixels mostly fall into the same texel cell: their tap
@@ -79,7 +92,7 @@ __global__ __launch_bounds__(256) void lm_bwd_accum(BwdAccumArgs a) {
   float c00[4] = {0, 0, 0, 0}, c01[4] = {0, 0, 0, 0}, c10[4] = {0, 0, 0, 0}, c11[4] = {0, 0, 0, 0};
   auto flush_cell = [&]() {
     if (cur_off >= 0) {
-      float* dp = a.d_sat + sat_base + cur_off;
+      float* dp = dsat_u + (cur_off + cl);
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         atomicAdd(dp + e * LPP, c00[e]);
@@ -89,28 +102,39 @@ __global__ __launch_bounds__(256) void lm_bwd_accum(BwdAccumArgs a) {
       }
     }
   };
-  double c12[12];
+  // the lane's 12 fp64 coefficient-adjoint sums live in LDS (one private column per thread, ds_add_f64): 24 registers less
 #pragma unroll
-  for (int k = 0; k < 12; ++k) c12[k] = 0.0;
-  const double kk = cf[12];
+  for (int k = 0; k < 12; ++k) c12s[k][t] = 0.0;
   for (int jr = 0; jr < RUN; ++jr) {
     const int i = grp * RUN + jr;
-    const bool live = i < np;
-    float q[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-    if (live) {
+    if (i < np) {
       const PixParam P = pp[i];
-      const float* sp = a.sat + sat_base + P.off;
-      const float* gq = a.grd + grd_base + (size_t)i * C;
-      float v00[4], v01[4], v10[4], v11[4], vg[4];
+      const float* sp = sat_u + (P.off + cl);
+      const float* gq = grd_u + (i * C + cl);
+      float* gp = dgrd_u + (i * C + cl);                               // this (pixel, channels) is owned by this lane
+      // a pixel inside the map that falls into another texel cell than the run so far: flush the cell's sums, start a new one
+      // (a pixel outside has all-zero weights: it adds exact zeros to whatever cell is open)
+      if (P.m != 0.f && (P.off != cur_off || P.dxo != cur_dxo || P.dyo != cur_dyo)) {
+        flush_cell();
+        cur_off = P.off; cur_dxo = P.dxo; cur_dyo = P.dyo;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        v00[e] = sp[e * LPP]; v01[e] = sp[P.dxo + e * LPP];
-        v10[e] = sp[P.dyo + e * LPP]; v11[e] = sp[P.dyo + P.dxo + e * LPP];
-        vg[e] = gq[e * LPP];
+        for (int e = 0; e < 4; ++e) c00[e] = c01[e] = c10[e] = c11[e] = 0.f;
       }
-      float d00[4], d01[4], d10[4], d11[4], dg[4];
+      float q0 = 0.f, q1 = 0.f, q2 = 0.f, q3 = 0.f, q4 = 0.f, q5 = 0.f, q6 = 0.f, q7 = 0.f, q8 = 0.f;
+      // two channels at a time: the loads of a half (10 or 12 dwords per lane) are in flight together, the second half's are
+      // issued after the first half's arithmetic -- half the load registers, and twice the waves to cover the latency instead
+      float v00[4], v01[4], v10[4], v11[4], vg[4], og[4];
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
+        if ((e & 1) == 0) {
+#pragma unroll
+          for (int f = e; f < e + 2; ++f) {
+            v00[f] = sp[f * LPP]; v01[f] = sp[P.dxo + f * LPP];
+            v10[f] = sp[P.dyo + f * LPP]; v11[f] = sp[P.dyo + P.dxo + f * LPP];
+            vg[f] = gq[f * LPP];
+            og[f] = a.grd_assign ? 0.f : gp[f * LPP];
+          }
+        }
         const float V00 = v00[e] * as, V01 = v01[e] * as, V10 = v10[e] * as, V11 = v11[e] * as;
         const float top = P.wx0 * V00 + P.wx1 * V01, bot = P.wx0 * V10 + P.wx1 * V11;
         const float s = P.wy0 * top + P.wy1 * bot;
@@ -126,57 +150,43 @@ __global__ __launch_bounds__(256) void lm_bwd_accum(BwdAccumArgs a) {
         const float ggr = 2.f * g * gG + w * (J0 * gV0 + J1 * gV1 + J2 * gV2);
         const float gJ0 = w * (aj0 + s * gU0 + g * gV0), gJ1 = w * (aj1 + s * gU1 + g * gV1), gJ2 = w * (aj2 + s * gU2 + g * gV2);
         const float gdsx = gJ0 * j0u + gJ1 * j1u + gJ2 * P.j2u, gdsy = gJ0 * j0v + gJ1 * j1v + gJ2 * P.j2v;
-        q[0] += gs * dsx + gdsy * dxy; q[1] += gs * dsy + gdsx * dxy;
-        q[2] += gJ0 * dsx; q[3] += gJ0 * dsy; q[4] += gJ1 * dsx; q[5] += gJ1 * dsy; q[6] += gJ2 * dsx; q[7] += gJ2 * dsy;
-        if (USE_W) q[8] += 0.5f * (J0 * aj0 + J1 * aj1 + J2 * aj2) + s * (J0 * gU0 + J1 * gU1 + J2 * gU2) + g * (J0 * gV0 + J1 * gV1 + J2 * gV2);
-        d00[e] = gs * P.wy0 * P.wx0 - gdsx * P.wy0 - gdsy * P.wx0;
-        d01[e] = gs * P.wy0 * P.wx1 + gdsx * P.wy0 - gdsy * P.wx1;
-        d10[e] = gs * P.wy1 * P.wx0 - gdsx * P.wy1 + gdsy * P.wx0;
-        d11[e] = gs * P.wy1 * P.wx1 + gdsx * P.wy1 + gdsy * P.wx1;
-        dg[e] = ggr * P.gm;
+        q0 += gs * dsx + gdsy * dxy; q1 += gs * dsy + gdsx * dxy;
+        q2 += gJ0 * dsx; q3 += gJ0 * dsy; q4 += gJ1 * dsx; q5 += gJ1 * dsy; q6 += gJ2 * dsx; q7 += gJ2 * dsy;
+        if (USE_W) q8 += 0.5f * (J0 * aj0 + J1 * aj1 + J2 * aj2) + s * (J0 * gU0 + J1 * gU1 + J2 * gU2) + g * (J0 * gV0 + J1 * gV1 + J2 * gV2);
+        c00[e] += gs * P.wy0 * P.wx0 - gdsx * P.wy0 - gdsy * P.wx0;
+        c01[e] += gs * P.wy0 * P.wx1 + gdsx * P.wy0 - gdsy * P.wx1;
+        c10[e] += gs * P.wy1 * P.wx0 - gdsx * P.wy1 + gdsy * P.wx0;
+        c11[e] += gs * P.wy1 * P.wx1 + gdsx * P.wy1 + gdsy * P.wx1;
+        gp[e * LPP] = og[e] + ggr * P.gm;
       }
-      if (P.m != 0.f) {
-        if (P.off != cur_off || P.dxo != cur_dxo || P.dyo != cur_dyo) {
-          flush_cell();
-          cur_off = P.off; cur_dxo = P.dxo; cur_dyo = P.dyo;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) { c00[e] = d00[e]; c01[e] = d01[e]; c10[e] = d10[e]; c11[e] = d11[e]; }
-        } else {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) { c00[e] += d00[e]; c01[e] += d01[e]; c10[e] += d10[e]; c11[e] += d11[e]; }
-        }
-      }
-      float* gp = a.d_grd + grd_base + (size_t)i * C;                  // this (pixel, channels) is owned by this lane
-#pragma unroll
-      for (int e = 0; e < 4; ++e) gp[e * LPP] += dg[e];
-    }
-    // pixel adjoints -> adjoints of the 12 projection coefficients.  The map is linear, so every lane applies it to its own
-    // partial sums (its 4 channels of the pixel) and accumulates in fp64 across its run of pixels; ONE cross-lane reduction at
-    // the end replaces round 2's per-pixel butterfly of eight values over the LPP lanes that share a pixel (72 of the loop's
-    // ~400 instructions) and the pass over an LDS copy of the per-pixel sums.
-    if (live) {
+      // pixel adjoints -> adjoints of the 12 projection coefficients.  The map is linear, so every lane applies it to its own
+      // partial sums (its 4 channels of the pixel) and accumulates in fp64 across its run of pixels; ONE cross-lane reduction at
+      // the end replaces round 2's per-pixel butterfly of eight values over the LPP lanes that share a pixel (72 of the loop's
+      // ~400 instructions) and the pass over an LDS copy of the per-pixel sums.
       const double X = pxyz[i][0], Y = pxyz[i][1], Z = pxyz[i][2];
-      const double gu = (double)q[0] - kk * (double)q[7];     // j2v = -k (u - ctr)
-      const double gv = (double)q[1] + kk * (double)q[6];     // j2u =  k (v - ctr)
-      c12[0] += gu * X; c12[1] += gu * Y; c12[2] += gu * Z; c12[3] += gu;
-      c12[4] += gv * X; c12[5] += gv * Y; c12[6] += gv * Z; c12[7] += gv;
-      c12[8] += (double)q[2]; c12[9] += (double)q[3]; c12[10] += (double)q[4]; c12[11] += (double)q[5];
-    }
-    if (USE_W) {       // d(loss)/d(confidence) is per pixel: that one value is still reduced over the pixel's lanes
-      float qw = q[8];
+      const double gu = (double)q0 - (double)kkf * (double)q7;     // j2v = -k (u - ctr)
+      const double gv = (double)q1 + (double)kkf * (double)q6;     // j2u =  k (v - ctr)
+      atomicAdd(&c12s[0][t], gu * X); atomicAdd(&c12s[1][t], gu * Y); atomicAdd(&c12s[2][t], gu * Z); atomicAdd(&c12s[3][t], gu);
+      atomicAdd(&c12s[4][t], gv * X); atomicAdd(&c12s[5][t], gv * Y); atomicAdd(&c12s[6][t], gv * Z); atomicAdd(&c12s[7][t], gv);
+      atomicAdd(&c12s[8][t], (double)q2); atomicAdd(&c12s[9][t], (double)q3); atomicAdd(&c12s[10][t], (double)q4);
+      atomicAdd(&c12s[11][t], (double)q5);
+      if (USE_W) {       // d(loss)/d(confidence) is per pixel: that one value is still reduced over the pixel's lanes
+        float qw = q8;   // (the LPP lanes of a pixel share `i`, so they are all inside this branch together)
 #pragma unroll
-      for (int o = LPP >> 1; o > 0; o >>= 1) qw += __shfl_xor(qw, o, 64);
-      if (live && (lane % LPP) == 0 && a.d_conf) {
-        const int p = p0 + i;
-        const int r = a.row0 + p / a.w, c = p % a.w;
-        a.d_conf[((size_t)b * a.hs + (r - a.rskip)) * a.w + c] += qw * pp[i].gm;
+        for (int o = LPP >> 1; o > 0; o >>= 1) qw += __shfl_xor(qw, o, 64);
+        if (cl == 0 && a.d_conf) {
+          const int p = p0 + i;
+          const int r = a.row0 + p / a.w, c = p % a.w;
+          a.d_conf[((size_t)b * a.hs + (r - a.rskip)) * a.w + c] += qw * P.gm;
+        }
       }
     }
   }
   flush_cell();
   __syncthreads();
+  double c12[12];
 #pragma unroll
-  for (int k = 0; k < 12; ++k) c12[k] = wave_sum_f64(c12[k]);
+  for (int k = 0; k < 12; ++k) c12[k] = wave_sum_f64(c12s[k][t]);
   if (lane == 0) {
 #pragma unroll
     for (int k = 0; k < 12; ++k) red[wave][k] = c12[k];
@@ -397,6 +407,7 @@ extern "C" int hla_s2g_lm_solve_bwd(const hla_s2g_config* cfg, const hla_s2g_lev
   };
 
   int nt_prev = 0;
+  unsigned visited = 0;       // levels whose d_grd rows this call has written already (cfg->grd_grad_overwrite)
   for (int k = steps - 1; k >= 0; --k) {
     const int l = step_level(k);
     const hla_s2g_level& v = lv[l];
@@ -426,6 +437,8 @@ extern "C" int hla_s2g_lm_solve_bwd(const hla_s2g_config* cfg, const hla_s2g_lev
     aa.A = v.A; aa.h = v.h; aa.w = v.w; aa.row0 = v.row0; aa.npix = (v.h - v.row0) * v.w;
     aa.hs = v.h - v.grd_row_skip; aa.rskip = v.grd_row_skip;
     aa.keep = cfg->keep ? cfg->keep + (size_t)k * cfg->keep_stride : nullptr;
+    aa.grd_assign = (cfg->grd_grad_overwrite && !((visited >> l) & 1u)) ? 1 : 0;
+    visited |= 1u << l;
     aa.TP = lm_pick_tile_bwd(aa.npix); aa.nt = (aa.npix + aa.TP - 1) / aa.TP; aa.B = B;
     aa.xcd_affine = (B >= 8) ? 1 : 0;
     const int nblk = aa.xcd_affine ? 8 * ((B + 7) / 8) * aa.nt : B * aa.nt;

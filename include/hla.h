@@ -264,6 +264,9 @@ typedef struct hla_s2g_config {
   int count_in_view;      /* != 0 (and normal_eq given): slot 14 of normal_eq = the number of pixels of the WHOLE level map whose
                              satellite coordinates fall inside the map in that step -- what `assert mask.sum() > 0`
                              (jacobian.py:172) tests, summed over the batch.  One small extra launch per step. */
+  int grd_grad_overwrite; /* hla_s2g_lm_solve_bwd only.  != 0: rows row0..h-1 of every level's d_grd_feat are WRITTEN, not added to
+                             (the level's first visit of the reversed loop stores, the later ones add): the caller need not
+                             zero-fill those rows (rows above row0 are never touched either way).  0: accumulate into the buffer */
 } hla_s2g_config;
 
 size_t hla_s2g_workspace_bytes(const hla_s2g_config* cfg, const hla_s2g_level* levels, int B);
@@ -282,7 +285,7 @@ int hla_s2g_lm_solve(const hla_s2g_config* cfg, const hla_s2g_level* levels, con
  * Backward of the LM pose loop (what autograd does in the reference through models_kitti.py:1176-1283,
  * SURVEY Appendix C): d(loss)/d(trace) -> d(loss)/d(feature maps).  Gradients are taken w.r.t. the
  * L2-NORMALISED maps (inv_norm * stored map when the level carries inv norms); buffers are ACCUMULATED into
- * (the caller zero-fills them), d_sat_feat with fp32 atomics.
+ * (the caller zero-fills them; d_grd_feat rows row0.. need not be with cfg->grd_grad_overwrite), d_sat_feat with fp32 atomics.
  * ------------------------------------------------------------------------- */
 /* ------------------------------------------------------------------------- *
  * The same loop in the ground -> satellite direction: LM_G2SP (models_kitti.py:22-499, proj == 'geo')
