@@ -2,7 +2,8 @@
 // N_iters x levels steps in reverse and accumulate d(loss)/d(sat map), d(loss)/d(grd map) [, d/d(grd conf),
 // d/d(damping)].  This is what autograd does in the reference through models_kitti.py:1176-1283 (gather values,
 // bilinear weights, both norms, J^T W J, torch.inverse, the pose->uv chain of every later step; SURVEY
-// Appendix C), restated as two kernels per step:
+// Appendix C), restated as two pieces per step (ONE launch: the accumulate kernel's last-arriving tile of a sample runs the
+// solve of the step before; only the very first solve is a launch of its own):
 //   lm_bwd_solve   one wave per sample: closes the previous (later) step -- reduces its 12 projection-
 //                  coefficient adjoints and pulls them back to the pose --, re-solves this step's damped
 //                  system from the saved sums, and turns d(loss)/d(pose_out) into adjoints of the 14 sums.
@@ -16,6 +17,141 @@
 int hla_s2g_validate(const char* who, const hla_s2g_config* cfg, const hla_s2g_level* lv, const float* R_FL,
                      const float* T_FL, int B);
 
+// ---------------------------------------------------------------------------------------------
+struct BwdSolveArgs {
+  // the later step (k+1) whose accum has just run, or part_next == null
+  const double* part_next; int nt_next; LmGeom geom_next;
+  // this step k
+  const double* normal_eq;    // [B,16] forward sums of step k
+  const float* pose_in;       // pose before step k: &trace[0][..][..][0] of step k-1, or pose0, or null (zeros)
+  int pose_in_stride;
+  const float* pose_out;      // pose after step k (= pose_in of step k+1), stride = trace_stride
+  const float* d_trace;       // d(loss)/d(pose after step k), stride = trace_stride
+  int trace_stride;
+  double* gid;                // [B,3] identity-path adjoint carried between launches
+  double* adj;                // [B,16] out
+  double* coef;               // [B,COEF_N] out: forward coefficients of step k
+  double* d_lambda;           // [3] accumulated over samples and steps
+  const float* R_FL; const float* T_FL;
+  int B, reinit, first;       // first: this is the last forward step (nothing to close, gid is not read)
+  // the ablation updaters (models_kitti.py:1056-1116): 1 SGD, 2 ADAM.  ADAM re-runs its moment recurrence from the saved
+  // sums of steps 0..t (neq_all) and carries the moment adjoints backwards in adam_adj [B,6]
+  int optimizer, t;
+  double beta1, beta2;
+  const double* neq_all;
+  double* adam_adj;
+  LmSolveCfg cfg; LmGeom geom;
+};
+
+// One wave per sample.  COHERENT: the tile sums of the later step were written by OTHER workgroups of the same launch (the
+// accumulate kernel whose last-arriving tile of the sample closes with this solve): read them with agent-scope loads.
+template <bool COHERENT>
+__device__ __forceinline__ void lm_bwd_solve_body(const BwdSolveArgs& a, int b, int lane) {
+  const float* R = a.R_FL ? a.R_FL + (size_t)b * 9 : nullptr;
+  const float* T = a.T_FL ? a.T_FL + (size_t)b * 3 : nullptr;
+  double c12[12];
+#pragma unroll
+  for (int k = 0; k < 12; ++k) c12[k] = 0.0;
+  if (a.part_next) {
+    for (int i = lane; i < a.nt_next; i += 64) {
+      const double* p = a.part_next + ((size_t)b * a.nt_next + i) * PART_N;
+#pragma unroll
+      for (int k = 0; k < 12; ++k) c12[k] += COHERENT ? __hip_atomic_load(p + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : p[k];
+    }
+#pragma unroll
+    for (int k = 0; k < 12; ++k) c12[k] = wave_sum_f64(c12[k]);
+  }
+  if (lane != 0) return;
+
+  const float* po = a.pose_out + (size_t)b * a.trace_stride;
+  const float* dt = a.d_trace + (size_t)b * a.trace_stride;
+  double gout[3] = {dt[0], dt[1], dt[2]};
+  if (!a.first) {
+    double g3[3] = {0, 0, 0};
+    if (a.part_next) lm_coefficients_bwd(a.geom_next, po[0], po[1], po[2], R, T, c12, g3);
+    for (int p = 0; p < 3; ++p) gout[p] += g3[p] + a.gid[(size_t)b * 3 + p];
+  }
+  float pin[3] = {0.f, 0.f, 0.f};
+  if (a.pose_in) { const float* pi = a.pose_in + (size_t)b * a.pose_in_stride; pin[0] = pi[0]; pin[1] = pi[1]; pin[2] = pi[2]; }
+
+  const double* s = a.normal_eq + (size_t)b * 16;
+  if (a.optimizer == 1 || a.optimizer == 2) {
+    // pose_out = pose_in - 0.01 * f(g),  g = 2 (J^T s - J^T g_grd) on the whole-map-normalised features; no re-initialisation
+    double gg[3];                    // adjoint of the raw gradient g
+    for (int p = 0; p < 3; ++p) a.gid[(size_t)b * 3 + p] = gout[p];
+    if (a.optimizer == 1) {
+      for (int p = 0; p < 3; ++p) gg[p] = -0.01 * gout[p];
+    } else {
+      double* am = a.adam_adj + (size_t)b * 6;
+      const double c1 = 1.0 - pow(a.beta1, a.t + 1), c2 = 1.0 - pow(a.beta2, a.t + 1);
+      for (int p = 0; p < 3; ++p) {
+        double m = 0.0, v = 0.0, g_t = 0.0;
+        for (int j = 0; j <= a.t; ++j) {           // moments after step t
+          const double* sj = a.neq_all + ((size_t)j * a.B + b) * 16;
+          g_t = 2.0 * (sj[8 + p] - sj[11 + p]);
+          m = a.beta1 * m + (1.0 - a.beta1) * g_t;
+          v = a.beta2 * v + (1.0 - a.beta2) * g_t * g_t;
+        }
+        const double mh = m / c1, vh = v / c2, rt = sqrt(vh), den = rt + 1e-8;
+        const double gd = -0.01 * gout[p];         // adjoint of delta_final
+        const double g_m = am[p] + gd / (c1 * den);
+        const double g_v = am[3 + p] + (rt > 0.0 ? -gd * mh / (den * den) * 0.5 / (rt * c2) : 0.0);
+        gg[p] = (1.0 - a.beta1) * g_m + 2.0 * (1.0 - a.beta2) * g_t * g_v;
+        am[p] = a.beta1 * g_m; am[3 + p] = a.beta2 * g_v;
+      }
+    }
+    double* ad = a.adj + (size_t)b * 16;
+    for (int k = 0; k < 16; ++k) ad[k] = 0.0;
+    for (int p = 0; p < 3; ++p) { ad[8 + p] = 2.0 * gg[p]; ad[11 + p] = -2.0 * gg[p]; }
+    lm_coefficients(a.geom, pin[0], pin[1], pin[2], R, T, a.coef + (size_t)b * COEF_N);
+    return;
+  }
+  double H[3][3], g[3], Mi[3][3], d[3], ns, ng;
+  lm_solve_step(a.cfg, s, H, g, Mi, d, ns, ng);
+  // which components survived the re-initialisation rule (models_kitti.py:1032-1033)?
+  double keep[3] = {1.0, 1.0, 1.0};
+  if (a.reinit) {
+    const float nu = (float)((double)pin[0] - d[0]), nv = (float)((double)pin[1] - d[1]);
+    if (!(nu > -2.5f && nu < 2.5f)) keep[0] = 0.0;
+    if (!(nv > -2.5f && nv < 2.5f)) keep[1] = 0.0;
+  }
+  double gnew[3], gd[3], y[3];
+  for (int p = 0; p < 3; ++p) { gnew[p] = gout[p] * keep[p]; a.gid[(size_t)b * 3 + p] = gnew[p]; gd[p] = -gnew[p]; }
+  for (int p = 0; p < 3; ++p) y[p] = Mi[p][0] * gd[0] + Mi[p][1] * gd[1] + Mi[p][2] * gd[2];
+  // d = M^-1 g  =>  g_bar = y,  M_bar = -y d^T
+  double gH[3][3];
+  for (int p = 0; p < 3; ++p) for (int q = 0; q < 3; ++q) gH[p][q] = -y[p] * d[q];
+  const int nl = a.cfg.dof == 3 ? 3 : (a.cfg.dof == 2 ? 2 : 1);
+  for (int i = 0; i < nl; ++i) {
+    const int p = a.cfg.dof == 1 ? 2 : i;
+    const double gM = gH[p][p];
+    if (!a.cfg.gn) atomicAdd(a.d_lambda + i, gM * (a.cfg.use_hessian ? H[p][p] : 1.0));     // GN_update has no damping
+    if (a.cfg.use_hessian) gH[p][p] += a.cfg.lam[i] * gM;
+  }
+  const double is2 = 1.0 / (ns * ns), isg = 1.0 / (ns * ng);
+  const double Hs[3][3] = {{s[2], s[3], s[4]}, {s[3], s[5], s[6]}, {s[4], s[6], s[7]}};
+  double g_is2 = 0.0, g_isg = 0.0;
+  for (int p = 0; p < 3; ++p) {
+    for (int q = 0; q < 3; ++q) g_is2 += gH[p][q] * Hs[p][q];
+    g_is2 += y[p] * s[8 + p];
+    g_isg -= y[p] * s[11 + p];
+  }
+  const double g_ns = -2.0 * g_is2 / (ns * ns * ns) - g_isg / (ns * ns * ng);
+  const double g_ng = -g_isg / (ns * ng * ng);
+  double* ad = a.adj + (size_t)b * 16;
+  ad[0] = sqrt(s[0]) > 1e-6 ? g_ns / (2.0 * ns) : 0.0;
+  ad[1] = (!a.cfg.gn && sqrt(s[1]) > 1e-6) ? g_ng / (2.0 * ng) : 0.0;      // GN: ng is the constant 1
+  ad[2] = 2.0 * is2 * gH[0][0]; ad[3] = is2 * (gH[0][1] + gH[1][0]); ad[4] = is2 * (gH[0][2] + gH[2][0]);
+  ad[5] = 2.0 * is2 * gH[1][1]; ad[6] = is2 * (gH[1][2] + gH[2][1]); ad[7] = 2.0 * is2 * gH[2][2];
+  for (int p = 0; p < 3; ++p) { ad[8 + p] = is2 * y[p]; ad[11 + p] = -isg * y[p]; }
+  ad[14] = ad[15] = 0.0;
+  lm_coefficients(a.geom, pin[0], pin[1], pin[2], R, T, a.coef + (size_t)b * COEF_N);
+}
+
+// stand-alone launch: the last forward step (nothing to close before it)
+__global__ __launch_bounds__(64) void lm_bwd_solve(BwdSolveArgs a) { lm_bwd_solve_body<false>(a, blockIdx.x, threadIdx.x); }
+
+
 struct BwdAccumArgs {
   const float* sat; const float* grd; const float* conf; const float* xyz;
   const double* coef;      // [B,COEF_N] forward coefficients of this step
@@ -27,11 +163,13 @@ struct BwdAccumArgs {
   int A, h, w, row0, npix, TP, nt, B, xcd_affine;
   int hs, rskip;      // stored rows of grd/conf (h - grd_row_skip) and the skip itself
   const unsigned char* keep;   // dropout: [npix] of this step, 1 = pixel takes part; or null
+  unsigned* ticket;   // [B] arrival counters of this step (zeroed before the loop): the LAST tile of a sample closes with the
+                      // solve of the step before (sa), or null: no closing
   int grd_assign;     // 1: d_grd rows row0.. are OVERWRITTEN by this launch (the first visit of the level: no zero-fill, no read), 0: added to
 };
 
 template <int C, bool USE_W>
-__global__ __launch_bounds__(256, USE_W ? 3 : 4) void lm_bwd_accum(BwdAccumArgs a) {
+__global__ __launch_bounds__(256, USE_W ? 3 : 4) void lm_bwd_accum(BwdAccumArgs a, BwdSolveArgs sa) {
   __shared__ PixParam pp[MAX_TP];
   __shared__ float pxyz[MAX_TP][3];       // the pixel's ground-plane point (the coefficient adjoints weight by it)
   __shared__ double red[4][12];
@@ -192,140 +330,23 @@ __global__ __launch_bounds__(256, USE_W ? 3 : 4) void lm_bwd_accum(BwdAccumArgs 
     for (int k = 0; k < 12; ++k) red[wave][k] = c12[k];
   }
   __syncthreads();
+  if (wave != 0) return;
   if (t < PART_N) {
     double v = 0.0;
     if (t < 12) v = (red[0][t] + red[1][t]) + (red[2][t] + red[3][t]);
-    a.part[((size_t)b * a.nt + tile) * PART_N + t] = v;
+    __hip_atomic_store(a.part + ((size_t)b * a.nt + tile) * PART_N + t, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
-}
-
-// ---------------------------------------------------------------------------------------------
-struct BwdSolveArgs {
-  // the later step (k+1) whose accum has just run, or part_next == null
-  const double* part_next; int nt_next; LmGeom geom_next;
-  // this step k
-  const double* normal_eq;    // [B,16] forward sums of step k
-  const float* pose_in;       // pose before step k: &trace[0][..][..][0] of step k-1, or pose0, or null (zeros)
-  int pose_in_stride;
-  const float* pose_out;      // pose after step k (= pose_in of step k+1), stride = trace_stride
-  const float* d_trace;       // d(loss)/d(pose after step k), stride = trace_stride
-  int trace_stride;
-  double* gid;                // [B,3] identity-path adjoint carried between launches
-  double* adj;                // [B,16] out
-  double* coef;               // [B,COEF_N] out: forward coefficients of step k
-  double* d_lambda;           // [3] accumulated over samples and steps
-  const float* R_FL; const float* T_FL;
-  int B, reinit, first;       // first: this is the last forward step (nothing to close, gid is not read)
-  // the ablation updaters (models_kitti.py:1056-1116): 1 SGD, 2 ADAM.  ADAM re-runs its moment recurrence from the saved
-  // sums of steps 0..t (neq_all) and carries the moment adjoints backwards in adam_adj [B,6]
-  int optimizer, t;
-  double beta1, beta2;
-  const double* neq_all;
-  double* adam_adj;
-  LmSolveCfg cfg; LmGeom geom;
-};
-
-__global__ __launch_bounds__(64) void lm_bwd_solve(BwdSolveArgs a) {
-  const int b = blockIdx.x, lane = threadIdx.x;
-  const float* R = a.R_FL ? a.R_FL + (size_t)b * 9 : nullptr;
-  const float* T = a.T_FL ? a.T_FL + (size_t)b * 3 : nullptr;
-  double c12[12];
-#pragma unroll
-  for (int k = 0; k < 12; ++k) c12[k] = 0.0;
-  if (a.part_next) {
-    for (int i = lane; i < a.nt_next; i += 64) {
-      const double* p = a.part_next + ((size_t)b * a.nt_next + i) * PART_N;
-#pragma unroll
-      for (int k = 0; k < 12; ++k) c12[k] += p[k];
-    }
-#pragma unroll
-    for (int k = 0; k < 12; ++k) c12[k] = wave_sum_f64(c12[k]);
-  }
-  if (lane != 0) return;
-
-  const float* po = a.pose_out + (size_t)b * a.trace_stride;
-  const float* dt = a.d_trace + (size_t)b * a.trace_stride;
-  double gout[3] = {dt[0], dt[1], dt[2]};
-  if (!a.first) {
-    double g3[3] = {0, 0, 0};
-    if (a.part_next) lm_coefficients_bwd(a.geom_next, po[0], po[1], po[2], R, T, c12, g3);
-    for (int p = 0; p < 3; ++p) gout[p] += g3[p] + a.gid[(size_t)b * 3 + p];
-  }
-  float pin[3] = {0.f, 0.f, 0.f};
-  if (a.pose_in) { const float* pi = a.pose_in + (size_t)b * a.pose_in_stride; pin[0] = pi[0]; pin[1] = pi[1]; pin[2] = pi[2]; }
-
-  const double* s = a.normal_eq + (size_t)b * 16;
-  if (a.optimizer == 1 || a.optimizer == 2) {
-    // pose_out = pose_in - 0.01 * f(g),  g = 2 (J^T s - J^T g_grd) on the whole-map-normalised features; no re-initialisation
-    double gg[3];                    // adjoint of the raw gradient g
-    for (int p = 0; p < 3; ++p) a.gid[(size_t)b * 3 + p] = gout[p];
-    if (a.optimizer == 1) {
-      for (int p = 0; p < 3; ++p) gg[p] = -0.01 * gout[p];
-    } else {
-      double* am = a.adam_adj + (size_t)b * 6;
-      const double c1 = 1.0 - pow(a.beta1, a.t + 1), c2 = 1.0 - pow(a.beta2, a.t + 1);
-      for (int p = 0; p < 3; ++p) {
-        double m = 0.0, v = 0.0, g_t = 0.0;
-        for (int j = 0; j <= a.t; ++j) {           // moments after step t
-          const double* sj = a.neq_all + ((size_t)j * a.B + b) * 16;
-          g_t = 2.0 * (sj[8 + p] - sj[11 + p]);
-          m = a.beta1 * m + (1.0 - a.beta1) * g_t;
-          v = a.beta2 * v + (1.0 - a.beta2) * g_t * g_t;
-        }
-        const double mh = m / c1, vh = v / c2, rt = sqrt(vh), den = rt + 1e-8;
-        const double gd = -0.01 * gout[p];         // adjoint of delta_final
-        const double g_m = am[p] + gd / (c1 * den);
-        const double g_v = am[3 + p] + (rt > 0.0 ? -gd * mh / (den * den) * 0.5 / (rt * c2) : 0.0);
-        gg[p] = (1.0 - a.beta1) * g_m + 2.0 * (1.0 - a.beta2) * g_t * g_v;
-        am[p] = a.beta1 * g_m; am[3 + p] = a.beta2 * g_v;
-      }
-    }
-    double* ad = a.adj + (size_t)b * 16;
-    for (int k = 0; k < 16; ++k) ad[k] = 0.0;
-    for (int p = 0; p < 3; ++p) { ad[8 + p] = 2.0 * gg[p]; ad[11 + p] = -2.0 * gg[p]; }
-    lm_coefficients(a.geom, pin[0], pin[1], pin[2], R, T, a.coef + (size_t)b * COEF_N);
-    return;
-  }
-  double H[3][3], g[3], Mi[3][3], d[3], ns, ng;
-  lm_solve_step(a.cfg, s, H, g, Mi, d, ns, ng);
-  // which components survived the re-initialisation rule (models_kitti.py:1032-1033)?
-  double keep[3] = {1.0, 1.0, 1.0};
-  if (a.reinit) {
-    const float nu = (float)((double)pin[0] - d[0]), nv = (float)((double)pin[1] - d[1]);
-    if (!(nu > -2.5f && nu < 2.5f)) keep[0] = 0.0;
-    if (!(nv > -2.5f && nv < 2.5f)) keep[1] = 0.0;
-  }
-  double gnew[3], gd[3], y[3];
-  for (int p = 0; p < 3; ++p) { gnew[p] = gout[p] * keep[p]; a.gid[(size_t)b * 3 + p] = gnew[p]; gd[p] = -gnew[p]; }
-  for (int p = 0; p < 3; ++p) y[p] = Mi[p][0] * gd[0] + Mi[p][1] * gd[1] + Mi[p][2] * gd[2];
-  // d = M^-1 g  =>  g_bar = y,  M_bar = -y d^T
-  double gH[3][3];
-  for (int p = 0; p < 3; ++p) for (int q = 0; q < 3; ++q) gH[p][q] = -y[p] * d[q];
-  const int nl = a.cfg.dof == 3 ? 3 : (a.cfg.dof == 2 ? 2 : 1);
-  for (int i = 0; i < nl; ++i) {
-    const int p = a.cfg.dof == 1 ? 2 : i;
-    const double gM = gH[p][p];
-    if (!a.cfg.gn) atomicAdd(a.d_lambda + i, gM * (a.cfg.use_hessian ? H[p][p] : 1.0));     // GN_update has no damping
-    if (a.cfg.use_hessian) gH[p][p] += a.cfg.lam[i] * gM;
-  }
-  const double is2 = 1.0 / (ns * ns), isg = 1.0 / (ns * ng);
-  const double Hs[3][3] = {{s[2], s[3], s[4]}, {s[3], s[5], s[6]}, {s[4], s[6], s[7]}};
-  double g_is2 = 0.0, g_isg = 0.0;
-  for (int p = 0; p < 3; ++p) {
-    for (int q = 0; q < 3; ++q) g_is2 += gH[p][q] * Hs[p][q];
-    g_is2 += y[p] * s[8 + p];
-    g_isg -= y[p] * s[11 + p];
-  }
-  const double g_ns = -2.0 * g_is2 / (ns * ns * ns) - g_isg / (ns * ns * ng);
-  const double g_ng = -g_isg / (ns * ng * ng);
-  double* ad = a.adj + (size_t)b * 16;
-  ad[0] = sqrt(s[0]) > 1e-6 ? g_ns / (2.0 * ns) : 0.0;
-  ad[1] = (!a.cfg.gn && sqrt(s[1]) > 1e-6) ? g_ng / (2.0 * ng) : 0.0;      // GN: ng is the constant 1
-  ad[2] = 2.0 * is2 * gH[0][0]; ad[3] = is2 * (gH[0][1] + gH[1][0]); ad[4] = is2 * (gH[0][2] + gH[2][0]);
-  ad[5] = 2.0 * is2 * gH[1][1]; ad[6] = is2 * (gH[1][2] + gH[2][1]); ad[7] = 2.0 * is2 * gH[2][2];
-  for (int p = 0; p < 3; ++p) { ad[8 + p] = is2 * y[p]; ad[11 + p] = -isg * y[p]; }
-  ad[14] = ad[15] = 0.0;
-  lm_coefficients(a.geom, pin[0], pin[1], pin[2], R, T, a.coef + (size_t)b * COEF_N);
+  if (!a.ticket) return;
+  // The last tile of the sample to get here closes with the NEXT launch's solve (the step before this one): one launch per
+  // step instead of two.  Same publication recipe as the forward (lm_solve.hip): agent-scope stores of the sums -> vmcnt(0) ->
+  // relaxed agent-scope ticket; the closing wave reads with agent-scope loads and overwrites this sample's adj / coef, which
+  // every other tile of the sample has finished reading (they drew their tickets).  The sums are added in tile order whoever closes.
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  unsigned old = 0;
+  if (lane == 0) old = __hip_atomic_fetch_add(a.ticket + b, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  old = __builtin_amdgcn_readfirstlane(old);
+  if (old + 1 != (unsigned)a.nt) return;
+  lm_bwd_solve_body<true>(sa, b, lane);
 }
 
 // pixels per block of lm_bwd_accum (level-dependent only)
@@ -334,7 +355,7 @@ __global__ __launch_bounds__(64) void lm_bwd_solve(BwdSolveArgs a) {
 static inline int lm_pick_tile_bwd(int npix) { return npix >= 4096 ? 256 : 128; }
 
 // ---------------------------------------------------------------------------------------------
-static size_t bwd_layout(const hla_s2g_config* cfg, const hla_s2g_level* lv, int B, size_t off[5]) {
+static size_t bwd_layout(const hla_s2g_config* cfg, const hla_s2g_level* lv, int B, size_t off[6]) {
   int max_nt = 1;
   for (int l = 0; l < cfg->n_levels; ++l) {
     const int npix = (lv[l].h - lv[l].row0) * lv[l].w;
@@ -347,21 +368,22 @@ static size_t bwd_layout(const hla_s2g_config* cfg, const hla_s2g_level* lv, int
   off[2] = o; o += hla_align_up((size_t)B * 3 * sizeof(double), 256);               // gid
   off[3] = o; o += hla_align_up((size_t)B * max_nt * PART_N * sizeof(double), 256); // part
   off[4] = o; o += hla_align_up((size_t)B * 6 * sizeof(double), 256);               // ADAM moment adjoints
+  off[5] = o; o += hla_align_up((size_t)B * cfg->n_levels * cfg->n_iters * sizeof(unsigned), 256);   // arrival tickets [steps][B]
   return o;
 }
 
 extern "C" size_t hla_s2g_bwd_workspace_bytes(const hla_s2g_config* cfg, const hla_s2g_level* levels, int B) {
-  size_t off[5];
+  size_t off[6];
   return bwd_layout(cfg, levels, B, off);
 }
 
 template <bool W>
-static void launch_bwd_accum(int C, dim3 grid, hipStream_t st, const BwdAccumArgs& a) {
+static void launch_bwd_accum(int C, dim3 grid, hipStream_t st, const BwdAccumArgs& a, const BwdSolveArgs& sa) {
   switch (C) {
-    case 256: hipLaunchKernelGGL((lm_bwd_accum<256, W>), grid, dim3(256), 0, st, a); break;
-    case 128: hipLaunchKernelGGL((lm_bwd_accum<128, W>), grid, dim3(256), 0, st, a); break;
-    case 64: hipLaunchKernelGGL((lm_bwd_accum<64, W>), grid, dim3(256), 0, st, a); break;
-    case 16: hipLaunchKernelGGL((lm_bwd_accum<16, W>), grid, dim3(256), 0, st, a); break;
+    case 256: hipLaunchKernelGGL((lm_bwd_accum<256, W>), grid, dim3(256), 0, st, a, sa); break;
+    case 128: hipLaunchKernelGGL((lm_bwd_accum<128, W>), grid, dim3(256), 0, st, a, sa); break;
+    case 64: hipLaunchKernelGGL((lm_bwd_accum<64, W>), grid, dim3(256), 0, st, a, sa); break;
+    case 16: hipLaunchKernelGGL((lm_bwd_accum<16, W>), grid, dim3(256), 0, st, a, sa); break;
   }
 }
 
@@ -377,7 +399,7 @@ extern "C" int hla_s2g_lm_solve_bwd(const hla_s2g_config* cfg, const hla_s2g_lev
     HLA_REQUIRE(gr[l].d_sat_feat && gr[l].d_grd_feat, "hla_s2g_lm_solve_bwd: level %d gradient buffers missing", l);
     HLA_REQUIRE(lv[l].feat_dtype == HLA_F32, "hla_s2g_lm_solve_bwd: level %d: the backward needs fp32 feature maps", l);
   }
-  size_t off[5];
+  size_t off[6];
   const size_t need = bwd_layout(cfg, lv, B, off);
   if (workspace_bytes < need) {
     hla_set_error("hla_s2g_lm_solve_bwd: workspace %zu < %zu", workspace_bytes, need);
@@ -392,6 +414,7 @@ extern "C" int hla_s2g_lm_solve_bwd(const hla_s2g_config* cfg, const hla_s2g_lev
   HLA_CHECK_HIP(hipMemsetAsync(d_damping, 0, 3 * sizeof(double), st));
   double* adam_adj = (double*)(ws + off[4]);
   if (cfg->optimizer == 2) HLA_CHECK_HIP(hipMemsetAsync(adam_adj, 0, (size_t)B * 6 * sizeof(double), st));
+  unsigned* tickets = (unsigned*)(ws + off[5]);
 
   const bool newton = cfg->optimizer == 0 || cfg->optimizer == 3;
   const bool reinit = (cfg->ford || cfg->dof == 3) && newton;
@@ -406,14 +429,20 @@ extern "C" int hla_s2g_lm_solve_bwd(const hla_s2g_config* cfg, const hla_s2g_lev
     return g;
   };
 
-  int nt_prev = 0;
-  unsigned visited = 0;       // levels whose d_grd rows this call has written already (cfg->grd_grad_overwrite)
-  for (int k = steps - 1; k >= 0; --k) {
-    const int l = step_level(k);
-    const hla_s2g_level& v = lv[l];
+  // One launch per step: lm_bwd_accum(k), whose last-arriving tile of every sample closes with the solve of step k - 1 (the
+  // pose adjoint pulled back through step k's coefficients, step k - 1's damped system re-solved -> its 14 sum adjoints).  Only
+  // the solve of the LAST forward step, which has nothing to close, is a launch of its own.
+  HLA_CHECK_HIP(hipMemsetAsync(tickets, 0, (size_t)B * L * N * sizeof(unsigned), st));
+  auto nt_of = [&](int l) {
+    const int npix = (lv[l].h - lv[l].row0) * lv[l].w;
+    const int tp = lm_pick_tile_bwd(npix);
+    return (npix + tp - 1) / tp;
+  };
+  auto solve_args = [&](int k) {
     BwdSolveArgs sa{};
+    const int l = step_level(k);
     sa.first = (k == steps - 1) ? 1 : 0;
-    if (!sa.first) { sa.part_next = part; sa.nt_next = nt_prev; sa.geom_next = geom(step_level(k + 1)); }
+    if (!sa.first) { sa.part_next = part; sa.nt_next = nt_of(step_level(k + 1)); sa.geom_next = geom(step_level(k + 1)); }
     sa.normal_eq = normal_eq + (size_t)k * B * 16;
     if (k > 0) { sa.pose_in = trace + slot(k - 1); sa.pose_in_stride = tstride; }
     else { sa.pose_in = pose0; sa.pose_in_stride = 3; }
@@ -426,10 +455,18 @@ extern "C" int hla_s2g_lm_solve_bwd(const hla_s2g_config* cfg, const hla_s2g_lev
     sa.optimizer = cfg->optimizer; sa.t = k; sa.beta1 = cfg->beta1; sa.beta2 = cfg->beta2;
     sa.neq_all = normal_eq; sa.adam_adj = adam_adj;
     sa.geom = geom(l);
+    return sa;
+  };
+  {
+    const BwdSolveArgs sa = solve_args(steps - 1);
     hla_prof_begin(K_LMSOLVE, 0, 0, st);
     hipLaunchKernelGGL(lm_bwd_solve, dim3(B), dim3(64), 0, st, sa);
     hla_prof_end(st);
-
+  }
+  unsigned visited = 0;       // levels whose d_grd rows this call has written already (cfg->grd_grad_overwrite)
+  for (int k = steps - 1; k >= 0; --k) {
+    const int l = step_level(k);
+    const hla_s2g_level& v = lv[l];
     BwdAccumArgs aa{};
     aa.sat = (const float*)v.sat_feat; aa.grd = (const float*)v.grd_feat; aa.conf = v.grd_conf; aa.xyz = v.xyz; aa.coef = coef; aa.adj = adj;
     aa.sat_inv = v.sat_inv_norm; aa.grd_inv = v.grd_inv_norm;
@@ -439,14 +476,16 @@ extern "C" int hla_s2g_lm_solve_bwd(const hla_s2g_config* cfg, const hla_s2g_lev
     aa.keep = cfg->keep ? cfg->keep + (size_t)k * cfg->keep_stride : nullptr;
     aa.grd_assign = (cfg->grd_grad_overwrite && !((visited >> l) & 1u)) ? 1 : 0;
     visited |= 1u << l;
-    aa.TP = lm_pick_tile_bwd(aa.npix); aa.nt = (aa.npix + aa.TP - 1) / aa.TP; aa.B = B;
+    aa.TP = lm_pick_tile_bwd(aa.npix); aa.nt = nt_of(l); aa.B = B;
     aa.xcd_affine = (B >= 8) ? 1 : 0;
+    // step 0 has no earlier step to solve for: no ticket, no closing
+    aa.ticket = k > 0 ? tickets + (size_t)k * B : nullptr;
+    const BwdSolveArgs sa = k > 0 ? solve_args(k - 1) : BwdSolveArgs{};
     const int nblk = aa.xcd_affine ? 8 * ((B + 7) / 8) * aa.nt : B * aa.nt;
     hla_prof_begin(K_LMBWD, 0, (double)B * (5.0 * (double)v.A * v.A + 3.0 * (double)aa.npix) * v.C * 4.0, st);
-    if (cfg->using_weight && newton) launch_bwd_accum<true>(v.C, dim3(nblk), st, aa);
-    else launch_bwd_accum<false>(v.C, dim3(nblk), st, aa);
+    if (cfg->using_weight && newton) launch_bwd_accum<true>(v.C, dim3(nblk), st, aa, sa);
+    else launch_bwd_accum<false>(v.C, dim3(nblk), st, aa, sa);
     hla_prof_end(st);
-    nt_prev = aa.nt;
   }
   HLA_CHECK_HIP(hipGetLastError());
   return HLA_OK;
