@@ -152,6 +152,9 @@ __device__ __forceinline__ void lm_bwd_solve_body(const BwdSolveArgs& a, int b, 
 __global__ __launch_bounds__(64) void lm_bwd_solve(BwdSolveArgs a) { lm_bwd_solve_body<false>(a, blockIdx.x, threadIdx.x); }
 
 
+#ifndef BWD_MAX_TP
+#define BWD_MAX_TP MAX_TP
+#endif
 struct BwdAccumArgs {
   const float* sat; const float* grd; const float* conf; const float* xyz;
   const double* coef;      // [B,COEF_N] forward coefficients of this step
@@ -170,8 +173,8 @@ struct BwdAccumArgs {
 
 template <int C, bool USE_W>
 __global__ __launch_bounds__(256, USE_W ? 3 : 4) void lm_bwd_accum(BwdAccumArgs a, BwdSolveArgs sa) {
-  __shared__ PixParam pp[MAX_TP];
-  __shared__ float pxyz[MAX_TP][3];       // the pixel's ground-plane point (the coefficient adjoints weight by it)
+  __shared__ PixParam pp[BWD_MAX_TP];
+  __shared__ float pxyz[BWD_MAX_TP][3];   // the pixel's ground-plane point (the coefficient adjoints weight by it)
   __shared__ double red[4][12];
   __shared__ double c12s[12][256];
   int b, tile;
@@ -181,8 +184,8 @@ __global__ __launch_bounds__(256, USE_W ? 3 : 4) void lm_bwd_accum(BwdAccumArgs 
   const int np = min(a.TP, a.npix - p0);
   const double* cf = a.coef + (size_t)b * COEF_N;
 
-  if (t < np) {
-    const int p = p0 + t;
+  for (int tt = t; tt < np; tt += 256) {
+    const int p = p0 + tt;
     const int r = a.row0 + p / a.w, c = p % a.w;
     const float cw = USE_W ? a.conf[((size_t)b * a.hs + (r - a.rskip)) * a.w + c] : 1.f;
     const float* qx = a.xyz + ((size_t)r * a.w + c) * 3;
@@ -190,8 +193,8 @@ __global__ __launch_bounds__(256, USE_W ? 3 : 4) void lm_bwd_accum(BwdAccumArgs 
     if (a.keep && !a.keep[p]) {          // dropped by args.dropout: the pixel leaves every sum (models_kitti.py:968-974)
       P.wx0 = P.wx1 = P.wy0 = P.wy1 = 0.f; P.off = P.dxo = P.dyo = 0; P.j2u = P.j2v = 0.f; P.gm = P.wt = P.m = 0.f;
     }
-    pp[t] = P;
-    pxyz[t][0] = qx[0]; pxyz[t][1] = qx[1]; pxyz[t][2] = qx[2];
+    pp[tt] = P;
+    pxyz[tt][0] = qx[0]; pxyz[tt][1] = qx[1]; pxyz[tt][2] = qx[2];
   }
   __syncthreads();
 
@@ -350,9 +353,17 @@ __global__ __launch_bounds__(256, USE_W ? 3 : 4) void lm_bwd_accum(BwdAccumArgs 
 }
 
 // pixels per block of lm_bwd_accum (level-dependent only)
+// (round 5, at 4 waves per SIMD, same box x2, us per launch C64 / C128 / C256: 256/256/128 (these) 321 / 154 / 104; 256/128/64 326 /
+//  167 / 110; 128/128/64 383 / 161 / 108; 128/64/32 385 / 227 / 120; 512/256/128 412 / 187 / 103; 512/512/256 414 / 181 / 143:
+//  smaller tiles merge fewer taps per texel cell, larger ones leave two blocks per CU)
 // (measured, same-box A/B twice: 256 / 128 / 64 -- the sizes LM_G2SP's kernels use -- 227.7 us per launch on average against
 // 218.3 for these; 128 / 128 / 64: 245)
-static inline int lm_pick_tile_bwd(int npix) { return npix >= 4096 ? 256 : 128; }
+#ifndef HLA_LMB_TP0
+#define HLA_LMB_TP0 256     // npix >= 16384 (KITTI: the 64-channel level)
+#define HLA_LMB_TP1 256     // npix >= 4096  (the 128-channel level)
+#define HLA_LMB_TP2 128     // below         (the 256-channel level)
+#endif
+static inline int lm_pick_tile_bwd(int npix) { return npix >= 16384 ? HLA_LMB_TP0 : (npix >= 4096 ? HLA_LMB_TP1 : HLA_LMB_TP2); }
 
 // ---------------------------------------------------------------------------------------------
 static size_t bwd_layout(const hla_s2g_config* cfg, const hla_s2g_level* lv, int B, size_t off[6]) {
