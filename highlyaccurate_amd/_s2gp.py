@@ -360,7 +360,7 @@ class S2GPBase(nn.Module):
 
     @_lib.on_device(lambda self, sat_feats, *a, **k: sat_feats[0])
     def lm_backward(self, sat_feats, grd_feats, grd_confs, grd_hw, trace, normal_eq, d_trace, extra=None, level_first=0,
-                    init_pose=None, sat_inv_norm=None, grd_inv_norm=None, keep=None, grd_first_row8=0):
+                    init_pose=None, sat_inv_norm=None, grd_inv_norm=None, keep=None, grd_first_row8=0, overwrite=True):
         """Backward of ``lm_solve``: d(loss)/d(trace) [B,N,L,3] -> (d_sat[l], d_grd[l], d_conf[l] or None, d_lambda[3]).
         ``keep``: the forward's dropout mask (``self.last_keep``), if args.dropout.
         Map gradients are NHWC fp32 and taken w.r.t. the L2-normalised maps (inv_norm * stored map)."""
@@ -375,11 +375,13 @@ class S2GPBase(nn.Module):
         # d_grd: the loop only touches rows h_l/2.. and WRITES them on each level's first visit (cfg.grd_grad_overwrite): no zero-fill
         # and no read-modify-write of half a map there.  What still has to be zero is what the consumer reads above them: with
         # hla_vgg_backward(first_row8 = f) two rows (it never reads d_grd[l] above row f * 2^l - 2), else the top half.
-        cfg.grd_grad_overwrite = 1
+        cfg.grd_grad_overwrite = 1 if overwrite else 0       # (0: zero-filled buffers, every step adds -- kept for callers of the C ABI)
         d_grd = []
         for l, t in enumerate(grd_feats):
             d = torch.empty_like(t)
             lo, hi = (max(0, (grd_first_row8 << l) - 2) if grd_first_row8 else 0), lv[l].row0 - lv[l].grd_row_skip
+            if not overwrite:
+                hi = t.shape[1]
             if hi > lo:
                 d[:, lo:hi].zero_()
             d_grd.append(d)

@@ -1024,6 +1024,13 @@ def test_lm_backward_small_vs_oracle_autograd(kw):
     trace = net.lm_solve(*feats, grd_hw, None, lf, init_pose=p0, keep_normal_eq=True)
     d_sat, d_grd, d_conf, d_lam = net.lm_backward(*feats, grd_hw, trace, net.last_normal_eq, coef.float(), None, lf, init_pose=p0,
                                                   keep=net.last_keep)
+    # hla_s2g_config.grd_grad_overwrite = 0 (zero-filled ground gradient buffers, every step adds) gives the same d_grd bit for bit
+    # (the ground side has no atomics: a pixel's sum is first-visit value + the later steps' terms in the same order either way)
+    acc = net.lm_backward(*feats, grd_hw, trace, net.last_normal_eq, coef.float(), None, lf, init_pose=p0, keep=net.last_keep,
+                          overwrite=False)
+    for l in range(L):
+        assert torch.equal(acc[1][l][:, grd_hw[0] >> (4 - l):], d_grd[l][:, grd_hw[0] >> (4 - l):]), l
+        assert not bool(d_grd[l][:, :grd_hw[0] >> (4 - l)].any())          # rows above h_l / 2: zero
     for l in range(L):
         for name, got, ref in (('sat', d_sat[l], sat64[l].grad), ('grd', d_grd[l], grd64[l].grad)):
             got = got.permute(0, 3, 1, 2).cpu().double().numpy()
