@@ -92,6 +92,7 @@ class _PoseLossFn(torch.autograd.Function):
         return (out[0],) + tuple(out[1 + j * L:1 + (j + 1) * L] for j in range(8))
 
     @staticmethod
+    @torch.autograd.function.once_differentiable       # (the gradient is piecewise constant: its own derivative is zero a.e.)
     def backward(ctx, *g):
         cols, saved = ctx.cols, ctx.saved_tensors
         nx = 1 if cols is not None else 3
