@@ -230,16 +230,21 @@ __global__ __launch_bounds__(256, USE_W ? 3 : 4) void lm_bwd_accum(BwdAccumArgs 
   const int RUN = (np + 4 * PPW - 1) / (4 * PPW);
   const int grp = wave * PPW + sub;
   int cur_off = -1, cur_dxo = 0, cur_dyo = 0;
-  float c00[4] = {0, 0, 0, 0}, c01[4] = {0, 0, 0, 0}, c10[4] = {0, 0, 0, 0}, c11[4] = {0, 0, 0, 0};
+  // Channel PAIRS (2h, 2h+1) as two-element vectors throughout: the loop compiles to v_pk_{mul,add,fma}_f32 on adjacent
+  // registers.  (Written per channel the SLP vectoriser paired values that lived in unrelated registers: 35 of the loop's 447
+  // instructions were v_mov_b32 shuffles.)
+  typedef float f2 __attribute__((ext_vector_type(2)));
+  f2 c00[2] = {f2{0.f, 0.f}, f2{0.f, 0.f}}, c01[2] = {f2{0.f, 0.f}, f2{0.f, 0.f}}, c10[2] = {f2{0.f, 0.f}, f2{0.f, 0.f}},
+     c11[2] = {f2{0.f, 0.f}, f2{0.f, 0.f}};
   auto flush_cell = [&]() {
     if (cur_off >= 0) {
       float* dp = dsat_u + (cur_off + cl);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        atomicAdd(dp + e * LPP, c00[e]);
-        atomicAdd(dp + cur_dxo + e * LPP, c01[e]);
-        atomicAdd(dp + cur_dyo + e * LPP, c10[e]);
-        atomicAdd(dp + cur_dyo + cur_dxo + e * LPP, c11[e]);
+      for (int h = 0; h < 2; ++h) {
+        atomicAdd(dp + (2 * h) * LPP, c00[h].x); atomicAdd(dp + (2 * h + 1) * LPP, c00[h].y);
+        atomicAdd(dp + cur_dxo + (2 * h) * LPP, c01[h].x); atomicAdd(dp + cur_dxo + (2 * h + 1) * LPP, c01[h].y);
+        atomicAdd(dp + cur_dyo + (2 * h) * LPP, c10[h].x); atomicAdd(dp + cur_dyo + (2 * h + 1) * LPP, c10[h].y);
+        atomicAdd(dp + cur_dyo + cur_dxo + (2 * h) * LPP, c11[h].x); atomicAdd(dp + cur_dyo + cur_dxo + (2 * h + 1) * LPP, c11[h].y);
       }
     }
   };
@@ -259,46 +264,48 @@ __global__ __launch_bounds__(256, USE_W ? 3 : 4) void lm_bwd_accum(BwdAccumArgs 
         flush_cell();
         cur_off = P.off; cur_dxo = P.dxo; cur_dyo = P.dyo;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) c00[e] = c01[e] = c10[e] = c11[e] = 0.f;
+        for (int h = 0; h < 2; ++h) c00[h] = c01[h] = c10[h] = c11[h] = f2{0.f, 0.f};
       }
       float q0 = 0.f, q1 = 0.f, q2 = 0.f, q3 = 0.f, q4 = 0.f, q5 = 0.f, q6 = 0.f, q7 = 0.f, q8 = 0.f;
-      // two channels at a time: the loads of a half (10 or 12 dwords per lane) are in flight together, the second half's are
-      // issued after the first half's arithmetic -- half the load registers, and twice the waves to cover the latency instead
-      float v00[4], v01[4], v10[4], v11[4], vg[4], og[4];
+      // two channels at a time: the loads of a pair (10 or 12 dwords per lane) are in flight together, the second pair's are
+      // issued after the first pair's arithmetic -- half the load registers, and twice the waves to cover the latency instead
+      const float w = USE_W ? P.wt : 1.f;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        if ((e & 1) == 0) {
-#pragma unroll
-          for (int f = e; f < e + 2; ++f) {
-            v00[f] = sp[f * LPP]; v01[f] = sp[P.dxo + f * LPP];
-            v10[f] = sp[P.dyo + f * LPP]; v11[f] = sp[P.dyo + P.dxo + f * LPP];
-            vg[f] = gq[f * LPP];
-            og[f] = a.grd_assign ? 0.f : gp[f * LPP];
-          }
+      for (int h = 0; h < 2; ++h) {
+        const int e0 = 2 * h * LPP, e1 = (2 * h + 1) * LPP;
+        const f2 V00 = f2{sp[e0], sp[e1]} * as, V01 = f2{sp[P.dxo + e0], sp[P.dxo + e1]} * as;
+        const f2 V10 = f2{sp[P.dyo + e0], sp[P.dyo + e1]} * as, V11 = f2{sp[P.dyo + P.dxo + e0], sp[P.dyo + P.dxo + e1]} * as;
+        const f2 vg = f2{gq[e0], gq[e1]};
+        const f2 og = a.grd_assign ? f2{0.f, 0.f} : f2{gp[e0], gp[e1]};
+        const f2 top = P.wx0 * V00 + P.wx1 * V01, bot = P.wx0 * V10 + P.wx1 * V11;
+        const f2 s = P.wy0 * top + P.wy1 * bot;
+        const f2 dsy = bot - top;
+        const f2 e01 = V01 - V00, e11 = V11 - V10;
+        const f2 dsx = P.wy0 * e01 + P.wy1 * e11;
+        const f2 dxy = (e11 - e01) * P.m;
+        const f2 g = vg * (ag * P.gm);
+        const f2 J0 = dsx * j0u + dsy * j0v, J1 = dsx * j1u + dsy * j1v, J2 = dsx * P.j2u + dsy * P.j2v;
+        const f2 aj0 = A00 * J0 + A01 * J1 + A02 * J2, aj1 = A01 * J0 + A11 * J1 + A12 * J2, aj2 = A02 * J0 + A12 * J1 + A22 * J2;
+        const f2 jU = J0 * gU0 + J1 * gU1 + J2 * gU2, jV = J0 * gV0 + J1 * gV1 + J2 * gV2;
+        const f2 gs = (2.f * gS) * s + w * jU;
+        const f2 ggr = (2.f * gG) * g + w * jV;
+        const f2 gJ0 = w * (aj0 + s * gU0 + g * gV0), gJ1 = w * (aj1 + s * gU1 + g * gV1), gJ2 = w * (aj2 + s * gU2 + g * gV2);
+        const f2 gdsx = gJ0 * j0u + gJ1 * j1u + gJ2 * P.j2u, gdsy = gJ0 * j0v + gJ1 * j1v + gJ2 * P.j2v;
+        const f2 t0 = gs * dsx + gdsy * dxy, t1 = gs * dsy + gdsx * dxy;
+        const f2 t2 = gJ0 * dsx, t3 = gJ0 * dsy, t4 = gJ1 * dsx, t5 = gJ1 * dsy, t6 = gJ2 * dsx, t7 = gJ2 * dsy;
+        q0 += t0.x + t0.y; q1 += t1.x + t1.y; q2 += t2.x + t2.y; q3 += t3.x + t3.y;
+        q4 += t4.x + t4.y; q5 += t5.x + t5.y; q6 += t6.x + t6.y; q7 += t7.x + t7.y;
+        if (USE_W) {
+          const f2 t8 = 0.5f * (J0 * aj0 + J1 * aj1 + J2 * aj2) + s * jU + g * jV;
+          q8 += t8.x + t8.y;
         }
-        const float V00 = v00[e] * as, V01 = v01[e] * as, V10 = v10[e] * as, V11 = v11[e] * as;
-        const float top = P.wx0 * V00 + P.wx1 * V01, bot = P.wx0 * V10 + P.wx1 * V11;
-        const float s = P.wy0 * top + P.wy1 * bot;
-        const float dsy = bot - top;
-        const float e01 = V01 - V00, e11 = V11 - V10;
-        const float dsx = P.wy0 * e01 + P.wy1 * e11;
-        const float dxy = (e11 - e01) * P.m;
-        const float g = vg[e] * ag * P.gm;
-        const float J0 = dsx * j0u + dsy * j0v, J1 = dsx * j1u + dsy * j1v, J2 = dsx * P.j2u + dsy * P.j2v;
-        const float w = USE_W ? P.wt : 1.f;
-        const float aj0 = A00 * J0 + A01 * J1 + A02 * J2, aj1 = A01 * J0 + A11 * J1 + A12 * J2, aj2 = A02 * J0 + A12 * J1 + A22 * J2;
-        const float gs = 2.f * s * gS + w * (J0 * gU0 + J1 * gU1 + J2 * gU2);
-        const float ggr = 2.f * g * gG + w * (J0 * gV0 + J1 * gV1 + J2 * gV2);
-        const float gJ0 = w * (aj0 + s * gU0 + g * gV0), gJ1 = w * (aj1 + s * gU1 + g * gV1), gJ2 = w * (aj2 + s * gU2 + g * gV2);
-        const float gdsx = gJ0 * j0u + gJ1 * j1u + gJ2 * P.j2u, gdsy = gJ0 * j0v + gJ1 * j1v + gJ2 * P.j2v;
-        q0 += gs * dsx + gdsy * dxy; q1 += gs * dsy + gdsx * dxy;
-        q2 += gJ0 * dsx; q3 += gJ0 * dsy; q4 += gJ1 * dsx; q5 += gJ1 * dsy; q6 += gJ2 * dsx; q7 += gJ2 * dsy;
-        if (USE_W) q8 += 0.5f * (J0 * aj0 + J1 * aj1 + J2 * aj2) + s * (J0 * gU0 + J1 * gU1 + J2 * gU2) + g * (J0 * gV0 + J1 * gV1 + J2 * gV2);
-        c00[e] += gs * P.wy0 * P.wx0 - gdsx * P.wy0 - gdsy * P.wx0;
-        c01[e] += gs * P.wy0 * P.wx1 + gdsx * P.wy0 - gdsy * P.wx1;
-        c10[e] += gs * P.wy1 * P.wx0 - gdsx * P.wy1 + gdsy * P.wx0;
-        c11[e] += gs * P.wy1 * P.wx1 + gdsx * P.wy1 + gdsy * P.wx1;
-        gp[e * LPP] = og[e] + ggr * P.gm;
+        const f2 gsy0 = gs * P.wy0, gsy1 = gs * P.wy1;
+        c00[h] += gsy0 * P.wx0 - gdsx * P.wy0 - gdsy * P.wx0;
+        c01[h] += gsy0 * P.wx1 + gdsx * P.wy0 - gdsy * P.wx1;
+        c10[h] += gsy1 * P.wx0 - gdsx * P.wy1 + gdsy * P.wx0;
+        c11[h] += gsy1 * P.wx1 + gdsx * P.wy1 + gdsy * P.wx1;
+        const f2 ng = og + ggr * P.gm;
+        gp[e0] = ng.x; gp[e1] = ng.y;
       }
       // pixel adjoints -> adjoints of the 12 projection coefficients.  The map is linear, so every lane applies it to its own
       // partial sums (its 4 channels of the pixel) and accumulates in fp64 across its run of pixels; ONE cross-lane reduction at

@@ -25,7 +25,7 @@ _lib.prof_enable(False)
 tot = sum(r[1] for r in recs)
 agg = {}
 for n, ms, fl, by in recs:
-    if ms > 0.1 or n.startswith('conv') or n.startswith('wgrad'):
+    if ms > 0.1 or n.startswith('conv') or n.startswith('wgrad') or n.startswith('lm_bwd'):
         print(f'{n:34s} {ms*1e3:8.1f} us  {fl/ms/1e9 if fl else 0:7.1f} TF  {by/ms/1e6 if by else 0:7.1f} GB/s')
     a = agg.setdefault(n, [0, 0.0]); a[0] += 1; a[1] += ms
 print('total kernel ms', tot)
