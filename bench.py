@@ -537,16 +537,23 @@ def train_leg(net, a, sat, grd, extra, B, world, rank, dist, dev, want_kt, extra
     tdts = []
     tele = Telemetry(torch.cuda.current_device()) if rank == 0 else None
     for blk in range(3):
-        if tele and blk == 1:
-            tele.__enter__()
         # (four warm-up steps, round 5: with two, the first block of a fresh process came out 2-47 % slower than the other two --
         #  Adam state, the caching allocator's backward-workspace segments on BOTH streams, and the clocks settling)
         tb, lossv = timed(a.train_steps, warm=4) if blk == 0 else timed(a.train_steps, warm=0)
-        if tele and blk == 1:
-            tele.__exit__()
         tdts.append(tb)
     blocks = [round(t / a.train_steps * 1e3, 3) for t in tdts]
     tdt = sorted(tdts)[1]
+    # clock / power: sampled over a FOURTH block of the same steps that is not part of `value`, so that the sampler cannot be
+    # suspected of what the blocks show.  (In full default runs the MIDDLE block comes out 8-35 % slow -- [47.2, 58.4, 47.7],
+    # [48.0, 52.6, 48.7] ms -- with the sampler in it or not; a process that runs this leg alone on a cool chip shows
+    # [47.0, 47.5, 47.7], and tools/probes/telemetry_ab.py measures no effect of the sampler on either leg: it is the chip's
+    # power management after the preceding legs, and the median is there for it.)
+    tele_block = None
+    if tele:
+        tele.__enter__()
+        tb4, _ = timed(a.train_steps, warm=0)
+        tele.__exit__()
+        tele_block = round(tb4 / a.train_steps * 1e3, 3)
     ar_bytes = ((net.grad_sync.bytes_reduced - ar0) // (3 * a.train_steps + 4)) if dist else 0      # 3 blocks of K steps + 4 warm-up steps
     trecs = []
     if not a.no_kernel_timing:  # per-kernel table from two extra steps (not part of the timing).  EVERY rank runs them --
@@ -587,7 +594,8 @@ def train_leg(net, a, sat, grd, extra, B, world, rank, dist, dev, want_kt, extra
         train['with_train_ground_crop'] = {'value': round(B * world * a.train_steps / cdt, 3), 'unit': 'pairs/s',
                                            'ms_per_step': round(cdt / a.train_steps * 1e3, 3)}
     if tele:
-        train['telemetry'] = tele.summary()      # sclk / socket power over the middle timed block
+        train['telemetry'] = dict(tele.summary(), block_ms_per_step=tele_block,
+                                  what='a fourth block of the same steps, sampled; not part of value')
     if trecs:
         tagg = aggregate(trecs)
         tot = sum(v[1] for v in tagg.values())
