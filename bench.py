@@ -548,13 +548,14 @@ def train_leg(net, a, sat, grd, extra, B, world, rank, dist, dev, want_kt, extra
     # [48.0, 52.6, 48.7] ms -- with the sampler in it or not; a process that runs this leg alone on a cool chip shows
     # [47.0, 47.5, 47.7], and tools/probes/telemetry_ab.py measures no effect of the sampler on either leg: it is the chip's
     # power management after the preceding legs, and the median is there for it.)
-    tele_block = None
+    # (EVERY rank runs the block -- a step contains the gradient all-reduce and `timed` its barriers -- only rank 0 samples)
     if tele:
         tele.__enter__()
-        tb4, _ = timed(a.train_steps, warm=0)
+    tb4, _ = timed(a.train_steps, warm=0)
+    if tele:
         tele.__exit__()
-        tele_block = round(tb4 / a.train_steps * 1e3, 3)
-    ar_bytes = ((net.grad_sync.bytes_reduced - ar0) // (3 * a.train_steps + 4)) if dist else 0      # 3 blocks of K steps + 4 warm-up steps
+    tele_block = round(tb4 / a.train_steps * 1e3, 3)
+    ar_bytes = ((net.grad_sync.bytes_reduced - ar0) // (4 * a.train_steps + 4)) if dist else 0      # 3 timed blocks + the telemetry block of K steps + 4 warm-up steps
     trecs = []
     if not a.no_kernel_timing:  # per-kernel table from two extra steps (not part of the timing).  EVERY rank runs them --
         if want_kt:             # a training step contains the gradient all-reduce -- but only rank 0 is instrumented
