@@ -779,6 +779,29 @@ def test_pose_loss_kernels_vs_reference_golden(form):
     np.testing.assert_allclose(float(res[0]), float(g['c0_out0']), rtol=1e-6)
 
 
+def test_pose_loss_dispatch_and_error_codes():
+    """What does NOT go through the kernels (more than 512 (iteration, level) pairs, fp16 poses, ground truth that requires grad) is
+    evaluated with the reference's tensor ops -- same values; the C entry refuses bad sizes with an error code and a message."""
+    import ctypes as C
+    from highlyaccurate_amd import _lib, _s2gp
+    from highlyaccurate_amd.models_kitti import loss_func
+    d = _dev()
+    g = torch.Generator().manual_seed(3)
+    for shape, dt, gt_grad in (((2, 100, 6), torch.float32, False), ((3, 4, 3), torch.float16, False), ((3, 4, 3), torch.float32, True)):
+        xs = [torch.randn(*shape, generator=g).to(d).to(dt).requires_grad_(True) for _ in range(3)]
+        gts = [torch.randn(shape[0], generator=g).to(d).requires_grad_(gt_grad) for _ in range(3)]
+        res = loss_func(0, None, None, None, *xs, *gts, None, None, 100, 50, 10)
+        assert 'PoseLossFn' not in type(res[0].grad_fn).__name__
+        ref = _s2gp._loss_tensor_ops(*xs, *gts, 100, 50, 10)
+        for a, b in zip(res[:9], ref):
+            assert torch.equal(a, b)
+    a = _lib.PoseLossArgs()
+    a.B, a.N, a.L = 2, 100, 6
+    out = torch.empty(49, device=d)
+    rc = _lib.load().hla_pose_loss(C.byref(a), _lib.ptr(out), _lib.stream_ptr())
+    assert rc != 0 and b'N * L' in _lib.load().hla_last_error()
+
+
 def test_train_mode_forward_values_vs_golden():
     """mode='train' 14-tuple values (no autograd yet) against the reference's fp64 tuple."""
     from oracle import ref_cpu as O
