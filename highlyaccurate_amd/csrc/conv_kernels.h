@@ -264,38 +264,74 @@ template <typename E, int NT> struct RowStager {
   // `mask` / `add` (optional) are indexed exactly like dst: v = (mask > 0 ? v : 0) + add, applied on the 16-B vectors
   // returns (not PLAIN, with a mask or an add) the max |v| of what was stored, i.e. AFTER mask and add: in split mode the scale
   // the consumer of this map will use
-  template <bool PLAIN = false>
+  template <bool PLAIN = false, int GG = 2>      // GG: vectors per lane whose mask / fan-in loads are in flight together
   static __device__ __forceinline__ float flush(const char* stage, E* dst, int npx, int npx_valid, int Cout, int lane,
                                                 const E* mask = nullptr, const E* add = nullptr,
                                                 int add_px_lo = 0, int add_px_hi = 1 << 30) {
     float vmax = 0.f;
     const int chunks = npx * CPP;
-    constexpr int EPV = 16 / (int)sizeof(E);
+    constexpr int EPV = 16 / (int)sizeof(E), NIT = 32 * CPP / 64;
+    if (PLAIN || !(mask || add)) {        // (kernel-uniform)
 #pragma unroll
-    for (int c0 = 0; c0 < 32 * CPP; c0 += 64) {
-      const int c = c0 + lane;
-      if (c0 < chunks && c < chunks) {
-        const int px = c / CPP, part = c % CPP;
-        if (px < npx_valid) {
-          uint4 v = *(const uint4*)(stage + px * PITCH + part * 16);
-          const unsigned off = (unsigned)px * (unsigned)Cout * (unsigned)sizeof(E) + part * 16;   // < 2^20: one row segment
-          if (!PLAIN && (mask || add)) {
-            E e[EPV], m[EPV], ad[EPV];
-            __builtin_memcpy(e, &v, 16);
-            if (mask) { const uint4 t = *(const uint4*)((const char*)mask + off); __builtin_memcpy(m, &t, 16); }
-            const bool addp = add && px >= add_px_lo && px < add_px_hi;
-            if (addp) { const uint4 t = *(const uint4*)((const char*)add + off); __builtin_memcpy(ad, &t, 16); }
-#pragma unroll
-            for (int k = 0; k < EPV; ++k) {
-              float f = (float)e[k];
-              if (mask && !((float)m[k] > 0.f)) f = 0.f;
-              if (addp) f += (float)ad[k];
-              e[k] = (E)f;
-              vmax = fmaxf(vmax, fabsf(f));
-            }
-            __builtin_memcpy(&v, e, 16);
+      for (int c0 = 0; c0 < 32 * CPP; c0 += 64) {
+        const int c = c0 + lane;
+        if (c0 < chunks && c < chunks) {
+          const int px = c / CPP, part = c % CPP;
+          if (px < npx_valid) {
+            const unsigned off = (unsigned)px * (unsigned)Cout * (unsigned)sizeof(E) + part * 16;   // < 2^20: one row segment
+            *(uint4*)((char*)dst + off) = *(const uint4*)(stage + px * PITCH + part * 16);
           }
-          *(uint4*)((char*)dst + off) = v;
+        }
+      }
+      return vmax;
+    }
+    // With a mask or a fan-in every 16-byte vector needs one or two global loads before it can be stored.  They are issued
+    // UNCONDITIONALLY (a lane without a vector reads the row segment's first one: valid memory, value unused) and GG
+    // vectors per lane ahead of the first use: as `if (lane has a vector) { load; use; store }` the compiler put each load in
+    // its own exec-masked block with s_waitcnt vmcnt(0) behind it -- 16 dependent HBM round trips per wave tile, a third of a
+    // data-gradient workgroup's life (round 5; the same pathology as the weight-gradient loaders').
+    constexpr int G = NIT < GG ? NIT : GG;
+#pragma unroll
+    for (int g0 = 0; g0 < NIT; g0 += G) {
+      bool ok[G], ap[G];
+      unsigned off[G];
+      int pxs[G], parts[G];
+      uint4 mk[G], ad[G];
+#pragma unroll
+      for (int k = 0; k < G; ++k) {
+        const int c0 = (g0 + k) * 64, c = c0 + lane;
+        const int px = c / CPP, part = c % CPP;
+        ok[k] = c0 < chunks && c < chunks && px < npx_valid;
+        pxs[k] = px; parts[k] = part;
+        off[k] = ok[k] ? (unsigned)px * (unsigned)Cout * (unsigned)sizeof(E) + part * 16 : 0u;   // < 2^20: one row segment
+        ap[k] = add && ok[k] && px >= add_px_lo && px < add_px_hi;
+      }
+      if (mask) {
+#pragma unroll
+        for (int k = 0; k < G; ++k) mk[k] = *(const uint4*)((const char*)mask + off[k]);
+      }
+      if (add) {
+#pragma unroll
+        for (int k = 0; k < G; ++k) ad[k] = *(const uint4*)((const char*)add + (ap[k] ? off[k] : 0u));
+      }
+#pragma unroll
+      for (int k = 0; k < G; ++k) {
+        if (ok[k]) {
+          uint4 v = *(const uint4*)(stage + pxs[k] * PITCH + parts[k] * 16);
+          E e[EPV], m[EPV], a2[EPV];
+          __builtin_memcpy(e, &v, 16);
+          if (mask) __builtin_memcpy(m, &mk[k], 16);
+          if (add) __builtin_memcpy(a2, &ad[k], 16);
+#pragma unroll
+          for (int j = 0; j < EPV; ++j) {
+            float f = (float)e[j];
+            if (mask && !((float)m[j] > 0.f)) f = 0.f;
+            if (ap[k]) f += (float)a2[j];
+            e[j] = (E)f;
+            vmax = fmaxf(vmax, fabsf(f));
+          }
+          __builtin_memcpy(&v, e, 16);
+          *(uint4*)((char*)dst + off[k]) = v;
         }
       }
     }
@@ -506,7 +542,8 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[MT][NT], const ConvA
       const size_t o = pix0 * a.Cout + cb;
       if (GEN || DG) {
         if (row_ok) {
-          const float fm = RowStager<T, NT>::flush(stage, (T*)a.out_act + o, NPX, nvalid, a.Cout, lane,
+          // (8-row tiles: a whole row's four vectors per lane at once; the 4-row tiles of small launches keep three workgroups per CU with two)
+          const float fm = RowStager<T, NT>::template flush<false, (MT >= 4 ? 4 : 2)>(stage, (T*)a.out_act + o, NPX, nvalid, a.Cout, lane,
                                                    a.mask_act ? (const T*)a.mask_act + o : nullptr,
                                                    (a.add_src && yo >= max(a.add_row_lo, addb.y0) && yo < addb.y1) ? (const T*)a.add_src + o : nullptr,
                                                    addb.x0 - xo0, addb.x1 - xo0);
