@@ -254,6 +254,13 @@ __device__ __forceinline__ FragOff frag_offsets(int lane, int row0) {
 // (measured: 16-28 k cycles per wave, up to half of a block's lifetime).  Instead every wave transposes one
 // pixel row at a time through a private LDS region (`stage`, >= 32*(NT*32*4+16) bytes) and stores it as whole
 // pixel rows: 16 B per lane, consecutive lanes on consecutive addresses.
+// The value of the neighbouring lane (lane ^ 1) as ONE VALU instruction (DPP quad_perm [1,0,3,2]).  `__shfl_xor(v, 1, 64)` compiles
+// to ds_bpermute_b32 -- an LDS-crossbar round trip with a wait behind it: the 2x2 pooling epilogues issued 64-128 of them per wave
+// tile (conv0 + conv2, conv7, conv14: 39 % of the inference step runs behind such an epilogue).
+__device__ __forceinline__ float lane_xor1(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, false));
+}
+
 template <typename E, int NT> struct RowStager {
   static constexpr int CW = NT * 32, PITCH = CW * (int)sizeof(E) + 16, CPP = CW * (int)sizeof(E) / 16;
   // lane-side write of 4 consecutive channels of pixel `px`
@@ -429,7 +436,7 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[MT][NT], const ConvA
               float t = acc[i][j][q * 4 + e];
               if (POOL) {
                 t = fmaxf(t, acc[i + 1][j][q * 4 + e]);
-                t = fmaxf(t, __shfl_xor(t, 1, 64));
+                t = fmaxf(t, lane_xor1(t));
               }
               if (Prec<T>::SPLIT) t *= dsc;
               w[e] = t;
@@ -469,10 +476,10 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[MT][NT], const ConvA
             const float u = acc[i + 1][j][q * 4 + e];
             if (pool_sum) {
               t += u;
-              t += __shfl_xor(t, 1, 64);
+              t += lane_xor1(t);
             } else {
               t = fmaxf(t, u);
-              t = fmaxf(t, __shfl_xor(t, 1, 64));
+              t = fmaxf(t, lane_xor1(t));
             }
           }
           if (Prec<T>::SPLIT) t *= dsc;           // exact: a power of two (and > 0, so it commutes with the pooling)
@@ -564,7 +571,7 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[MT][NT], const ConvA
             const float t0 = acc[i][j][q * 4 + e], u = acc[i + 1][j][q * 4 + e];
             const float rown = u > t0 ? 1.f : 0.f;             // first maximum wins, like F.max_pool2d
             const float t = fmaxf(t0, u);
-            const float t2 = __shfl_xor(t, 1, 64), r2 = __shfl_xor(rown, 1, 64);
+            const float t2 = lane_xor1(t), r2 = lane_xor1(rown);
             am[e] = t2 > t ? 2.f * r2 + 1.f : 2.f * rown;
           }
           if (!(x & 1)) RowStager<unsigned char, NT>::put(stage, px, j * 32 + q * 8 + g * 4, am[0], am[1], am[2], am[3]);
