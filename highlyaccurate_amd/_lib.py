@@ -17,7 +17,8 @@ HLA_F32, HLA_BF16, HLA_F16, HLA_F16X3 = 0, 1, 2, 3
 HLA_VGG_WANT_CONF, HLA_VGG_DEFER_NORM, HLA_VGG_SAVE_FOR_BACKWARD, HLA_VGG_FEAT16 = 1, 2, 4, 8
 HLA_VGG_BWD_SCALE_INVARIANT = 1
 HLA_VGG_BWD_DENSE = 2
-ABI_VERSION = 20
+HLA_VGG_BWD_WGRAD_TWO_PHASE = 4
+ABI_VERSION = 21
 
 
 class HlaError(RuntimeError):
@@ -41,7 +42,11 @@ class S2GConfig(C.Structure):
                 ('shift_range_lat', C.c_double), ('shift_range_lon', C.c_double), ('rotation_range', C.c_double),
                 ('damping', C.c_double * 3), ('keep', C.c_void_p), ('keep_stride', C.c_size_t),
                 ('optimizer', C.c_int), ('beta1', C.c_double), ('beta2', C.c_double), ('count_in_view', C.c_int),
-                ('grd_grad_overwrite', C.c_int)]
+                ('grd_grad_overwrite', C.c_int), ('deterministic', C.c_int)]
+
+
+class FillRegion(C.Structure):
+    _fields_ = [('ptr', C.c_void_p), ('chunk_bytes', C.c_size_t), ('stride_bytes', C.c_size_t), ('n_chunks', C.c_int)]
 
 
 class VggGrads(C.Structure):
@@ -80,7 +85,7 @@ def _check_binary(lib: C.CDLL, path: str) -> None:
     except AttributeError:
         raise HlaError(f'{path}: no hla_sizeof_struct export; rebuild it') from None
     fn.restype, fn.argtypes = C.c_size_t, [C.c_int]
-    for sid, cls in enumerate((VggParams, VggGrads, S2GLevel, S2GConfig, S2GLevelGrad, ProfRecord, PoseLossArgs)):
+    for sid, cls in enumerate((VggParams, VggGrads, S2GLevel, S2GConfig, S2GLevelGrad, ProfRecord, PoseLossArgs, FillRegion)):
         if fn(sid) != C.sizeof(cls):
             raise HlaError(f'{path}: sizeof({cls.__name__}) is {fn(sid)} in the library and {C.sizeof(cls)} in the binding')
 
@@ -158,6 +163,8 @@ def load() -> C.CDLL:
     lib.hla_s2g_lm_solve_bwd.restype = i
     lib.hla_s2g_lm_solve_bwd.argtypes = [C.POINTER(S2GConfig), C.POINTER(S2GLevel), C.POINTER(S2GLevelGrad), vp, vp, vp, vp,
                                          vp, vp, vp, vp, sz, i, vp]
+    lib.hla_zero_fill.restype = i
+    lib.hla_zero_fill.argtypes = [C.POINTER(FillRegion), i, i, vp]
     lib.hla_pose_loss.restype = i
     lib.hla_pose_loss.argtypes = [C.POINTER(PoseLossArgs), vp, vp]
     lib.hla_pose_loss_bwd.restype = i
@@ -172,6 +179,18 @@ def load() -> C.CDLL:
     lib.hla_prof_fetch.argtypes = [C.POINTER(ProfRecord), i, C.POINTER(i)]
     _lib = lib
     return lib
+
+
+def zero_fill(regions, max_blocks: int = 0, stream=None) -> None:
+    """``hla_zero_fill``: regions = [(tensor_or_ptr, chunk_bytes, stride_bytes, n_chunks)] (<= 16), cleared by ONE launch on the
+    current stream (``max_blocks`` > 0: a background fill with that many workgroups per region).  A tensor stands for its data pointer (it must stay alive until the launch has run, as for any kernel)."""
+    if not regions:
+        return
+    arr = (FillRegion * len(regions))()
+    for k, (t, cb, sb, n) in enumerate(regions):
+        arr[k].ptr = t.data_ptr() if hasattr(t, 'data_ptr') else int(t)
+        arr[k].chunk_bytes, arr[k].stride_bytes, arr[k].n_chunks = int(cb), int(sb), int(n)
+    check(load().hla_zero_fill(arr, len(regions), int(max_blocks), stream_ptr() if stream is None else stream), 'hla_zero_fill')
 
 
 def prof_enable(on: bool) -> None:

@@ -22,6 +22,16 @@ FORD_H_FL, FORD_W_FL = 860, 1656                                                
 
 _FEAT_DTYPES = {torch.float32: _lib.HLA_F32, torch.bfloat16: _lib.HLA_BF16, torch.float16: _lib.HLA_F16}
 
+# Phase marks of a training step (bench.py's train.step_breakdown): when set, ``PHASE_HOOK(name)`` is called on the host right
+# after the launches of phase ``name`` were enqueued on the CURRENT stream (the hook records an event there).  None: no cost.
+PHASE_HOOK = None
+
+
+def _phase(name: str):
+    h = PHASE_HOOK
+    if h is not None:
+        h(name)
+
 
 def ground_plane_table(K_ori, grd_H, grd_W, ori_H, ori_W):
     """Back-project the pixel grid onto the ground plane y = camera height
@@ -123,8 +133,9 @@ class _PoseLossFn(torch.autograd.Function):
 
 def _pose_loss(cols, xs, gts, coes):
     """The nine tensors of loss_func method 0.  Device fp32 poses with fp32 / fp64 ground truth on the same device go through
-    libhla (one launch each way, same values: batch means summed in fp64, then the reference's operation order in its result
-    type); anything else (CPU tensors, other dtypes, ground truth that requires grad, tensor-valued coefficients) is evaluated
+    libhla (one launch each way; the batch means are summed in fp64 and rounded once, i.e. within 1 ulp of torch's fp32
+    reduction, then the reference's operation order in its result type; a second backward through the gradient raises
+    (once_differentiable) where the reference would return zeros); anything else (CPU tensors, other dtypes, ground truth that requires grad, tensor-valued coefficients) is evaluated
     with the reference's own tensor ops on the tensors' device -- that is the reference function, not a fallback of a kernel."""
     views = [xs[0][..., c] for c in cols] if cols is not None else list(xs)
     fused = (all(isinstance(c, (int, float)) for c in coes)
@@ -172,10 +183,17 @@ class S2GPBase(nn.Module):
     #   train_ground_crop  0; 1: the same for training (changes the returned confidence maps above the crop)   DESIGN.md 3.5
     #   bwd_trim           1: the backward skips rows / tiles whose gradient is exactly zero; 0: dense walk     DESIGN.md 6
     #   bwd_two_streams    1: the two extractors' backward passes run on two streams (single-GPU training)       DESIGN.md 6
+    #   bwd_prefill        0: the LM backward's gradient buffers are cleared by one launch in front of it; 1: allocated and cleared
+    #                      during the forward, on a side stream; n > 1: as a background fill of n workgroups per buffer
+    #                      (an experiment kept as a switch: measured neutral, EXPERIMENTS.md round 6)
+    #   wgrad_two_phase    0; 1: weight gradients on the two-phase kernels (A/B and tests: HLA_VGG_BWD_WGRAD_TWO_PHASE)
     #   strict_errors      0; 1: reproduce jacobian.py:172's AssertionError (costs a host sync per forward)     DESIGN.md 1
     #   small_batch_two_streams  4: inference batches up to this size run the two extractors on two streams        DESIGN.md 5
-    #   fwd_two_streams    unset; -1 / 0: inference at ANY batch with the satellite extractor on a side stream of that priority --
-    #                      an experiment kept as a switch: 0.3-0.6 % SLOWER at B = 32 (EXPERIMENTS.md round 5)
+    #   fwd_two_streams    unset / None / 0: off.  -1 or 1: inference at ANY batch with the satellite extractor on a side stream
+    #                      (-1: a high-priority one, 1: equal priority) -- an experiment kept as a switch: 0.3-0.6 % SLOWER at B = 32
+    #                      (EXPERIMENTS.md round 5)
+    #   deterministic_backward  0; 1: lm_bwd_accum accumulates d(loss)/d(sat map) in a fixed order instead of with fp32 atomics:
+    #                      the same batch twice gives bitwise equal parameter gradients
     def __init__(self, args):
         super().__init__()
         self.args = args
@@ -359,12 +377,47 @@ class S2GPBase(nn.Module):
         self.last_trace, self.last_normal_eq = trace.detach(), neq
         return trace
 
+    def lm_grad_buffers(self, sat_feats, grd_feats, grd_confs, row0s, row_skips, grd_first_row8=0, overwrite=True, deterministic=False,
+                        max_blocks=0):
+        """The buffers ``hla_s2g_lm_solve_bwd`` accumulates into, cleared where they have to be by ONE launch (``hla_zero_fill``) on
+        the current stream: (d_sat[l], d_grd[l], d_conf[l] or None, d_lambda[4]).
+        * d_sat: zero-filled (the scatter adds); with ``deterministic`` not at all (the closing pass writes every element).
+        * d_grd: the loop only touches rows h_l/2.. and WRITES them on each level's first visit (cfg.grd_grad_overwrite): no
+          zero-fill and no read-modify-write of half a map there.  What still has to be zero is what the consumer reads above
+          them: with hla_vgg_backward(first_row8 = f) two rows (it never reads d_grd[l] above row f * 2^l - 2), else the top half.
+        * d_conf: zero-filled (added to).  d_lambda: written by the call."""
+        L = len(sat_feats)
+        regions = []
+        d_sat = [torch.empty_like(t) for t in sat_feats]
+        if not deterministic:
+            regions += [(d, d.numel() * 4, d.numel() * 4, 1) for d in d_sat]
+        d_grd = []
+        for l, t in enumerate(grd_feats):
+            d = torch.empty_like(t)
+            lo, hi = (max(0, (grd_first_row8 << l) - 2) if grd_first_row8 else 0), row0s[l] - row_skips[l]
+            if not overwrite:
+                hi = t.shape[1]
+            if hi > lo:
+                row = t.shape[2] * t.shape[3] * 4
+                regions.append((d.data_ptr() + lo * row, (hi - lo) * row, t.shape[1] * row, t.shape[0]))
+            d_grd.append(d)
+        d_conf = [torch.empty_like(grd_confs[l]) if (self.using_weight and grd_confs[l] is not None) else None for l in range(L)]
+        regions += [(d, d.numel() * 4, d.numel() * 4, 1) for d in d_conf if d is not None]
+        d_lambda = torch.empty(4, device=sat_feats[0].device, dtype=torch.float64)
+        keep = d_sat + d_grd                      # (the regions of d_grd are raw pointers into tensors that are alive here)
+        for k0 in range(0, len(regions), 16):
+            _lib.zero_fill(regions[k0:k0 + 16], max_blocks)
+        del keep
+        return d_sat, d_grd, d_conf, d_lambda
+
     @_lib.on_device(lambda self, sat_feats, *a, **k: sat_feats[0])
     def lm_backward(self, sat_feats, grd_feats, grd_confs, grd_hw, trace, normal_eq, d_trace, extra=None, level_first=0,
-                    init_pose=None, sat_inv_norm=None, grd_inv_norm=None, keep=None, grd_first_row8=0, overwrite=True):
-        """Backward of ``lm_solve``: d(loss)/d(trace) [B,N,L,3] -> (d_sat[l], d_grd[l], d_conf[l] or None, d_lambda[3]).
+                    init_pose=None, sat_inv_norm=None, grd_inv_norm=None, keep=None, grd_first_row8=0, overwrite=True, bufs=None):
+        """Backward of ``lm_solve``: d(loss)/d(trace) [B,N,L,3] -> (d_sat[l], d_grd[l], d_conf[l] or None, d_lambda[4]).
         ``keep``: the forward's dropout mask (``self.last_keep``), if args.dropout.
-        Map gradients are NHWC fp32 and taken w.r.t. the L2-normalised maps (inv_norm * stored map)."""
+        Map gradients are NHWC fp32 and taken w.r.t. the L2-normalised maps (inv_norm * stored map).
+        ``bufs``: what ``lm_grad_buffers`` returned for the same maps and flags (training allocates and clears them while the
+        forward's convolutions run); None: made here.  ``args.deterministic_backward``: hla_s2g_config.deterministic."""
         lib = _lib.load()
         dev = sat_feats[0].device
         B, L = sat_feats[0].shape[0], len(sat_feats)
@@ -372,27 +425,17 @@ class S2GPBase(nn.Module):
                                                sat_inv_norm, grd_inv_norm)
         if keep is not None:
             cfg.keep, cfg.keep_stride = keep.data_ptr(), keep.shape[1]
-        d_sat = [torch.zeros_like(t) for t in sat_feats]
-        # d_grd: the loop only touches rows h_l/2.. and WRITES them on each level's first visit (cfg.grd_grad_overwrite): no zero-fill
-        # and no read-modify-write of half a map there.  What still has to be zero is what the consumer reads above them: with
-        # hla_vgg_backward(first_row8 = f) two rows (it never reads d_grd[l] above row f * 2^l - 2), else the top half.
+        det = bool(getattr(self.args, 'deterministic_backward', 0))
+        cfg.deterministic = 1 if det else 0
         cfg.grd_grad_overwrite = 1 if overwrite else 0       # (0: zero-filled buffers, every step adds -- kept for callers of the C ABI)
-        d_grd = []
-        for l, t in enumerate(grd_feats):
-            d = torch.empty_like(t)
-            lo, hi = (max(0, (grd_first_row8 << l) - 2) if grd_first_row8 else 0), lv[l].row0 - lv[l].grd_row_skip
-            if not overwrite:
-                hi = t.shape[1]
-            if hi > lo:
-                d[:, lo:hi].zero_()
-            d_grd.append(d)
-        d_conf = [torch.zeros_like(grd_confs[l]) if (self.using_weight and grd_confs[l] is not None) else None
-                  for l in range(L)]
+        if bufs is None:
+            bufs = self.lm_grad_buffers(sat_feats, grd_feats, grd_confs, [lv[l].row0 for l in range(L)],
+                                        [lv[l].grd_row_skip for l in range(L)], grd_first_row8, overwrite, det)
+        d_sat, d_grd, d_conf, d_lambda = bufs
         gr = (_lib.S2GLevelGrad * L)()
         for l in range(L):
             gr[l].d_sat_feat, gr[l].d_grd_feat = d_sat[l].data_ptr(), d_grd[l].data_ptr()
             gr[l].d_grd_conf = d_conf[l].data_ptr() if d_conf[l] is not None else 0
-        d_lambda = torch.zeros(3, device=dev, dtype=torch.float64)
         dtr = d_trace.to(dev).float().contiguous()
         nbytes = lib.hla_s2g_bwd_workspace_bytes(C.byref(cfg), lv, B)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
@@ -401,7 +444,11 @@ class S2GPBase(nn.Module):
                                       _lib.ptr(normal_eq), _lib.ptr(dtr), _lib.ptr(d_lambda), _lib.ptr(ws), nbytes, B,
                                       _lib.stream_ptr())
         _lib.check(rc, 'hla_s2g_lm_solve_bwd')
-        return d_sat, d_grd, d_conf, d_lambda
+        if det and float(d_lambda[3]) != 0.0:        # (a host sync per step: the price of the check in this opt-in mode)
+            raise RuntimeError(f'deterministic_backward: the fixed-point range of d(loss)/d(sat map) was exceeded in {int(d_lambda[3])} '
+                               '(step, sample) pairs -- the gradient of a later LM step outgrew the first one\'s bound by more than 2^9; '
+                               'the result is not valid (run without args.deterministic_backward)')
+        return d_sat, d_grd, d_conf, d_lambda[:3]
 
     def _features(self, sat_map, grd_img, want_conf, return_confs):
         """Both extractors of the inference path: (sat_feats, sat_inv, grd_feats, grd_confs, grd_inv), normalisation deferred."""
@@ -416,10 +463,11 @@ class S2GPBase(nn.Module):
         # ground branch's (B <= args.small_batch_two_streams, default 4: B = 1 0.700 -> 0.615 ms, B = 4 1.195 -> 1.122; at B = 32, where both are dense, the same split measured
         # 2 % slower: DESIGN 3.1).
         small = sat_map.shape[0] <= int(getattr(self.args, 'small_batch_two_streams', 4))
-        # args.fwd_two_streams (round 5 experiment, default 0): the same split at ANY batch, the satellite branch on a side stream of
-        # the given priority (-1: high, so its chain owns the chip and the ground branch's launches fill the gaps its launch
-        # boundaries leave; 0: equal priority)
+        # args.fwd_two_streams (round 5 experiment, default off = None / 0): the same split at ANY batch, the satellite branch on a side
+        # stream: -1 = a high-priority one (its chain owns the chip and the ground branch's launches fill the gaps its launch
+        # boundaries leave), 1 = equal priority
         prio = getattr(self.args, 'fwd_two_streams', None)
+        prio = None if not prio else (-1 if int(prio) < 0 else 0)
         small = small or prio is not None
         if small:
             cur = torch.cuda.current_stream()
@@ -541,6 +589,14 @@ def dead_ground_rows(H: int) -> int:
     return max(0, ((H // 2 - 34) // 8) * 8)
 
 
+def _bwd_first_row8(model, grd_hw, x21_rows: int) -> int:
+    """hla_vgg_backward's first_row8 for the ground branch: the ground maps' gradient lives in rows h_l/2.. (all the LM loop reads),
+    so the backward skips the rows above its support (level 3, LM_update, args.bwd_trim)."""
+    inv = getattr(model.args, 'Optimizer', 'LM') == 'LM'
+    f8 = (grd_hw[0] // 8) // 2 - (grd_hw[0] - x21_rows * 2) // 8
+    return f8 if (inv and f8 >= 4 and model.level == 3 and bool(getattr(model.args, 'bwd_trim', 1))) else 0
+
+
 class _LocaliseFn(torch.autograd.Function):
     """forward: trace [B,N,L,3] (+ the three ground confidence maps); backward: parameter gradients from HIP kernels."""
 
@@ -548,6 +604,7 @@ class _LocaliseFn(torch.autograd.Function):
     def forward(ctx, model, names, sat_map, grd_img, want_conf, extra, level_first, init_pose, *params):
         sat_feats, _, sat_inv, cs = vgg_forward_nhwc(model.SatFeatureNet, sat_map, want_conf=False, defer_norm=True,
                                                      save_for_backward=True)
+        _phase('fwd_sat')
         # args.train_ground_crop (an extension, default 0): train on the image rows that can reach the loss only.  The loss
         # sees the ground branch through rows h_l/2.. of its maps, so the gradient of every other row is exactly zero and the
         # rows above `dead_ground_rows` influence neither the loss nor any gradient (the L2_norm scale cancels in
@@ -559,11 +616,30 @@ class _LocaliseFn(torch.autograd.Function):
         grd_in = grd_img[:, :, skip:, :] if skip else grd_img      # (a view: the extractor takes the window's plane stride)
         grd_feats, grd_confs, grd_inv, cg = vgg_forward_nhwc(model.GrdFeatureNet, grd_in, want_conf=want_conf,
                                                              defer_norm=True, save_for_backward=True)
+        _phase('fwd_grd')
         L = model._levels
         ctx.conf0 = grd_confs[0] if (model.level == 2 and grd_confs is not None) else None      # (the head's backward needs its own map)
         sat_feats, sat_inv, grd_feats, grd_confs, grd_inv = L(sat_feats), L(sat_inv), L(grd_feats), L(grd_confs), L(grd_inv)
+        # args.bwd_prefill (round 6 experiment, default 0): allocate and clear the buffers the LM backward accumulates into NOW, on
+        # the side stream (1.4 GB of zero-fill at B = 32), so that it runs under the extractors' convolutions queued above instead
+        # of in front of the LM backward.  Measured neutral (same-box A/B, bf16 23.20 / 23.39 / 23.31 ms for off / on / a 16-workgroup
+        # background fill; fp16x3 53.51 / 53.53 / 53.65): the fill takes from the 2-stage layers it runs under what it saves
+        # (conv5 281 -> 439 us under a 204-us fill).  Default: ONE hla_zero_fill launch in front of the LM backward.
+        ctx.bufs = None
+        prefill = int(getattr(model.args, 'bwd_prefill', 0))
+        if prefill:
+            f8 = _bwd_first_row8(model, tuple(grd_img.shape[-2:]), grd_feats[-1].shape[1])
+            tabs = model.xyz_tables(grd_img.shape[-2], grd_img.shape[-1], sat_map.device)
+            row0s = [t.shape[0] // 2 for t in tabs]
+            skips = [t.shape[0] - g.shape[1] for t, g in zip(tabs, grd_feats)]
+            side = _side_stream(sat_map.device)
+            with torch.cuda.stream(side):
+                ctx.bufs = model.lm_grad_buffers(sat_feats, grd_feats, grd_confs, row0s, skips, f8, True,
+                                                 bool(getattr(model.args, 'deterministic_backward', 0)),
+                                                 max_blocks=prefill if prefill > 1 else 0)
         trace = model.lm_solve(sat_feats, grd_feats, grd_confs, grd_img.shape[-2:], extra, level_first, init_pose,
                                sat_inv, grd_inv, keep_normal_eq=True)
+        _phase('lm_fwd')
         ctx.model, ctx.names, ctx.extra, ctx.level_first, ctx.init_pose = model, names, extra, level_first, init_pose
         ctx.state = (sat_feats, grd_feats, grd_confs, tuple(grd_img.shape[-2:]), trace.detach(), model.last_normal_eq, sat_inv, grd_inv, cs, cg,
                      model.last_keep)
@@ -573,24 +649,35 @@ class _LocaliseFn(torch.autograd.Function):
             if skip:                                    # full-size maps for the caller, zero above the crop
                 out_confs = tuple(torch.nn.functional.pad(c, (0, 0, skip >> (3 - l), 0)) for l, c in enumerate(grd_confs))
             ctx.mark_non_differentiable(*out_confs)     # loss_method 0 does not read them; their LM-weight role is in backward()
+        # (no zero tensors for the outputs that got no gradient: autograd would fill three [B,h,w] maps per step just to hand
+        #  them to a backward that ignores them)
+        ctx.set_materialize_grads(False)
         return (trace,) + out_confs
 
     @staticmethod
     def backward(ctx, d_trace, *unused):
         model = ctx.model
+        _phase('loss')
         if ctx.state is None:
             raise RuntimeError('backward through the same forward twice: the saved activations (GBs at B = 32) are released after '
                                'the first backward; retain_graph is not supported by the HIP backward')
         sat_feats, grd_feats, grd_confs, grd_hw, trace, neq, sat_inv, grd_inv, cs, cg, keep = ctx.state
+        if d_trace is None:         # (only the confidence maps were used downstream: they are non-differentiable outputs)
+            d_trace = torch.zeros_like(trace)
         # LM_update renormalises both maps, so d_feat is orthogonal to feat: HLA_VGG_BWD_SCALE_INVARIANT (include/hla.h)
         inv = getattr(model.args, 'Optimizer', 'LM') == 'LM'
         trim = bool(getattr(model.args, 'bwd_trim', 1))
         # the ground maps' gradient lives in rows h_l/2.. (all the LM loop reads): the backward skips the rows above its support
-        x21 = grd_feats[1 if model.level == 2 else 2]       # the H/2 map (level 2: [x18, x21])
-        f8 = (grd_hw[0] // 8) // 2 - (grd_hw[0] - x21.shape[1] * 2) // 8
-        f8 = f8 if (inv and f8 >= 4 and model.level == 3 and trim) else 0
+        f8 = _bwd_first_row8(model, grd_hw, grd_feats[-1].shape[1])       # (grd_feats[-1]: the H/2 map)
+        bufs, ctx.bufs = ctx.bufs, None
+        if bufs is not None:          # cleared on the side stream during the forward: long done, but the order must be stated
+            cur = torch.cuda.current_stream()
+            cur.wait_stream(_side_stream(sat_feats[0].device))
+            for t in list(bufs[0]) + list(bufs[1]) + [c for c in bufs[2] if c is not None] + [bufs[3]]:
+                t.record_stream(cur)
         d_sat, d_grd, d_conf, d_lam = model.lm_backward(sat_feats, grd_feats, grd_confs, grd_hw, trace, neq, d_trace, ctx.extra,
-                                                   ctx.level_first, ctx.init_pose, sat_inv, grd_inv, keep, grd_first_row8=f8)
+                                                   ctx.level_first, ctx.init_pose, sat_inv, grd_inv, keep, grd_first_row8=f8, bufs=bufs)
+        _phase('lm_bwd')
         if model.level == 2:        # x15 takes no part in the loop: its gradient (and its confidence map's) is zero
             zf = lambda cx: torch.zeros_like(cx['feats'][0], dtype=torch.float32)
             d_sat, d_grd = [zf(cs)] + list(d_sat), [zf(cg)] + list(d_grd)
@@ -609,22 +696,23 @@ class _LocaliseFn(torch.autograd.Function):
         # caching allocator, so the freed block cannot be reused for the ground branch's workspace on the main stream: peak
         # training memory is one backward workspace higher (GB-class at B = 32 in fp32) for that 1.4 %.
         two = bool(getattr(model.args, 'bwd_two_streams', 1)) and sync is None
+        tp = bool(getattr(model.args, 'wgrad_two_phase', 0))       # (A/B and tests: HLA_VGG_BWD_WGRAD_TWO_PHASE)
         if two:
             cur = torch.cuda.current_stream()
             side = _side_stream(d_sat[0].device)
             side.wait_stream(cur)
             with torch.cuda.stream(side):
                 g_sat, flat_sat = vgg_backward_nhwc(model.SatFeatureNet, cs, d_sat, scale_invariant=inv, flat=True, dense=not trim,
-                                                    stats=getattr(model, 'bwd_stats', None))
+                                                    stats=getattr(model, 'bwd_stats', None), wgrad_two_phase=tp)
             for t in d_sat:
                 t.record_stream(side)
         else:
             g_sat, flat_sat = vgg_backward_nhwc(model.SatFeatureNet, cs, d_sat, scale_invariant=inv, flat=True, dense=not trim,
-                                                stats=getattr(model, 'bwd_stats', None))
+                                                stats=getattr(model, 'bwd_stats', None), wgrad_two_phase=tp)
         h1 = sync.start({'SatFeatureNet.' + k: v for k, v in g_sat.items()}, flat_sat) if sync else None
         use_w = model.using_weight and all(c is not None for c in d_conf)
         g_grd, flat_grd = vgg_backward_nhwc(model.GrdFeatureNet, cg, d_grd, grd_confs if use_w else None, d_conf if use_w else None,
-                                            scale_invariant=inv, first_row8=f8, flat=True, dense=not trim)
+                                            scale_invariant=inv, first_row8=f8, flat=True, dense=not trim, wgrad_two_phase=tp)
         h2 = sync.start({'GrdFeatureNet.' + k: v for k, v in g_grd.items()}, flat_grd) if sync else None
         if two:
             torch.cuda.current_stream().wait_stream(side)
@@ -648,6 +736,7 @@ class _LocaliseFn(torch.autograd.Function):
             if sync:
                 sync.finish(sync.start({'damping': grads['damping']}))
         ctx.state = None            # release the saved workspaces now, not when the loss tensor dies
+        _phase('vgg_bwd')
         return (None,) * 8 + tuple(grads.get(n) for n in ctx.names)
 
 

@@ -10,7 +10,7 @@ CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'libhla.so')
 # (source, HLA_TU_DTYPE): the conv-heavy files are compiled once per dtype (kernels) plus once as the dispatcher (-1)
 SOURCES = [('capi.hip', -1), ('prof.hip', -1), ('lm_solve.hip', -1), ('lm_backward.hip', -1), ('lm_g2s.hip', -1),
-           ('grid_sample.hip', -1), ('sat_tile.hip', -1), ('pose_loss.hip', -1)] + \
+           ('grid_sample.hip', -1), ('sat_tile.hip', -1), ('pose_loss.hip', -1), ('fill.hip', -1)] + \
           [(f, d) for f in ('vgg.hip', 'vgg_backward.hip') for d in (0, 1, 2, 3, -1)]
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=fast', '-munsafe-fp-atomics', '-Wno-unused-result']
 

@@ -32,6 +32,7 @@ extern "C" size_t hla_sizeof_struct(int id) {
     case HLA_STRUCT_S2G_LEVEL_GRAD: return sizeof(hla_s2g_level_grad);
     case HLA_STRUCT_PROF_RECORD: return sizeof(hla_prof_record);
     case HLA_STRUCT_POSE_LOSS_ARGS: return sizeof(hla_pose_loss_args);
+    case HLA_STRUCT_FILL_REGION: return sizeof(hla_fill_region);
     default: return 0;
   }
 }

@@ -41,7 +41,7 @@ struct HlaPerDeviceOnce {
   template <typename F> hipError_t run(F&& f) {
     int d = 0;
     (void)hipGetDevice(&d);
-    const unsigned long long bit = 1ull << (d & 63);
+    const unsigned long long bit = (d >= 0 && d < 64) ? 1ull << d : 0ull;      // (device ids >= 64: never remembered, f() is idempotent)
     if (mask.load(std::memory_order_acquire) & bit) return hipSuccess;
     const hipError_t e = f();
     if (e == hipSuccess) mask.fetch_or(bit, std::memory_order_release);

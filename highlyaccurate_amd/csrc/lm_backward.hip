@@ -11,8 +11,10 @@
 //                  d/d(sat) to the 4 taps with fp32 atomics, adds d/d(grd) in place, and reduces the adjoints
 //                  of the pixel coordinates / uv-Jacobians to 12 sums per tile.
 // Gradients are w.r.t. the L2-NORMALISED maps (inv_norm * stored map); hla_vgg_backward applies the
-// normalisation Jacobian.  d/d(sat) accumulation order is not deterministic (atomics).
+// normalisation Jacobian.  d/d(sat) accumulation order is not deterministic (fp32 atomics) unless cfg->deterministic, which
+// accumulates it in 64-bit fixed point (integer atomics commute: any order gives the same bits), see DetScale below.
 #include "lm_common.h"
+#include <math.h>
 
 int hla_s2g_validate(const char* who, const hla_s2g_config* cfg, const hla_s2g_level* lv, const float* R_FL,
                      const float* T_FL, int B);
@@ -31,7 +33,9 @@ struct BwdSolveArgs {
   double* gid;                // [B,3] identity-path adjoint carried between launches
   double* adj;                // [B,16] out
   double* coef;               // [B,COEF_N] out: forward coefficients of step k
-  double* d_lambda;           // [3] accumulated over samples and steps
+  double* dlam;               // [B,4] per-sample sums of d(loss)/d(lambda_i) over the steps (one wave per sample and step adds, in
+                              // step order: fixed order, no atomics) + [3]: deterministic mode's range-check counter; the
+                              // LAST accumulate launch adds them up over the samples in sample order (BwdAccumArgs::dlam_final)
   const float* R_FL; const float* T_FL;
   int B, reinit, first;       // first: this is the last forward step (nothing to close, gid is not read)
   // the ablation updaters (models_kitti.py:1056-1116): 1 SGD, 2 ADAM.  ADAM re-runs its moment recurrence from the saved
@@ -41,7 +45,52 @@ struct BwdSolveArgs {
   const double* neq_all;
   double* adam_adj;
   LmSolveCfg cfg; LmGeom geom;
+  // cfg->deterministic: the fixed-point exponent of this step's level and sample is chosen (q_first: the level's first visit of
+  // the reversed loop) or checked against this step's bound (DetScale)
+  int* qexp;                  // [B] of this step's level, or null
+  int q_first, A;             // A: side of this step's satellite map (bounds |d(uv)/d(theta)|)
+  // stand-alone launch only: zero this sample's tickets / ADAM adjoints / d_lambda sums (no memsets in front of the loop)
+  unsigned* zero_ticket; int zero_steps;
 };
+
+// cfg->deterministic.  Every tap contribution c to d(loss)/d(sat map) is added as the integer rint(c / q) with one power-of-two
+// quantum q per (level, sample), so the sum does not depend on the order of the atomics.  q comes from a rigorous bound of |c| in
+// the step that visits the level first: with unit-norm maps (|feature| <= 1, |feature difference| <= 2), the step's 14 sum
+// adjoints and jm_i = |d u/d pose_i| + |d v/d pose_i|,
+//   |J_i| <= 2 jm_i,  |gs| <= 2|gS| + 2 sum_i |gU_i| jm_i,  |gJ_i| <= 2 sum_j |A_ij| jm_j + |gU_i| + |gV_i|,
+//   |c| <= |gs| + 2 sum_i |gJ_i| jm_i  =: bound < 2^e,     q = 2^(e - DET_P).
+// A texel collects at most 2^13 contributions over all visits of its level (KITTI: <= 400 ground pixels per texel cell x 4 cells x
+// 5 visits), so |sum / q| < 2^(DET_P + 13) * (largest bound / first bound): with DET_P = 40 a later visit's bound may exceed the
+// first one's by 2^9 before the 63-bit range is at risk -- checked per step and sample (the same bound, so the check itself is
+// reproducible) and counted in d_damping[3], which the caller must find zero.  Typical contributions are ~2^-11 of the bound
+// (|feature| ~ 1 / sqrt(A A C)): they keep ~29 significant bits, more than the fp32 atomics' 24.
+#define DET_P 40
+__device__ static inline int det_bound_exp(const double* ad, const double* cf, int A) {
+  const double jm[3] = {fabs(cf[8]) + fabs(cf[9]), fabs(cf[10]) + fabs(cf[11]), 2.0 * fabs(cf[12]) * (double)A};
+  const double Am[3][3] = {{fabs(ad[2]), fabs(ad[3]), fabs(ad[4])}, {fabs(ad[3]), fabs(ad[5]), fabs(ad[6])}, {fabs(ad[4]), fabs(ad[6]), fabs(ad[7])}};
+  double gs = 2.0 * fabs(ad[0]), tail = 0.0;
+  for (int i = 0; i < 3; ++i) {
+    gs += 2.0 * fabs(ad[8 + i]) * jm[i];
+    double gJ = fabs(ad[8 + i]) + fabs(ad[11 + i]);
+    for (int j = 0; j < 3; ++j) gJ += 2.0 * Am[i][j] * jm[j];
+    tail += gJ * jm[i];
+  }
+  const double bound = gs + 2.0 * tail;
+  if (!(bound > 0.0) || !(bound < 1e300)) return bound > 0.0 ? 1000 : -100;       // zero adjoints / a diverged solve
+  const int e = ilogb(bound) + 1;
+  return e < -100 ? -100 : e;
+}
+
+__device__ static inline void det_scale(const BwdSolveArgs& a, int b, const double* ad, const double* cf) {
+  if (!a.qexp) return;
+  const int e = det_bound_exp(ad, cf, a.A);
+  if (a.q_first) {
+    int q = e - DET_P;
+    a.qexp[b] = q < -126 ? -126 : (q > 100 ? 100 : q);
+  } else if (e - DET_P > a.qexp[b] + 9) {
+    a.dlam[(size_t)b * 4 + 3] += 1.0;           // this step's contributions could leave the 63-bit range: reported, never silent
+  }
+}
 
 // One wave per sample.  COHERENT: the tile sums of the later step were written by OTHER workgroups of the same launch (the
 // accumulate kernel whose last-arriving tile of the sample closes with this solve): read them with agent-scope loads.
@@ -104,6 +153,7 @@ __device__ __forceinline__ void lm_bwd_solve_body(const BwdSolveArgs& a, int b, 
     for (int k = 0; k < 16; ++k) ad[k] = 0.0;
     for (int p = 0; p < 3; ++p) { ad[8 + p] = 2.0 * gg[p]; ad[11 + p] = -2.0 * gg[p]; }
     lm_coefficients(a.geom, pin[0], pin[1], pin[2], R, T, a.coef + (size_t)b * COEF_N);
+    det_scale(a, b, ad, a.coef + (size_t)b * COEF_N);
     return;
   }
   double H[3][3], g[3], Mi[3][3], d[3], ns, ng;
@@ -125,7 +175,7 @@ __device__ __forceinline__ void lm_bwd_solve_body(const BwdSolveArgs& a, int b, 
   for (int i = 0; i < nl; ++i) {
     const int p = a.cfg.dof == 1 ? 2 : i;
     const double gM = gH[p][p];
-    if (!a.cfg.gn) atomicAdd(a.d_lambda + i, gM * (a.cfg.use_hessian ? H[p][p] : 1.0));     // GN_update has no damping
+    if (!a.cfg.gn) a.dlam[(size_t)b * 4 + i] += gM * (a.cfg.use_hessian ? H[p][p] : 1.0);     // GN_update has no damping
     if (a.cfg.use_hessian) gH[p][p] += a.cfg.lam[i] * gM;
   }
   const double is2 = 1.0 / (ns * ns), isg = 1.0 / (ns * ng);
@@ -146,10 +196,21 @@ __device__ __forceinline__ void lm_bwd_solve_body(const BwdSolveArgs& a, int b, 
   for (int p = 0; p < 3; ++p) { ad[8 + p] = is2 * y[p]; ad[11 + p] = -isg * y[p]; }
   ad[14] = ad[15] = 0.0;
   lm_coefficients(a.geom, pin[0], pin[1], pin[2], R, T, a.coef + (size_t)b * COEF_N);
+  det_scale(a, b, ad, a.coef + (size_t)b * COEF_N);
 }
 
 // stand-alone launch: the last forward step (nothing to close before it)
-__global__ __launch_bounds__(64) void lm_bwd_solve(BwdSolveArgs a) { lm_bwd_solve_body<false>(a, blockIdx.x, threadIdx.x); }
+__global__ __launch_bounds__(64) void lm_bwd_solve(BwdSolveArgs a) {
+  const int b = blockIdx.x, lane = threadIdx.x;
+  // the per-sample state of the whole reversed loop starts here: arrival tickets of every step, ADAM's moment adjoints, the
+  // d_lambda sums (three hipMemsetAsync launches in front of the loop until round 6)
+  for (int k = lane; k < a.zero_steps; k += 64) a.zero_ticket[(size_t)k * a.B + b] = 0u;
+  if (lane < 6 && a.adam_adj) a.adam_adj[(size_t)b * 6 + lane] = 0.0;
+  if (lane < 4) a.dlam[(size_t)b * 4 + lane] = 0.0;
+  __builtin_amdgcn_s_waitcnt(0);          // (lane 0 adds to its own zeroes below: same lane, program order)
+  __syncthreads();
+  lm_bwd_solve_body<false>(a, b, lane);
+}
 
 
 #ifndef BWD_MAX_TP
@@ -169,9 +230,13 @@ struct BwdAccumArgs {
   unsigned* ticket;   // [B] arrival counters of this step (zeroed before the loop): the LAST tile of a sample closes with the
                       // solve of the step before (sa), or null: no closing
   int grd_assign;     // 1: d_grd rows row0.. are OVERWRITTEN by this launch (the first visit of the level: no zero-fill, no read), 0: added to
+  // cfg->deterministic (DET instantiation): d(loss)/d(sat) goes to `d_sat_fix` as integers of the per-sample quantum 2^qexp[b]
+  long long* d_sat_fix; const int* qexp;
+  // the LAST launch of the reversed loop (step 0) only: add the per-sample d_lambda sums up in sample order -> d_damping[4]
+  const double* dlam_final; double* d_damping_out;
 };
 
-template <int C, bool USE_W>
+template <int C, bool USE_W, bool DET = false>
 __global__ __launch_bounds__(256, USE_W ? 3 : 4) void lm_bwd_accum(BwdAccumArgs a, BwdSolveArgs sa) {
   __shared__ PixParam pp[BWD_MAX_TP];
   __shared__ float pxyz[BWD_MAX_TP][3];   // the pixel's ground-plane point (the coefficient adjoints weight by it)
@@ -180,6 +245,11 @@ __global__ __launch_bounds__(256, USE_W ? 3 : 4) void lm_bwd_accum(BwdAccumArgs 
   int b, tile;
   if (!lm_block_map(a.xcd_affine, a.nt, a.B, b, tile)) return;
   const int t = threadIdx.x;
+  if (a.dlam_final && b == 0 && tile == 0 && t < 4) {      // (step 0's launch: every sample's last solve ran in the launch before)
+    double sum = 0.0;
+    for (int bb = 0; bb < a.B; ++bb) sum += a.dlam_final[(size_t)bb * 4 + t];
+    a.d_damping_out[t] = sum;
+  }
   const int p0 = tile * a.TP;
   const int np = min(a.TP, a.npix - p0);
   const double* cf = a.coef + (size_t)b * COEF_N;
@@ -236,15 +306,26 @@ __global__ __launch_bounds__(256, USE_W ? 3 : 4) void lm_bwd_accum(BwdAccumArgs 
   typedef float f2 __attribute__((ext_vector_type(2)));
   f2 c00[2] = {f2{0.f, 0.f}, f2{0.f, 0.f}}, c01[2] = {f2{0.f, 0.f}, f2{0.f, 0.f}}, c10[2] = {f2{0.f, 0.f}, f2{0.f, 0.f}},
      c11[2] = {f2{0.f, 0.f}, f2{0.f, 0.f}};
+  // DET: 1 / quantum of this sample (a power of two: the product below is exact, one rounding to the nearest integer)
+  float qinv = 1.f;
+  unsigned long long* dfix_u = nullptr;
+  if constexpr (DET) {
+    qinv = uni(ldexpf(1.f, -a.qexp[b]));
+    dfix_u = (unsigned long long*)a.d_sat_fix + (size_t)b * a.A * a.A * C;
+  }
+  auto add1 = [&](int off, float v) __attribute__((always_inline)) {
+    if constexpr (DET) atomicAdd(dfix_u + off, (unsigned long long)__float2ll_rn(v * qinv));      // two's complement: order-free
+    else atomicAdd(dsat_u + off, v);
+  };
   auto flush_cell = [&]() {
     if (cur_off >= 0) {
-      float* dp = dsat_u + (cur_off + cl);
+      const int o = cur_off + cl;
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
-        atomicAdd(dp + (2 * h) * LPP, c00[h].x); atomicAdd(dp + (2 * h + 1) * LPP, c00[h].y);
-        atomicAdd(dp + cur_dxo + (2 * h) * LPP, c01[h].x); atomicAdd(dp + cur_dxo + (2 * h + 1) * LPP, c01[h].y);
-        atomicAdd(dp + cur_dyo + (2 * h) * LPP, c10[h].x); atomicAdd(dp + cur_dyo + (2 * h + 1) * LPP, c10[h].y);
-        atomicAdd(dp + cur_dyo + cur_dxo + (2 * h) * LPP, c11[h].x); atomicAdd(dp + cur_dyo + cur_dxo + (2 * h + 1) * LPP, c11[h].y);
+        add1(o + (2 * h) * LPP, c00[h].x); add1(o + (2 * h + 1) * LPP, c00[h].y);
+        add1(o + cur_dxo + (2 * h) * LPP, c01[h].x); add1(o + cur_dxo + (2 * h + 1) * LPP, c01[h].y);
+        add1(o + cur_dyo + (2 * h) * LPP, c10[h].x); add1(o + cur_dyo + (2 * h + 1) * LPP, c10[h].y);
+        add1(o + cur_dyo + cur_dxo + (2 * h) * LPP, c11[h].x); add1(o + cur_dyo + cur_dxo + (2 * h + 1) * LPP, c11[h].y);
       }
     }
   };
@@ -351,10 +432,7 @@ __global__ __launch_bounds__(256, USE_W ? 3 : 4) void lm_bwd_accum(BwdAccumArgs 
   // step instead of two.  Same publication recipe as the forward (lm_solve.hip): agent-scope stores of the sums -> vmcnt(0) ->
   // relaxed agent-scope ticket; the closing wave reads with agent-scope loads and overwrites this sample's adj / coef, which
   // every other tile of the sample has finished reading (they drew their tickets).  The sums are added in tile order whoever closes.
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  unsigned old = 0;
-  if (lane == 0) old = __hip_atomic_fetch_add(a.ticket + b, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  old = __builtin_amdgcn_readfirstlane(old);
+  const unsigned old = lm_draw_ticket(a.ticket + b, lane);      // (lm_common.h)
   if (old + 1 != (unsigned)a.nt) return;
   lm_bwd_solve_body<true>(sa, b, lane);
 }
@@ -373,7 +451,9 @@ __global__ __launch_bounds__(256, USE_W ? 3 : 4) void lm_bwd_accum(BwdAccumArgs 
 static inline int lm_pick_tile_bwd(int npix) { return npix >= 16384 ? HLA_LMB_TP0 : (npix >= 4096 ? HLA_LMB_TP1 : HLA_LMB_TP2); }
 
 // ---------------------------------------------------------------------------------------------
-static size_t bwd_layout(const hla_s2g_config* cfg, const hla_s2g_level* lv, int B, size_t off[6]) {
+// off[0..5]: coef, adj, gid, part, ADAM adjoints, tickets; off[6]: dlam [B,4]; off[7]: qexp [L,B]; off[8 + l]: level l's 64-bit
+// fixed-point d(loss)/d(sat) accumulators (cfg->deterministic only)
+static size_t bwd_layout(const hla_s2g_config* cfg, const hla_s2g_level* lv, int B, size_t off[12]) {
   int max_nt = 1;
   for (int l = 0; l < cfg->n_levels; ++l) {
     const int npix = (lv[l].h - lv[l].row0) * lv[l].w;
@@ -387,21 +467,42 @@ static size_t bwd_layout(const hla_s2g_config* cfg, const hla_s2g_level* lv, int
   off[3] = o; o += hla_align_up((size_t)B * max_nt * PART_N * sizeof(double), 256); // part
   off[4] = o; o += hla_align_up((size_t)B * 6 * sizeof(double), 256);               // ADAM moment adjoints
   off[5] = o; o += hla_align_up((size_t)B * cfg->n_levels * cfg->n_iters * sizeof(unsigned), 256);   // arrival tickets [steps][B]
+  off[6] = o; o += hla_align_up((size_t)B * 4 * sizeof(double), 256);               // per-sample d_lambda sums + range counter
+  off[7] = o; o += hla_align_up((size_t)B * 4 * sizeof(int), 256);                  // fixed-point exponents [4 levels][B]
+  for (int l = 0; l < 4; ++l) {
+    off[8 + l] = o;
+    if (cfg->deterministic && l < cfg->n_levels) o += hla_align_up((size_t)B * lv[l].A * lv[l].A * lv[l].C * sizeof(long long), 256);
+  }
   return o;
 }
 
 extern "C" size_t hla_s2g_bwd_workspace_bytes(const hla_s2g_config* cfg, const hla_s2g_level* levels, int B) {
-  size_t off[6];
+  size_t off[12];
   return bwd_layout(cfg, levels, B, off);
 }
 
-template <bool W>
+// cfg->deterministic: the fixed-point sums -> the caller's fp32 d_sat_feat buffers (every element written: no zero-fill needed there)
+struct DetConvertArgs { const long long* fix[4]; float* out[4]; const int* qexp; size_t per[4]; int B; };
+static __global__ __launch_bounds__(256) void det_convert_kernel(DetConvertArgs a) {
+  const int l = blockIdx.z, b = blockIdx.y;
+  const double q = ldexp(1.0, a.qexp[(size_t)l * a.B + b]);
+  const long long* src = a.fix[l] + (size_t)b * a.per[l];
+  float* dst = a.out[l] + (size_t)b * a.per[l];
+  typedef long long ll2 __attribute__((ext_vector_type(2)));
+  const size_t n4 = a.per[l] / 4;                       // (C is a multiple of 16)
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+    const ll2 v0 = ((const ll2*)src)[2 * i], v1 = ((const ll2*)src)[2 * i + 1];
+    ((float4*)dst)[i] = make_float4((float)((double)v0.x * q), (float)((double)v0.y * q), (float)((double)v1.x * q), (float)((double)v1.y * q));
+  }
+}
+
+template <bool W, bool DET>
 static void launch_bwd_accum(int C, dim3 grid, hipStream_t st, const BwdAccumArgs& a, const BwdSolveArgs& sa) {
   switch (C) {
-    case 256: hipLaunchKernelGGL((lm_bwd_accum<256, W>), grid, dim3(256), 0, st, a, sa); break;
-    case 128: hipLaunchKernelGGL((lm_bwd_accum<128, W>), grid, dim3(256), 0, st, a, sa); break;
-    case 64: hipLaunchKernelGGL((lm_bwd_accum<64, W>), grid, dim3(256), 0, st, a, sa); break;
-    case 16: hipLaunchKernelGGL((lm_bwd_accum<16, W>), grid, dim3(256), 0, st, a, sa); break;
+    case 256: hipLaunchKernelGGL((lm_bwd_accum<256, W, DET>), grid, dim3(256), 0, st, a, sa); break;
+    case 128: hipLaunchKernelGGL((lm_bwd_accum<128, W, DET>), grid, dim3(256), 0, st, a, sa); break;
+    case 64: hipLaunchKernelGGL((lm_bwd_accum<64, W, DET>), grid, dim3(256), 0, st, a, sa); break;
+    case 16: hipLaunchKernelGGL((lm_bwd_accum<16, W, DET>), grid, dim3(256), 0, st, a, sa); break;
   }
 }
 
@@ -417,7 +518,7 @@ extern "C" int hla_s2g_lm_solve_bwd(const hla_s2g_config* cfg, const hla_s2g_lev
     HLA_REQUIRE(gr[l].d_sat_feat && gr[l].d_grd_feat, "hla_s2g_lm_solve_bwd: level %d gradient buffers missing", l);
     HLA_REQUIRE(lv[l].feat_dtype == HLA_F32, "hla_s2g_lm_solve_bwd: level %d: the backward needs fp32 feature maps", l);
   }
-  size_t off[6];
+  size_t off[12];
   const size_t need = bwd_layout(cfg, lv, B, off);
   if (workspace_bytes < need) {
     hla_set_error("hla_s2g_lm_solve_bwd: workspace %zu < %zu", workspace_bytes, need);
@@ -429,10 +530,17 @@ extern "C" int hla_s2g_lm_solve_bwd(const hla_s2g_config* cfg, const hla_s2g_lev
   double* adj = (double*)(ws + off[1]);
   double* gid = (double*)(ws + off[2]);
   double* part = (double*)(ws + off[3]);
-  HLA_CHECK_HIP(hipMemsetAsync(d_damping, 0, 3 * sizeof(double), st));
+  // (tickets, ADAM adjoints and the d_lambda sums are zeroed by the first launch, lm_bwd_solve: no memset launches here)
   double* adam_adj = (double*)(ws + off[4]);
-  if (cfg->optimizer == 2) HLA_CHECK_HIP(hipMemsetAsync(adam_adj, 0, (size_t)B * 6 * sizeof(double), st));
   unsigned* tickets = (unsigned*)(ws + off[5]);
+  double* dlam = (double*)(ws + off[6]);
+  int* qexp = (int*)(ws + off[7]);
+  const bool det = cfg->deterministic != 0;
+  HLA_REQUIRE(cfg->n_levels <= 4, "hla_s2g_lm_solve_bwd: at most 4 levels");
+  if (det) {      // the fixed-point accumulators of all levels are one contiguous region
+    const size_t bytes = need - off[8];
+    HLA_CHECK_HIP(hipMemsetAsync(ws + off[8], 0, bytes, st));
+  }
 
   const bool newton = cfg->optimizer == 0 || cfg->optimizer == 3;
   const bool reinit = (cfg->ford || cfg->dof == 3) && newton;
@@ -450,7 +558,6 @@ extern "C" int hla_s2g_lm_solve_bwd(const hla_s2g_config* cfg, const hla_s2g_lev
   // One launch per step: lm_bwd_accum(k), whose last-arriving tile of every sample closes with the solve of step k - 1 (the
   // pose adjoint pulled back through step k's coefficients, step k - 1's damped system re-solved -> its 14 sum adjoints).  Only
   // the solve of the LAST forward step, which has nothing to close, is a launch of its own.
-  HLA_CHECK_HIP(hipMemsetAsync(tickets, 0, (size_t)B * L * N * sizeof(unsigned), st));
   auto nt_of = [&](int l) {
     const int npix = (lv[l].h - lv[l].row0) * lv[l].w;
     const int tp = lm_pick_tile_bwd(npix);
@@ -465,7 +572,12 @@ extern "C" int hla_s2g_lm_solve_bwd(const hla_s2g_config* cfg, const hla_s2g_lev
     if (k > 0) { sa.pose_in = trace + slot(k - 1); sa.pose_in_stride = tstride; }
     else { sa.pose_in = pose0; sa.pose_in_stride = 3; }
     sa.pose_out = trace + slot(k); sa.d_trace = d_trace + slot(k); sa.trace_stride = tstride;
-    sa.gid = gid; sa.adj = adj; sa.coef = coef; sa.d_lambda = d_damping;
+    sa.gid = gid; sa.adj = adj; sa.coef = coef; sa.dlam = dlam;
+    if (det) {       // is step k the first visit of its level in the reversed loop?
+      bool first_visit = true;
+      for (int j = k + 1; j < steps; ++j) if (step_level(j) == l) first_visit = false;
+      sa.qexp = qexp + (size_t)l * B; sa.q_first = first_visit ? 1 : 0; sa.A = lv[l].A;
+    }
     sa.R_FL = R_FL; sa.T_FL = T_FL; sa.B = B; sa.reinit = reinit ? 1 : 0;
     sa.cfg.gn = cfg->optimizer == 3 ? 1 : 0;
     sa.cfg.dof = cfg->dof; sa.cfg.use_hessian = sa.cfg.gn ? 0 : cfg->use_hessian;
@@ -476,7 +588,8 @@ extern "C" int hla_s2g_lm_solve_bwd(const hla_s2g_config* cfg, const hla_s2g_lev
     return sa;
   };
   {
-    const BwdSolveArgs sa = solve_args(steps - 1);
+    BwdSolveArgs sa = solve_args(steps - 1);
+    sa.zero_ticket = tickets; sa.zero_steps = steps;
     hla_prof_begin(K_LMSOLVE, 0, 0, st);
     hipLaunchKernelGGL(lm_bwd_solve, dim3(B), dim3(64), 0, st, sa);
     hla_prof_end(st);
@@ -499,10 +612,28 @@ extern "C" int hla_s2g_lm_solve_bwd(const hla_s2g_config* cfg, const hla_s2g_lev
     // step 0 has no earlier step to solve for: no ticket, no closing
     aa.ticket = k > 0 ? tickets + (size_t)k * B : nullptr;
     const BwdSolveArgs sa = k > 0 ? solve_args(k - 1) : BwdSolveArgs{};
+    if (det) { aa.d_sat_fix = (long long*)(ws + off[8 + l]); aa.qexp = qexp + (size_t)l * B; }
+    if (k == 0) { aa.dlam_final = dlam; aa.d_damping_out = d_damping; }
     const int nblk = aa.xcd_affine ? 8 * ((B + 7) / 8) * aa.nt : B * aa.nt;
     hla_prof_begin(K_LMBWD, 0, (double)B * (5.0 * (double)v.A * v.A + 3.0 * (double)aa.npix) * v.C * 4.0, st);
-    if (cfg->using_weight && newton) launch_bwd_accum<true>(v.C, dim3(nblk), st, aa, sa);
-    else launch_bwd_accum<false>(v.C, dim3(nblk), st, aa, sa);
+    const bool w = cfg->using_weight && newton;
+    if (det) { if (w) launch_bwd_accum<true, true>(v.C, dim3(nblk), st, aa, sa); else launch_bwd_accum<false, true>(v.C, dim3(nblk), st, aa, sa); }
+    else { if (w) launch_bwd_accum<true, false>(v.C, dim3(nblk), st, aa, sa); else launch_bwd_accum<false, false>(v.C, dim3(nblk), st, aa, sa); }
+    hla_prof_end(st);
+  }
+  if (det) {
+    DetConvertArgs ca{};
+    size_t maxper = 0;
+    for (int l = 0; l < L; ++l) {
+      ca.fix[l] = (const long long*)(ws + off[8 + l]); ca.out[l] = gr[l].d_sat_feat;
+      ca.per[l] = (size_t)lv[l].A * lv[l].A * lv[l].C;
+      maxper = ca.per[l] > maxper ? ca.per[l] : maxper;
+    }
+    ca.qexp = qexp; ca.B = B;
+    int gx = (int)((maxper / 4 + 255) / 256);
+    gx = gx > 256 ? 256 : (gx < 1 ? 1 : gx);
+    hla_prof_begin(K_ELEMWISE, 0, 0, st);
+    hipLaunchKernelGGL(det_convert_kernel, dim3(gx, B, L), dim3(256), 0, st, ca);
     hla_prof_end(st);
   }
   HLA_CHECK_HIP(hipGetLastError());

@@ -22,6 +22,30 @@ static inline int lm_pick_tile(int npix) {
   return 64;
 }
 
+// Arrival ticket of the fused accumulate + closing-solve kernels: a tile publishes its sums (8-byte agent-scope `sc1` stores,
+// which write through this XCD's L2) and draws a ticket; the LAST arriver of a sample reads every tile's sums with agent-scope
+// loads (they bypass its CU's L1 and its XCD's L2) and closes the step.
+//   HLA_LM_FORMAL_FENCE = 0 (shipped): s_waitcnt vmcnt(0) -- the sc1 stores have been acknowledged by memory -- then a RELAXED
+//     agent-scope ticket; the asm's "memory" clobber keeps the compiler from moving anything across it.  This is the write-through
+//     recipe of cdna_hip_programming.md (guideline 16); it relies on the gfx942 / gfx950 meaning of sc1 on stores and loads.
+//   HLA_LM_FORMAL_FENCE = 1: the ticket is an ACQ_REL agent-scope atomic, i.e. what the language memory model asks for.  On gfx950
+//     that is `buffer_wbl2 sc1` (write back EVERY dirty line of this XCD's L2 -- the d_sat atomics and d_grd stores of the whole
+//     XCD, not just this tile's sums) before the ticket and `buffer_inv sc1` behind it, per tile.  Kept as a same-box A/B switch
+//     (EXPERIMENTS.md round 6); tests and fuzz pass either way.
+#ifndef HLA_LM_FORMAL_FENCE
+#define HLA_LM_FORMAL_FENCE 0
+#endif
+__device__ __forceinline__ unsigned lm_draw_ticket(unsigned* ticket, int lane) {
+  unsigned old = 0;
+#if HLA_LM_FORMAL_FENCE
+  if (lane == 0) old = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+#else
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the partials have left this CU before the ticket is drawn
+  if (lane == 0) old = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+  return (unsigned)__builtin_amdgcn_readfirstlane((int)old);
+}
+
 // block -> (sample, tile).  With >= 8 samples keep every tile of a sample on one XCD (blocks are dealt
 // round-robin to the 8 XCDs) so its satellite map stays in that XCD's L2.  Returns false for idle blocks.
 __device__ __forceinline__ bool lm_block_map(int xcd_affine, int nt, int B, int& b, int& tile) {

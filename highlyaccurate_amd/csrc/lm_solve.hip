@@ -285,10 +285,7 @@ __global__ __launch_bounds__(256, LM_OCC) void lm_accum(AccumArgs a, SolveArgs s
     }
     __hip_atomic_store(a.part + ((size_t)b * a.nt + tile) * PART_N + t, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the partials have left this CU before the ticket is drawn
-  unsigned old = 0;
-  if (lane == 0) old = __hip_atomic_fetch_add(a.ticket + b, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  old = __builtin_amdgcn_readfirstlane(old);
+  const unsigned old = lm_draw_ticket(a.ticket + b, lane);      // (publication recipe: lm_common.h)
   if (old + 1 != (unsigned)a.nt) return;
   lm_solve_body<true>(sa, b, lane);
 }

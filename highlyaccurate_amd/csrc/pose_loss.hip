@@ -87,7 +87,8 @@ __global__ __launch_bounds__(256) void pose_loss_bwd_kernel(PoseLossArgs a) {
     const OT gk = (gl * (OT)a.coe[k] + gd) / (OT)a.B;      // ... * coe, then mean(dim=0) backward: / B
     const float xv = a.x[k][(long long)b * a.sB[k] + (long long)n * a.sN[k] + (long long)l * a.sL[k]];
     const OT v = (OT)xv - ((const OT*)a.gt[k])[(long long)b * a.sG[k]];
-    const OT sg = v > (OT)0 ? (OT)1 : (v < (OT)0 ? (OT)-1 : (OT)0);      // abs backward: grad * sign(x), 0 at 0
+    // abs backward: grad * sign(x), 0 at 0; a NaN pose (a diverged solve) gives a NaN gradient, like torch's sgn
+    const OT sg = v != v ? v : (v > (OT)0 ? (OT)1 : (v < (OT)0 ? (OT)-1 : (OT)0));
     a.dx[k][(long long)b * a.dB[k] + (long long)n * a.dN[k] + (long long)l * a.dL[k]] = (float)(gk * sg);
   }
 }

@@ -6,6 +6,12 @@
 #ifndef HLA_VGG_CHUNK_DEFAULT
 #define HLA_VGG_CHUNK_DEFAULT 0      // 0: whole batch per launch
 #endif
+// Timing-only switches that are read from the environment (HLA_VGG_CHUNK, HLA_ABL_C02) exist in TOOLING builds only
+// (`python -m highlyaccurate_amd.build --out=libhla_abl.so -DHLA_ABLATIONS=1`, selected with HLA_LIB): the product library reads no
+// environment variable on its compute path (HLA_ABL_C02 leaves the backward's relu(conv0) / argmax buffers unwritten).
+#ifndef HLA_ABLATIONS
+#define HLA_ABLATIONS 0
+#endif
 
 template <typename T>
 void vgg_pack_all(const hla_vgg_params* prm, char* packed, int dtype, hipStream_t st) {
@@ -45,10 +51,14 @@ void vgg_pack_all(const hla_vgg_params* prm, char* packed, int dtype, hipStream_
   }
 }
 
-// Samples per launch of the full- / half-resolution layers (see vgg_forward_t).  HLA_VGG_CHUNK=n overrides (tooling: same-box A/B).
+// Samples per launch of the full- / half-resolution layers (see vgg_forward_t).  Tooling builds (HLA_ABLATIONS): HLA_VGG_CHUNK=n overrides.
 static int vgg_chunk(int B, int H, int W, size_t es) {
+#if HLA_ABLATIONS
   static const int env = [] { const char* e = getenv("HLA_VGG_CHUNK"); return e ? atoi(e) : -1; }();
   int c = env >= 0 ? env : HLA_VGG_CHUNK_DEFAULT;
+#else
+  int c = HLA_VGG_CHUNK_DEFAULT;
+#endif
   (void)H; (void)W; (void)es;
   if (c <= 0 || c > B) c = B;
   return c;
@@ -80,11 +90,13 @@ int vgg_forward_t(const float* x, size_t x_plane, const hla_vgg_params* prm, con
     }
     if (level4) a.a2_out = w + pl.x2r + (size_t)b0 * px * 64 * es;
     auto AMb = [&](int slot) { unsigned* p = AM(slot); return p ? p + b0 : p; };
+#if HLA_ABLATIONS
     {      // timing-only ablations (tools/probes/conv02_probe.py): HLA_ABL_C02 bit 0 = no relu(conv0) copy, bit 1 = no pool argmax
       static const int abl = [] { const char* e = getenv("HLA_ABL_C02"); return e ? atoi(e) : 0; }();
       if (abl & 1) a.a0_out = nullptr;
       if (abl & 2) a.idx_out = nullptr;
     }
+#endif
     a.wtail = wtail; a.amax_out = AMb(AM_X3); a.amax_a2_out = level4 ? AMb(AM_X2) : nullptr;
     a.amax_a0_out = (flags & HLA_VGG_SAVE_FOR_BACKWARD) ? AMb(AM_A0) : nullptr;
     // (first_row8, see below: x3 is needed from row 4f-16 on = conv2 row 8f-32)

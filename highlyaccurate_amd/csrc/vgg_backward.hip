@@ -1635,7 +1635,12 @@ enum { GA_X21 = 0, GA_D2A, GA_X18, GA_X3P, GA_D1A, GA_X15, GA_X8P, GA_A12, GA_A1
        GA_X2P, GA_C2, kGradAmaxSlots = 24 };
 
 static std::atomic<unsigned long long> g_wgrad_dma_ok{0};     // per device: wgrad_dma_kernel's LDS request was accepted
-static std::atomic<unsigned long long> g_wgrad_ws_ok{0};      // per device: wgrad_split_ws_kernel's LDS request was accepted
+// per device (bit = device id; ids >= 64 never set a bit and take the fallback kernels): the wave-specialised weight-gradient
+// kernel's LDS request was accepted.  One word per kernel -- wgrad_split_ws_kernel asks for 115 KB, wgrad_ws_kernel<T> for 96 KB:
+// a device or partition mode may grant one and refuse the other.
+static std::atomic<unsigned long long> g_wgrad_split_ws_ok{0};
+static std::atomic<unsigned long long> g_wgrad_ws_ok{0};
+static inline unsigned long long dev_bit(int d) { return (d >= 0 && d < 64) ? 1ull << d : 0ull; }
 static int wgrad_ksplit(int Cout, int Cin, int ntile, int resident = 512) {
   const int pairs = (Cout / 64) * (Cin / 64);
   int ks = resident / (pairs > 0 ? pairs : 1);     // 512 workgroups = one resident generation (2 per CU)
@@ -1733,7 +1738,7 @@ int vgg_backward_t(const float* x, size_t x_plane, const hla_vgg_params* prm, co
         int d = 0;
         (void)hipGetDevice(&d);
         const bool ok = hipFuncSetAttribute((const void*)wgrad_split_ws_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, wgs_ws_lds_bytes()) == hipSuccess;
-        if (ok) g_wgrad_ws_ok.fetch_or(1ull << (d & 63)); else (void)hipGetLastError();
+        if (ok) g_wgrad_split_ws_ok.fetch_or(dev_bit(d)); else (void)hipGetLastError();
       }
       return hipFuncSetAttribute((const void*)wgrad_split_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, wgs_lds_bytes());
     }
@@ -1742,13 +1747,13 @@ int vgg_backward_t(const float* x, size_t x_plane, const hla_vgg_params* prm, co
         int d = 0;                                          // the plain launches fall back to wgrad_kernel<T>
         (void)hipGetDevice(&d);
         const bool ok = hipFuncSetAttribute((const void*)wgrad_dma_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, wgd_lds_bytes()) == hipSuccess;
-        if (ok) g_wgrad_dma_ok.fetch_or(1ull << (d & 63)); else (void)hipGetLastError();
+        if (ok) g_wgrad_dma_ok.fetch_or(dev_bit(d)); else (void)hipGetLastError();
       }
       if constexpr (sizeof(T) == 2 && HLA_WGRAD_WS) {      // 96 KB of dynamic LDS: refused -> the launches fall back (g_wgrad_ws_ok)
         int d = 0;
         (void)hipGetDevice(&d);
         const bool ok = hipFuncSetAttribute((const void*)wgrad_ws_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, wg_ws_lds_bytes<T>()) == hipSuccess;
-        if (ok) g_wgrad_ws_ok.fetch_or(1ull << (d & 63)); else (void)hipGetLastError();
+        if (ok) g_wgrad_ws_ok.fetch_or(dev_bit(d)); else (void)hipGetLastError();
       }
       return hipFuncSetAttribute((const void*)wgrad_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, wg_lds_bytes<T>());
     }
@@ -1905,12 +1910,13 @@ int vgg_backward_t(const float* x, size_t x_plane, const hla_vgg_params* prm, co
     {
       int d = 0;
       (void)hipGetDevice(&d);
-      dma_ok = (g_wgrad_dma_ok.load() >> (d & 63)) & 1;
+      dma_ok = (g_wgrad_dma_ok.load() & dev_bit(d)) != 0;
     }
     if constexpr (SPLIT || (sizeof(T) == 2 && HLA_WGRAD_WS)) {      // wave-specialised kernels: one 8-wave workgroup per CU -> 256
       int d = 0;                                                    // workgroups are one resident generation
       (void)hipGetDevice(&d);
-      ws = (SPLIT ? HLA_WGRAD_SPLIT_WS : HLA_WGRAD_WS) && (g_wgrad_ws_ok.load() >> (d & 63) & 1) && !getenv("HLA_WGRAD_NO_WS");
+      ws = (SPLIT ? HLA_WGRAD_SPLIT_WS : HLA_WGRAD_WS) && ((SPLIT ? g_wgrad_split_ws_ok : g_wgrad_ws_ok).load() & dev_bit(d)) != 0 &&
+           !(flags & HLA_VGG_BWD_WGRAD_TWO_PHASE);
       if (ws) a.KS = wgrad_ksplit(a.Cout, a.Cin, a.ntile, 256);
     }
     a.part = (float*)(bw + bp.part);

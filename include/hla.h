@@ -61,12 +61,12 @@ const char* hla_last_error(void);
  * with its own struct sizes (ctypes structs are positional: a mismatch corrupts silently).  highlyaccurate_amd/_lib.py
  * does both at load time, and rebuilds or refuses a binary whose hla_source_hash() is not the hash of the sources
  * next to it (the library is git-ignored but shipped prebuilt). */
-#define HLA_ABI_VERSION 20
+#define HLA_ABI_VERSION 21
 int hla_abi_version(void);
 const char* hla_source_hash(void); /* sha256 (hex) of the csrc sources, this header and the compiler flags at build time */
 typedef enum hla_struct_id {
   HLA_STRUCT_VGG_PARAMS = 0, HLA_STRUCT_VGG_GRADS = 1, HLA_STRUCT_S2G_LEVEL = 2, HLA_STRUCT_S2G_CONFIG = 3,
-  HLA_STRUCT_S2G_LEVEL_GRAD = 4, HLA_STRUCT_PROF_RECORD = 5, HLA_STRUCT_POSE_LOSS_ARGS = 6
+  HLA_STRUCT_S2G_LEVEL_GRAD = 4, HLA_STRUCT_PROF_RECORD = 5, HLA_STRUCT_POSE_LOSS_ARGS = 6, HLA_STRUCT_FILL_REGION = 7
 } hla_struct_id;
 size_t hla_sizeof_struct(int id);  /* sizeof of the struct with that hla_struct_id, 0 for an unknown id */
 
@@ -173,6 +173,9 @@ size_t hla_vgg_bwd_workspace_bytes(int B, int H, int W, int level, int dtype);
  *                  ignored (0) otherwise and at level 4. */
 #define HLA_VGG_BWD_SCALE_INVARIANT 1
 #define HLA_VGG_BWD_DENSE 2           /* visit every tile even where the incoming gradient is exactly zero (A/B and tests) */
+#define HLA_VGG_BWD_WGRAD_TWO_PHASE 4 /* weight gradients on the two-phase kernels (512 workgroups, what a device that refuses the
+                                         wave-specialised kernels' 96-115 KB LDS request runs) instead of the wave-specialised
+                                         ones: the same products in another split-K grouping (A/B and tests) */
 int hla_vgg_backward(const float* x, size_t x_plane, const hla_vgg_params* params, const void* packed_weights_T,
                      const void* fwd_workspace, const float* const feat[4], const double* inv_norm,
                      const float* const d_feat[4], const float* const conf[4], const float* const d_conf[4],
@@ -267,6 +270,13 @@ typedef struct hla_s2g_config {
   int grd_grad_overwrite; /* hla_s2g_lm_solve_bwd only.  != 0: rows row0..h-1 of every level's d_grd_feat are WRITTEN, not added to
                              (the level's first visit of the reversed loop stores, the later ones add): the caller need not
                              zero-fill those rows (rows above row0 are never touched either way).  0: accumulate into the buffer */
+  int deterministic;      /* hla_s2g_lm_solve_bwd only.  0: d(loss)/d(sat map) is scattered with fp32 atomics (their order, and with it
+                             the last bits of every gradient behind it, varies from run to run).  != 0: it is accumulated in 64-bit
+                             fixed point in the workspace (integer atomics commute) and written -- every element, no zero-fill needed --
+                             to d_sat_feat by a closing pass: the same inputs give bitwise the same gradients.  The quantum is a
+                             power of two per (level, sample) taken from a bound of that sample's contributions; d_damping[3]
+                             counts the (step, sample) pairs whose bound outgrew the 63-bit range (must be 0).  Costs 8 B per
+                             satellite-map element of workspace, its memset and the closing pass */
 } hla_s2g_config;
 
 size_t hla_s2g_workspace_bytes(const hla_s2g_config* cfg, const hla_s2g_level* levels, int B);
@@ -285,7 +295,8 @@ int hla_s2g_lm_solve(const hla_s2g_config* cfg, const hla_s2g_level* levels, con
  * Backward of the LM pose loop (what autograd does in the reference through models_kitti.py:1176-1283,
  * SURVEY Appendix C): d(loss)/d(trace) -> d(loss)/d(feature maps).  Gradients are taken w.r.t. the
  * L2-NORMALISED maps (inv_norm * stored map when the level carries inv norms); buffers are ACCUMULATED into
- * (the caller zero-fills them; d_grd_feat rows row0.. need not be with cfg->grd_grad_overwrite), d_sat_feat with fp32 atomics.
+ * (the caller zero-fills them -- hla_zero_fill does it in one launch; d_grd_feat rows row0.. need not be with
+ * cfg->grd_grad_overwrite, d_sat_feat not at all with cfg->deterministic), d_sat_feat with fp32 atomics unless cfg->deterministic.
  * ------------------------------------------------------------------------- */
 /* ------------------------------------------------------------------------- *
  * The same loop in the ground -> satellite direction: LM_G2SP (models_kitti.py:22-499, proj == 'geo')
@@ -312,7 +323,8 @@ typedef struct hla_s2g_level_grad {
 size_t hla_s2g_bwd_workspace_bytes(const hla_s2g_config* cfg, const hla_s2g_level* levels, int B);
 
 /* trace, normal_eq: outputs of the forward call (normal_eq is required here);  d_trace [B,n_iters,n_levels,3] fp32
- * d_damping [3] fp64 out: d(loss)/d(lambda_i) summed over samples and steps (for train_damping) */
+ * d_damping [4] fp64 out (overwritten): [0..2] d(loss)/d(lambda_i) summed over samples and steps (for train_damping; summed per
+ *           sample in step order, then over the samples in sample order: reproducible), [3] cfg->deterministic's range counter */
 int hla_s2g_lm_solve_bwd(const hla_s2g_config* cfg, const hla_s2g_level* levels, const hla_s2g_level_grad* grads,
                          const float* R_FL, const float* T_FL, const float* pose0, const float* trace,
                          const double* normal_eq, const float* d_trace, double* d_damping, void* workspace,
@@ -328,6 +340,21 @@ int hla_g2s_lm_solve_bwd(const hla_s2g_config* cfg, const hla_s2g_level* levels,
                          const double* normal_eq, const float* d_trace, double* d_damping, void* workspace,
                          size_t workspace_bytes, int B, hla_stream_t stream);
 
+
+/* Zero-fill up to 16 (strided) regions of device memory in ONE launch: what a caller of hla_s2g_lm_solve_bwd has to clear in front
+ * of it (three d_sat_feat maps, the rows of the d_grd_feat maps its consumer reads above row0, d_grd_conf) -- as separate
+ * fill launches these were ~10 of the ~25 small launches between the LM loop and its backward (the reference: autograd's own
+ * zeros_like / accumulate nodes).  Region i = n_chunks pieces of chunk_bytes, stride_bytes apart, starting at ptr; ptr,
+ * chunk_bytes and stride_bytes must be multiples of 16. */
+typedef struct hla_fill_region {
+  void* ptr;
+  size_t chunk_bytes, stride_bytes;
+  int n_chunks;
+} hla_fill_region;
+int hla_zero_fill(const hla_fill_region* regions, int n_regions, int max_blocks, hla_stream_t stream);
+/* max_blocks: 0 = as fast as the memory system takes it (up to 2048 workgroups per region); > 0 caps the workgroups per region --
+ * a background fill on a side stream that leaves the chip to the kernels it runs under (training clears the LM backward's
+ * 1.4 GB of gradient buffers that way while the forward's convolutions run) */
 
 /* ------------------------------------------------------------------------- *
  * loss_func, loss_method 0  (models_ford.py:1041-1093; models_kitti.py imports the same function)

@@ -67,3 +67,52 @@ def test_bench_line_carries_the_round5_fields():
     for key in ("res['roofline']['clock_mhz_mean']", "res['roofline']['power_w_mean']", "res['roofline']['mfma_sustained_clock_mhz_mean']",
                 "res['roofline']['mfma_sustained_power_w_mean']", "train['roofline']", "train['gflop_per_pair_executed']", "train['telemetry']"):
         assert key in src, key
+
+
+def test_bench_line_carries_the_round6_fields():
+    """`matched_accuracy` at the top level (the fp16x3 numbers next to `value`), `train.step_breakdown` with the
+    named phases and `inter_step_idle`, the secondary legs in fp16x3 with their pose deviation, and the headline's clock / power
+    sampled over a separate >= 1 s block -- pinned on bench.py's source and on step_breakdown's arithmetic (fake events)."""
+    import os
+    import bench
+    src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'bench.py')).read()
+    for key in ("res['matched_accuracy']", "'step_breakdown': breakdown", "'inter_step_idle'", "secondary[key]['accuracy']", "'fp16x3'", "n_tele",
+                "'final_pose_dev_shift_m': acc.get('final_pose_dev_shift_m')", "block_steps=n_tele"):
+        assert key in src, key
+    for k in ('fwd_sat', 'fwd_grd', 'lm_fwd', 'glue', 'lm_bwd', 'vgg_bwd', 'optimizer', 'inter_step_idle', 'host_enqueue_ms'):
+        assert f"'{k}'" in src, k
+
+
+def test_step_breakdown_arithmetic_on_fake_events(monkeypatch):
+    """bench.step_breakdown: phase = time between consecutive marks, inter_step_idle = optimizer mark -> next step's begin mark."""
+    import torch
+    import bench
+    from highlyaccurate_amd import _s2gp
+    clock = {'t': 0.0}
+
+    class Ev:
+        def __init__(self, enable_timing=True):
+            self.t = None
+
+        def record(self):
+            self.t = clock['t']
+
+        def elapsed_time(self, other):
+            return other.t - self.t
+
+    monkeypatch.setattr(torch.cuda, 'Event', Ev)
+    monkeypatch.setattr(torch.cuda, 'synchronize', lambda *a, **k: None)
+    durs = dict(fwd_sat=4.0, fwd_grd=3.0, lm_fwd=1.0, loss=0.25, lm_bwd=2.5, vgg_bwd=9.0)
+
+    def tstep():
+        for name, dt in durs.items():
+            clock['t'] += dt
+            _s2gp._phase(name)
+        clock['t'] += 0.5          # the optimizer, marked by step_breakdown itself right after tstep returns
+    def tstep_with_idle():
+        clock['t'] += 0.125        # (work in front of the first mark of a step lands in its first phase)
+        tstep()
+    out = bench.step_breakdown(tstep_with_idle, 3)
+    assert out['steps'] == 3 and out['fwd_sat'] == 4.125 and out['fwd_grd'] == 3.0 and out['glue'] == 0.25 and out['vgg_bwd'] == 9.0
+    assert out['optimizer'] == 0.5 and out['inter_step_idle'] == 0.0 and abs(out['sum'] - 20.375) < 1e-9
+    assert _s2gp.PHASE_HOOK is None

@@ -1004,7 +1004,9 @@ def test_split_fp16_scaling_is_robust_and_sample_local():
 
 @pytest.mark.parametrize('kw', [dict(), dict(using_weight=1), dict(use_hessian=1, damping=0.5),
                                 dict(rotation_range=0.0), dict(level_first=1), dict(train_damping=1),
-                                dict(train_damping=1, use_hessian=1), dict(dropout=1, using_weight=1)])
+                                dict(train_damping=1, use_hessian=1), dict(dropout=1, using_weight=1),
+                                dict(deterministic_backward=1), dict(deterministic_backward=1, using_weight=1, train_damping=1),
+                                dict(deterministic_backward=1, level_first=1)])
 def test_lm_backward_small_vs_oracle_autograd(kw):
     """hla_s2g_lm_solve_bwd against torch autograd through the fp64 oracle's unrolled loop
     (gather values, bilinear weights, norms, J^T W J, inverse, pose->uv chain of later steps)."""
@@ -1054,6 +1056,14 @@ def test_lm_backward_small_vs_oracle_autograd(kw):
     for l in range(L):
         assert torch.equal(acc[1][l][:, grd_hw[0] >> (4 - l):], d_grd[l][:, grd_hw[0] >> (4 - l):]), l
         assert not bool(d_grd[l][:, :grd_hw[0] >> (4 - l)].any())          # rows above h_l / 2: zero
+    if getattr(args, 'deterministic_backward', 0):
+        # hla_s2g_config.deterministic: d(loss)/d(sat map) accumulated in 64-bit fixed point -- the two calls above (and a third)
+        # give the same bits whatever order the atomics ran in; d_lambda is summed in a fixed order in either mode
+        again = net.lm_backward(*feats, grd_hw, trace, net.last_normal_eq, coef.float(), None, lf, init_pose=p0, keep=net.last_keep)
+        for l in range(L):
+            assert torch.equal(again[0][l], d_sat[l]) and torch.equal(acc[0][l], d_sat[l]), l
+            assert bool(d_sat[l].any())
+        assert torch.equal(again[3], d_lam)
     for l in range(L):
         for name, got, ref in (('sat', d_sat[l], sat64[l].grad), ('grd', d_grd[l], grd64[l].grad)):
             got = got.permute(0, 3, 1, 2).cpu().double().numpy()
@@ -2273,7 +2283,7 @@ def test_fp32_class_modes_need_fp32_lm_maps():
 @pytest.mark.parametrize('precision', ['fp16x3', 'bf16'])
 def test_wave_specialised_wgrad_matches_the_two_phase_kernels(precision, monkeypatch):
     """Round 5's weight-gradient kernels (wgrad_split_ws_kernel / wgrad_ws_kernel: 4 matrix + 4 loader waves per CU, 256 resident
-    workgroups) against the round-4 kernels they replace (HLA_WGRAD_NO_WS=1, read per call: wgrad_split_kernel / wgrad_dma_kernel /
+    workgroups) against the round-4 kernels they replace (args.wgrad_two_phase = 1 -> HLA_VGG_BWD_WGRAD_TWO_PHASE: wgrad_split_kernel / wgrad_dma_kernel /
     wgrad_kernel, 512 workgroups): the same products in a different split-K grouping, so every weight and bias gradient of a
     full-shape training step must agree to the order of the partial sums: 1e-5 of the tensor's norm in split mode, whose products
     are fp32-class; for bf16 2e-3 or four times what the SAME kernels differ by from one run to the next (the LM backward's
@@ -2298,9 +2308,9 @@ def test_wave_specialised_wgrad_matches_the_two_phase_kernels(precision, monkeyp
         r[0].backward()
         return {n: p.grad.detach().double().clone() for n, p in net.named_parameters() if p.grad is not None}
 
-    monkeypatch.delenv('HLA_WGRAD_NO_WS', raising=False)
+    net.args.wgrad_two_phase = 0
     g_ws, g_ws2 = grads(), grads()          # twice: the step's own run-to-run noise (LM-backward atomics), per tensor
-    monkeypatch.setenv('HLA_WGRAD_NO_WS', '1')
+    net.args.wgrad_two_phase = 1
     g_old = grads()
     rel = lambda a, b: float((a - b).norm() / max(float(b.norm()), 1e-30))
     tol = 1e-5 if precision == 'fp16x3' else 2e-3
@@ -2313,3 +2323,87 @@ def test_wave_specialised_wgrad_matches_the_two_phase_kernels(precision, monkeyp
             bad.append((n, e, noise))
     print(f'ws vs two-phase wgrad [{precision}]: worst relative L2 {worst:.2e} ({wn}; the same kernels twice: {wnoise:.2e}), {len(g_ws)} tensors')
     assert len(g_ws) >= 36 and not bad, bad
+
+
+@pytest.mark.parametrize('precision', ['fp16x3', 'bf16'])
+def test_deterministic_backward_gives_bitwise_equal_gradients(precision):
+    """args.deterministic_backward = 1 (hla_s2g_config.deterministic, VERDICT r05 #2c): the same batch twice gives BITWISE equal
+    parameter gradients -- the LM backward's scatter into d(loss)/d(sat map) is the one place of the training step whose summation
+    order varies from run to run (fp32 atomics), and everything behind it (the satellite extractor's whole backward, incl. its
+    data-dependent tile lists) inherits that.  With the flag the scatter adds integers of a per-sample power-of-two quantum.
+    Also: the deterministic gradients agree with the default mode's to the atomics' own run-to-run noise, and the default mode
+    is NOT bitwise reproducible on this input (if it ever becomes so this test says so instead of silently testing nothing).
+    Ragged batch (B = 3), full KITTI shape, both streams of the backward in use."""
+    from oracle import ref_cpu as O
+    from highlyaccurate_amd.models_kitti import LM_S2GP
+    d = _dev()
+    net = LM_S2GP(O.default_args(precision=precision))
+    net.load_state_dict(O.synth_model_state(5))
+    net = net.to(d).train()
+    B = 3
+    sat, grd, gu, gv, gh = O.synth_images(105, B)
+    sat, grd, gt = sat.to(d), grd.to(d), [gu.to(d), gv.to(d), gh.to(d)]
+
+    def grads():
+        net.zero_grad(set_to_none=True)
+        torch.manual_seed(3)
+        r = net(sat, grd, *gt, mode='train')
+        r[0].backward()
+        torch.cuda.synchronize()
+        return {n: p.grad.detach().clone() for n, p in net.named_parameters() if p.grad is not None}
+
+    net.args.deterministic_backward = 1
+    g1, g2, g3 = grads(), grads(), grads()
+    assert len(g1) >= 36
+    for n in g1:
+        assert torch.equal(g1[n], g2[n]) and torch.equal(g1[n], g3[n]), n
+    net.args.deterministic_backward = 0
+    a1, a2 = grads(), grads()
+    rel = lambda a, b: float((a.double() - b.double()).norm() / max(float(b.double().norm()), 1e-30))
+    worst = max(rel(g1[n], a1[n]) for n in g1)
+    noise = max(rel(a1[n], a2[n]) for n in g1)
+    same = all(torch.equal(a1[n], a2[n]) for n in a1)
+    print(f'deterministic backward [{precision}]: 3 runs bitwise equal over {len(g1)} tensors; vs the atomics mode: worst relative L2 '
+          f'{worst:.2e} (the atomics mode against itself: {noise:.2e}, bitwise equal: {same})')
+    tol = 1e-5 if precision == 'fp16x3' else 2e-3
+    assert worst < max(tol, 4 * noise)
+
+
+def test_zero_fill_clears_strided_regions_in_one_launch():
+    """hla_zero_fill (include/hla.h): up to 16 strided regions cleared by one launch; everything outside them untouched."""
+    from highlyaccurate_amd import _lib
+    d = _dev()
+    a = torch.full((5, 7, 64), 3.0, device=d)
+    b = torch.full((1000003 * 4,), 2.0, device=d)
+    c = torch.full((4, 4), 1.0, device=d, dtype=torch.float64)
+    row = 64 * 4
+    _lib.zero_fill([(a.data_ptr() + 2 * row, 3 * row, 7 * row, 5), (b, b.numel() * 4, b.numel() * 4, 1), (c.data_ptr() + 32, 32, 32, 1)])
+    torch.cuda.synchronize()
+    ref = torch.full((5, 7, 64), 3.0)
+    ref[:, 2:5] = 0
+    assert torch.equal(a.cpu(), ref) and not bool(b.any())
+    rc = torch.ones(4, 4, dtype=torch.float64)
+    rc[1] = 0
+    assert torch.equal(c.cpu(), rc)
+    with pytest.raises(_lib.HlaError):
+        _lib.zero_fill([(a.data_ptr() + 4, 16, 16, 1)])           # misaligned
+    b.fill_(2.0)
+    _lib.zero_fill([(b, b.numel() * 4, b.numel() * 4, 1)], max_blocks=3)      # a background fill: same result
+    torch.cuda.synchronize()
+    assert not bool(b.any())
+
+
+def test_pose_loss_backward_propagates_nan_like_torch():
+    """A diverged (NaN) pose gives a NaN loss AND NaN gradients, like torch's abs / sgn backward: the fused backward
+    used to hand finite zeros to the optimizer there."""
+    from highlyaccurate_amd._s2gp import loss_func
+    d = _dev()
+    x = [torch.rand(4, 2, 3, device=d).requires_grad_(True) for _ in range(3)]
+    gt = [torch.rand(4, device=d) for _ in range(3)]
+    with torch.no_grad():
+        x[1][2, 1, 0] = float('nan')
+    out = loss_func(0, None, None, None, x[0], x[1], x[2], gt[0], gt[1], gt[2], None, None)
+    assert torch.isnan(out[0])
+    out[0].backward()
+    assert torch.isnan(x[1].grad[2, 1, 0]) and torch.isfinite(x[0].grad).all() and torch.isfinite(x[2].grad).all()
+    assert int(torch.isnan(x[1].grad).sum()) == 1

@@ -35,3 +35,16 @@ for r in seg:
     print(f"{s/1e3:10.1f} us  +{(e-s)/1e3:8.1f} us  q{q:>3s}  {short(name(r))}")
 end = max(int(r['End_Timestamp']) for r in seg) - t0
 print(f'step span {end/1e6:.3f} ms; busy per queue:', {q: round(v / 1e6, 3) for q, v in busy.items()})
+# the step PERIOD (this step's first launch to the next step's first launch) and what it does not contain: the idle gap between the
+# last kernel of the step and the first one of the next -- the host's lateness, which no kernel trace row shows
+nxt = int(rows[b]['Start_Timestamp']) - t0
+print(f'step period {nxt/1e6:.3f} ms; idle between this step\'s last kernel and the next step\'s first: {(nxt - end)/1e3:.1f} us')
+# gaps > 20 us inside the step (queue-agnostic: time during which NO kernel of either queue runs)
+iv = sorted((int(r['Start_Timestamp']) - t0, int(r['End_Timestamp']) - t0) for r in seg)
+cur_end, gaps = iv[0][1], []
+for s0, e0 in iv[1:]:
+    if s0 - cur_end > 20000:
+        gaps.append((cur_end, s0 - cur_end))
+    cur_end = max(cur_end, e0)
+print('idle gaps > 20 us inside the step (at us, length us):', [(round(a0 / 1e3, 1), round(g / 1e3, 1)) for a0, g in gaps],
+      'sum', round(sum(g for _, g in gaps) / 1e3, 1))
