@@ -151,7 +151,7 @@ def vgg_forward_nhwc(module: 'VGGUnet', x: torch.Tensor, want_conf: bool = True,
 @_lib.on_device(lambda module, ctx, *a, **k: ctx['x'])
 def vgg_backward_nhwc(module: 'VGGUnet', ctx: dict, d_feats, confs=None, d_confs=None, scale_invariant: bool = False,
                       first_row8: int = 0, flat: bool = False, dense: bool = False, stats: dict = None,
-                      wgrad_two_phase: bool = False):
+                      wgrad_two_phase: int = 0):
     """Backward of ``vgg_forward_nhwc(..., defer_norm=True, save_for_backward=True)``.
     d_feats[l]: NHWC fp32 gradient w.r.t. the L2-normalised map l.  Returns {parameter name: gradient} for the
     22 tensors that receive one at level 3 (conv0..conv14 weights+biases, conv_dec1/2 weights), plus the conf head weights
@@ -164,7 +164,8 @@ def vgg_backward_nhwc(module: 'VGGUnet', ctx: dict, d_feats, confs=None, d_confs
     HLA_VGG_BWD_SCALE_INVARIANT); ``dense=True`` (``args.bwd_trim = 0`` on the models) visits all of them (A/B, tests).
     ``stats`` (a dict, diagnostics: costs a device synchronisation) receives 'live_tiles' / 'total_tiles' per sample, summed over
     the data- and weight-gradient launches; both 0 when the call took the dense walk.
-    ``wgrad_two_phase`` (``args.wgrad_two_phase`` on the models; A/B and tests): HLA_VGG_BWD_WGRAD_TWO_PHASE."""
+    ``wgrad_two_phase`` (``args.wgrad_two_phase`` on the models; A/B and tests): bit 0 HLA_VGG_BWD_WGRAD_TWO_PHASE, bit 1
+    HLA_VGG_BWD_WGRAD0_UNFUSED (conv0's weight gradient from a stored map of conv2's data gradient, as before round 6)."""
     lib = _lib.load()
     x, dt = ctx['x'], ctx['dt']
     if x._version != ctx.get('x_version', x._version):
@@ -223,7 +224,8 @@ def vgg_backward_nhwc(module: 'VGGUnet', ctx: dict, d_feats, confs=None, d_confs
                               dp, cp, dcp, C.byref(gs), _lib.ptr(ws), nbytes, B, H, W, L, dt,
                               (_lib.HLA_VGG_BWD_SCALE_INVARIANT if scale_invariant else 0)
                               | (_lib.HLA_VGG_BWD_DENSE if dense else 0)
-                              | (_lib.HLA_VGG_BWD_WGRAD_TWO_PHASE if wgrad_two_phase else 0),
+                              | (_lib.HLA_VGG_BWD_WGRAD_TWO_PHASE if int(wgrad_two_phase) & 1 else 0)
+                              | (_lib.HLA_VGG_BWD_WGRAD0_UNFUSED if int(wgrad_two_phase) & 2 else 0),
                               int(first_row8), _lib.stream_ptr())
     _lib.check(rc, 'hla_vgg_backward')
     if stats is not None:

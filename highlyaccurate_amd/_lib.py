@@ -18,6 +18,7 @@ HLA_VGG_WANT_CONF, HLA_VGG_DEFER_NORM, HLA_VGG_SAVE_FOR_BACKWARD, HLA_VGG_FEAT16
 HLA_VGG_BWD_SCALE_INVARIANT = 1
 HLA_VGG_BWD_DENSE = 2
 HLA_VGG_BWD_WGRAD_TWO_PHASE = 4
+HLA_VGG_BWD_WGRAD0_UNFUSED = 8
 ABI_VERSION = 21
 
 

@@ -186,7 +186,8 @@ class S2GPBase(nn.Module):
     #   bwd_prefill        0: the LM backward's gradient buffers are cleared by one launch in front of it; 1: allocated and cleared
     #                      during the forward, on a side stream; n > 1: as a background fill of n workgroups per buffer
     #                      (an experiment kept as a switch: measured neutral, EXPERIMENTS.md round 6)
-    #   wgrad_two_phase    0; 1: weight gradients on the two-phase kernels (A/B and tests: HLA_VGG_BWD_WGRAD_TWO_PHASE)
+    #   wgrad_two_phase    0; 1: weight gradients on the two-phase kernels (A/B and tests: HLA_VGG_BWD_WGRAD_TWO_PHASE); 2: only conv0's
+    #                      from a stored map of conv2's data gradient instead of inside that kernel's epilogue (..._WGRAD0_UNFUSED)
     #   strict_errors      0; 1: reproduce jacobian.py:172's AssertionError (costs a host sync per forward)     DESIGN.md 1
     #   small_batch_two_streams  4: inference batches up to this size run the two extractors on two streams        DESIGN.md 5
     #   fwd_two_streams    unset / None / 0: off.  -1 or 1: inference at ANY batch with the satellite extractor on a side stream
@@ -696,7 +697,7 @@ class _LocaliseFn(torch.autograd.Function):
         # caching allocator, so the freed block cannot be reused for the ground branch's workspace on the main stream: peak
         # training memory is one backward workspace higher (GB-class at B = 32 in fp32) for that 1.4 %.
         two = bool(getattr(model.args, 'bwd_two_streams', 1)) and sync is None
-        tp = bool(getattr(model.args, 'wgrad_two_phase', 0))       # (A/B and tests: HLA_VGG_BWD_WGRAD_TWO_PHASE)
+        tp = int(getattr(model.args, 'wgrad_two_phase', 0))       # (A/B and tests: bit 0 HLA_VGG_BWD_WGRAD_TWO_PHASE, bit 1 ..._WGRAD0_UNFUSED)
         if two:
             cur = torch.cuda.current_stream()
             side = _side_stream(d_sat[0].device)

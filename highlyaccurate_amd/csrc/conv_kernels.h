@@ -125,6 +125,44 @@ template <> __device__ __forceinline__ void mma16<float>(f32x16& acc, const uint
   acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(w.w), __uint_as_float(p.w), acc, 0, 0, 0);
 }
 
+// ---- k-major operand fragments (weight-gradient kernels, vgg_backward.hip; the fused conv0 weight gradient below)
+typedef short v4s __attribute__((ext_vector_type(4)));
+
+// fragment of a k-major LDS tile T[k = pixel][i = channel] (row stride `stride` bytes) in MFMA operand order:
+// lane l -> row i = ch0 + (l & 31), its 16 bytes = the K-step's k values of its half (see mma16<T>).
+//   bf16: K-step = 16 pixels, lane group g = l>>5 holds k = 8g..8g+7
+//   fp32: K-step =  8 pixels, element t of lane group g is k = 2t+g
+template <typename T> struct KStep;
+template <> struct KStep<bf16> { static constexpr int PX = 16; };
+template <> struct KStep<f16> { static constexpr int PX = 16; };
+template <> struct KStep<float> { static constexpr int PX = 8; };
+
+template <typename T> __device__ __forceinline__ uint4 frag_kmajor(const char* tile, int stride, int px0, int ch0, int lane);
+template <> __device__ __forceinline__ uint4 frag_kmajor<bf16>(const char* tile, int stride, int px0, int ch0, int lane) {
+  const int t = lane & 15, i0 = ch0 + 16 * ((lane >> 4) & 1), k0 = px0 + 8 * (lane >> 5);
+  const char* p = tile + (k0 + (t >> 2)) * stride + (i0 + 4 * (t & 3)) * 2;
+  const v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s*)(p));
+  const v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s*)(p + 4 * stride));
+  uint4 r;
+  __builtin_memcpy(&r.x, &lo, 8);
+  __builtin_memcpy(&r.z, &hi, 8);
+  return r;
+}
+template <> __device__ __forceinline__ uint4 frag_kmajor<f16>(const char* tile, int stride, int px0, int ch0, int lane) {
+  return frag_kmajor<bf16>(tile, stride, px0, ch0, lane);     // same 16-bit transpose read
+}
+template <> __device__ __forceinline__ uint4 frag_kmajor<float>(const char* tile, int stride, int px0, int ch0, int lane) {
+  const char* p = tile + (px0 + (lane >> 5)) * stride + (ch0 + (lane & 31)) * 4;
+  uint4 r;
+  r.x = *(const unsigned*)(p); r.y = *(const unsigned*)(p + 2 * stride);
+  r.z = *(const unsigned*)(p + 4 * stride); r.w = *(const unsigned*)(p + 6 * stride);
+  return r;
+}
+template <typename T> __device__ __forceinline__ uint4 frag_ones();
+template <> __device__ __forceinline__ uint4 frag_ones<bf16>() { return make_uint4(0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u); }
+template <> __device__ __forceinline__ uint4 frag_ones<f16>() { return make_uint4(0x3C003C00u, 0x3C003C00u, 0x3C003C00u, 0x3C003C00u); }
+template <> __device__ __forceinline__ uint4 frag_ones<float>() { return make_uint4(0x3F800000u, 0x3F800000u, 0x3F800000u, 0x3F800000u); }
+
 __device__ __forceinline__ void store4(bf16* p, float a, float b, float c, float d) {
   const bf16 h[4] = {(bf16)a, (bf16)b, (bf16)c, (bf16)d};
   *(uint2*)p = __builtin_bit_cast(uint2, h);
@@ -192,6 +230,11 @@ struct ConvArgs {
   const unsigned* amax2;            // likewise for src2, or null; the two sources share one scale
   unsigned* amax_out;               // [B] atomicMax target for max |out_act| per sample (zeroed before the forward), or null
   const float* wscale;              // the power-of-two scale baked into wpk (device scalar written by the packer)
+  // --- conv0's weight gradient fused into the epilogue of conv2's data gradient (EPI_DGRAD_WG0; UNPOOL, Cout = 64 only):
+  //     the masked gradient tile is contracted with the image patch on the spot and never stored (out_act is not written)
+  const float* wg0_x;               // [B,3,H,W] NCHW fp32 network input, channel planes wg0_x_plane elements apart, or null
+  size_t wg0_x_plane;
+  float* wg0_part;                  // [workgroup][64 co][32]: k = c*9 + tap in columns 0..26, the bias gradient in column 27
 };
 
 // Data-dependent trimming (the backward of a branch whose incoming gradient has a small footprint, vgg_backward.hip): tables in
@@ -230,6 +273,9 @@ constexpr int HALO_TAP0 = 2, HALO_TAP1 = 6;
 constexpr int HLA_CONV_DMA_TAP = 1;
 #ifndef HLA_A0_ABL
 #define HLA_A0_ABL 0
+#endif
+#ifndef HLA_UNPOOL_NT1_OCC
+#define HLA_UNPOOL_NT1_OCC 3         // workgroups per CU of conv2's data gradient (the one launch of the UNPOOL, 32-channel-wave-tile kernel)
 #endif
 #ifndef HLA_CONV_SMALL_GRID
 #define HLA_CONV_SMALL_GRID 320      // workgroups: below this a forward launch takes 4-row tiles (launch_conv)
@@ -355,8 +401,10 @@ enum { EPI_GENERIC = 0,   // everything, decided at run time (backward / trainin
        EPI_ACT = 1,       // out_act = relu(acc + bias) only
        EPI_ACT_RAW = 2,   // + the raw fp32 copy and its per-sample sum of squares (the three feature layers)
        EPI_ACT_RAW_NOBIAS = 3,    // the same for a layer without bias (the decoder's): 32 registers less
-       EPI_DGRAD = 4 };   // backward data gradient: out_act = (mask > 0 ? acc : 0) [+ add], no bias, no ReLU of its own
+       EPI_DGRAD = 4,     // backward data gradient: out_act = (mask > 0 ? acc : 0) [+ add], no bias, no ReLU of its own
+       EPI_DGRAD_WG0 = 5 };   // conv2's data gradient, not stored: contracted with the image patch into conv0's weight gradient
 __host__ __device__ __forceinline__ int epilogue_mode(const ConvArgs& a) {
+  if (a.wg0_part) return EPI_DGRAD_WG0;
   if (a.mask_act && a.out_act && !a.relu_act && !a.bias && !a.out_raw && !a.sumsq && !a.idx_out && !a.pool_sum) return EPI_DGRAD;
   // (a 16-bit raw copy without the activation output: the last decoder layer when nothing consumes relu(x21) -- vgg.hip)
   if (!a.out_act && a.out_raw && a.raw16 && a.sumsq && !a.bias && !a.mask_act && !a.add_src && !a.idx_out && !a.pool_sum)
@@ -600,6 +648,190 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[MT][NT], const ConvA
 }
 
 // ---------------------------------------------------------------------------------------------
+// conv0's weight gradient fused into the epilogue of conv2's (un-pooling) data gradient -- VGG.py:123-128 backwards.
+// The data gradient of conv2 is d(loss)/d(relu(conv0)) [B,H,W,64] at full resolution: 1.07 GB (16-bit) / 2.1 GB (fp32 storage)
+// per branch at B = 32 that only conv0's weight gradient ever read back (wgrad0_kernel).  Here every wave masks its 4 x 32-pixel x
+// 32-channel piece of the tile (ReLU mask = relu(conv0) > 0, the vectors prefetched at the top), leaves it in its LDS stager in
+// [pixel][channel] order and contracts it over the PIXELS with the im2col of the 3-channel image patch (K = pixels; the A
+// fragments by the transposing LDS read of the weight-gradient kernels, frag_kmajor):
+//   dW0[co][k = c*9+tap] += sum_px g[px][co] * x[c][py+ky-1][px+kx-1],    column 27 multiplies ones: the bias gradient.
+// One [64][32] fp32 partial per workgroup (8 KB instead of the tile's 32 / 64 KB of gradient map) goes to wg0_part[blockIdx.x];
+// reduce_rows_kernel + reduce_partials_kernel add them in a fixed order.  Arithmetic per mode: 16-bit -- the tile rounded to T
+// exactly as the stored map was; exact fp32 -- v_mfma_f32_32x32x2_f32; split -- g and x as (hi, lo) fp16 pairs (g with a
+// power-of-two scale per wave row from the un-masked maximum, x with one per patch), three MFMAs per product into a zeroed
+// accumulator that is descaled into the running sum.
+template <typename T, int MT>
+__device__ __forceinline__ void conv_epilogue_wg0(f32x16 (&acc)[MT][1], const ConvArgs& a, int b, int y0, int x0, char* lds, float dsc) {
+  constexpr bool SPLIT = Prec<T>::SPLIT;
+  using ET = std::conditional_t<SPLIT, float, T>;            // element type of the stored maps (the mask)
+  using FT = std::conditional_t<SPLIT, f16, ET>;             // element type of the MFMA fragments
+  constexpr int TH = 2 * MT, IH = TH + 2, IW = 48;           // image patch [3][IH][IW]: 34 columns + the K-step's overrun
+  constexpr int PITCH = RowStager<ET, 1>::PITCH, CPP = RowStager<ET, 1>::CPP, NIT = 32 * CPP / 64, EPV = 16 / (int)sizeof(ET);
+  constexpr int HP = RowStager<f16, 1>::PITCH, HTILE = 32 * HP;      // split mode: the hi / lo fp16 tiles of a row
+  constexpr int KPX = KStep<FT>::PX, STG = 5120;
+  static_assert(32 * PITCH <= STG && 2 * HTILE <= STG, "wave stager");
+  static_assert(4 * STG + 3 * IH * IW * 4 + 2 * 16 * 64 * 4 + 16 <= 2 * (TH + 2) * HWID * PSTR, "fits the halo buffers");
+  int tid = threadIdx.x;
+  asm volatile("" : "+v"(tid));      // (see conv_epilogue: nothing of this is to be hoisted above the main loop)
+  const int lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6), wm = wv >> 1, wn = wv & 1, x = lane & 31, g = lane >> 5;
+  char* stage = lds + wv * STG;
+  float* in = (float*)(lds + 4 * STG);
+  float* xr = in + 3 * IH * IW;                              // [wn][16][64]: the lower row half's sums for the upper one
+  float* redm = xr + 2 * 16 * 64;                            // [4]
+  const int nvalid = min(32, a.W - x0), cb = wn * 32;
+
+  // the ReLU mask's vectors: addressed like RowStager::flush's (a lane without a vector reads the row segment's first one)
+  int pxs[NIT], parts[NIT];
+  unsigned voff[NIT];
+#pragma unroll
+  for (int k = 0; k < NIT; ++k) {
+    const int c = k * 64 + lane;
+    pxs[k] = c / CPP; parts[k] = c % CPP;
+    voff[k] = pxs[k] < nvalid ? (unsigned)pxs[k] * 64u * (unsigned)sizeof(ET) + parts[k] * 16 : 0u;
+  }
+  constexpr int PRE = sizeof(ET) == 2 ? MT : 2;             // rows whose mask vectors are in flight ahead
+  uint4 mk[MT][NIT];
+  auto load_mask = [&](int i) __attribute__((always_inline)) {
+    const int y = min(y0 + wm * MT + i, a.H - 1);
+    const char* mrow = (const char*)((const ET*)a.mask_act + (((size_t)b * a.H + y) * a.W + x0) * 64 + cb);
+#pragma unroll
+    for (int k = 0; k < NIT; ++k) mk[i][k] = *(const uint4*)(mrow + voff[k]);
+  };
+#pragma unroll
+  for (int i = 0; i < PRE; ++i) load_mask(i);
+
+  // image patch (1-pixel border) -> LDS; split mode: its maximum -> one power-of-two scale
+  constexpr int NIN = (3 * IH * IW + 255) / 256;
+  float vin[NIN], amx = 0.f;
+#pragma unroll
+  for (int it = 0; it < NIN; ++it) {
+    const int e = tid + it * 256;
+    const int c = e / (IH * IW), r = e % (IH * IW), iy = r / IW, ix = r % IW;
+    const int y = y0 - 1 + iy, xx = x0 - 1 + ix;
+    vin[it] = 0.f;
+    if (e < 3 * IH * IW && ix < HWID && y >= 0 && y < a.H && xx >= 0 && xx < a.W)
+      vin[it] = a.wg0_x[((size_t)b * 3 + c) * a.wg0_x_plane + (size_t)y * a.W + xx];
+  }
+#pragma unroll
+  for (int it = 0; it < NIN; ++it) {
+    const int e = tid + it * 256;
+    if (e < 3 * IH * IW) in[e] = vin[it];
+    if (SPLIT) amx = fmaxf(amx, fabsf(vin[it]));
+  }
+  if (SPLIT) {
+    amx = wave_max_f32(amx);
+    if (lane == 0) redm[wv] = amx;
+  }
+  __syncthreads();
+  float s_in = 1.f;
+  if (SPLIT) s_in = split_scale(__float_as_uint(fmaxf(fmaxf(redm[0], redm[1]), fmaxf(redm[2], redm[3]))));
+
+  f32x16 accw;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) accw[r] = 0.f;
+  const int j = lane & 31, g5 = lane >> 5;                   // B operand: column j = k index (c, ky, kx); 27 = ones (bias)
+  const int jc = j < 27 ? j / 9 : 0, jky = (j % 9) / 3, jkx = j % 3;
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    if (i + PRE < MT) load_mask(i + PRE);
+    const int rt = wm * MT + i;                              // row inside the tile
+    const bool row_ok = y0 + rt < a.H;                       // wave-uniform
+    float sG = 1.f;
+    if (SPLIT) {
+      float m = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) m = fmaxf(m, fabsf(acc[i][0][r]));
+      sG = split_scale(__float_as_uint(wave_max_f32(m) * dsc));
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      float w0 = acc[i][0][q * 4 + 0], w1 = acc[i][0][q * 4 + 1], w2 = acc[i][0][q * 4 + 2], w3 = acc[i][0][q * 4 + 3];
+      if (SPLIT) { w0 *= dsc; w1 *= dsc; w2 *= dsc; w3 *= dsc; }
+      RowStager<ET, 1>::put(stage, x, q * 8 + g * 4, w0, w1, w2, w3);
+    }
+    uint4 v[NIT];
+#pragma unroll
+    for (int k = 0; k < NIT; ++k) {
+      v[k] = *(const uint4*)(stage + pxs[k] * PITCH + parts[k] * 16);
+      ET e[EPV], m[EPV];
+      __builtin_memcpy(e, &v[k], 16);
+      __builtin_memcpy(m, &mk[i][k], 16);
+      const bool ok = row_ok && pxs[k] < nvalid;
+#pragma unroll
+      for (int t = 0; t < EPV; ++t)
+        if (!ok || !((float)m[t] > 0.f)) e[t] = (ET)0.f;
+      __builtin_memcpy(&v[k], e, 16);
+    }
+    if constexpr (SPLIT) {
+#pragma unroll
+      for (int k = 0; k < NIT; ++k) {      // (all of the row's fp32 vectors are in registers: the fp16 tiles overwrite them)
+        uint2 hi, lo;
+        split4(__uint_as_float(v[k].x), __uint_as_float(v[k].y), __uint_as_float(v[k].z), __uint_as_float(v[k].w), sG, hi, lo);
+        *(uint2*)(stage + pxs[k] * HP + parts[k] * 8) = hi;
+        *(uint2*)(stage + HTILE + pxs[k] * HP + parts[k] * 8) = lo;
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < NIT; ++k) *(uint4*)(stage + pxs[k] * PITCH + parts[k] * 16) = v[k];
+    }
+    if (row_ok) {
+      f32x16 tmp;
+      if (SPLIT) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) tmp[r] = 0.f;
+      }
+#pragma unroll
+      for (int kk = 0; kk < 32 / KPX; ++kk) {
+        const float* row = in + (jc * IH + rt + jky) * IW + jkx + kk * KPX;
+        if constexpr (SPLIT) {
+          float xs[8];
+#pragma unroll
+          for (int jj = 0; jj < 8; ++jj) xs[jj] = j < 27 ? row[8 * g5 + jj] : 0.f;
+          uint2 h0, l0, h1, l1;
+          split4(xs[0], xs[1], xs[2], xs[3], s_in, h0, l0);
+          split4(xs[4], xs[5], xs[6], xs[7], s_in, h1, l1);
+          uint4 bhi = make_uint4(h0.x, h0.y, h1.x, h1.y);
+          const uint4 blo = make_uint4(l0.x, l0.y, l1.x, l1.y);
+          if (j == 27) bhi = frag_ones<f16>();
+          const uint4 ahi = frag_kmajor<f16>(stage, HP, kk * KPX, 0, lane), alo = frag_kmajor<f16>(stage + HTILE, HP, kk * KPX, 0, lane);
+          mma16<f16>(tmp, ahi, bhi);
+          mma16<f16>(tmp, alo, bhi);
+          mma16<f16>(tmp, ahi, blo);
+        } else {
+          const uint4 A = frag_kmajor<ET>(stage, PITCH, kk * KPX, 0, lane);
+          ET e[EPV];
+#pragma unroll
+          for (int jj = 0; jj < EPV; ++jj) {
+            const int k = sizeof(ET) == 2 ? 8 * g5 + jj : 2 * jj + g5;      // pixel offset inside the K-step (KStep)
+            e[jj] = (ET)(j < 27 ? row[k] : (j == 27 ? 1.f : 0.f));
+          }
+          mma16<ET>(accw, A, __builtin_bit_cast(uint4, e));
+        }
+      }
+      if (SPLIT) {
+        const float ds = j == 27 ? 1.f / sG : 1.f / (sG * s_in);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accw[r] += tmp[r] * ds;
+      }
+    }
+  }
+  // the two row halves of a channel half: lower + upper, in that order
+  if (wm == 1) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) xr[(wn * 16 + r) * 64 + lane] = accw[r];
+  }
+  __syncthreads();
+  if (wm == 0) {
+    float* dst = a.wg0_part + (size_t)blockIdx.x * 64 * 32;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int co = cb + (r & 3) + 8 * (r >> 2) + 4 * g5;
+      dst[co * 32 + j] = accw[r] + xr[(wn * 16 + r) * 64 + lane];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // One pipeline stage of MFMAs: 9 taps x 2 k-groups against the halo tile at `cur` (the stage buffer; `fo` holds this lane's
 // offsets into it: the wave's first row, the lane's pixel and the swizzled slot of its k-half).  Weight fragments come from global memory through a ring of
 // WD+1 register sets filled WD taps ahead; `mid(tap)` runs right after the weight loads of each tap (used to
@@ -709,7 +941,7 @@ __device__ __forceinline__ void stage_mma(f32x16 (&acc)[MT][NT], const char* cur
 // of a piece next to the piece and applies them when the piece is WRITTEN to LDS -- masking right behind the load put an
 // s_waitcnt vmcnt(0) after every single piece, six full memory round trips per stage in the middle of the MFMA stream.
 template <typename T, int MT, int NT, int WM, int WN, bool POOL, int WD, bool UNPOOL = false>
-__global__ __launch_bounds__(256, NT == 1 ? 3 : 2) void conv3x3_kernel(ConvArgs a) {
+__global__ __launch_bounds__(256, NT == 1 ? (UNPOOL ? HLA_UNPOOL_NT1_OCC : 3) : 2) void conv3x3_kernel(ConvArgs a) {
   static_assert(WM * WN == 4, "4 waves per block");
   constexpr int EPL = 16 / sizeof(T), KC = SB / sizeof(T);     // channels per stage: 32 (bf16) / 16 (fp32)
   constexpr int TH = WM * MT, HPIX = (TH + 2) * HWID;
@@ -1003,6 +1235,12 @@ __global__ __launch_bounds__(256, NT == 1 ? 3 : 2) void conv3x3_kernel(ConvArgs 
     // the generic path's 21 k -- so only its bias-free form is compiled there; that is the one the model uses: dec1.3)
     constexpr bool RAW_SPECIAL = POOL || NT == 1;
     constexpr bool T16 = sizeof(T) == 2;
+    if constexpr (UNPOOL && NT == 1 && MT == 4 && WN == 2) {      // conv2's data gradient: the only launch of this instantiation
+      if (mode == EPI_DGRAD_WG0) {
+        conv_epilogue_wg0<T, MT>(acc, a, b, y0, x0, lds, dsc);
+        return;
+      }
+    }
     if (mode == EPI_ACT) conv_epilogue<T, MT, NT, POOL, EPI_ACT, false, LDSB / 4>(acc, a, b, y0 + wm * MT, x0, ntg0 * 32, red, stager, dsc, addb);
     // (16-bit raw copy, HLA_VGG_FEAT16: only the three feature layers ask for it -- conv14: pooled + bias; dec1.3 / dec2.3:
     // no bias -- and exactly those forms are compiled)
@@ -1613,7 +1851,7 @@ static bool launch_conv(hipStream_t st, ConvArgs a, bool pool) {
   const bool big = a.Cout >= 128;
   const dim3 grid(a.tiles_x * a.tiles_y * a.B, big ? a.Cout / 128 : 1);
   const size_t es = sizeof(T), P = (size_t)a.B * (a.H - a.row_begin) * a.W, Po = pool ? P / 4 : P;
-  const double flops = 2.0 * 9.0 * (a.C1 + a.C2) * a.Cout * (double)P;
+  const double flops = 2.0 * 9.0 * (a.C1 + a.C2) * a.Cout * (double)P + (a.wg0_part ? 2.0 * 27 * 64 * (double)P : 0.0);
   const double bytes = (double)P * ((a.up1 ? a.C1 / 4.0 : a.C1) + a.C2) * es + (double)Po * a.Cout * ((a.out_act ? es : 0) + (a.out_raw ? 4 : 0));
   // (a data-dependent launch visits n_live of its tiles_x * tiles_y tiles per sample: the record carries the executed share)
   hla_prof_begin_dyn(a.Cout >= 128 ? (pool ? K_CONV_NT2_POOL : K_CONV_NT2) : (pool ? K_CONV_NT1_POOL : K_CONV_NT1), flops, bytes, st,

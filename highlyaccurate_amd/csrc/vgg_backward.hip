@@ -13,42 +13,7 @@
 #include "conv_kernels.h"
 #include "vgg_layers.h"
 
-typedef short v4s __attribute__((ext_vector_type(4)));
-
-// fragment of a k-major LDS tile T[k = pixel][i = channel] (row stride `stride` bytes) in MFMA operand order:
-// lane l -> row i = ch0 + (l & 31), its 16 bytes = the K-step's k values of its half (see mma16<T>).
-//   bf16: K-step = 16 pixels, lane group g = l>>5 holds k = 8g..8g+7
-//   fp32: K-step =  8 pixels, element t of lane group g is k = 2t+g
-template <typename T> struct KStep;
-template <> struct KStep<bf16> { static constexpr int PX = 16; };
-template <> struct KStep<f16> { static constexpr int PX = 16; };
-template <> struct KStep<float> { static constexpr int PX = 8; };
-
-template <typename T> __device__ __forceinline__ uint4 frag_kmajor(const char* tile, int stride, int px0, int ch0, int lane);
-template <> __device__ __forceinline__ uint4 frag_kmajor<bf16>(const char* tile, int stride, int px0, int ch0, int lane) {
-  const int t = lane & 15, i0 = ch0 + 16 * ((lane >> 4) & 1), k0 = px0 + 8 * (lane >> 5);
-  const char* p = tile + (k0 + (t >> 2)) * stride + (i0 + 4 * (t & 3)) * 2;
-  const v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s*)(p));
-  const v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s*)(p + 4 * stride));
-  uint4 r;
-  __builtin_memcpy(&r.x, &lo, 8);
-  __builtin_memcpy(&r.z, &hi, 8);
-  return r;
-}
-template <> __device__ __forceinline__ uint4 frag_kmajor<f16>(const char* tile, int stride, int px0, int ch0, int lane) {
-  return frag_kmajor<bf16>(tile, stride, px0, ch0, lane);     // same 16-bit transpose read
-}
-template <> __device__ __forceinline__ uint4 frag_kmajor<float>(const char* tile, int stride, int px0, int ch0, int lane) {
-  const char* p = tile + (px0 + (lane >> 5)) * stride + (ch0 + (lane & 31)) * 4;
-  uint4 r;
-  r.x = *(const unsigned*)(p); r.y = *(const unsigned*)(p + 2 * stride);
-  r.z = *(const unsigned*)(p + 4 * stride); r.w = *(const unsigned*)(p + 6 * stride);
-  return r;
-}
-template <typename T> __device__ __forceinline__ uint4 frag_ones();
-template <> __device__ __forceinline__ uint4 frag_ones<bf16>() { return make_uint4(0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u); }
-template <> __device__ __forceinline__ uint4 frag_ones<f16>() { return make_uint4(0x3C003C00u, 0x3C003C00u, 0x3C003C00u, 0x3C003C00u); }
-template <> __device__ __forceinline__ uint4 frag_ones<float>() { return make_uint4(0x3F800000u, 0x3F800000u, 0x3F800000u, 0x3F800000u); }
+// (frag_kmajor / frag_ones / KStep: conv_kernels.h -- the fused conv0 weight gradient in the data-gradient epilogue uses them too)
 
 // ---------------------------------------------------------------------------------------------
 constexpr int WG_TH = 4;                                  // pixel tile of the weight-gradient kernels: 4 rows x 32 px
@@ -1241,6 +1206,23 @@ static __global__ __launch_bounds__(256) void reduce_partials4_kernel(const floa
   }
 }
 
+// first level of a two-level fixed-order reduction over MANY partial rows (the fused conv0 weight gradient: one [64][32] row per
+// data-gradient workgroup, up to 32768 of them): slab s = blockIdx.x sums rows s, s + gridDim.x, ... in that order into out2[s].
+// K on the device for a data-dependent launch: n_live (the first int of its ConvDyn) x B workgroups wrote a row.
+static __global__ __launch_bounds__(256) void reduce_rows_kernel(const float4* __restrict__ part, float4* __restrict__ out2, int n4, int K,
+                                                                 const int* __restrict__ dyn_nlive, int B) {
+  const int Kd = dyn_nlive ? *dyn_nlive * B : K, s = blockIdx.x, ns = gridDim.x;
+  for (int c = threadIdx.x; c < n4; c += 256) {
+    float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 4
+    for (int k = s; k < Kd; k += ns) {
+      const float4 v = part[(size_t)k * n4 + c];
+      sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
+    }
+    out2[(size_t)s * n4 + c] = sum;
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // L2_norm backward: y = a*x with a = 1/||x||  =>  dx = a*dy - a^3 * (x . dy) * x      (per sample)
 static __global__ __launch_bounds__(256) void l2bwd_dot_kernel(const float* __restrict__ x, const float* __restrict__ dy,
@@ -1723,6 +1705,9 @@ int vgg_backward_t(const float* x, size_t x_plane, const hla_vgg_params* prm, co
                           const float* const feat[4], const double* inv_norm, const float* const d_feat[4],
                           const float* const conf[4], const float* const d_conf[4], const hla_vgg_grads* gr, char* bw, const BwdPlan& bp, int B, int H, int W, int flags, int first_row8, hipStream_t st) {
   const bool level4 = bp.g_x24 != 0;
+  // conv0's weight gradient inside the epilogue of conv2's data gradient (conv_epilogue_wg0); the two-phase flag keeps the
+  // stored map + wgrad0_kernel (A/B and tests; level 4 reads conv2's gradient from a materialised map anyway)
+  const bool fuse0 = !level4 && !(flags & (HLA_VGG_BWD_WGRAD_TWO_PHASE | HLA_VGG_BWD_WGRAD0_UNFUSED));
   const int NL = level4 ? 4 : 3;
   VggPlan fp;
   vgg_plan(B, H, W, dtype, true, &fp, level4);
@@ -1884,14 +1869,17 @@ int vgg_backward_t(const float* x, size_t x_plane, const hla_vgg_params* prm, co
   bool launch_ok = true;
   auto dgrad = [&](int l, int c0, int n, const void* gsrc, const unsigned char* unpool, int Hout, int Wout, void* out,
                    const void* mask, const void* add, bool pool_sum, int row_begin = 0, int src_lo = 0, int add_lo = 0, int dc = -1,
-                   int ga_src = -1, int ga_out = -1) {
+                   int ga_src = -1, int ga_out = -1, bool fuse_wg0 = false) {
     ConvArgs a{};
+    if (fuse_wg0) {      // conv2's data gradient contracted into conv0's weight gradient in its epilogue; `out` receives the partials
+      a.wg0_x = x; a.wg0_x_plane = x_plane ? x_plane : (size_t)H * W; a.wg0_part = (float*)out;
+    }
     a.amax1 = GA(ga_src); a.amax_out = GA(ga_out); a.wscale = SPLIT ? wtailT + l : nullptr;
     a.dyn = (dynamic && dc >= 0) ? dynp : nullptr; a.dyn_desc = dc >= 0 ? dl.conv_desc[dc] : 0;
     a.src1 = gsrc; a.C1 = kLayers[l].cout; a.unpool_idx = unpool;
     const int nstage = kLayers[l].cout / KC;
     a.wpk = (const uint4*)(packedT + packed_offset(l, dtype)) + (size_t)(c0 / 32) * nstage * 18 * 64;
-    a.out_act = out; a.mask_act = mask; a.add_src = add; a.pool_sum = pool_sum ? 1 : 0;
+    a.out_act = fuse_wg0 ? nullptr : out; a.mask_act = mask; a.add_src = add; a.pool_sum = pool_sum ? 1 : 0;
     a.B = B; a.H = Hout; a.W = Wout; a.Cout = n; a.relu_act = 0;
     a.row_begin = row_begin > 0 ? row_begin : 0; a.src_row_lo = src_lo > 0 ? src_lo : 0; a.add_row_lo = add_lo > 0 ? add_lo : 0;
     if (!launch_conv<T, true>(st, a, pool_sum)) launch_ok = false;
@@ -1992,10 +1980,22 @@ int vgg_backward_t(const float* x, size_t x_plane, const hla_vgg_params* prm, co
     dgrad(1, 0, 64, G(bp.g_c2), nullptr, H, W, G(bp.g_a0), F(fp.a0), nullptr, false, 0, 0, 0, -1, GA_C2, GA_A0);
     wgrad(1, F(fp.a0), 64, nullptr, 0, 0, G(bp.g_c2), nullptr, H, W, 0, -1, AM_A0, -1, GA_C2);
   } else {
-    dgrad(1, 0, 64, G(bp.g_x3), idx3, H, W, G(bp.g_a0), F(fp.a0), nullptr, false, n_a0, 2 * n_x3, 0, DC_1, GA_X3, GA_A0);
+    dgrad(1, 0, 64, G(bp.g_x3), idx3, H, W, G(bp.g_a0), F(fp.a0), nullptr, false, n_a0, 2 * n_x3, 0, DC_1, GA_X3, fuse0 ? -1 : GA_A0, fuse0);
     wgrad(1, F(fp.a0), 64, nullptr, 0, 0, G(bp.g_x3), idx3, H, W, 2 * n_x3, DW_1, AM_A0, -1, GA_X3);
   }
-  {
+  if (fuse0) {
+    // conv0's weight gradient left the data gradient's epilogue as one [64][32] partial per workgroup, in the place of the map
+    // (8 KB per 8 x 32-pixel tile against the map's 32 / 64 KB): 1024 slabs, then the generic gather (k < 27: dW0, column 27: db0)
+    const int tiles = ((W + 31) / 32) * ((H - (n_a0 > 0 ? n_a0 : 0) + 7) / 8) * B, NS = 1024;
+    const bool dyn1 = dynamic;
+    float* slab = (float*)(bw + bp.part);
+    hla_prof_begin(K_ELEMWISE, 0, (double)tiles * 8192.0 * (dyn1 ? 0.5 : 1.0), st);
+    hipLaunchKernelGGL(reduce_rows_kernel, dim3(NS), dim3(256), 0, st, (const float4*)G(bp.g_a0), (float4*)slab, 512, tiles,
+                       dyn1 ? dynp + dl.conv_desc[DC_1] : (const int*)nullptr, B);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((64 * 27 + 15) / 16), dim3(256), 0, st, (const float*)slab, gr->dw[0], (size_t)64 * 27, NS, 64 * 32, 27, 32);
+    if (gr->db[0]) hipLaunchKernelGGL(reduce_partials_kernel, dim3(4), dim3(256), 0, st, (const float*)slab + 27, gr->db[0], (size_t)64, NS, 64 * 32, 1, 32);
+    hla_prof_end(st);
+  } else {
     Wgrad0Args a{};
     a.x = x; a.x_plane = x_plane ? x_plane : (size_t)H * W; a.g = G(bp.g_a0); a.B = B; a.H = H; a.W = W;
     a.row_begin = level4 ? 0 : n_a0;

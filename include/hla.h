@@ -175,7 +175,10 @@ size_t hla_vgg_bwd_workspace_bytes(int B, int H, int W, int level, int dtype);
 #define HLA_VGG_BWD_DENSE 2           /* visit every tile even where the incoming gradient is exactly zero (A/B and tests) */
 #define HLA_VGG_BWD_WGRAD_TWO_PHASE 4 /* weight gradients on the two-phase kernels (512 workgroups, what a device that refuses the
                                          wave-specialised kernels' 96-115 KB LDS request runs) instead of the wave-specialised
-                                         ones: the same products in another split-K grouping (A/B and tests) */
+                                         ones: the same products in another split-K grouping (A/B and tests); implies the next */
+#define HLA_VGG_BWD_WGRAD0_UNFUSED 8  /* conv2's data gradient stored as a map and conv0's weight gradient computed from it by a
+                                         kernel of its own (rounds 1-5), instead of inside that data gradient's epilogue, where the
+                                         map is never written (level 3; A/B and tests) */
 int hla_vgg_backward(const float* x, size_t x_plane, const hla_vgg_params* params, const void* packed_weights_T,
                      const void* fwd_workspace, const float* const feat[4], const double* inv_norm,
                      const float* const d_feat[4], const float* const conf[4], const float* const d_conf[4],

@@ -2325,6 +2325,52 @@ def test_wave_specialised_wgrad_matches_the_two_phase_kernels(precision, monkeyp
     assert len(g_ws) >= 36 and not bad, bad
 
 
+@pytest.mark.parametrize('precision', ['fp32', 'fp16x3', 'bf16'])
+def test_fused_conv0_weight_gradient_matches_the_stored_map_kernel(precision):
+    """Round 6: conv0's weight / bias gradient is formed inside the epilogue of conv2's un-pooling data gradient
+    (conv_epilogue_wg0: the 64-channel full-resolution gradient map is never written) instead of by wgrad0_kernel from the stored
+    map (args.wgrad_two_phase = 2 -> HLA_VGG_BWD_WGRAD0_UNFUSED).  The same products -- exact fp32: the same MFMAs; split mode:
+    (hi, lo) fp16 pairs of both operands instead of the fp32 MFMA, i.e. 2^-22 per product; bf16: the map rounded to bf16 in both --
+    in another summation grouping, so the two agree to the order of the partial sums.  Ragged batch (B = 3), full KITTI shape:
+    the satellite branch's data-dependent tile list and the ground branch's ODD first row both go through the fused epilogue.
+    Everything else of the step must not move at all beyond the LM backward's atomics."""
+    from oracle import ref_cpu as O
+    from highlyaccurate_amd.models_kitti import LM_S2GP
+    d = _dev()
+    net = LM_S2GP(O.default_args(precision=precision))
+    net.load_state_dict(O.synth_model_state(5))
+    net = net.to(d).train()
+    net.args.bwd_two_streams = 0
+    B = 3
+    sat, grd, gu, gv, gh = O.synth_images(105, B)
+    sat, grd, gt = sat.to(d), grd.to(d), [gu.to(d), gv.to(d), gh.to(d)]
+
+    def grads():
+        net.zero_grad(set_to_none=True)
+        torch.manual_seed(3)
+        r = net(sat, grd, *gt, mode='train')
+        r[0].backward()
+        return {n: p.grad.detach().double().clone() for n, p in net.named_parameters() if p.grad is not None}
+
+    net.args.wgrad_two_phase = 0
+    g_f, g_f2 = grads(), grads()
+    net.args.wgrad_two_phase = 2
+    g_u = grads()
+    net.args.wgrad_two_phase = 0
+    rel = lambda a, b: float((a - b).norm() / max(float(b.norm()), 1e-30))
+    tol = {'fp32': 1e-5, 'fp16x3': 3e-5, 'bf16': 2e-3}[precision]
+    bad, seen = [], 0
+    for n in g_f:
+        e, noise = rel(g_f[n], g_u[n]), rel(g_f[n], g_f2[n])
+        if 'conv0.' in n:
+            seen += 1
+            print(f'fused vs stored-map conv0 gradient [{precision}] {n}: {e:.2e} (the fused kernels twice: {noise:.2e})')
+            assert float(g_f[n].norm()) > 0
+        if e > max(tol, 4 * noise):
+            bad.append((n, e, noise))
+    assert seen == 4 and not bad, bad
+
+
 @pytest.mark.parametrize('precision', ['fp16x3', 'bf16'])
 def test_deterministic_backward_gives_bitwise_equal_gradients(precision):
     """args.deterministic_backward = 1 (hla_s2g_config.deterministic, VERDICT r05 #2c): the same batch twice gives BITWISE equal
