@@ -15,6 +15,18 @@ void hla_prof_begin(int id, double flops, double bytes, hipStream_t st);
 void hla_prof_begin_dyn(int id, double flops, double bytes, hipStream_t st, const int* dev_live, int denom);
 void hla_prof_end(hipStream_t st);
 
+// per-wave cycle stamps of ONE conv3x3_kernel launch (tooling builds only: python -m highlyaccurate_amd.build --out=libhla_stamps.so
+// -DHLA_CONV_STAMPS=1; tools/probes/conv_stamps.py): launch_conv hands `buf` to the launch whose ordinal since the last
+// hla_debug_conv_stamps call equals `want`; every wave writes HLA_STAMP_N 64-bit words at ((blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave).
+#ifndef HLA_CONV_STAMPS
+#define HLA_CONV_STAMPS 0
+#endif
+#if HLA_CONV_STAMPS
+constexpr int HLA_STAMP_N = 8;
+struct HlaStampCfg { unsigned long long* buf; int want; int counter; unsigned grid_x, grid_y; };
+extern HlaStampCfg g_hla_stamp;      // prof.hip
+#endif
+
 #define HLA_CHECK_HIP(expr)                                                              \
   do {                                                                                   \
     hipError_t _e = (expr);                                                              \
@@ -50,6 +62,21 @@ struct HlaPerDeviceOnce {
 };
 
 static inline size_t hla_align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// compute units of the current device (cached per device id < 64; 256 on MI355X)
+static inline int hla_num_cus() {
+  static std::atomic<int> cache[64];
+  int d = 0;
+  (void)hipGetDevice(&d);
+  if (d >= 0 && d < 64) {
+    const int c = cache[d].load(std::memory_order_relaxed);
+    if (c > 0) return c;
+  }
+  int n = 0;
+  if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, d) != hipSuccess || n <= 0) { (void)hipGetLastError(); n = 256; }
+  if (d >= 0 && d < 64) cache[d].store(n, std::memory_order_relaxed);
+  return n;
+}
 
 // 64-lane butterfly sum (all lanes end with the total)
 __device__ __forceinline__ float wave_sum_f32(float v) {

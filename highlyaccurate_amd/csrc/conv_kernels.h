@@ -235,7 +235,21 @@ struct ConvArgs {
   const float* wg0_x;               // [B,3,H,W] NCHW fp32 network input, channel planes wg0_x_plane elements apart, or null
   size_t wg0_x_plane;
   float* wg0_part;                  // [workgroup][64 co][32]: k = c*9 + tap in columns 0..26, the bias gradient in column 27
+#if HLA_CONV_STAMPS
+  unsigned long long* stamps;       // tooling build: per-wave cycle stamps of this launch, or null (common.h)
+#endif
 };
+#if HLA_CONV_STAMPS
+// s_memtime (shader-clock cycles), HW_ID / XCC_ID: which CU / SIMD / slot the wave ran on
+#define HLA_STAMP(K) do { if (a.stamps) { const unsigned long long ts_ = __builtin_readcyclecounter(); \
+    if ((threadIdx.x & 63) == 0) a.stamps[((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 4 + (threadIdx.x >> 6)) * HLA_STAMP_N + (K)] = ts_; } } while (0)
+#define HLA_STAMP_HWID() do { if (a.stamps && (threadIdx.x & 63) == 0) { \
+    const unsigned long long hw_ = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4), xc_ = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 20); \
+    a.stamps[((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 4 + (threadIdx.x >> 6)) * HLA_STAMP_N + 7] = hw_ | (xc_ << 32); } } while (0)
+#else
+#define HLA_STAMP(K) do {} while (0)
+#define HLA_STAMP_HWID() do {} while (0)
+#endif
 
 // Data-dependent trimming (the backward of a branch whose incoming gradient has a small footprint, vgg_backward.hip): tables in
 // DEVICE memory, written by an earlier kernel on the same stream.  Only the `n_live` tiles of the list are computed (the same
@@ -271,6 +285,9 @@ constexpr int HALO_TAP0 = 2, HALO_TAP1 = 6;
 #define HLA_CONV_HALO_DMA 1
 #endif
 constexpr int HLA_CONV_DMA_TAP = 1;
+#ifndef HLA_CONV_DMA_EARLY1
+#define HLA_CONV_DMA_EARLY1 0
+#endif
 #ifndef HLA_A0_ABL
 #define HLA_A0_ABL 0
 #endif
@@ -961,6 +978,8 @@ __global__ __launch_bounds__(256, NT == 1 ? (UNPOOL ? HLA_UNPOOL_NT1_OCC : 3) : 
   __shared__ __attribute__((aligned(16))) char lds[LDSB];
   __shared__ float red[8];
 
+  HLA_STAMP(0);
+  HLA_STAMP_HWID();
   // (readfirstlane: the wave index is uniform, which lets every address that depends on it live in scalar registers)
   const int t = threadIdx.x, lane = t & 63, wv = __builtin_amdgcn_readfirstlane(t >> 6), wm = wv / WN, wn = wv % WN;
   // source / fan-in bounds: the image (and the caller's static first rows), narrowed by the device-side boxes if there are any
@@ -1183,6 +1202,14 @@ __global__ __launch_bounds__(256, NT == 1 ? (UNPOOL ? HLA_UNPOOL_NT1_OCC : 3) : 
   ring.prime();              // the first weight fragments do not depend on the halo tile: request them ahead of it
   if constexpr (DMA) {
     dma_stage(0, 0);
+#if HLA_CONV_DMA_EARLY1
+    // the second stage's tile is requested right behind the first: both round trips overlap, and the first stage no longer
+    // ends on a tile that was requested one prologue later (per-wave cycle stamps, profiles/r06_conv_cycle_table_*.json)
+    if (nstage > 1) {
+      dma_stage(1, 1);
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPIECE) : "memory");
+    } else
+#endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   } else {
     uint4 st1[NHALF];        // the prologue has registers to spare: both halves are requested back to back
@@ -1193,6 +1220,7 @@ __global__ __launch_bounds__(256, NT == 1 ? (UNPOOL ? HLA_UNPOOL_NT1_OCC : 3) : 
     write_stage(lds, 0, 1, st1, ids1);
   }
   __syncthreads();
+  HLA_STAMP(1);
   stagger_priority();
 
   for (int sg = 0; sg < nstage; ++sg) {
@@ -1200,7 +1228,7 @@ __global__ __launch_bounds__(256, NT == 1 ? (UNPOOL ? HLA_UNPOOL_NT1_OCC : 3) : 
     char* nxt = lds + ((sg + 1) & 1) * BUF;
     stage_mma<T, MT, NT, WD, PF>(acc, lds + (sg & 1) * BUF, fo, ring, [&](int tap) __attribute__((always_inline)) {
       if constexpr (DMA) {
-        if (tap == HLA_CONV_DMA_TAP && more) dma_stage(sg + 1, (sg + 1) & 1);
+        if (tap == HLA_CONV_DMA_TAP && more && !(HLA_CONV_DMA_EARLY1 && sg == 0)) dma_stage(sg + 1, (sg + 1) & 1);
       } else {
         if (tap == HALO_TAP0 && more) load_stage(sg + 1, 0, st, ids);
         if (tap == HALO_TAP1 && more) { write_stage(nxt, sg + 1, 0, st, ids); load_stage(sg + 1, 1, st, ids); }
@@ -1215,8 +1243,11 @@ __global__ __launch_bounds__(256, NT == 1 ? (UNPOOL ? HLA_UNPOOL_NT1_OCC : 3) : 
     } else {
       if (more) write_stage(nxt, sg + 1, 1, st, ids);
     }
+    if (sg == 0) HLA_STAMP(2);      // the first stage's MFMAs issued (+ the next tile awaited / written), before its barrier
     __syncthreads();
+    if (sg == 0) HLA_STAMP(3);
   }
+  HLA_STAMP(4);
   // the loop's last barrier guarantees nobody still reads the halo buffers: reuse them as 4 wave-private stagers
   static_assert((LDSB / 4) % 16 == 0, "stager alignment");
   {
@@ -1255,6 +1286,7 @@ __global__ __launch_bounds__(256, NT == 1 ? (UNPOOL ? HLA_UNPOOL_NT1_OCC : 3) : 
       conv_epilogue<T, MT, NT, POOL, (RAW_SPECIAL || sizeof(T) == 2) ? EPI_ACT_RAW_NOBIAS : EPI_GENERIC>(acc, a, b, y0 + wm * MT, x0, ntg0 * 32, red, stager, dsc, addb);
     else conv_epilogue<T, MT, NT, POOL, EPI_GENERIC>(acc, a, b, y0 + wm * MT, x0, ntg0 * 32, red, stager, dsc, addb);
   }
+  HLA_STAMP(5);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1277,6 +1309,9 @@ struct Conv02Args {
   unsigned* amax_out;      // [B] atomicMax target: max of out_act per sample
   unsigned* amax_a2_out;   // likewise for a2_out (level 4), or null
   unsigned* amax_a0_out;   // likewise for a0_out (training: the split-mode weight gradient of conv2 scales its input by it), or null
+#if HLA_CONV_STAMPS
+  unsigned long long* stamps;
+#endif
 };
 
 // conv0's 64 output channels are conv2's K.  With 2-byte activations they are two 32-channel stages = 54 KB of halo tile and
@@ -1305,6 +1340,11 @@ __global__ __launch_bounds__(256, Prec<T>::SPLIT ? 2 : 3) void conv02_kernel(Con
   __shared__ float red[8];
   __shared__ float red2[4];
   float a0mx = 0.f;                                  // split mode, training: max of the relu(conv0) copy this thread wrote
+#if HLA_CONV_STAMPS
+  struct { unsigned long long* stamps; } a = {a0.stamps};
+#endif
+  HLA_STAMP(0);
+  HLA_STAMP_HWID();
 
   const int t = threadIdx.x, lane = t & 63, wv = __builtin_amdgcn_readfirstlane(t >> 6), wm = wv / WN, wn = wv % WN;
   int bid = blockIdx.x;                    // (the XCD-contiguous order measured 2-3 % slower for this kernel)
@@ -1358,6 +1398,7 @@ __global__ __launch_bounds__(256, Prec<T>::SPLIT ? 2 : 3) void conv02_kernel(Con
     if (lane == 0) red[4 + wv] = amx;
   }
   __syncthreads();
+  HLA_STAMP(1);
 
   // phase B: conv0 on the 10x34 halo pixels, 32 pixels per MFMA tile, straight into the conv2 halo buffers
   float4 bias0[JPR][4];
@@ -1466,7 +1507,9 @@ __global__ __launch_bounds__(256, Prec<T>::SPLIT ? 2 : 3) void conv02_kernel(Con
         }
     }
   }
+  HLA_STAMP(2);
   __syncthreads();
+  HLA_STAMP(3);
 
   // phase C: conv2 over this round's resident stages (no further loads, no barriers)
   if (rd == 0) {                // (16-bit types: the accumulators start at conv2's bias, like conv3x3_kernel's)
@@ -1492,6 +1535,7 @@ __global__ __launch_bounds__(256, Prec<T>::SPLIT ? 2 : 3) void conv02_kernel(Con
 #pragma unroll 1
   for (int sg = 0; sg < SPR; ++sg)
     stage_mma<T, MT, NT, WD>(acc, lds + sg * BUF, fo, ring, [](int) {});
+  HLA_STAMP(4);
   if (rd + 1 < ROUNDS) {
 #pragma unroll
     for (int jj = 0; jj < JPR; ++jj) {
@@ -1563,7 +1607,12 @@ __global__ __launch_bounds__(256, Prec<T>::SPLIT ? 2 : 3) void conv02_kernel(Con
     if (lane == 0) red2[wv] = a0mx;
   }
 
+#if HLA_CONV_STAMPS
+  ConvArgs ae{};
+#define a ae
+#else
   ConvArgs a{};
+#endif
   a.bias = a0.b2; a.out_act = a0.out_act; a.B = a0.B; a.H = a0.H; a.W = a0.W; a.Cout = 64; a.relu_act = 1;
   a.tiles_x = a0.tiles_x; a.tiles_y = a0.tiles_y; a.idx_out = a0.idx_out; a.amax_out = a0.amax_out;
   __syncthreads();   // all waves are done with the halo buffers; reuse them as wave-private stagers
@@ -1581,6 +1630,10 @@ __global__ __launch_bounds__(256, Prec<T>::SPLIT ? 2 : 3) void conv02_kernel(Con
   }
   if (a.idx_out) conv_epilogue<T, MT, NT, true, EPI_GENERIC>(acc, a, b, y0 + wm * MT, x0, wn * 32, red, lds + wv * (SPR * BUF / 4), dsc2, PixBox{0, 1 << 30, 0, 1 << 30}, pb2);
   else conv_epilogue<T, MT, NT, true, EPI_ACT, false, SPR * BUF / 4>(acc, a, b, y0 + wm * MT, x0, wn * 32, red, lds + wv * (SPR * BUF / 4), dsc2, PixBox{0, 1 << 30, 0, 1 << 30}, pb2);
+#if HLA_CONV_STAMPS
+#undef a
+  { struct { unsigned long long* stamps; } a = {a0.stamps}; HLA_STAMP(5); }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1847,6 +1900,13 @@ static bool launch_conv(hipStream_t st, ConvArgs a, bool pool) {
   }
   a.tiles_x = (a.W + 31) / 32;
   a.tiles_y = (a.H - a.row_begin + 7) / 8;
+#if HLA_CONV_STAMPS
+  a.stamps = nullptr;
+  if (g_hla_stamp.buf && g_hla_stamp.counter++ == g_hla_stamp.want) {
+    a.stamps = g_hla_stamp.buf;
+    g_hla_stamp.grid_x = a.tiles_x * a.tiles_y * a.B; g_hla_stamp.grid_y = a.Cout >= 128 ? a.Cout / 128 : 1;
+  }
+#endif
   // (the 64-channel block at three workgroups per CU for the Cout >= 128 layers as well: 259 against 244 us per launch, same-box A/B)
   const bool big = a.Cout >= 128;
   const dim3 grid(a.tiles_x * a.tiles_y * a.B, big ? a.Cout / 128 : 1);

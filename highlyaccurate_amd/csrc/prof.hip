@@ -79,6 +79,14 @@ extern "C" int hla_prof_fetch(hla_prof_record* out, int max_records, int* n_out)
   return HLA_OK;
 }
 
+#if HLA_CONV_STAMPS
+HlaStampCfg g_hla_stamp = {nullptr, -1, 0, 0, 0};
+// tooling builds only: arm the stamps for the `want`-th launch_conv call from now on (buf: device memory, HLA_STAMP_N * 8 bytes per
+// wave of that launch); grid_out (2 ints, may be null) receives that launch's grid after it ran
+extern "C" int hla_debug_conv_stamps(void* buf, int want) { g_hla_stamp.buf = (unsigned long long*)buf; g_hla_stamp.want = want; g_hla_stamp.counter = 0; return 0; }
+extern "C" int hla_debug_conv_stamps_grid(unsigned* gx, unsigned* gy) { *gx = g_hla_stamp.grid_x; *gy = g_hla_stamp.grid_y; return 0; }
+#endif
+
 // ---------------------------------------------------------------------------------------------
 // hla_prof_mfma_peak: what the matrix pipe of THIS chip sustains -- back-to-back v_mfma_f32_32x32x16_{bf16,f16} on
 // register-resident operands, two waves per SIMD (the conv kernels' occupancy), every CU busy for `ms_target` milliseconds;

@@ -109,6 +109,13 @@ int vgg_forward_t(const float* x, size_t x_plane, const hla_vgg_params* prm, con
     HLA_CHECK_HIP(attr_once.run([] {
       return hipFuncSetAttribute((const void*)conv02_kernel<T, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
     }));
+#if HLA_CONV_STAMPS
+    a.stamps = nullptr;      // (tooling build: want = -10 - k arms the k-th conv02 launch since the call)
+    if (g_hla_stamp.buf && g_hla_stamp.want <= -10 && g_hla_stamp.want++ == -10) {
+      a.stamps = g_hla_stamp.buf; g_hla_stamp.want = -1000;
+      g_hla_stamp.grid_x = a.tiles_x * a.tiles_y * nb; g_hla_stamp.grid_y = 1;
+    }
+#endif
     hla_prof_begin(K_CONV02, 2.0 * 9 * (3 + 64) * 64 * P, P * (3 * 4 + 16 * sizeof(T)), st);
     hipLaunchKernelGGL((conv02_kernel<T, 2>), dim3(a.tiles_x * a.tiles_y * nb), dim3(256), lds_bytes, st, a);
     hla_prof_end(st);
