@@ -486,7 +486,7 @@ def workload_name(model, sat_a, grd_hw, n_iters):
             f"{n_iters} LM iters x 3 levels, 3-DoF, random-init weights")
 
 
-def step_breakdown(tstep, nsteps, dist=None):
+def step_breakdown(tstep, nsteps, dist=None, sync=None):
     """Phase times of a training step from HIP events recorded on the launch (current) stream at the phase boundaries the model
     marks (``_s2gp.PHASE_HOOK``): the two extractor forwards, the LM loop, `glue` (the pose loss forward + its backward, i.e.
     everything between the LM loop and the model's backward), the LM backward (incl. the zero-fills in front of it), both
@@ -508,6 +508,8 @@ def step_breakdown(tstep, nsteps, dist=None):
     if dist:
         dist.barrier()
     _s2gp.PHASE_HOOK = hook
+    if sync is not None:
+        sync.timing, sync._timeline = True, []
     try:
         for _ in range(nsteps + 1):
             cur = []
@@ -520,6 +522,9 @@ def step_breakdown(tstep, nsteps, dist=None):
         torch.cuda.synchronize()
     finally:
         _s2gp.PHASE_HOOK = None
+        if sync is not None:
+            sync.timing = False
+    overlap = sync.overlap_report() if sync is not None else []
     rows = []
     for i in range(nsteps):
         ev = dict(steps[i])
@@ -542,6 +547,15 @@ def step_breakdown(tstep, nsteps, dist=None):
                 'host_enqueue_ms': round(float(np.median(host[:-1])) * 1e3, 3),
                 'what': 'HIP events on the launch stream at the phase marks (median over the steps of a block that is not part of value); '
                         'fwd_sat includes the weight repacking after the optimizer step; vgg_bwd = both extractors (two streams, joined)'})
+    if overlap:      # N > 1 (or the forced one-rank group): how much of the gradient all-reduce the backward did NOT cover
+        ov = overlap[:nsteps]
+        out['allreduce_exposed_ms'] = round(float(np.median([o['exposed_ms'] for o in ov])), 3)
+        nb = min(len(o['bucket_issue_ms_before_backward_end']) for o in ov)
+        out['allreduce_buckets'] = [{'bytes': ov[0]['bucket_bytes'][k],
+                                     'issued_ms_before_backward_end': round(float(np.median([o['bucket_issue_ms_before_backward_end'][k] for o in ov])), 3)}
+                                    for k in range(nb)]
+        out['allreduce_what'] = ('events on the launch stream: a bucket is issued when its branch\'s weight gradients are complete; '
+                                 'exposed = from the first wait (the whole backward is enqueued behind it) to the last collective returning')
     return out
 
 
@@ -629,7 +643,7 @@ def train_leg(net, a, sat, grd, extra, B, world, rank, dist, dev, want_kt, extra
     tele_block = round(tb4 / a.train_steps * 1e3, 3)
     # ---- where the step goes: events on the launch stream at the phase boundaries (highlyaccurate_amd._s2gp.PHASE_HOOK), a block
     # of its own, not part of `value`.  Every rank runs it (the step contains the all-reduce), rank 0 reports.
-    breakdown = step_breakdown(tstep, max(3, min(a.train_steps, 6)), dist)
+    breakdown = step_breakdown(tstep, max(3, min(a.train_steps, 6)), dist, getattr(net, 'grad_sync', None) if dist else None)
     n_bd = breakdown.pop('_steps_run')
     ar_bytes = ((net.grad_sync.bytes_reduced - ar0) // (4 * a.train_steps + 4 + n_bd)) if dist else 0      # 3 timed blocks + the telemetry block of K steps + 4 warm-up steps + the breakdown block
     trecs = []

@@ -60,6 +60,12 @@ class GradSync:
         self.op = dist.ReduceOp.AVG if self.avg_in_collective else dist.ReduceOp.SUM
         self.bytes_reduced = 0
         self.collectives = 0
+        # evidence hook (bench.py, N > 1): with ``timing`` on, every bucket records an event on the launch stream where its
+        # all-reduce is issued, and ``finish`` one before its first wait (= the backward's kernels are all enqueued behind it) and one
+        # behind its last; ``overlap_report()`` turns them into "how long before the backward's end each bucket started" and
+        # "how long the launch stream then still waited for the collectives" (allreduce_exposed_ms).  CUDA tensors only.
+        self.timing = False
+        self._timeline = []      # per start(): [(event, bytes)], per finish(): (pre, post)
 
     @staticmethod
     def _inside(t: torch.Tensor, flat: torch.Tensor) -> bool:
@@ -75,18 +81,63 @@ class GradSync:
             rest = {n: g for n, g in grads.items() if not self._inside(g, flat)}
             self.bytes_reduced += flat.numel() * 4
             self.collectives += 1
+            self._mark_start(flat)
             works.append((dist.all_reduce(flat, op=self.op, group=self.group, async_op=True), flat, None, None))
         if rest:
             names = sorted(rest)                      # identical order on every rank
             stage = torch.cat([rest[n].reshape(-1).float() for n in names])
             self.bytes_reduced += stage.numel() * 4
             self.collectives += 1
+            self._mark_start(stage)
             works.append((dist.all_reduce(stage, op=self.op, group=self.group, async_op=True), stage, names, rest))
         return works
+
+    def _mark_start(self, buf: torch.Tensor):
+        if self.timing and buf.is_cuda:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            self._timeline.append(('start', ev, buf.numel() * 4))
+
+    def _mark(self, kind: str, buf: torch.Tensor):
+        if self.timing and buf.is_cuda:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            self._timeline.append((kind, ev, 0))
+
+    def overlap_report(self):
+        """After a device synchronisation: per training step (= one run of start()s followed by finish()es) the buckets' issue
+        times relative to the first finish (negative: the collective was in flight under that much of the backward) and the
+        time the launch stream spent between the first wait and the last one returning.  Clears the record."""
+        steps, cur = [], {'starts': [], 'pre': None, 'post': None}
+        for kind, ev, nbytes in self._timeline:
+            if kind == 'start':
+                if nbytes < 4096:      # (a trainable `damping`: four floats reduced behind the two buckets -- part of the same step)
+                    continue
+                if cur['post'] is not None:
+                    steps.append(cur)
+                    cur = {'starts': [], 'pre': None, 'post': None}
+                cur['starts'].append((ev, nbytes))
+            elif kind == 'pre' and cur['pre'] is None:
+                cur['pre'] = ev
+            elif kind == 'post':
+                cur['post'] = ev
+        if cur['post'] is not None:
+            steps.append(cur)
+        self._timeline = []
+        out = []
+        for st in steps:
+            if st['pre'] is None:
+                continue
+            out.append({'exposed_ms': st['pre'].elapsed_time(st['post']),
+                        'bucket_issue_ms_before_backward_end': [round(ev.elapsed_time(st['pre']), 3) for ev, _ in st['starts']],
+                        'bucket_bytes': [b for _, b in st['starts']]})
+        return out
 
     def finish(self, handle):
         if handle is None:
             return
+        if handle:
+            self._mark('pre', handle[0][1])
         for work, buf, names, grads in handle:
             work.wait()
             if not self.avg_in_collective:
@@ -98,6 +149,8 @@ class GradSync:
                 g = grads[n]
                 g.copy_(buf[o:o + g.numel()].view_as(g))
                 o += g.numel()
+        if handle:
+            self._mark('post', handle[-1][1])
 
 
 def allreduce_module_grads(module: torch.nn.Module, group=None):

@@ -83,6 +83,52 @@ def test_bench_line_carries_the_round6_fields():
         assert f"'{k}'" in src, k
 
 
+def test_grad_sync_overlap_report_arithmetic_on_fake_events(monkeypatch):
+    """parallel.GradSync.overlap_report (the evidence hook of the N > 1 line): per step, a bucket's issue time
+    relative to the first wait and the time from the first wait to the last collective returning; bench.step_breakdown puts the
+    medians into the line (pinned on its source)."""
+    import os
+    import torch
+    from highlyaccurate_amd.parallel import GradSync
+    clock = {'t': 0.0}
+
+    class Ev:
+        def __init__(self, enable_timing=True):
+            self.t = None
+
+        def record(self):
+            self.t = clock['t']
+
+        def elapsed_time(self, other):
+            return other.t - self.t
+
+    monkeypatch.setattr(torch.cuda, 'Event', Ev)
+    gs = GradSync()
+    gs.timing = True
+
+    class Buf:
+        is_cuda = True
+
+        def __init__(self, n):
+            self._n = n
+
+        def numel(self):
+            return self._n
+
+    for step in range(2):
+        clock['t'] += 10.0; gs._mark_start(Buf(10000))          # satellite bucket: issued 5 ms before the backward's end
+        clock['t'] += 4.0; gs._mark_start(Buf(5000))            # ground bucket: 1 ms before
+        clock['t'] += 1.0; gs._mark('pre', Buf(1)); clock['t'] += 0.25; gs._mark('post', Buf(1))
+        gs._mark('pre', Buf(1)); clock['t'] += 0.5; gs._mark('post', Buf(1))        # second finish(): its wait extends the exposure
+    rep = gs.overlap_report()
+    assert len(rep) == 2 and gs._timeline == []
+    for r in rep:
+        assert r['bucket_issue_ms_before_backward_end'] == [5.0, 1.0] and r["bucket_bytes"] == [40000, 20000] and abs(r['exposed_ms'] - 0.75) < 1e-9, r
+    src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'bench.py')).read()
+    for key in ("out['allreduce_exposed_ms']", "out['allreduce_buckets']", "'issued_ms_before_backward_end'"):
+        assert key in src, key
+
+
 def test_step_breakdown_arithmetic_on_fake_events(monkeypatch):
     """bench.step_breakdown: phase = time between consecutive marks, inter_step_idle = optimizer mark -> next step's begin mark."""
     import torch

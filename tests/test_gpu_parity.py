@@ -2125,6 +2125,11 @@ def test_bench_single_rank_through_rccl():
     assert abs(t['allreduce_bytes_per_step'] - 19.78e6) < 0.02e6, t['allreduce_bytes_per_step']
     assert t['loss_finite'] and t['value'] > 0
     assert t['roofline']['bound'] == 'mfma' and 0.05 < t['roofline']['frac'] < 1.0 and 300 < t['gflop_per_pair_executed'] < 1000, t.get('roofline')
+    # round 6: the overlap evidence of the gradient all-reduce is in the line whenever the collectives run
+    sb = t['step_breakdown']
+    assert 0.0 <= sb['allreduce_exposed_ms'] < 5.0 and len(sb['allreduce_buckets']) == 2, sb
+    assert all(abs(b['bytes'] - 9.89e6) < 0.02e6 for b in sb['allreduce_buckets']), sb['allreduce_buckets']
+    assert sb['allreduce_buckets'][0]['issued_ms_before_backward_end'] > sb['allreduce_buckets'][1]['issued_ms_before_backward_end'] >= 0.0, sb
 
 
 def test_grad_sync_over_rccl_leaves_one_rank_gradients_unchanged():
