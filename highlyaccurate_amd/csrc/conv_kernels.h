@@ -1269,6 +1269,7 @@ __global__ __launch_bounds__(256, NT == 1 ? (UNPOOL ? HLA_UNPOOL_NT1_OCC : 3) : 
     if constexpr (UNPOOL && NT == 1 && MT == 4 && WN == 2) {      // conv2's data gradient: the only launch of this instantiation
       if (mode == EPI_DGRAD_WG0) {
         conv_epilogue_wg0<T, MT>(acc, a, b, y0, x0, lds, dsc);
+        HLA_STAMP(5);
         return;
       }
     }
