@@ -5,11 +5,19 @@ struct FillTable { hla_fill_region r[16]; };
 
 static __global__ __launch_bounds__(256) void zero_fill_kernel(FillTable t) {
   const hla_fill_region& r = t.r[blockIdx.y];
-  const size_t v_per = r.chunk_bytes / 16, total = v_per * (size_t)r.n_chunks;
-  const uint4 z = make_uint4(0u, 0u, 0u, 0u);
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-    const size_t c = i / v_per, o = i - c * v_per;
-    *(uint4*)((char*)r.ptr + c * r.stride_bytes + o * 16) = z;
+  if ((((size_t)r.ptr | r.chunk_bytes | r.stride_bytes) & 15) == 0) {      // (per region: uniform)
+    const size_t v_per = r.chunk_bytes / 16, total = v_per * (size_t)r.n_chunks;
+    const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+      const size_t c = i / v_per, o = i - c * v_per;
+      *(uint4*)((char*)r.ptr + c * r.stride_bytes + o * 16) = z;
+    }
+  } else {      // a map whose size is not a multiple of four floats (odd level sizes: [B,h,w] confidence gradients): word stores
+    const size_t v_per = r.chunk_bytes / 4, total = v_per * (size_t)r.n_chunks;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+      const size_t c = i / v_per, o = i - c * v_per;
+      *(unsigned*)((char*)r.ptr + c * r.stride_bytes + o * 4) = 0u;
+    }
   }
 }
 
@@ -22,9 +30,9 @@ extern "C" int hla_zero_fill(const hla_fill_region* regions, int n_regions, int 
   for (int i = 0; i < n_regions; ++i) {
     const hla_fill_region& r = regions[i];
     HLA_REQUIRE(r.n_chunks >= 0 && (r.n_chunks == 0 || r.ptr), "hla_zero_fill: region %d: null pointer", i);
-    HLA_REQUIRE(((size_t)r.ptr | r.chunk_bytes | r.stride_bytes) % 16 == 0, "hla_zero_fill: region %d: pointer, chunk and stride must be multiples of 16 bytes", i);
+    HLA_REQUIRE(((size_t)r.ptr | r.chunk_bytes | r.stride_bytes) % 4 == 0, "hla_zero_fill: region %d: pointer, chunk and stride must be multiples of 4 bytes", i);
     t.r[i] = r;
-    const size_t v = r.chunk_bytes / 16 * (size_t)r.n_chunks;
+    const size_t v = r.chunk_bytes / 16 * (size_t)r.n_chunks + 1;
     most = v > most ? v : most;
   }
   if (most == 0) return HLA_OK;

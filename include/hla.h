@@ -348,7 +348,7 @@ int hla_g2s_lm_solve_bwd(const hla_s2g_config* cfg, const hla_s2g_level* levels,
  * of it (three d_sat_feat maps, the rows of the d_grd_feat maps its consumer reads above row0, d_grd_conf) -- as separate
  * fill launches these were ~10 of the ~25 small launches between the LM loop and its backward (the reference: autograd's own
  * zeros_like / accumulate nodes).  Region i = n_chunks pieces of chunk_bytes, stride_bytes apart, starting at ptr; ptr,
- * chunk_bytes and stride_bytes must be multiples of 16. */
+ * chunk_bytes and stride_bytes must be multiples of 4 (a region whose three are multiples of 16 is cleared with 16-byte stores). */
 typedef struct hla_fill_region {
   void* ptr;
   size_t chunk_bytes, stride_bytes;

@@ -2436,8 +2436,13 @@ def test_zero_fill_clears_strided_regions_in_one_launch():
     rc = torch.ones(4, 4, dtype=torch.float64)
     rc[1] = 0
     assert torch.equal(c.cpu(), rc)
+    # a region that is only 4-byte granular (odd map sizes: a [B, h, w] confidence gradient of 3 x 27 x 5 floats) takes word stores
+    d2 = torch.full((3 * 27 * 5 + 2,), 5.0, device=d)
+    _lib.zero_fill([(d2.data_ptr() + 4, 3 * 27 * 5 * 4, 3 * 27 * 5 * 4, 1)])
+    torch.cuda.synchronize()
+    assert float(d2[0]) == 5.0 and float(d2[-1]) == 5.0 and float(d2[1:-1].abs().max()) == 0.0
     with pytest.raises(_lib.HlaError):
-        _lib.zero_fill([(a.data_ptr() + 4, 16, 16, 1)])           # misaligned
+        _lib.zero_fill([(a.data_ptr() + 2, 16, 16, 1)])           # misaligned
     b.fill_(2.0)
     _lib.zero_fill([(b, b.numel() * 4, b.numel() * 4, 1)], max_blocks=3)      # a background fill: same result
     torch.cuda.synchronize()
