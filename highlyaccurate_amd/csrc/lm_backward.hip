@@ -48,7 +48,7 @@ struct BwdSolveArgs {
   // cfg->deterministic: the fixed-point exponent of this step's level and sample is chosen (q_first: the level's first visit of
   // the reversed loop) or checked against this step's bound (DetScale)
   int* qexp;                  // [B] of this step's level, or null
-  int q_first, A;             // A: side of this step's satellite map (bounds |d(uv)/d(theta)|)
+  int q_first, A, det_p;      // A: side of this step's satellite map (bounds |d(uv)/d(theta)|); det_p: precision bits below the bound
   // stand-alone launch only: zero this sample's tickets / ADAM adjoints / d_lambda sums (no memsets in front of the loop)
   unsigned* zero_ticket; int zero_steps;
 };
@@ -60,11 +60,17 @@ struct BwdSolveArgs {
 //   |J_i| <= 2 jm_i,  |gs| <= 2|gS| + 2 sum_i |gU_i| jm_i,  |gJ_i| <= 2 sum_j |A_ij| jm_j + |gU_i| + |gV_i|,
 //   |c| <= |gs| + 2 sum_i |gJ_i| jm_i  =: bound < 2^e,     q = 2^(e - DET_P).
 // A texel collects at most 2^13 contributions over all visits of its level (KITTI: <= 400 ground pixels per texel cell x 4 cells x
-// 5 visits), so |sum / q| < 2^(DET_P + 13) * (largest bound / first bound): with DET_P = 40 a later visit's bound may exceed the
-// first one's by 2^9 before the 63-bit range is at risk -- checked per step and sample (the same bound, so the check itself is
-// reproducible) and counted in d_damping[3], which the caller must find zero.  Typical contributions are ~2^-11 of the bound
-// (|feature| ~ 1 / sqrt(A A C)): they keep ~29 significant bits, more than the fp32 atomics' 24.
-#define DET_P 40
+// 5 visits), so |sum / q| < 2^(P + 13) * (largest bound / first bound): a later visit's bound may exceed the first one's by
+// 2^(50 - P) before the 63-bit range is at risk -- checked per step and sample (the same bound, so the check itself is reproducible)
+// and counted in d_damping[3], which the caller must find zero.  P = cfg->deterministic (1: 40; 16..46: that many bits).  Typical
+// contributions are ~2^-11 of the bound (|feature| ~ 1 / sqrt(A A C)): at P = 40 they keep ~29 significant bits, more than the fp32
+// atomics' 24 (deterministic against atomics gradients 1e-6 apart = the atomics' own run-to-run noise); at P = 32, 21 bits (1.6e-5).
+// The reversed loop visits the LAST LM step first, whose adjoints are the smallest of the chain: at bench shapes with random
+// weights an earlier step's bound outgrew it by more than the 2^10 that P = 40 leaves after a few Adam steps -- the host side
+// (_s2gp.lm_backward) then repeats the call with P = 30 (2^20), which for given inputs is as reproducible as the first attempt.
+#define DET_P_DEFAULT 40
+#define DET_P_MIN 16
+#define DET_P_MAX 46
 __device__ static inline int det_bound_exp(const double* ad, const double* cf, int A) {
   const double jm[3] = {fabs(cf[8]) + fabs(cf[9]), fabs(cf[10]) + fabs(cf[11]), 2.0 * fabs(cf[12]) * (double)A};
   const double Am[3][3] = {{fabs(ad[2]), fabs(ad[3]), fabs(ad[4])}, {fabs(ad[3]), fabs(ad[5]), fabs(ad[6])}, {fabs(ad[4]), fabs(ad[6]), fabs(ad[7])}};
@@ -85,9 +91,9 @@ __device__ static inline void det_scale(const BwdSolveArgs& a, int b, const doub
   if (!a.qexp) return;
   const int e = det_bound_exp(ad, cf, a.A);
   if (a.q_first) {
-    int q = e - DET_P;
+    int q = e - a.det_p;
     a.qexp[b] = q < -126 ? -126 : (q > 100 ? 100 : q);
-  } else if (e - DET_P > a.qexp[b] + 9) {
+  } else if (e - a.det_p > a.qexp[b] + (50 - a.det_p)) {
     a.dlam[(size_t)b * 4 + 3] += 1.0;           // this step's contributions could leave the 63-bit range: reported, never silent
   }
 }
@@ -577,6 +583,7 @@ extern "C" int hla_s2g_lm_solve_bwd(const hla_s2g_config* cfg, const hla_s2g_lev
       bool first_visit = true;
       for (int j = k + 1; j < steps; ++j) if (step_level(j) == l) first_visit = false;
       sa.qexp = qexp + (size_t)l * B; sa.q_first = first_visit ? 1 : 0; sa.A = lv[l].A;
+      sa.det_p = cfg->deterministic == 1 ? DET_P_DEFAULT : (cfg->deterministic < DET_P_MIN ? DET_P_MIN : (cfg->deterministic > DET_P_MAX ? DET_P_MAX : cfg->deterministic));
     }
     sa.R_FL = R_FL; sa.T_FL = T_FL; sa.B = B; sa.reinit = reinit ? 1 : 0;
     sa.cfg.gn = cfg->optimizer == 3 ? 1 : 0;

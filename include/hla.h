@@ -277,9 +277,11 @@ typedef struct hla_s2g_config {
                              the last bits of every gradient behind it, varies from run to run).  != 0: it is accumulated in 64-bit
                              fixed point in the workspace (integer atomics commute) and written -- every element, no zero-fill needed --
                              to d_sat_feat by a closing pass: the same inputs give bitwise the same gradients.  The quantum is a
-                             power of two per (level, sample) taken from a bound of that sample's contributions; d_damping[3]
-                             counts the (step, sample) pairs whose bound outgrew the 63-bit range (must be 0).  Costs 8 B per
-                             satellite-map element of workspace, its memset and the closing pass */
+                             power of two per (level, sample): 2^-P of a bound of that sample's contributions at the level's first
+                             visit (P = 40 for the value 1, or the value itself, 16..46); d_damping[3] counts the (step, sample)
+                             pairs whose bound outgrew the first one's by more than 2^(50 - P), i.e. put the 63-bit range at
+                             risk (must be 0: repeat the call with a smaller P).  Costs 8 B per satellite-map element of
+                             workspace, its memset and the closing pass */
 } hla_s2g_config;
 
 size_t hla_s2g_workspace_bytes(const hla_s2g_config* cfg, const hla_s2g_level* levels, int B);
