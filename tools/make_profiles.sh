@@ -21,9 +21,6 @@ rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch_tr -- python $R
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write_tr -- python $ROOT/bench.py $TR > /dev/null 2>> $OUT/bench.err
 python $ROOT/tools/pmc_hbm.py $OUT/pmc_fetch_tr $OUT/pmc_write_tr $OUT/${TAG}_pmc_hbm_traffic_train.json > /dev/null
 cp $OUT/${TAG}_pmc_hbm_traffic_train.json $ROOT/profiles/${TAG}_pmc_hbm_traffic_train.json
-# fetch bytes per layer, whole batch per launch against 8-sample chunks of the high-resolution chain
-HLA_VGG_CHUNK=8 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch_c8 -- python $ROOT/bench.py --steps 2 --warmup 1 --no-kernel-timing $HEAD > /dev/null 2>> $OUT/bench.err
-python $ROOT/tools/pmc_per_layer.py $OUT/pmc_fetch $OUT/pmc_fetch_c8 > $OUT/${TAG}_fetch_per_layer_chunk0_vs_8.json
 # per launch of both branches: workgroups, resident generations, tail bound, microseconds
 python $ROOT/tools/probes/occupancy_table.py bf16 > $OUT/${TAG}_per_layer.json 2>> $OUT/bench.err
 # the full default line (by_precision, secondary, train, cpu_baseline)
@@ -45,5 +42,5 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python $RO
 cp $OUT/stats/*/*kernel_stats.csv $OUT/${TAG}_rocprofv3_kernel_stats_train_fp16x3.csv
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $OUT/pmc_sq -- python $ROOT/bench.py --steps 2 --warmup 1 --no-kernel-timing $HEAD > /dev/null 2>> $OUT/bench.err
 python $ROOT/tools/pmc_summary.py $OUT/pmc_sq > $OUT/${TAG}_pmc_sq_counters.txt
-rm -rf $OUT/stats $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_sq $OUT/pmc_fetch_tr $OUT/pmc_write_tr $OUT/pmc_fetch_c8
+rm -rf $OUT/stats $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_sq $OUT/pmc_fetch_tr $OUT/pmc_write_tr
 ls -la $OUT
