@@ -1,4 +1,5 @@
-"""Build libhla.so (gfx950) in-tree with hipcc.  `python -m highlyaccurate_amd.build [--force] [--verbose] [--out=NAME.so] [-DX=1]`"""
+"""Build libhla.so (gfx950) in-tree with hipcc.  `python -m highlyaccurate_amd.build [--force] [--verbose] [--out=NAME.so] [-DX=1]`
+(A/B tooling: `-DX=<flag>` passes <flag> to hipcc verbatim, e.g. `-DX=-mllvm -DX=-amdgpu-sched-strategy=max-ilp --out=libhla_ilp.so`.)"""
 from __future__ import annotations
 
 import os
@@ -140,7 +141,7 @@ def _build_locked(verbose: bool, defines: tuple) -> str:
     os.makedirs(os.path.join(HERE, 'build'), exist_ok=True)
     for s, tu in SOURCES:
         o = os.path.join(HERE, 'build', s.replace('.hip', f'.{os.path.basename(LIB)}.t{tu + 1}.o'))
-        cmd = [hipcc, *FLAGS, *[f'-D{d}' for d in defines], f'-DHLA_TU_DTYPE={tu}', '-c', os.path.join(CSRC, s), '-o', o]
+        cmd = [hipcc, *FLAGS, *[(d[2:] if d.startswith('X=') else f'-D{d}') for d in defines], f'-DHLA_TU_DTYPE={tu}', '-c', os.path.join(CSRC, s), '-o', o]
         if s == 'capi.hip':
             cmd.insert(-4, f'-DHLA_SOURCE_HASH_HEX="{srchash}"')
         if verbose:
